@@ -1,0 +1,218 @@
+// Generic fused fp32 GEMM for gfx950 on the f32-input MFMA (v_mfma_f32_32x32x2_f32).
+//
+// C[m,n] = epi(sum_k A(m,k) B(k,n)) with element-strided / windowed / masked operands: see
+// include/a2f_hip.h (a2f_gemm_f32).  One kernel serves every Linear and every strided (3,1)/(1,3)/(4,1)
+// convolution (as implicit GEMM over overlapping activation windows) of the reference models,
+// forward, data-gradient and weight-gradient (split-K, fp32 atomics).
+//
+// Tiling (wave64): workgroup = 256 threads = 4 waves stacked along M; tile BM=128 x BN in {32,64,96,128},
+// BK=16; each wave owns 32 rows x BN columns = BN/32 MFMA 32x32 accumulators (16 VGPR each).
+// LDS images are k-major ([k][m], [k][n], row pitch +4 floats) so the A/B fragment reads
+// (lane -> m or n, lane>>5 -> k) are conflict-free ds_read_b32; global->LDS goes through registers with the
+// next tile's loads issued before the current tile's MFMAs (two LDS buffers, one barrier per k-tile).
+// Exact fp32: the f32 MFMA is a k-ordered fmaf chain, so results match torch CPU fp32 to rounding order.
+#include "a2f_common.h"
+
+namespace a2f {
+
+constexpr int G_BM = 128;
+constexpr int G_BK = 16;
+constexpr int G_THREADS = 256;
+
+template <int BN>
+__global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const a2f_gemm_desc d) {
+  constexpr int NT = BN / 32;
+  constexpr int LDA = G_BM + 4;
+  constexpr int LDB = BN + 4;
+  constexpr int A_PER = G_BK * G_BM / G_THREADS;   // 8
+  constexpr int B_PER = (G_BK * BN + G_THREADS - 1) / G_THREADS;
+  __shared__ float smem[2 * G_BK * LDA + 2 * G_BK * LDB];
+  float* As = smem;                       // [2][BK][LDA]
+  float* Bs = smem + 2 * G_BK * LDA;      // [2][BK][LDB]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int M = (int)d.M, N = (int)d.N, K = (int)d.K;
+  const int Neff = N + (d.ones_out ? 1 : 0);
+  const int m0 = blockIdx.x * G_BM;
+  const int n0 = blockIdx.y * BN;
+
+  // split-K range
+  int kbeg = 0, kend = K;
+  if (d.split_k > 1) {
+    const int ktiles = (K + G_BK - 1) / G_BK;
+    const int per = (ktiles + d.split_k - 1) / d.split_k;
+    kbeg = (int)blockIdx.z * per * G_BK;
+    kend = min(K, kbeg + per * G_BK);
+    if (kbeg >= kend) return;
+  }
+  const int nkt = (kend - kbeg + G_BK - 1) / G_BK;
+
+  const bool a_kfast = (d.a_rs != 1);     // K-contiguous (or generic) rows vs M-contiguous storage
+  const bool b_kfast = (d.b_cs != 1);     // N-contiguous storage unless the column stride is not 1
+  const float* __restrict__ Ap = d.A + d.a_off;
+  const float* __restrict__ Bp = d.B + d.b_off;
+
+  // per-thread element coordinates inside a tile (fixed across k-tiles)
+  int a_mm[A_PER], a_kk[A_PER];
+  unsigned a_rowmask = 0;                 // bit i: row of element i is a masked (padding) row
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    const int e = t + i * G_THREADS;
+    if (a_kfast) { a_kk[i] = e % G_BK; a_mm[i] = e / G_BK; }
+    else         { a_mm[i] = e % G_BM; a_kk[i] = e / G_BM; }
+    if (d.mask_operand == 1) {
+      const int m = m0 + a_mm[i];
+      if (m % d.mask_period == d.mask_phase) a_rowmask |= (1u << i);
+    }
+  }
+  int b_nn[B_PER], b_kk[B_PER];
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    const int e = t + i * G_THREADS;
+    if (b_kfast) { b_kk[i] = e % G_BK; b_nn[i] = e / G_BK; }
+    else         { b_nn[i] = e % BN;   b_kk[i] = e / BN; }
+  }
+
+  float ra[A_PER], rb[B_PER];
+
+  auto load_tile = [&](int kt) {
+    const int k0 = kbeg + kt * G_BK;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int m = m0 + a_mm[i];
+      const int k = k0 + a_kk[i];
+      bool ok = (m < M) && (k < kend);
+      if ((a_rowmask >> i) & 1u) ok = ok && !(k >= d.mask_lo && k < d.mask_hi);
+      ra[i] = ok ? Ap[(int64_t)m * d.a_rs + (int64_t)k * d.a_cs] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int e = t + i * G_THREADS;
+      float v = 0.f;
+      if (e < G_BK * BN) {
+        const int n = n0 + b_nn[i];
+        const int k = k0 + b_kk[i];
+        if (k < kend) {
+          if (n < N) {
+            bool ok = true;
+            if (d.mask_operand == 2) ok = !((k % d.mask_period == d.mask_phase) && n >= d.mask_lo && n < d.mask_hi);
+            if (ok) v = Bp[(int64_t)k * d.b_rs + (int64_t)n * d.b_cs];
+          } else if (n == N && d.ones_out) {
+            v = 1.f;
+          }
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* as = As + buf * G_BK * LDA;
+    float* bs = Bs + buf * G_BK * LDB;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) as[a_kk[i] * LDA + a_mm[i]] = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int e = t + i * G_THREADS;
+      if (e < G_BK * BN) bs[b_kk[i] * LDB + b_nn[i]] = rb[i];
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int frag_row = wave * 32 + (lane & 31);
+  const int frag_k = lane >> 5;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    const float* as = As + buf * G_BK * LDA;
+    const float* bs = Bs + buf * G_BK * LDB;
+#pragma unroll
+    for (int kk = 0; kk < G_BK; kk += 2) {
+      const float a = as[(kk + frag_k) * LDA + frag_row];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float b = bs[(kk + frag_k) * LDB + j * 32 + (lane & 31)];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool atomic = d.split_k > 1;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + j * 32 + (lane & 31);
+    if (col >= Neff) continue;
+    const float bias = (d.bias && col < N) ? d.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row >= M) continue;
+      float v = acc[j][r];
+      if (col == N) {                       // virtual ones column -> bias gradient
+        if (atomic) atomicAdd(d.ones_out + row, v);
+        else d.ones_out[row] = d.accumulate ? d.ones_out[row] + v : v;
+        continue;
+      }
+      float* cp = d.C + (int64_t)row * d.ldc + col;
+      if (atomic) { atomicAdd(cp, v); continue; }
+      v += bias;
+      if (d.accumulate) v += *cp;
+      if (d.act == 1) v = fmaxf(v, 0.f);
+      else if (d.act == 2) v = tanhf(v);
+      if (d.aux_mode) {
+        const float ax = d.aux[(int64_t)row * d.ldaux + col];
+        if (d.aux_mode == 1) v = ax > 0.f ? v : 0.f;
+        else if (d.aux_mode == 2) v *= (1.f - ax * ax);
+        else v += ax;
+      }
+      *cp = v;
+    }
+  }
+}
+
+}  // namespace a2f
+
+extern "C" int a2f_gemm_f32(const a2f_gemm_desc* dp, a2f_stream_t stream) {
+  using namespace a2f;
+  A2F_CHECK_ARG(dp != nullptr, "gemm: null descriptor");
+  const a2f_gemm_desc d = *dp;
+  A2F_CHECK_ARG(d.A && d.B && d.C, "gemm: null operand pointer");
+  A2F_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0, "gemm: empty problem M=%lld N=%lld K=%lld", (long long)d.M, (long long)d.N, (long long)d.K);
+  A2F_CHECK_ARG(d.M < (1ll << 30) && d.N < (1ll << 30) && d.K < (1ll << 30), "gemm: dimension too large");
+  A2F_CHECK_ARG(d.ldc >= d.N, "gemm: ldc %lld < N %lld", (long long)d.ldc, (long long)d.N);
+  A2F_CHECK_ARG(d.act >= 0 && d.act <= 2 && d.aux_mode >= 0 && d.aux_mode <= 3, "gemm: bad act/aux_mode");
+  A2F_CHECK_ARG(d.aux_mode == 0 || d.aux != nullptr, "gemm: aux_mode without aux");
+  A2F_CHECK_ARG(d.mask_operand >= 0 && d.mask_operand <= 2, "gemm: bad mask_operand");
+  A2F_CHECK_ARG(d.mask_operand == 0 || d.mask_period > 0, "gemm: mask_period must be > 0");
+  const int split = d.split_k > 1 ? d.split_k : 1;
+  if (split > 1)
+    A2F_CHECK_ARG(d.act == 0 && d.aux_mode == 0 && d.bias == nullptr && !d.accumulate,
+                  "gemm: split_k only with a linear epilogue into a zeroed C");
+  A2F_CHECK_ARG(split <= 65535, "gemm: split_k too large");
+  const int64_t neff = d.N + (d.ones_out ? 1 : 0);
+  const int bn = neff <= 32 ? 32 : neff <= 64 ? 64 : neff <= 96 ? 96 : 128;
+  dim3 grid((unsigned)cdiv(d.M, G_BM), (unsigned)cdiv(neff, bn), (unsigned)split);
+  A2F_CHECK_ARG(grid.y <= 65535, "gemm: N too large for grid.y");
+  hipStream_t s = (hipStream_t)stream;
+  switch (bn) {
+    case 32: hipLaunchKernelGGL(gemm_f32_kernel<32>, grid, dim3(G_THREADS), 0, s, d); break;
+    case 64: hipLaunchKernelGGL(gemm_f32_kernel<64>, grid, dim3(G_THREADS), 0, s, d); break;
+    case 96: hipLaunchKernelGGL(gemm_f32_kernel<96>, grid, dim3(G_THREADS), 0, s, d); break;
+    default: hipLaunchKernelGGL(gemm_f32_kernel<128>, grid, dim3(G_THREADS), 0, s, d); break;
+  }
+  A2F_CHECK_LAUNCH("gemm_f32");
+  return A2F_OK;
+}

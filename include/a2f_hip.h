@@ -1,0 +1,186 @@
+/*
+ * a2f_hip.h - C ABI of liba2f_hip.so: the MI355X (gfx950) hot path of the audio -> face-mesh
+ * regression models (VOCA / Audio2Mesh / FaceFormer decoder + 15069-wide vertex head + per-vertex
+ * L2/velocity loss + Adam), forward and backward.
+ *
+ * The reference (xtliu97/audio2face-pytorch) is pure Python on torch and has no FFI of its own; each
+ * entry point below names the reference code (file:line under /root/reference) whose arithmetic it
+ * replaces.  The drop-in boundary a reference maintainer sees is the Python nn.Module API
+ * (src/model/lightning_model.py:50-73,96,111-117,155); this C ABI is what those modules call through
+ * ctypes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (torch tensor .data_ptr()), fp32 unless noted,
+ *    dense row-major unless a stride is given; nothing is retained after the call returns;
+ *  - work is enqueued asynchronously on `stream` (a hipStream_t, passed as void*); no entry point
+ *    synchronises, allocates device memory, or keeps mutable global state (hipGraph-capturable);
+ *  - return value: 0 on success, negative A2F_E* on failure; a2f_last_error() gives a thread-local message;
+ *  - `ws` is caller-provided scratch of at least the matching *_ws_bytes(); contents are undefined on entry.
+ */
+#ifndef A2F_HIP_H
+#define A2F_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A2F_VERSION 100          /* 0.1.0 */
+#define A2F_OK 0
+#define A2F_EINVAL (-1)          /* bad shape / null pointer / unsupported combination */
+#define A2F_ELAUNCH (-2)         /* hipLaunch / runtime error */
+#define A2F_EWORKSPACE (-3)      /* workspace too small */
+
+typedef void* a2f_stream_t;      /* hipStream_t */
+
+int a2f_version(void);
+const char* a2f_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Generic fused fp32 GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32, exact fp32 fma chain):
+ *     C[m,n] = epi( sum_k A(m,k) * B(k,n) )          m<M, n<N, k<K
+ * A(m,k) = A[a_off + m*a_rs + k*a_cs],  B(k,n) = B[b_off + k*b_rs + n*b_cs]  (element strides; either
+ * may alias overlapping windows of an activation buffer, which is how the (3,1)/(1,3) strided
+ * convolutions of voca.py:19-28 / audio2face.py:13-47 run as implicit GEMMs without im2col).
+ * Window mask (zero padding of those convolutions): with mask_operand = 1 (A) elements with
+ * (m % mask_period == mask_phase) and mask_lo <= k < mask_hi read as 0; mask_operand = 2 (B) does the
+ * same on (k % mask_period == mask_phase), mask_lo <= n < mask_hi.
+ * epi: v = acc; if bias: v += bias[n]; if accumulate: v += C_old; act (0 none, 1 relu, 2 tanh);
+ *      aux_mode 1: v *= (aux[m*ldaux+n] > 0)      (ReLU backward)
+ *      aux_mode 2: v *= 1 - aux^2                 (tanh backward)
+ *      aux_mode 3: v += aux                       (template add, voca.py:49)
+ * ones_out != NULL appends a virtual all-ones column n == N to B and routes it to ones_out[m]
+ * (bias gradients as part of the weight-gradient GEMM).
+ * split_k > 1 partitions K over grid.z and accumulates with fp32 atomics into a C (and ones_out)
+ * that the caller has zeroed; only valid with act = aux_mode = 0, bias = NULL.
+ * Replaces torch.nn.Linear / Conv2d forward+backward as dispatched by the reference models.
+ */
+typedef struct a2f_gemm_desc {
+  const float* A; int64_t a_off, a_rs, a_cs;
+  const float* B; int64_t b_off, b_rs, b_cs;
+  float* C; int64_t ldc;
+  int64_t M, N, K;
+  const float* bias;
+  const float* aux; int64_t ldaux;
+  float* ones_out;
+  int32_t act, aux_mode, accumulate, split_k;
+  int32_t mask_operand, mask_period, mask_phase, mask_lo, mask_hi;
+  int32_t reserved;
+} a2f_gemm_desc;
+
+int a2f_gemm_f32(const a2f_gemm_desc* d, a2f_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * VocaLoss (src/loss/loss.py:24-55); FaceFormerLoss (loss.py:4-17) is the same call on the
+ * even-length prefix of the (T, n) frame matrix.
+ *   rec = mean_{b,v} sum_xyz (p-g)^2 ; vel = same on (row 2k+1 - row 2k) differences ; loss = k_rec*rec + k_vel*vel
+ * pred, gt: (B, n) with n = 3*n_verts, B even. out3 = {loss, rec, vel}.
+ * fwd is deterministic (fixed-order two-stage reduction through ws).
+ * bwd writes grad_pred (B, n) = g_loss*dloss/dpred + g_rec*drec/dpred + g_vel*dvel/dpred, upstream
+ * scalars read from the DEVICE array g3 = {g_loss, g_rec, g_vel}.
+ */
+size_t a2f_vocaloss_ws_bytes(int64_t B, int64_t n);
+int a2f_vocaloss_fwd(const float* pred, const float* gt, int64_t B, int64_t n, float k_rec, float k_vel,
+                     float* out3, void* ws, size_t ws_bytes, a2f_stream_t stream);
+int a2f_vocaloss_bwd(const float* pred, const float* gt, const float* g3, int64_t B, int64_t n,
+                     float k_rec, float k_vel, float* grad_pred, a2f_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused vertex head + loss + head backward in ONE pass over the (B, n) frame matrix
+ * (decoder.4 / output_net.4 / vertice_map_r: voca.py:35,48-49, audio2face.py:54,65-66,
+ *  faceformer.py:129,181,187; loss.py:24-55):
+ *   pred[b,:] = H[b,:] Wt + bias + template[b or 0,:]              (written once)
+ *   partial sums of rec / vel                                      -> out3 = {loss, rec, vel}
+ *   G = dloss/dpred (never stored);  dH = G W ; dW = G^T H ; dbias = colsum G
+ * H (B,K) K<=64; W (n,K) torch Linear layout; template (B,n) or (1,n) when template_rows == 1;
+ * gt (B,n).  B must be even.  dH (B,K), dW (n,K), dbias (n) are overwritten.
+ * `Bloss` frames (even, <= B) enter the loss (FaceFormerLoss drops an odd tail frame, loss.py:13-15);
+ * all B rows of pred are written.
+ */
+size_t a2f_head_fused_ws_bytes(int64_t B, int64_t n, int64_t K);
+int a2f_head_fused(const float* H, const float* W, const float* bias, const float* templ, int64_t template_rows,
+                   const float* gt, int64_t B, int64_t Bloss, int64_t n, int64_t K, float k_rec, float k_vel,
+                   float* pred, float* out3, float* dH, float* dW, float* dbias,
+                   void* ws, size_t ws_bytes, a2f_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * VOCA input packing (voca.py:40-45): x (B,29,16), one_hot (B,n_onehot>=8) ->
+ *   a0 (B,16,37) channels-last window [h][c]: c<29: x[b,c,h]; c>=29: one_hot[b, h%8]  (repeat(1,16).view quirk)
+ *   cat72[:,64:72] = one_hot[:, :8]                                (voca.py:47; cat72 is (B,72))
+ * Audio2Mesh input packing (audio2face.py:59-62): x (B,52,32), one_hot (B,12) ->
+ *   a0 (B,64,32) rows 0..51 = x, row 52+r col c = one_hot[b,(32r+c)%12]; cat268[:,256:268] = one_hot
+ */
+int a2f_voca_pack(const float* x, const float* one_hot, int64_t B, int64_t n_onehot, float* a0, float* cat72,
+                  a2f_stream_t stream);
+int a2f_a2m_pack(const float* x, const float* one_hot, int64_t B, int64_t n_onehot, float* a0, float* cat,
+                 int64_t cat_ld, int64_t cat_off, a2f_stream_t stream);
+
+/* Conv weight re-layout  w (Co,Ci,KH) <-> wg (Co, KH*Ci) [k = kh*Ci+ci]; dir 0: w->wg, 1: wg->w(+=0 overwrite) */
+int a2f_conv_weight_pack(const float* src, float* dst, int64_t Co, int64_t Ci, int64_t KH, int32_t dir, a2f_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm2d over channels-last rows (audio2face.py:15-46), training-mode batch statistics:
+ *   x (R, C) rows = (b,h,w) positions.  stats: mean[c], invstd[c] (biased var, eps); running buffers
+ *   updated with momentum and the unbiased variance exactly like nn.BatchNorm2d.
+ *   y = (x-mean)*invstd*gamma + beta, optional ReLU.
+ * eval mode: pass training = 0, statistics come from running_mean / running_var.
+ */
+size_t a2f_bn_ws_bytes(int64_t R, int64_t C);
+int a2f_bn_fwd(const float* x, int64_t R, int64_t C, const float* gamma, const float* beta,
+               float* running_mean, float* running_var, float momentum, float eps, int32_t training, int32_t relu,
+               float* y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, a2f_stream_t stream);
+/* dy is the gradient w.r.t. the (post-ReLU if relu) output y; y is the saved forward output. */
+int a2f_bn_bwd(const float* x, const float* y, const float* dy, int64_t R, int64_t C, const float* gamma,
+               const float* save_mean, const float* save_invstd, int32_t training, int32_t relu,
+               float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, a2f_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * FaceFormer decoder recurrence (faceformer.py:154-185 evaluated incrementally):
+ * one workgroup per sequence, S sequences of T frames each.  Inputs per sequence s:
+ *   cross (S,T,64)  = out_proj(v_proj(memory)) of the diagonal cross-attention (identity 3)
+ *   style (S,64)    = obj_vector(one_hot)
+ * params: packed decoder parameter block (layout in a2f_ff_param_offsets), A (64x64) and c (64): collapsed feedback.
+ * Outputs: y (S,T,64) decoder rows; saved activations for backward in `save` (a2f_ff_save_bytes).
+ */
+#define A2F_FF_D 64
+#define A2F_FF_HEADS 4
+#define A2F_FF_FF 128
+/* float offsets inside the packed parameter block */
+enum {
+  A2F_FF_WQKV = 0,                       /* (192,64) self_attn.in_proj_weight */
+  A2F_FF_BQKV = A2F_FF_WQKV + 192 * 64,  /* (192) */
+  A2F_FF_WO = A2F_FF_BQKV + 192,         /* (64,64) self_attn.out_proj.weight */
+  A2F_FF_BO = A2F_FF_WO + 64 * 64,       /* (64) */
+  A2F_FF_W1 = A2F_FF_BO + 64,            /* (128,64) linear1 */
+  A2F_FF_B1 = A2F_FF_W1 + 128 * 64,      /* (128) */
+  A2F_FF_W2 = A2F_FF_B1 + 128,           /* (64,128) linear2 */
+  A2F_FF_B2 = A2F_FF_W2 + 64 * 128,      /* (64) */
+  A2F_FF_LN = A2F_FF_B2 + 64,            /* norm1.w, norm1.b, norm2.w, norm2.b, norm3.w, norm3.b (6 x 64) */
+  A2F_FF_A = A2F_FF_LN + 6 * 64,         /* (64,64) collapsed feedback A = Wm Wr */
+  A2F_FF_C = A2F_FF_A + 64 * 64,         /* (64)    c = Wm br + bm */
+  A2F_FF_PARAM_FLOATS = A2F_FF_C + 64
+};
+size_t a2f_ff_save_bytes(int64_t S, int64_t T);
+int a2f_ff_decoder_fwd(const float* params, const float* cross, const float* style, int64_t S, int64_t T,
+                       int32_t period, float* y, void* save, size_t save_bytes, a2f_stream_t stream);
+/* dy (S,T,64) -> dparams (A2F_FF_PARAM_FLOATS, accumulated with atomics into a zeroed block),
+ * dcross (S,T,64), dstyle (S,64). */
+int a2f_ff_decoder_bwd(const float* params, const float* cross, const float* style, const float* dy,
+                       int64_t S, int64_t T, int32_t period, const void* save, size_t save_bytes,
+                       float* dparams, float* dcross, float* dstyle, a2f_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused Adam step on flat fp32 buffers (torch.optim.Adam semantics as configured at
+ * lightning_model.py:209-213: L2-style weight decay added to the gradient, bias correction, eps outside sqrt):
+ *   g = grad*grad_scale + wd*p ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+ *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ */
+int a2f_adam_step(float* p, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float grad_scale, int32_t step, a2f_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* A2F_HIP_H */

@@ -1,0 +1,90 @@
+"""ctypes binding of liba2f_hip.so (C ABI declared in include/a2f_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, this raises.  Every compute entry of
+the product goes through here; the CPU oracle under ``oracle/`` is never imported by the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from ._build import LIB_PATH
+
+c_f32p = C.c_void_p          # device pointers travel as integers (tensor.data_ptr())
+i64 = C.c_int64
+i32 = C.c_int32
+f32 = C.c_float
+sz = C.c_size_t
+
+
+class GemmDesc(C.Structure):
+    """Mirror of ``a2f_gemm_desc`` (include/a2f_hip.h)."""
+    _fields_ = [
+        ("A", c_f32p), ("a_off", i64), ("a_rs", i64), ("a_cs", i64),
+        ("B", c_f32p), ("b_off", i64), ("b_rs", i64), ("b_cs", i64),
+        ("C", c_f32p), ("ldc", i64),
+        ("M", i64), ("N", i64), ("K", i64),
+        ("bias", c_f32p),
+        ("aux", c_f32p), ("ldaux", i64),
+        ("ones_out", c_f32p),
+        ("act", i32), ("aux_mode", i32), ("accumulate", i32), ("split_k", i32),
+        ("mask_operand", i32), ("mask_period", i32), ("mask_phase", i32), ("mask_lo", i32), ("mask_hi", i32),
+        ("reserved", i32),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/a2f_hip.h declares
+SIGNATURES = {
+    "a2f_version": (C.c_int, []),
+    "a2f_last_error": (C.c_char_p, []),
+    "a2f_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "a2f_vocaloss_ws_bytes": (sz, [i64, i64]),
+    "a2f_vocaloss_fwd": (C.c_int, [c_f32p, c_f32p, i64, i64, f32, f32, c_f32p, C.c_void_p, sz, C.c_void_p]),
+    "a2f_vocaloss_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, i64, i64, f32, f32, c_f32p, C.c_void_p]),
+    "a2f_head_fused_ws_bytes": (sz, [i64, i64, i64]),
+    "a2f_head_fused": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, c_f32p, i64, i64, i64, i64, f32, f32,
+                                 c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
+    "a2f_voca_pack": (C.c_int, [c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, C.c_void_p]),
+    "a2f_a2m_pack": (C.c_int, [c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, i64, i64, C.c_void_p]),
+    "a2f_conv_weight_pack": (C.c_int, [c_f32p, c_f32p, i64, i64, i64, i32, C.c_void_p]),
+    "a2f_bn_ws_bytes": (sz, [i64, i64]),
+    "a2f_bn_fwd": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, c_f32p, f32, f32, i32, i32,
+                             c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
+    "a2f_bn_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, i32, i32,
+                             c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
+    "a2f_ff_save_bytes": (sz, [i64, i64]),
+    "a2f_ff_decoder_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, i64, i64, i32, c_f32p, C.c_void_p, sz, C.c_void_p]),
+    "a2f_ff_decoder_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, i32, C.c_void_p, sz,
+                                     c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "a2f_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, f32, f32, f32, f32, f32, f32, i32, C.c_void_p]),
+}
+
+_LIB = None
+
+
+class A2FError(RuntimeError):
+    pass
+
+
+def load(path: str | None = None):
+    """Load (once) and return the ctypes handle; raises A2FError if the library is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise A2FError(f"HIP extension not built: {path} is missing. Run `python __graft_entry__.py` (build()) "
+                       f"or `python audio2face-pytorch_amd/_build.py`. There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().a2f_last_error()
+        raise A2FError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

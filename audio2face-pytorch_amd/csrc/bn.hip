@@ -1,0 +1,220 @@
+// BatchNorm2d over channels-last rows x (R, C)  (/root/reference/src/model/audio2face.py:15-46, nn.BatchNorm2d
+// semantics: training-mode batch statistics with biased variance for normalisation, unbiased for the running
+// buffer, momentum 0.1, eps 1e-5; optional fused ReLU).
+//
+// HBM-bound elementwise + column reductions.  Reductions are deterministic two-stage: every workgroup reduces a
+// slab of rows into double partials [block][2][C] in the workspace, one finishing workgroup folds them in fixed order.
+// Channel index = flat index mod C, so consecutive lanes read consecutive addresses (fully coalesced) for any C.
+#include "a2f_common.h"
+
+namespace a2f {
+
+constexpr int BN_THREADS = 256;
+constexpr int BN_MAX_BLOCKS = 1024;
+constexpr int BN_MAX_C = 1024;
+
+__host__ __device__ inline int bn_blocks(int64_t R, int C) {
+  // each block owns a contiguous slab of rows; lanes map to (row-in-pass, channel)
+  const int rows_per_pass = BN_THREADS / C > 0 ? BN_THREADS / C : 1;
+  int64_t b = (R + (int64_t)rows_per_pass * 64 - 1) / ((int64_t)rows_per_pass * 64);
+  if (b > BN_MAX_BLOCKS) b = BN_MAX_BLOCKS;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// part[blk][0][c] = sum_r u(r,c) ; part[blk][1][c] = sum_r u(r,c)*w(r,c)
+//   MODE 0 (fwd stats): u = x, w = x
+//   MODE 1 (bwd):       u = dy' , w = xhat   (dy' = relu ? dy*(y>0) : dy)
+template <int MODE>
+__global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                 const float* __restrict__ dy, int64_t R, int C,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 int relu, double* __restrict__ part) {
+  const int t = threadIdx.x;
+  double s0 = 0.0, s1 = 0.0;
+  const int64_t rows_per_block = (R + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  // C <= 256: lane -> (row offset t / C, channel t % C); C > 256: channels strided over lanes, one row per pass
+  if (C <= BN_THREADS) {
+    const int rpp = BN_THREADS / C;
+    const int c = t % C, ro = t / C;
+    if (ro < rpp) {
+      float mu = 0.f, is = 0.f;
+      if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+      for (int64_t r = r0 + ro; r < r1; r += rpp) {
+        const int64_t i = r * C + c;
+        if (MODE == 0) {
+          const float v = x[i];
+          s0 += v; s1 += (double)v * v;
+        } else {
+          float g = dy[i];
+          if (relu && !(y[i] > 0.f)) g = 0.f;
+          s0 += g; s1 += (double)g * ((x[i] - mu) * is);
+        }
+      }
+    }
+    // fold the rpp row-lanes of each channel through LDS
+    __shared__ double sh[2][BN_THREADS];
+    sh[0][t] = s0; sh[1][t] = s1;
+    __syncthreads();
+    if (t < C) {
+      double a = 0.0, b = 0.0;
+      for (int k = 0; k < rpp; ++k) { a += sh[0][t + k * C]; b += sh[1][t + k * C]; }
+      part[((int64_t)blockIdx.x * 2 + 0) * C + t] = a;
+      part[((int64_t)blockIdx.x * 2 + 1) * C + t] = b;
+    }
+  } else {
+    for (int c = t; c < C; c += BN_THREADS) {
+      s0 = 0.0; s1 = 0.0;
+      float mu = 0.f, is = 0.f;
+      if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+      for (int64_t r = r0; r < r1; ++r) {
+        const int64_t i = r * C + c;
+        if (MODE == 0) { const float v = x[i]; s0 += v; s1 += (double)v * v; }
+        else { float g = dy[i]; if (relu && !(y[i] > 0.f)) g = 0.f; s0 += g; s1 += (double)g * ((x[i] - mu) * is); }
+      }
+      part[((int64_t)blockIdx.x * 2 + 0) * C + c] = s0;
+      part[((int64_t)blockIdx.x * 2 + 1) * C + c] = s1;
+    }
+  }
+}
+
+__global__ void bn_finish_stats_kernel(const double* __restrict__ part, int nblk, int64_t R, int C, float momentum, float eps,
+                                       float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ save_mean,
+                                       float* __restrict__ save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; ++b) { s += part[((int64_t)b * 2 + 0) * C + c]; q += part[((int64_t)b * 2 + 1) * C + c]; }
+  const double mean = s / (double)R;
+  double var = q / (double)R - mean * mean;
+  if (var < 0.0) var = 0.0;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  const double unb = R > 1 ? var * ((double)R / (double)(R - 1)) : var;
+  rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mean);
+  rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+}
+
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, int C, float eps,
+                                     float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  save_mean[c] = rmean[c];
+  save_invstd[c] = (float)(1.0 / sqrt((double)rvar[c] + (double)eps));
+}
+
+__global__ void bn_finish_bwd_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; ++b) { s += part[((int64_t)b * 2 + 0) * C + c]; q += part[((int64_t)b * 2 + 1) * C + c]; }
+  dbeta[c] = (float)s;
+  dgamma[c] = (float)q;
+}
+
+// y = (x - mean) * invstd * gamma + beta  [relu]
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float* __restrict__ x, int64_t total, int C,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               int relu, float* __restrict__ y) {
+  __shared__ float sc[BN_MAX_C], sh[BN_MAX_C];
+  for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+    const float s = invstd[c] * gamma[c];
+    sc[c] = s;
+    sh[c] = beta[c] - mean[c] * s;
+  }
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * BN_THREADS;
+  for (int64_t i = blockIdx.x * (int64_t)BN_THREADS + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    float v = x[i] * sc[c] + sh[c];
+    if (relu) v = fmaxf(v, 0.f);
+    y[i] = v;
+  }
+}
+
+// training: dx = gamma*invstd/R * (R*dy' - dbeta - xhat*dgamma) ; eval: dx = dy'*gamma*invstd
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                   const float* __restrict__ dy, int64_t total, int C, float invR,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, const float* __restrict__ dgamma,
+                                                                   const float* __restrict__ dbeta, int training, int relu,
+                                                                   float* __restrict__ dx) {
+  __shared__ float s_gi[BN_MAX_C], s_mu[BN_MAX_C], s_is[BN_MAX_C], s_db[BN_MAX_C], s_dg[BN_MAX_C];
+  for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+    s_gi[c] = gamma[c] * invstd[c];
+    s_mu[c] = mean[c];
+    s_is[c] = invstd[c];
+    s_db[c] = training ? dbeta[c] * invR : 0.f;
+    s_dg[c] = training ? dgamma[c] * invR : 0.f;
+  }
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * BN_THREADS;
+  for (int64_t i = blockIdx.x * (int64_t)BN_THREADS + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    float g = dy[i];
+    if (relu && !(y[i] > 0.f)) g = 0.f;
+    const float xhat = (x[i] - s_mu[c]) * s_is[c];
+    dx[i] = s_gi[c] * (g - s_db[c] - xhat * s_dg[c]);
+  }
+}
+
+}  // namespace a2f
+
+extern "C" size_t a2f_bn_ws_bytes(int64_t R, int64_t C) {
+  if (R <= 0 || C <= 0) return 16;
+  return (size_t)a2f::bn_blocks(R, (int)C) * 2 * (size_t)C * sizeof(double);
+}
+
+extern "C" int a2f_bn_fwd(const float* x, int64_t R, int64_t C, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, float momentum, float eps, int32_t training, int32_t relu, float* y,
+                          float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, a2f_stream_t stream) {
+  using namespace a2f;
+  A2F_CHECK_ARG(x && gamma && beta && running_mean && running_var && y && save_mean && save_invstd, "bn_fwd: null pointer");
+  A2F_CHECK_ARG(R > 0 && C > 0 && C <= BN_MAX_C, "bn_fwd: R=%lld C=%lld (C <= %d)", (long long)R, (long long)C, BN_MAX_C);
+  hipStream_t s = (hipStream_t)stream;
+  const int cb = (int)cdiv(C, 256);
+  if (training) {
+    A2F_CHECK_ARG(ws != nullptr, "bn_fwd: null workspace");
+    if (ws_bytes < a2f_bn_ws_bytes(R, C)) return set_err(A2F_EWORKSPACE, "bn_fwd: workspace %zu < %zu", ws_bytes, a2f_bn_ws_bytes(R, C));
+    const int nblk = bn_blocks(R, (int)C);
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblk), dim3(BN_THREADS), 0, s, x, (const float*)nullptr, (const float*)nullptr, R,
+                       (int)C, (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
+    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(cb), dim3(256), 0, s, (const double*)ws, nblk, R, (int)C, momentum, eps,
+                       running_mean, running_var, save_mean, save_invstd);
+  } else {
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cb), dim3(256), 0, s, running_mean, running_var, (int)C, eps, save_mean, save_invstd);
+  }
+  const int64_t total = R * C;
+  int64_t blocks = cdiv(total, BN_THREADS * 4);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(BN_THREADS), 0, s, x, total, (int)C, gamma, beta, save_mean,
+                     save_invstd, (int)relu, y);
+  A2F_CHECK_LAUNCH("bn_fwd");
+  return A2F_OK;
+}
+
+extern "C" int a2f_bn_bwd(const float* x, const float* y, const float* dy, int64_t R, int64_t C, const float* gamma,
+                          const float* save_mean, const float* save_invstd, int32_t training, int32_t relu, float* dx,
+                          float* dgamma, float* dbeta, void* ws, size_t ws_bytes, a2f_stream_t stream) {
+  using namespace a2f;
+  A2F_CHECK_ARG(x && y && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws, "bn_bwd: null pointer");
+  A2F_CHECK_ARG(R > 0 && C > 0 && C <= BN_MAX_C, "bn_bwd: R=%lld C=%lld (C <= %d)", (long long)R, (long long)C, BN_MAX_C);
+  if (ws_bytes < a2f_bn_ws_bytes(R, C)) return set_err(A2F_EWORKSPACE, "bn_bwd: workspace %zu < %zu", ws_bytes, a2f_bn_ws_bytes(R, C));
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = bn_blocks(R, (int)C);
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(BN_THREADS), 0, s, x, y, dy, R, (int)C, save_mean, save_invstd, (int)relu,
+                     (double*)ws);
+  hipLaunchKernelGGL(bn_finish_bwd_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, s, (const double*)ws, nblk, (int)C, dgamma, dbeta);
+  const int64_t total = R * C;
+  int64_t blocks = cdiv(total, BN_THREADS * 4);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(BN_THREADS), 0, s, x, y, dy, total, (int)C, 1.0f / (float)R, gamma,
+                     save_mean, save_invstd, dgamma, dbeta, (int)training, (int)relu, dx);
+  A2F_CHECK_LAUNCH("bn_bwd");
+  return A2F_OK;
+}

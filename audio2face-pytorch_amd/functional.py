@@ -1,0 +1,305 @@
+"""Autograd functions of the drop-in modules: each forward/backward is a fixed sequence of HIP launches.
+
+Saved activations live in channels-last layout (frames, positions, channels) so every strided
+convolution is an implicit GEMM over contiguous windows (see ops.conv_fwd).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .ops import ACT_NONE, ACT_TANH, AUX_ADD, AUX_RELU_BWD, AUX_TANH_BWD
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+# =================================================================================================
+# VocaLoss / FaceFormerLoss   (reference: src/loss/loss.py:4-55)
+# =================================================================================================
+class VocaLossFn(torch.autograd.Function):
+    """(pred (B,n), gt (B,n)) -> out3 = [loss, rec_loss, vel_loss]; the backward gradient of out3 is consumed on device."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, k_rec, k_vel):
+        be = ops.backend()
+        B, n = pred.shape
+        p, g = _f32c(pred), _f32c(gt)
+        out3 = torch.empty(3, device=p.device, dtype=torch.float32)
+        be.vocaloss_fwd(p, g, B, n, float(k_rec), float(k_vel), out3)
+        ctx.save_for_backward(p, g)
+        ctx.k = (float(k_rec), float(k_vel))
+        return out3
+
+    @staticmethod
+    def backward(ctx, g3):
+        be = ops.backend()
+        p, g = ctx.saved_tensors
+        B, n = p.shape
+        grad = torch.empty_like(p)
+        be.vocaloss_bwd(p, g, _f32c(g3), B, n, ctx.k[0], ctx.k[1], grad)
+        return grad, None, None, None
+
+
+# =================================================================================================
+# Vertex head: pred = H W^T + b + template   (decoder.4 / output_net.4 / vertice_map_r)
+# =================================================================================================
+class HeadFn(torch.autograd.Function):
+    """H (B,K), W (n,K), b (n), template (B,n) or (1,n) broadcast over frames -> pred (B,n)."""
+
+    @staticmethod
+    def forward(ctx, H, W, b, template):
+        be = ops.backend()
+        B, K = H.shape
+        n = W.shape[0]
+        Hc, Wc, bc, tc = _f32c(H), _f32c(W), _f32c(b), _f32c(template).reshape(-1, n)
+        pred = torch.empty(B, n, device=Hc.device, dtype=torch.float32)
+        ops.linear_fwd(be, Hc, Wc, bc, pred, B, n, K, aux=tc, ldaux=(n if tc.shape[0] == B and B > 1 else 0), aux_mode=AUX_ADD,
+                       tag="head_fwd")
+        ctx.save_for_backward(Hc, Wc)
+        ctx.trows = tc.shape[0]
+        return pred
+
+    @staticmethod
+    def backward(ctx, G):
+        be = ops.backend()
+        Hc, Wc = ctx.saved_tensors
+        B, K = Hc.shape
+        n = Wc.shape[0]
+        G = _f32c(G)
+        dH = torch.zeros(B, K, device=G.device, dtype=torch.float32)
+        be.gemm(G, Wc, dH, B, K, n, (0, n, 1), (0, K, 1), K, split_k=2, tag="head_dH")
+        dW = torch.zeros(n, K, device=G.device, dtype=torch.float32)
+        db = torch.zeros(n, device=G.device, dtype=torch.float32)
+        ops.linear_bwd_weight(be, G, Hc, dW, db, B, n, K, tag="head_dW")
+        dT = None
+        if ctx.needs_input_grad[3]:
+            dT = G if ctx.trows == B else G.sum(dim=0, keepdim=True)
+        return dH, dW, db, dT
+
+
+# =================================================================================================
+# VOCA trunk   (reference: src/model/voca.py:38-48 up to the 50-wide bottleneck)
+# =================================================================================================
+VOCA_CONVS = ((37, 32, 8), (32, 32, 4), (32, 64, 2), (64, 64, 1))      # (Cin, Cout, positions out); input has 16 positions
+
+
+class VocaTrunkFn(torch.autograd.Function):
+    """x (B,29,16), one_hot (B,>=8), 8 conv tensors, 6 decoder tensors -> h3 (B,50)."""
+
+    @staticmethod
+    def forward(ctx, x, one_hot, *params):
+        be = ops.backend()
+        cw = params[0:8]                  # time_conv.{0,2,4,6}.{weight,bias}
+        fw0, fb0, fw1, fb1, fw3, fb3 = (_f32c(p) for p in params[8:14])
+        B = x.shape[0]
+        dev = x.device
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        xc, oh = _f32c(x), _f32c(one_hot)
+        a0, cat = new(B, 16, 37), new(B, 72)
+        be.voca_pack(xc, oh, B, oh.shape[1], a0, cat)
+        acts, wgs = [a0], []
+        for li, (ci, co, pout) in enumerate(VOCA_CONVS):
+            w, b = _f32c(cw[2 * li]), _f32c(cw[2 * li + 1])
+            wg = new(co, 3 * ci)
+            be.conv_weight_pack(w, wg, co, ci, 3, 0)
+            last = pout == 1
+            out = cat if last else new(B, pout, co)
+            ops.conv_fwd(be, acts[-1], wg, b, out, B * pout, pout, ci, co, ldc=72 if last else co)
+            acts.append(out)
+            wgs.append(wg)
+        z1, z2, h3 = new(B, 72), new(B, 128), new(B, 50)
+        ops.linear_fwd(be, cat, fw0, fb0, z1, B, 72, 72)                      # decoder.0
+        ops.linear_fwd(be, z1, fw1, fb1, z2, B, 128, 72, act=ACT_TANH)        # decoder.1 + Tanh
+        ops.linear_fwd(be, z2, fw3, fb3, h3, B, 50, 128)                      # decoder.3
+        ctx.save_for_backward(a0, acts[1], acts[2], acts[3], cat, z1, z2, fw0, fw1, fw3, *wgs)
+        return h3
+
+    @staticmethod
+    def backward(ctx, dh3):
+        be = ops.backend()
+        a0, a1, a2, a3, cat, z1, z2, fw0, fw1, fw3, wg1, wg2, wg3, wg4 = ctx.saved_tensors
+        B = cat.shape[0]
+        dev = cat.device
+        zeros = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        dh3 = _f32c(dh3)
+        # decoder.3 (128 -> 50)
+        dW3, db3 = zeros(50, 128), zeros(50)
+        ops.linear_bwd_weight(be, dh3, z2, dW3, db3, B, 50, 128)
+        dz2 = new(B, 128)
+        ops.linear_bwd_input(be, dh3, fw3, dz2, B, 50, 128, aux=z2, ldaux=128, aux_mode=AUX_TANH_BWD)
+        # decoder.1 (72 -> 128)
+        dW1, db1 = zeros(128, 72), zeros(128)
+        ops.linear_bwd_weight(be, dz2, z1, dW1, db1, B, 128, 72)
+        dz1 = new(B, 72)
+        ops.linear_bwd_input(be, dz2, fw1, dz1, B, 128, 72)
+        # decoder.0 (72 -> 72); only the 64 conv features need an input gradient (ReLU of conv 4 applied here)
+        dW0, db0 = zeros(72, 72), zeros(72)
+        ops.linear_bwd_weight(be, dz1, cat, dW0, db0, B, 72, 72)
+        d_act = new(B, 64)
+        ops.linear_bwd_input(be, dz1, fw0, d_act, B, 72, 72, n_cols=64, aux=cat, ldaux=72, aux_mode=AUX_RELU_BWD)
+        # temporal conv stack, last to first
+        acts = (a0, a1, a2, a3)
+        wgs = (wg1, wg2, wg3, wg4)
+        conv_grads = [None] * 8
+        for li in (3, 2, 1, 0):
+            ci, co, pout = VOCA_CONVS[li]
+            R = B * pout
+            dwg, dbias = zeros(co, 3 * ci), zeros(co)
+            ops.conv_bwd_weight(be, acts[li], d_act, dwg, dbias, R, pout, ci, co)
+            dw = new(co, ci, 3, 1)
+            be.conv_weight_pack(dwg, dw, co, ci, 3, 1)
+            conv_grads[2 * li], conv_grads[2 * li + 1] = dw, dbias
+            if li > 0:
+                d_in = new(B, 2 * pout, ci)
+                ops.conv_k3s2_bwd_input(be, d_act, wgs[li], d_in, R, pout, ci, co, relu_of=acts[li])
+                d_act = d_in
+        return (None, None, *conv_grads, dW0, db0, dW1, db1, dW3, db3)
+
+
+# =================================================================================================
+# Audio2Mesh trunk   (reference: src/model/audio2face.py:57-65 up to the 50-wide bottleneck)
+# =================================================================================================
+A2M_CH = (1, 72, 108, 162, 243, 256)           # analysis channels; width 32 -> 16 -> 8 -> 4 -> 2 -> 1   (audio2face.py:13-29)
+A2M_BN_MOMENTUM, A2M_BN_EPS = 0.1, 1e-5
+
+
+class A2MTrunkFn(torch.autograd.Function):
+    """x (B,52,32), one_hot (B,n_onehot), training flag, BN buffers, parameters -> h3 (B,50).
+
+    Activations are channels-last: analysis stage (B*64 rows-of-W, W, C), articulation stage (B, H, 256).
+    args: x, one_hot, training, 20 buffers (10 x running_mean, running_var in layer order), then parameters:
+          10 conv (w,b) pairs in layer order, 10 BN (gamma,beta) pairs in layer order, 3 Linear (w,b) pairs.
+    """
+
+    @staticmethod
+    def forward(ctx, x, one_hot, training, *rest):
+        be = ops.backend()
+        bufs, params = rest[:20], rest[20:]
+        convs = [(_f32c(params[2 * i]), _f32c(params[2 * i + 1])) for i in range(10)]
+        bns = [(_f32c(params[20 + 2 * i]), _f32c(params[21 + 2 * i])) for i in range(10)]
+        fcs = [(_f32c(params[40 + 2 * i]), _f32c(params[41 + 2 * i])) for i in range(3)]
+        B, no = x.shape[0], one_hot.shape[1]
+        H0 = 52 + no
+        dev = x.device
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        ncat = 256 + no
+        a0, cat = new(B, H0, 32), new(B, ncat)
+        be.a2m_pack(_f32c(x), _f32c(one_hot), B, no, a0, cat, ncat, 256)
+        sv = {"wg": [], "conv_in": [], "bn_x": [], "bn_y": [], "stats": []}
+
+        def bn(i, xin, R, C, relu):
+            g, b = bns[i]
+            y, mu, istd = new(R, C), new(C), new(C)
+            be.bn_fwd(xin, R, C, g, b, bufs[2 * i], bufs[2 * i + 1], A2M_BN_MOMENTUM, A2M_BN_EPS, training, relu, y, mu, istd)
+            sv["bn_x"].append(xin); sv["bn_y"].append(y); sv["stats"].append((mu, istd))
+            return y
+
+        def conv(i, xin, R, P_out, Ci, Co, KH=3, stride=2, pad=1, relu=False, out=None, ldc=None):
+            w, b = convs[i]
+            wg = new(Co, KH * Ci)
+            be.conv_weight_pack(w, wg, Co, Ci, KH, 0)
+            o = out if out is not None else new(R, Co)
+            ops.conv_fwd(be, xin, wg, b, o, R, P_out, Ci, Co, KH=KH, stride=stride, pad=pad, relu=relu, ldc=ldc)
+            sv["wg"].append(wg); sv["conv_in"].append(xin)
+            return o
+
+        act, Wd = a0, 32
+        for l in range(5):                                   # analysis: conv over W -> BN -> ReLU
+            ci, co = A2M_CH[l], A2M_CH[l + 1]
+            Wd //= 2
+            R = B * H0 * Wd
+            act = bn(l, conv(l, act, R, Wd, ci, co), R, co, True)
+        Hd = H0
+        for l in range(5, 8):                                # articulation: conv over H -> BN -> ReLU
+            Hd //= 2
+            R = B * Hd
+            act = bn(l, conv(l, act, R, Hd, 256, 256), R, 256, True)
+        act = bn(8, act, B * Hd, 256, False)                 # BN -> conv -> ReLU   (order flip, audio2face.py:41-43)
+        Hd //= 2
+        z = conv(8, act, B * Hd, Hd, 256, 256, relu=True)
+        zb = bn(9, z, B * Hd, 256, False)                    # BN -> conv(4,1)/s4 -> ReLU  (audio2face.py:44-46)
+        conv(9, zb, B, 1, 256, 256, KH=Hd, stride=Hd, pad=0, relu=True, out=cat, ldc=ncat)
+        z1, z2, h3 = new(B, 72), new(B, 128), new(B, 50)
+        ops.linear_fwd(be, cat, fcs[0][0], fcs[0][1], z1, B, 72, ncat)
+        ops.linear_fwd(be, z1, fcs[1][0], fcs[1][1], z2, B, 128, 72, act=ACT_TANH)
+        ops.linear_fwd(be, z2, fcs[2][0], fcs[2][1], h3, B, 50, 128)
+        ctx.sv = sv
+        ctx.misc = (B, no, H0, Hd, training, cat, z, z1, z2, [f[0] for f in fcs], [b[0] for b in bns])
+        return h3
+
+    @staticmethod
+    def backward(ctx, dh3):
+        be = ops.backend()
+        sv = ctx.sv
+        B, no, H0, Hlast, training, cat, z, z1, z2, fw, gammas = ctx.misc
+        dev = cat.device
+        ncat = 256 + no
+        zeros = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        dh3 = _f32c(dh3)
+        g_conv, g_bn, g_fc = [None] * 20, [None] * 20, [None] * 6
+        # output_net.3, .1, .0
+        dW, db = zeros(50, 128), zeros(50)
+        ops.linear_bwd_weight(be, dh3, z2, dW, db, B, 50, 128); g_fc[4], g_fc[5] = dW, db
+        dz2 = new(B, 128)
+        ops.linear_bwd_input(be, dh3, fw[2], dz2, B, 50, 128, aux=z2, ldaux=128, aux_mode=AUX_TANH_BWD)
+        dW, db = zeros(128, 72), zeros(128)
+        ops.linear_bwd_weight(be, dz2, z1, dW, db, B, 128, 72); g_fc[2], g_fc[3] = dW, db
+        dz1 = new(B, 72)
+        ops.linear_bwd_input(be, dz2, fw[1], dz1, B, 128, 72)
+        dW, db = zeros(72, ncat), zeros(72)
+        ops.linear_bwd_weight(be, dz1, cat, dW, db, B, 72, ncat); g_fc[0], g_fc[1] = dW, db
+        d = new(B, 256)                                       # grad w.r.t. conv-9 pre-activation (ReLU mask of cat fused)
+        ops.linear_bwd_input(be, dz1, fw[0], d, B, 72, ncat, n_cols=256, aux=cat, ldaux=ncat, aux_mode=AUX_RELU_BWD)
+
+        def conv_wgrad(i, dout, R, P_out, Ci, Co, KH=3, stride=2, pad=1):
+            dwg, dbias = zeros(Co, KH * Ci), zeros(Co)
+            ops.conv_bwd_weight(be, sv["conv_in"][i], dout, dwg, dbias, R, P_out, Ci, Co, KH=KH, stride=stride, pad=pad)
+            shape = (Co, Ci, 1, KH) if i < 5 else (Co, Ci, KH, 1)
+            dw = new(*shape)
+            be.conv_weight_pack(dwg, dw, Co, Ci, KH, 1)
+            g_conv[2 * i], g_conv[2 * i + 1] = dw, dbias
+
+        def bn_bwd(i, dy, R, C, relu):
+            mu, istd = sv["stats"][i]
+            dx, dg, dbt = new(R, C), new(C), new(C)
+            be.bn_bwd(sv["bn_x"][i], sv["bn_y"][i], dy, R, C, gammas[i], mu, istd, training, relu, dx, dg, dbt)
+            g_bn[2 * i], g_bn[2 * i + 1] = dg, dbt
+            return dx
+
+        # conv 9: (4,1)/s4 no pad, input zb (B, Hlast*256)
+        KH9 = Hlast
+        conv_wgrad(9, d, B, 1, 256, 256, KH=KH9, stride=KH9, pad=0)
+        dzb = new(B, KH9 * 256)
+        ops.conv_nonoverlap_bwd_input(be, d, sv["wg"][9], dzb, B, 256, 256, KH9)
+        dz = bn_bwd(9, dzb, B * Hlast, 256, False)
+        # conv 8 output z carries a ReLU: mask dz by (z > 0) while forming its gradient -> done by a tiny masked copy GEMM-free:
+        dz = torch.where(z.view(B * Hlast, 256) > 0, dz, torch.zeros_like(dz))
+        conv_wgrad(8, dz, B * Hlast, Hlast, 256, 256)
+        Hd = 2 * Hlast
+        dact = new(B * Hd, 256)
+        ops.conv_k3s2_bwd_input(be, dz, sv["wg"][8], dact, B * Hlast, Hlast, 256, 256)
+        d = bn_bwd(8, dact, B * Hd, 256, False)               # BN 8 input = ReLU output of block 7 -> its BN bwd masks below
+        for l in (7, 6, 5):                                   # articulation conv -> BN -> ReLU blocks
+            R = B * Hd
+            draw = bn_bwd(l, d, R, 256, True)
+            conv_wgrad(l, draw, R, Hd, 256, 256)
+            din = new(B * 2 * Hd, 256)
+            ops.conv_k3s2_bwd_input(be, draw, sv["wg"][l], din, R, Hd, 256, 256)
+            d, Hd = din, 2 * Hd
+        Wd = 1
+        for l in (4, 3, 2, 1, 0):                             # analysis blocks
+            ci, co = A2M_CH[l], A2M_CH[l + 1]
+            R = B * H0 * Wd
+            draw = bn_bwd(l, d, R, co, True)
+            conv_wgrad(l, draw, R, Wd, ci, co)
+            if l > 0:
+                din = new(R * 2, ci)
+                ops.conv_k3s2_bwd_input(be, draw, sv["wg"][l], din, R, Wd, ci, co)
+                d = din
+            Wd *= 2
+        ctx.sv = None
+        return (None, None, None) + (None,) * 20 + tuple(g_conv) + tuple(g_bn) + tuple(g_fc)

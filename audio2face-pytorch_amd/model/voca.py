@@ -1,0 +1,50 @@
+"""Drop-in ``Voca`` (reference: /root/reference/src/model/voca.py:5-52) on the HIP hot path.
+
+Same constructor signature, same sub-module names / parameter shapes / construction order (so seeded
+initialisation and ``state_dict`` interchange with the reference), same ``forward(x, one_hot,
+template, **kwargs)`` / ``predict`` surface.  The arithmetic is not torch.nn: forward and backward are
+launches of liba2f_hip.so (implicit-GEMM temporal convolutions, fused Linear epilogues, fused head).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ..functional import HeadFn, VocaTrunkFn, VOCA_CONVS
+
+_FC = ((72, 72), (72, 128), None, (128, 50))        # decoder slots 0,1,(2 = Tanh),3; slot 4 is the vertex head
+
+
+class Voca(nn.Module):
+    def __init__(self, n_verts: int, n_onehot: int):
+        super().__init__()
+        self.n_verts = n_verts
+        self.n_onehot = n_onehot
+        tc = []
+        for ci, co, _ in VOCA_CONVS:                          # voca.py:19-28
+            tc += [nn.Conv2d(ci, co, kernel_size=(3, 1), stride=(2, 1), padding=(1, 0)), nn.ReLU()]
+        self.time_conv = nn.Sequential(*tc)
+        dec = [nn.Tanh() if s is None else nn.Linear(*s) for s in _FC]
+        dec.append(nn.Linear(50, n_verts))                    # voca.py:30-36
+        self.decoder = nn.Sequential(*dec)
+
+    def _trunk_params(self):
+        ps = []
+        for i in (0, 2, 4, 6):
+            ps += [self.time_conv[i].weight, self.time_conv[i].bias]
+        for i in (0, 1, 3):
+            ps += [self.decoder[i].weight, self.decoder[i].bias]
+        return ps
+
+    def trunk(self, x, one_hot):
+        """(B,29,16),(B,n_onehot) -> 50-wide bottleneck (B,50)."""
+        return VocaTrunkFn.apply(x, one_hot, *self._trunk_params())
+
+    def forward(self, x, one_hot, template, **kwargs):
+        bs = x.size(0)
+        h3 = self.trunk(x, one_hot)
+        pred = HeadFn.apply(h3, self.decoder[4].weight, self.decoder[4].bias, template.reshape(bs, -1))
+        return pred.view(bs, -1, 3)
+
+    def predict(self, x, one_hot, template, **kwargs):
+        return self(x, one_hot, template, **kwargs)

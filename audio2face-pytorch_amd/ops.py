@@ -1,0 +1,255 @@
+"""Host-side launch layer: torch tensors in, HIP kernels (liba2f_hip.so, C ABI) out.
+
+``HipBackend`` is the only backend the product ever instantiates; every method is a 1:1 call of an
+``a2f_*`` entry point on the current torch HIP stream.  The layer composers below (implicit-GEMM
+convolutions, Linear forward/backward) are written against the backend *interface* so that the
+CPU test-suite can check their index arithmetic with an emulator injected through ``set_backend``
+(tests only; the package itself never does that and has no CPU path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import A2FError, GemmDesc
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+AUX_NONE, AUX_RELU_BWD, AUX_TANH_BWD, AUX_ADD = 0, 1, 2, 3
+
+
+def _ptr(t: Optional[torch.Tensor], off: int = 0) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr() + 4 * off
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if t.device.type != "cuda":
+            raise A2FError("a2f ops need HIP (cuda) tensors; this package has no CPU path")
+        if t.dtype != torch.float32:
+            raise A2FError(f"a2f ops compute in fp32; got {t.dtype}")
+        if not t.is_contiguous():
+            raise A2FError("a2f ops need contiguous tensors")
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self.prof = None          # when a dict: tag -> list of (start_event, end_event) recorded on the launch stream
+
+    @staticmethod
+    def _stream(t: torch.Tensor):
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+    # ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----
+    def _prof_begin(self, tag):
+        if self.prof is None or tag is None:
+            return None
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        return ev
+
+    def _prof_end(self, tag, ev):
+        if ev is not None:
+            ev[1].record()
+            self.prof.setdefault(tag, []).append(ev)
+
+    # ---- a2f_gemm_f32 -------------------------------------------------------------------------
+    def gemm(self, A, B, Cout, M, N, K, a: Tuple[int, int, int], b: Tuple[int, int, int], ldc, *, c_off=0, bias=None,
+             act=ACT_NONE, aux=None, aux_off=0, ldaux=0, aux_mode=AUX_NONE, accumulate=False, split_k=1, ones_out=None,
+             mask: Optional[Tuple[int, int, int, int, int]] = None, tag: Optional[str] = None):
+        _chk(A, B, Cout, bias, aux, ones_out)
+        d = GemmDesc()
+        d.A, d.a_off, d.a_rs, d.a_cs = _ptr(A), a[0], a[1], a[2]
+        d.B, d.b_off, d.b_rs, d.b_cs = _ptr(B), b[0], b[1], b[2]
+        d.C, d.ldc = _ptr(Cout, c_off), ldc
+        d.M, d.N, d.K = M, N, K
+        d.bias = _ptr(bias)
+        d.aux, d.ldaux = _ptr(aux, aux_off), ldaux
+        d.ones_out = _ptr(ones_out)
+        d.act, d.aux_mode, d.accumulate, d.split_k = act, aux_mode, int(accumulate), split_k
+        if mask is not None:
+            d.mask_operand, d.mask_period, d.mask_phase, d.mask_lo, d.mask_hi = mask
+        ev = self._prof_begin(tag)
+        _lib.check(self.lib.a2f_gemm_f32(C.byref(d), self._stream(Cout)), "a2f_gemm_f32")
+        self._prof_end(tag, ev)
+
+    # ---- loss ---------------------------------------------------------------------------------
+    def vocaloss_fwd(self, pred, gt, B, n, k_rec, k_vel, out3):
+        _chk(pred, gt, out3)
+        nb = self.lib.a2f_vocaloss_ws_bytes(B, n)
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=pred.device)
+        ev = self._prof_begin("loss_fwd")
+        _lib.check(self.lib.a2f_vocaloss_fwd(_ptr(pred), _ptr(gt), B, n, k_rec, k_vel, _ptr(out3), _ptr(ws), nb,
+                                             self._stream(pred)), "a2f_vocaloss_fwd")
+        self._prof_end("loss_fwd", ev)
+
+    def vocaloss_bwd(self, pred, gt, g3, B, n, k_rec, k_vel, grad):
+        _chk(pred, gt, g3, grad)
+        ev = self._prof_begin("loss_bwd")
+        _lib.check(self.lib.a2f_vocaloss_bwd(_ptr(pred), _ptr(gt), _ptr(g3), B, n, k_rec, k_vel, _ptr(grad),
+                                             self._stream(pred)), "a2f_vocaloss_bwd")
+        self._prof_end("loss_bwd", ev)
+
+    def head_fused(self, H, W, bias, templ, template_rows, gt, B, Bloss, n, K, k_rec, k_vel, pred, out3, dH, dW, dbias):
+        _chk(H, W, bias, templ, gt, pred, out3, dH, dW, dbias)
+        nb = self.lib.a2f_head_fused_ws_bytes(B, n, K)
+        ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=H.device)
+        ev = self._prof_begin("head_fused")
+        _lib.check(self.lib.a2f_head_fused(_ptr(H), _ptr(W), _ptr(bias), _ptr(templ), template_rows, _ptr(gt), B, Bloss, n, K,
+                                           k_rec, k_vel, _ptr(pred), _ptr(out3), _ptr(dH), _ptr(dW), _ptr(dbias),
+                                           _ptr(ws), nb, self._stream(H)), "a2f_head_fused")
+        self._prof_end("head_fused", ev)
+
+    # ---- packing ------------------------------------------------------------------------------
+    def voca_pack(self, x, one_hot, B, n_onehot, a0, cat72):
+        _chk(x, one_hot, a0, cat72)
+        _lib.check(self.lib.a2f_voca_pack(_ptr(x), _ptr(one_hot), B, n_onehot, _ptr(a0), _ptr(cat72), self._stream(x)), "a2f_voca_pack")
+
+    def a2m_pack(self, x, one_hot, B, n_onehot, a0, cat, cat_ld, cat_off):
+        _chk(x, one_hot, a0, cat)
+        _lib.check(self.lib.a2f_a2m_pack(_ptr(x), _ptr(one_hot), B, n_onehot, _ptr(a0), _ptr(cat), cat_ld, cat_off,
+                                         self._stream(x)), "a2f_a2m_pack")
+
+    def conv_weight_pack(self, src, dst, Co, Ci, KH, direction):
+        _chk(src, dst)
+        _lib.check(self.lib.a2f_conv_weight_pack(_ptr(src), _ptr(dst), Co, Ci, KH, direction, self._stream(src)), "a2f_conv_weight_pack")
+
+    # ---- batch norm ---------------------------------------------------------------------------
+    def bn_fwd(self, x, R, Cc, gamma, beta, rmean, rvar, momentum, eps, training, relu, y, save_mean, save_invstd):
+        _chk(x, gamma, beta, rmean, rvar, y, save_mean, save_invstd)
+        nb = self.lib.a2f_bn_ws_bytes(R, Cc)
+        ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.a2f_bn_fwd(_ptr(x), R, Cc, _ptr(gamma), _ptr(beta), _ptr(rmean), _ptr(rvar), momentum, eps,
+                                       int(training), int(relu), _ptr(y), _ptr(save_mean), _ptr(save_invstd), _ptr(ws), nb,
+                                       self._stream(x)), "a2f_bn_fwd")
+
+    def bn_bwd(self, x, y, dy, R, Cc, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta):
+        _chk(x, y, dy, gamma, save_mean, save_invstd, dx, dgamma, dbeta)
+        nb = self.lib.a2f_bn_ws_bytes(R, Cc)
+        ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.a2f_bn_bwd(_ptr(x), _ptr(y), _ptr(dy), R, Cc, _ptr(gamma), _ptr(save_mean), _ptr(save_invstd),
+                                       int(training), int(relu), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb,
+                                       self._stream(x)), "a2f_bn_bwd")
+
+    # ---- FaceFormer recurrence ----------------------------------------------------------------
+    def ff_save_floats(self, S, T):
+        return self.lib.a2f_ff_save_bytes(S, T) // 4
+
+    def ff_decoder_fwd(self, params, cross, style, S, T, period, y, save):
+        _chk(params, cross, style, y, save)
+        _lib.check(self.lib.a2f_ff_decoder_fwd(_ptr(params), _ptr(cross), _ptr(style), S, T, period, _ptr(y), _ptr(save),
+                                               save.numel() * 4, self._stream(y)), "a2f_ff_decoder_fwd")
+
+    def ff_decoder_bwd(self, params, cross, style, dy, S, T, period, save, dparams, dcross, dstyle):
+        _chk(params, cross, style, dy, save, dparams, dcross, dstyle)
+        _lib.check(self.lib.a2f_ff_decoder_bwd(_ptr(params), _ptr(cross), _ptr(style), _ptr(dy), S, T, period, _ptr(save),
+                                               save.numel() * 4, _ptr(dparams), _ptr(dcross), _ptr(dstyle),
+                                               self._stream(dy)), "a2f_ff_decoder_bwd")
+
+    # ---- optimiser ----------------------------------------------------------------------------
+    def adam_step(self, p, g, m, v, n, lr, b1, b2, eps, wd, grad_scale, step):
+        _chk(p, g, m, v)
+        _lib.check(self.lib.a2f_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, b1, b2, eps, wd, grad_scale, step,
+                                          self._stream(p)), "a2f_adam_step")
+
+
+_BACKEND = None
+
+
+def backend():
+    """The process-wide backend; created on first use.  Raises A2FError if liba2f_hip.so is missing."""
+    global _BACKEND
+    if _BACKEND is None:
+        _BACKEND = HipBackend()
+    return _BACKEND
+
+
+def set_backend(b):
+    """TEST HOOK ONLY (tests/emu_backend.py injects a CPU emulator of the C ABI to check host logic)."""
+    global _BACKEND
+    old = _BACKEND
+    _BACKEND = b
+    return old
+
+
+# =================================================================================================
+# Layer composers (pure index arithmetic over backend.gemm)
+# =================================================================================================
+def split_k_for(rows: int, tiles: int = 1) -> int:
+    """K-splits for a weight-gradient GEMM whose contraction runs over `rows` (frames x positions)."""
+    want = max(1, min(512, (rows + 255) // 256))
+    return max(1, min(want, max(1, 1024 // max(tiles, 1))))
+
+
+def linear_fwd(be, x, W, bias, out, M, N, K, *, ldx=None, ldc=None, act=ACT_NONE, aux=None, ldaux=0, aux_mode=AUX_NONE, tag=None):
+    """out[M,N] = act(x[M,K] W[N,K]^T + bias)  (torch.nn.Linear layout)."""
+    be.gemm(x, W, out, M, N, K, (0, ldx or K, 1), (0, 1, K), ldc or N, bias=bias, act=act, aux=aux, ldaux=ldaux, aux_mode=aux_mode, tag=tag)
+
+
+def linear_bwd_input(be, dy, W, dx, M, N, K, *, ld_dy=None, n_cols=None, ldc=None, aux=None, ldaux=0, aux_mode=AUX_NONE):
+    """dx[M,:n_cols] = (dy[M,N] W[N,K])[:, :n_cols], optionally times an activation derivative (aux)."""
+    nc = n_cols or K
+    be.gemm(dy, W, dx, M, nc, N, (0, ld_dy or N, 1), (0, K, 1), ldc or nc, aux=aux, ldaux=ldaux, aux_mode=aux_mode)
+
+
+def linear_bwd_weight(be, dy, x, dW, db, M, N, K, *, ld_dy=None, ldx=None, tag=None):
+    """dW[N,K] = dy[M,N]^T x[M,K];  db[N] = colsum(dy).  dW/db must be zero on entry (split-K atomics)."""
+    tiles = ((N + 127) // 128) * ((K + 1 + 127) // 128)
+    be.gemm(dy, x, dW, N, K, M, (0, 1, ld_dy or N), (0, ldx or K, 1), K, ones_out=db, split_k=split_k_for(M, tiles), tag=tag)
+
+
+def conv_fwd(be, act_in, wg, bias, out, R, P_out, Cin, Co, *, KH=3, stride=2, pad=1, ldc=None, c_off=0, relu=True):
+    """Strided 1-D convolution over channels-last rows as an implicit GEMM.
+
+    act_in: (groups, P_in, Cin) flattened, P_in = stride*P_out; output row r = (group, p_out), R = groups*P_out.
+    The im2col row of r is the contiguous window act_in[(r*stride - pad)*Cin : +KH*Cin]; the left zero padding of the
+    first position of every group is a mask on the first pad*Cin window elements.
+    wg: (Co, KH*Cin) packed as k = kh*Cin + ci.
+    """
+    mask = (1, P_out, 0, 0, pad * Cin) if pad else None
+    be.gemm(act_in, wg, out, R, Co, KH * Cin, (-pad * Cin, stride * Cin, 1), (0, 1, KH * Cin), ldc or Co, c_off=c_off,
+            bias=bias, act=ACT_RELU if relu else ACT_NONE, mask=mask)
+
+
+def conv_bwd_weight(be, act_in, dout, dwg, dbias, R, P_out, Cin, Co, *, KH=3, stride=2, pad=1, ld_dout=None):
+    """dwg[Co, KH*Cin] = dout[R,Co]^T windows(act_in);  dbias = colsum(dout).  Outputs zeroed by the caller."""
+    mask = (2, P_out, 0, 0, pad * Cin) if pad else None
+    tiles = ((Co + 127) // 128) * ((KH * Cin + 1 + 127) // 128)
+    be.gemm(dout, act_in, dwg, Co, KH * Cin, R, (0, 1, ld_dout or Co), (-pad * Cin, stride * Cin, 1), KH * Cin,
+            ones_out=dbias, split_k=split_k_for(R, tiles), mask=mask)
+
+
+def conv_k3s2_bwd_input(be, dout, wg, d_in, R, P_out, Cin, Co, *, relu_of=None):
+    """Data gradient of the k=3, stride=2, pad=1 convolution, gather form (no atomics, no col2im buffer).
+
+    d_in: (groups, 2*P_out, Cin).  Input position 2p (even) is touched only by tap kh=1 of output p; position 2p+1 (odd)
+    by tap kh=2 of output p and tap kh=0 of output p+1 (if it exists in the same group).
+    relu_of: the forward activation stored at d_in's addresses; when given, the result is masked by (act > 0).
+    """
+    C3 = 3 * Cin
+    am = AUX_RELU_BWD if relu_of is not None else AUX_NONE
+    # even positions
+    be.gemm(dout, wg, d_in, R, Cin, Co, (0, Co, 1), (Cin, C3, 1), 2 * Cin, aux=relu_of, ldaux=2 * Cin, aux_mode=am)
+    # odd positions
+    if P_out == 1:
+        be.gemm(dout, wg, d_in, R, Cin, Co, (0, Co, 1), (2 * Cin, C3, 1), 2 * Cin, c_off=Cin, aux=relu_of, aux_off=Cin,
+                ldaux=2 * Cin, aux_mode=am)
+    else:
+        be.gemm(dout, wg, d_in, R, Cin, Co, (0, Co, 1), (2 * Cin, C3, 1), 2 * Cin, c_off=Cin)
+        be.gemm(dout, wg, d_in, R, Cin, Co, (Co, Co, 1), (0, C3, 1), 2 * Cin, c_off=Cin, accumulate=True,
+                aux=relu_of, aux_off=Cin, ldaux=2 * Cin, aux_mode=am, mask=(1, P_out, P_out - 1, 0, Co))
+
+
+def conv_nonoverlap_bwd_input(be, dout, wg, d_in, R, Cin, Co, KH, *, relu_of=None):
+    """Data gradient when stride == kernel and pad == 0 (audio2face.py:45): d_in[r, kh*Cin+ci] = dout[r,:] wg[:, kh*Cin+ci]."""
+    am = AUX_RELU_BWD if relu_of is not None else AUX_NONE
+    be.gemm(dout, wg, d_in, R, KH * Cin, Co, (0, Co, 1), (0, KH * Cin, 1), KH * Cin, aux=relu_of, ldaux=KH * Cin, aux_mode=am)

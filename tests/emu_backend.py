@@ -1,0 +1,261 @@
+"""CPU emulator of the liba2f_hip.so C ABI (TEST INFRASTRUCTURE ONLY).
+
+Implements the *semantics* documented in include/a2f_hip.h with plain torch CPU ops so that
+ (a) the host-side composers in ``ops.py`` / the drop-in modules can be checked against the oracle
+     without a GPU (index arithmetic of the implicit-GEMM convolutions, gradient plumbing), and
+ (b) the GPU tests can compare every HIP entry point against the same contract on random operands.
+The product never imports this file.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+
+def _flat(t):
+    return t.reshape(-1)
+
+
+def _window(t, off, rs, cs, R, Ccols):
+    """Matrix view M[r,c] = flat[off + r*rs + c*cs] with out-of-range elements read as 0."""
+    flat = _flat(t).double()
+    r = torch.arange(R).view(-1, 1)
+    c = torch.arange(Ccols).view(1, -1)
+    idx = off + r * rs + c * cs
+    ok = (idx >= 0) & (idx < flat.numel())
+    return torch.where(ok, flat[idx.clamp(0, flat.numel() - 1)], torch.zeros((), dtype=torch.double)), ok
+
+
+class EmuBackend:
+    name = "emu"
+
+    def __init__(self, strict_bounds: bool = True):
+        self.strict = strict_bounds
+        self.calls = []
+
+    # ------------------------------------------------------------------ gemm
+    def gemm(self, A, B, Cout, M, N, K, a, b, ldc, *, c_off=0, bias=None, act=0, aux=None, aux_off=0, ldaux=0, aux_mode=0,
+             accumulate=False, split_k=1, ones_out=None, mask=None, tag=None):
+        self.calls.append(("gemm", M, N, K))
+        Am, Aok = _window(A, a[0], a[1], a[2], M, K)
+        Bm, Bok = _window(B, b[0], b[1], b[2], K, N)
+        if mask is not None:
+            op, period, phase, lo, hi = mask
+            if op == 1:
+                rows = (torch.arange(M) % period == phase).view(-1, 1)
+                cols = ((torch.arange(K) >= lo) & (torch.arange(K) < hi)).view(1, -1)
+                m = rows & cols
+                Am = Am.masked_fill(m, 0.0); Aok = Aok | m
+            elif op == 2:
+                rows = (torch.arange(K) % period == phase).view(-1, 1)
+                cols = ((torch.arange(N) >= lo) & (torch.arange(N) < hi)).view(1, -1)
+                m = rows & cols
+                Bm = Bm.masked_fill(m, 0.0); Bok = Bok | m
+        if self.strict:      # every unmasked element must be inside its buffer (a kernel would fault otherwise)
+            assert bool(Aok.all()), "gemm emu: A window reads outside its buffer"
+            assert bool(Bok.all()), "gemm emu: B window reads outside its buffer"
+        v = Am @ Bm
+        cflat = _flat(Cout)
+        r = torch.arange(M).view(-1, 1)
+        cidx = c_off + r * ldc + torch.arange(N).view(1, -1)
+        assert int(cidx.max()) < cflat.numel(), "gemm emu: C write outside its buffer"
+        if split_k > 1:
+            assert act == 0 and aux_mode == 0 and bias is None and not accumulate
+            cflat[cidx] = (cflat[cidx].double() + v).float()          # atomics into zeroed C
+            if ones_out is not None:
+                ones_out[:M] += Am.sum(dim=1).float()
+            return
+        if bias is not None:
+            v = v + bias.double().view(1, -1)
+        if accumulate:
+            v = v + cflat[cidx].double()
+        if act == 1:
+            v = v.clamp_min(0)
+        elif act == 2:
+            v = torch.tanh(v)
+        if aux_mode:
+            ax = _flat(aux)[aux_off + r * ldaux + torch.arange(N).view(1, -1)].double()
+            if aux_mode == 1:
+                v = torch.where(ax > 0, v, torch.zeros_like(v))
+            elif aux_mode == 2:
+                v = v * (1 - ax * ax)
+            else:
+                v = v + ax
+        cflat[cidx] = v.float()
+        if ones_out is not None:
+            s = Am.sum(dim=1).float()
+            ones_out[:M] = ones_out[:M] + s if accumulate else s
+
+    # ------------------------------------------------------------------ loss
+    def vocaloss_fwd(self, pred, gt, B, n, k_rec, k_vel, out3):
+        d = (pred.reshape(B, n) - gt.reshape(B, n)).double()
+        V = n // 3
+        rec = (d ** 2).sum() / (B * V)
+        dv = d[1::2] - d[0::2]
+        vel = (dv ** 2).sum() / ((B // 2) * V)
+        out3[0] = float(rec * k_rec + vel * k_vel); out3[1] = float(rec); out3[2] = float(vel)
+
+    def vocaloss_bwd(self, pred, gt, g3, B, n, k_rec, k_vel, grad):
+        d = (pred.reshape(B, n) - gt.reshape(B, n)).double()
+        V = n // 3
+        cr = (float(g3[0]) * k_rec + float(g3[1])) * 2.0 / (B * V)
+        cv = (float(g3[0]) * k_vel + float(g3[2])) * 2.0 / ((B // 2) * V)
+        dv = cv * (d[1::2] - d[0::2])
+        g = cr * d
+        g[0::2] -= dv
+        g[1::2] += dv
+        grad.reshape(B, n).copy_(g.float())
+
+    def head_fused(self, H, W, bias, templ, template_rows, gt, B, Bloss, n, K, k_rec, k_vel, pred, out3, dH, dW, dbias):
+        Hd, Wd = H.reshape(B, K).double(), W.reshape(n, K).double()
+        t = templ.reshape(template_rows, n).double()
+        p = Hd @ Wd.t() + bias.double().view(1, -1) + (t if template_rows == B else t[:1])
+        pred.reshape(B, n).copy_(p.float())
+        V = n // 3
+        d = (p - gt.reshape(B, n).double())[:Bloss]
+        rec = (d ** 2).sum() / (Bloss * V)
+        dvv = d[1::2] - d[0::2]
+        vel = (dvv ** 2).sum() / ((Bloss // 2) * V)
+        out3[0] = float(rec * k_rec + vel * k_vel); out3[1] = float(rec); out3[2] = float(vel)
+        cr = k_rec * 2.0 / (Bloss * V)
+        cv = k_vel * 2.0 / ((Bloss // 2) * V)
+        G = torch.zeros(B, n, dtype=torch.double)
+        G[:Bloss] = cr * d
+        G[0:Bloss:2] -= cv * dvv
+        G[1:Bloss:2] += cv * dvv
+        dH.reshape(B, K).copy_((G @ Wd).float())
+        dW.reshape(n, K).copy_((G.t() @ Hd).float())
+        dbias.copy_(G.sum(dim=0).float())
+
+    # ------------------------------------------------------------------ packing
+    def voca_pack(self, x, one_hot, B, n_onehot, a0, cat72):
+        a0v = a0.reshape(B, 16, 37)
+        a0v[:, :, :29] = x.reshape(B, 29, 16).transpose(1, 2)
+        h = torch.arange(16)
+        a0v[:, :, 29:] = one_hot.reshape(B, n_onehot)[:, h % 8].unsqueeze(2).expand(B, 16, 8)
+        cat72.reshape(B, 72)[:, 64:] = one_hot.reshape(B, n_onehot)[:, :8]
+
+    def a2m_pack(self, x, one_hot, B, n_onehot, a0, cat, cat_ld, cat_off):
+        rows = 52 + n_onehot
+        a0v = a0.reshape(B, rows, 32)
+        a0v[:, :52] = x.reshape(B, 52, 32)
+        r = torch.arange(n_onehot).view(-1, 1)
+        c = torch.arange(32).view(1, -1)
+        a0v[:, 52:] = one_hot.reshape(B, n_onehot)[:, (32 * r + c) % n_onehot]
+        cat.reshape(B, cat_ld)[:, cat_off:cat_off + n_onehot] = one_hot.reshape(B, n_onehot)
+
+    def conv_weight_pack(self, src, dst, Co, Ci, KH, direction):
+        if direction == 0:
+            dst.reshape(Co, KH, Ci).copy_(src.reshape(Co, Ci, KH).permute(0, 2, 1))
+        else:
+            dst.reshape(Co, Ci, KH).copy_(src.reshape(Co, KH, Ci).permute(0, 2, 1))
+
+    # ------------------------------------------------------------------ batch norm (channels-last rows)
+    def bn_fwd(self, x, R, Cc, gamma, beta, rmean, rvar, momentum, eps, training, relu, y, save_mean, save_invstd):
+        xv = x.reshape(R, Cc).double()
+        if training:
+            mean = xv.mean(dim=0)
+            var = xv.var(dim=0, unbiased=False)
+            rmean.mul_(1 - momentum).add_((momentum * mean).float())
+            unb = var * (R / max(R - 1, 1))
+            rvar.mul_(1 - momentum).add_((momentum * unb).float())
+        else:
+            mean, var = rmean.double(), rvar.double()
+        invstd = 1.0 / torch.sqrt(var + eps)
+        out = (xv - mean) * invstd * gamma.double() + beta.double()
+        if relu:
+            out = out.clamp_min(0)
+        y.reshape(R, Cc).copy_(out.float())
+        save_mean.copy_(mean.float()); save_invstd.copy_(invstd.float())
+
+    def bn_bwd(self, x, y, dy, R, Cc, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta):
+        xv, dyv = x.reshape(R, Cc).double(), dy.reshape(R, Cc).double()
+        if relu:
+            dyv = torch.where(y.reshape(R, Cc) > 0, dyv, torch.zeros_like(dyv))
+        mean, invstd, g = save_mean.double(), save_invstd.double(), gamma.double()
+        xhat = (xv - mean) * invstd
+        db = dyv.sum(dim=0)
+        dg = (dyv * xhat).sum(dim=0)
+        if training:
+            dxv = (g * invstd / R) * (R * dyv - db - xhat * dg)
+        else:
+            dxv = dyv * g * invstd
+        dx.reshape(R, Cc).copy_(dxv.float()); dgamma.copy_(dg.float()); dbeta.copy_(db.float())
+
+    # ------------------------------------------------------------------ FaceFormer recurrence (autograd on the spec)
+    @staticmethod
+    def _ff_unpack(p):
+        o, D, F_ = 0, 64, 128
+        def take(n, shape):
+            nonlocal o
+            t = p[o:o + n].view(*shape); o += n
+            return t
+        Wqkv = take(192 * D, (192, D)); bqkv = take(192, (192,))
+        Wo = take(D * D, (D, D)); bo = take(D, (D,))
+        W1 = take(F_ * D, (F_, D)); b1 = take(F_, (F_,))
+        W2 = take(D * F_, (D, F_)); b2 = take(D, (D,))
+        ln = take(6 * D, (6, D))
+        A = take(D * D, (D, D)); c = take(D, (D,))
+        return Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, ln, A, c
+
+    @classmethod
+    def ff_spec(cls, params, cross, style, period):
+        """Differentiable torch statement of the recurrence the HIP kernel implements (double precision)."""
+        import torch.nn.functional as F
+        Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, ln, A, c = cls._ff_unpack(params)
+        S, T, D = cross.shape
+        H, hd = 4, 16
+        slopes = torch.tensor([2.0 ** (-2 * (h + 1)) for h in range(H)], dtype=params.dtype)
+        i2 = torch.arange(0, D, 2, dtype=params.dtype)
+        div = torch.exp(i2 * (-math.log(10000.0) / D))
+        ys = []
+        for s in range(S):
+            ks, vs, rows = [], [], []
+            emb = style[s]
+            for i in range(T):
+                pos = float(i % period)
+                pe = torch.zeros(D, dtype=params.dtype)
+                pe[0::2] = torch.sin(pos * div); pe[1::2] = torch.cos(pos * div)
+                x = emb + pe
+                qkv = F.linear(x, Wqkv, bqkv)
+                q = qkv[:D].view(H, hd) * 0.25
+                ks.append(qkv[D:2 * D]); vs.append(qkv[2 * D:])
+                Kc = torch.stack(ks).view(i + 1, H, hd); Vc = torch.stack(vs).view(i + 1, H, hd)
+                sc = torch.einsum("hd,jhd->hj", q, Kc)
+                steps = torch.div(i - torch.arange(i + 1), period, rounding_mode="floor").to(params.dtype)
+                sc = sc - slopes.view(-1, 1) * steps.view(1, -1)
+                a = torch.softmax(sc, dim=-1)
+                ctx = torch.einsum("hj,jhd->hd", a, Vc).reshape(D)
+                y = F.layer_norm(x + F.linear(ctx, Wo, bo), (D,), ln[0], ln[1], 1e-5)
+                y = F.layer_norm(y + cross[s, i], (D,), ln[2], ln[3], 1e-5)
+                y = F.layer_norm(y + F.linear(F.relu(F.linear(y, W1, b1)), W2, b2), (D,), ln[4], ln[5], 1e-5)
+                rows.append(y)
+                emb = A @ y + c + style[s]
+            ys.append(torch.stack(rows))
+        return torch.stack(ys)
+
+    def ff_save_floats(self, S, T):
+        return 1
+
+    def ff_decoder_fwd(self, params, cross, style, S, T, period, y, save):
+        with torch.no_grad():
+            out = self.ff_spec(params.double(), cross.reshape(S, T, 64).double(), style.reshape(S, 64).double(), period)
+        y.reshape(S, T, 64).copy_(out.float())
+
+    def ff_decoder_bwd(self, params, cross, style, dy, S, T, period, save, dparams, dcross, dstyle):
+        p = params.double().requires_grad_(True)
+        cr = cross.reshape(S, T, 64).double().requires_grad_(True)
+        st = style.reshape(S, 64).double().requires_grad_(True)
+        out = self.ff_spec(p, cr, st, period)
+        out.backward(dy.reshape(S, T, 64).double())
+        dparams.add_(p.grad.float()); dcross.reshape(S, T, 64).copy_(cr.grad.float()); dstyle.reshape(S, 64).copy_(st.grad.float())
+
+    # ------------------------------------------------------------------ Adam
+    def adam_step(self, p, g, m, v, n, lr, b1, b2, eps, wd, grad_scale, step):
+        gg = g[:n] * grad_scale + wd * p[:n]
+        m[:n].mul_(b1).add_(gg, alpha=1 - b1)
+        v[:n].mul_(b2).addcmul_(gg, gg, value=1 - b2)
+        c1 = 1 - b1 ** step
+        c2 = 1 - b2 ** step
+        p[:n].addcdiv_(m[:n], (v[:n].sqrt() / math.sqrt(c2)).add_(eps), value=-lr / c1)

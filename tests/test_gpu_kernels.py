@@ -1,0 +1,201 @@
+"""GPU: every HIP entry point of liba2f_hip.so against the CPU emulator of its contract (include/a2f_hip.h).
+
+All calls go through the C ABI (ctypes) exactly as the product does.  fp32 tolerance: the f32 MFMA is an exact fp32
+fma chain, so only summation order differs from the float64 emulator -> 2e-5 relative L2 is ample; parity against the
+reference goldens is in test_gpu_models.py at the 1e-4 bar of BASELINE.json.
+"""
+import math
+
+import pytest
+import torch
+
+import a2f_amd
+from a2f_amd import ops
+from emu_backend import EmuBackend
+from golden_util import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def run_gemm_both(A, B, Cinit, M, N, K, a, b, ldc, **kw):
+    hip, emu = ops.HipBackend(), EmuBackend()
+    outs = []
+    for be, dev in ((hip, DEV), (emu, "cpu")):
+        kk = dict(kw)
+        for name in ("bias", "aux", "ones_out"):
+            if kk.get(name) is not None:
+                kk[name] = kk[name].clone().to(dev)
+        Cc = Cinit.clone().to(dev)
+        be.gemm(A.to(dev), B.to(dev), Cc, M, N, K, a, b, ldc, **kk)
+        outs.append((Cc.cpu(), kk["ones_out"].cpu() if kk.get("ones_out") is not None else None))
+    return outs
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 50, 50), (128, 32, 16), (300, 72, 111), (513, 129, 67), (200, 96, 192), (64, 15, 3)])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_plain_layouts(M, N, K, layout):
+    if layout == "nt":      # A (M,K) row-major, B = W (N,K) row-major (torch Linear)
+        A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+        a, b = (0, K, 1), (0, 1, K)
+    elif layout == "nn":    # B (K,N) row-major
+        A, B = rnd(M, K, seed=1), rnd(K, N, seed=2)
+        a, b = (0, K, 1), (0, N, 1)
+    else:                   # A stored (K,M) row-major
+        A, B = rnd(K, M, seed=1), rnd(K, N, seed=2)
+        a, b = (0, 1, M), (0, N, 1)
+    (c_hip, _), (c_emu, _) = run_gemm_both(A, B, torch.zeros(M, N), M, N, K, a, b, N)
+    assert rel_l2(c_hip, c_emu) < 2e-5
+
+
+@pytest.mark.parametrize("act,aux_mode", [(0, 0), (1, 0), (2, 0), (0, 1), (0, 2), (0, 3), (1, 3)])
+def test_gemm_epilogues(act, aux_mode):
+    M, N, K = 211, 77, 45
+    A, B = rnd(M, K, seed=3), rnd(N, K, seed=4)
+    bias = rnd(N, seed=5)
+    aux = rnd(M, N + 3, seed=6) if aux_mode else None
+    C0 = rnd(M, N + 5, seed=7)
+    for accumulate in (False, True):
+        (c_hip, _), (c_emu, _) = run_gemm_both(A, B, C0, M, N, K, (0, K, 1), (0, 1, K), N + 5, bias=bias, act=act, aux=aux,
+                                               ldaux=N + 3, aux_mode=aux_mode, accumulate=accumulate)
+        assert rel_l2(c_hip, c_emu) < 2e-5
+        assert torch.equal(c_hip[:, N:], C0[:, N:])          # columns beyond N untouched (ldc > N)
+
+
+def test_gemm_broadcast_aux_row_and_c_offset():
+    M, N, K = 70, 40, 20
+    A, B = rnd(M, K, seed=8), rnd(N, K, seed=9)
+    aux = rnd(1, N, seed=10)
+    C0 = torch.zeros(M + 1, N)
+    (c_hip, _), (c_emu, _) = run_gemm_both(A, B, C0, M, N, K, (0, K, 1), (0, 1, K), N, c_off=N, aux=aux, ldaux=0, aux_mode=3)
+    assert rel_l2(c_hip, c_emu) < 2e-5 and float(c_hip[0].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("B_,P_out,Cin,Co", [(5, 8, 37, 32), (3, 4, 32, 32), (7, 2, 32, 64), (6, 1, 64, 64), (2, 16, 1, 72), (3, 2, 243, 256)])
+def test_conv_implicit_gemm_fwd_wgrad_dgrad(B_, P_out, Cin, Co):
+    """k=3/s=2/p=1 convolution over channels-last rows == torch conv1d, forward, weight grad and data grad."""
+    P_in = 2 * P_out
+    act = rnd(B_, P_in, Cin, seed=11).abs() * torch.sign(rnd(B_, P_in, Cin, seed=12))      # mixed signs for the ReLU mask
+    w = rnd(Co, Cin, 3, seed=13, scale=0.2)
+    bias = rnd(Co, seed=14)
+    x = act.permute(0, 2, 1).clone().requires_grad_(True)                      # (B, Cin, P_in)
+    wt = w.clone().requires_grad_(True)
+    bt = bias.clone().requires_grad_(True)
+    y = torch.relu(torch.nn.functional.conv1d(x, wt, bt, stride=2, padding=1))   # (B, Co, P_out)
+    dy = rnd(B_, P_out, Co, seed=15)
+    y.backward(dy.permute(0, 2, 1))
+    be = ops.HipBackend()
+    wg = torch.empty(Co, 3 * Cin, device=DEV)
+    be.conv_weight_pack(w.to(DEV), wg, Co, Cin, 3, 0)
+    assert torch.equal(wg.cpu().view(Co, 3, Cin), w.permute(0, 2, 1))
+    out = torch.empty(B_, P_out, Co, device=DEV)
+    R = B_ * P_out
+    ops.conv_fwd(be, act.to(DEV), wg, bias.to(DEV), out, R, P_out, Cin, Co)
+    assert rel_l2(out.cpu(), y.detach().permute(0, 2, 1)) < 2e-5
+    d_pre = (dy * (out.cpu() > 0)).to(DEV).contiguous()                       # gradient w.r.t. the pre-ReLU output
+    dwg = torch.zeros(Co, 3 * Cin, device=DEV)
+    dbias = torch.zeros(Co, device=DEV)
+    ops.conv_bwd_weight(be, act.to(DEV), d_pre, dwg, dbias, R, P_out, Cin, Co)
+    dw = torch.empty(Co, Cin, 3, device=DEV)
+    be.conv_weight_pack(dwg, dw, Co, Cin, 3, 1)
+    assert rel_l2(dw.cpu(), wt.grad) < 5e-5
+    assert rel_l2(dbias.cpu(), bt.grad) < 5e-5
+    d_in = torch.full((B_, P_in, Cin), float("nan"), device=DEV)
+    ops.conv_k3s2_bwd_input(be, d_pre, wg, d_in, R, P_out, Cin, Co)
+    assert rel_l2(d_in.cpu(), x.grad.permute(0, 2, 1)) < 5e-5
+    # with the ReLU mask of the layer below fused in
+    d_in2 = torch.full((B_, P_in, Cin), float("nan"), device=DEV)
+    ops.conv_k3s2_bwd_input(be, d_pre, wg, d_in2, R, P_out, Cin, Co, relu_of=act.to(DEV))
+    assert rel_l2(d_in2.cpu(), x.grad.permute(0, 2, 1) * (act > 0)) < 5e-5
+
+
+def test_gemm_splitk_ones_column():
+    M, N, K = 50, 128, 5000
+    dy, x = rnd(K, M, seed=16), rnd(K, N, seed=17)
+    dW = torch.zeros(M, N)
+    db = torch.zeros(M)
+    for split in (1, 7, 64):
+        (c_hip, o_hip), (c_emu, o_emu) = run_gemm_both(dy, x, dW, M, N, K, (0, 1, M), (0, N, 1), N, ones_out=db, split_k=split)
+        assert rel_l2(c_hip, dy.double().t() @ x.double()) < 2e-5
+        assert rel_l2(o_hip, dy.double().sum(0)) < 2e-5
+        assert rel_l2(c_hip, c_emu) < 2e-5
+
+
+def test_gemm_rejects_bad_arguments():
+    be = ops.HipBackend()
+    A = torch.zeros(4, 4, device=DEV)
+    with pytest.raises(a2f_amd.A2FError):
+        be.gemm(A, A, A, 0, 4, 4, (0, 4, 1), (0, 1, 4), 4)
+    with pytest.raises(a2f_amd.A2FError):
+        be.gemm(A, A, A, 4, 4, 4, (0, 4, 1), (0, 1, 4), 2)            # ldc < N
+    with pytest.raises(a2f_amd.A2FError):
+        be.gemm(A, A, A, 4, 4, 4, (0, 4, 1), (0, 1, 4), 4, split_k=2, act=1)
+    with pytest.raises(a2f_amd.A2FError):
+        be.gemm(A.cpu(), A, A, 4, 4, 4, (0, 4, 1), (0, 1, 4), 4)      # CPU tensor: no CPU path
+
+
+@pytest.mark.parametrize("B_,n", [(2, 33), (6, 15069), (64, 15069), (10, 3)])
+def test_vocaloss_fwd_bwd(B_, n):
+    pred, gt = rnd(B_, n, seed=20, scale=3.0), rnd(B_, n, seed=21, scale=3.0)
+    g3 = torch.tensor([1.0, 0.25, -0.5])
+    hip, emu = ops.HipBackend(), EmuBackend()
+    o_h, o_e = torch.empty(3, device=DEV), torch.empty(3)
+    hip.vocaloss_fwd(pred.to(DEV), gt.to(DEV), B_, n, 1.0, 10.0, o_h)
+    emu.vocaloss_fwd(pred, gt, B_, n, 1.0, 10.0, o_e)
+    assert torch.allclose(o_h.cpu(), o_e, rtol=2e-6, atol=0)
+    g_h, g_e = torch.empty(B_, n, device=DEV), torch.empty(B_, n)
+    hip.vocaloss_bwd(pred.to(DEV), gt.to(DEV), g3.to(DEV), B_, n, 1.0, 10.0, g_h)
+    emu.vocaloss_bwd(pred, gt, g3, B_, n, 1.0, 10.0, g_e)
+    assert rel_l2(g_h.cpu(), g_e) < 1e-6
+    # determinism of the forward reduction
+    o2 = torch.empty(3, device=DEV)
+    hip.vocaloss_fwd(pred.to(DEV), gt.to(DEV), B_, n, 1.0, 10.0, o2)
+    assert torch.equal(o2, o_h)
+
+
+def test_vocaloss_rejects_odd_batch():
+    be = ops.HipBackend()
+    p = torch.zeros(3, 6, device=DEV)
+    with pytest.raises(a2f_amd.A2FError):
+        be.vocaloss_fwd(p, p, 3, 6, 1.0, 10.0, torch.empty(3, device=DEV))
+
+
+def test_pack_kernels():
+    hip, emu = ops.HipBackend(), EmuBackend()
+    B_ = 9
+    x, oh = rnd(B_, 29, 16, seed=30), rnd(B_, 12, seed=31)
+    a_h, c_h = torch.zeros(B_, 16, 37, device=DEV), torch.zeros(B_, 72, device=DEV)
+    a_e, c_e = torch.zeros(B_, 16, 37), torch.zeros(B_, 72)
+    hip.voca_pack(x.to(DEV), oh.to(DEV), B_, 12, a_h, c_h)
+    emu.voca_pack(x, oh, B_, 12, a_e, c_e)
+    assert torch.equal(a_h.cpu(), a_e) and torch.equal(c_h.cpu(), c_e)
+    x2 = rnd(B_, 52, 32, seed=32)
+    a_h, c_h = torch.zeros(B_, 64, 32, device=DEV), torch.zeros(B_, 268, device=DEV)
+    a_e, c_e = torch.zeros(B_, 64, 32), torch.zeros(B_, 268)
+    hip.a2m_pack(x2.to(DEV), oh.to(DEV), B_, 12, a_h, c_h, 268, 256)
+    emu.a2m_pack(x2, oh, B_, 12, a_e, c_e, 268, 256)
+    assert torch.equal(a_h.cpu(), a_e) and torch.equal(c_h.cpu(), c_e)
+
+
+def test_adam_matches_torch_optim():
+    n = 100003
+    p0, g = rnd(n, seed=40), rnd(n, seed=41)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-4, weight_decay=1e-5)
+    be = ops.HipBackend()
+    npad = (n + 3) // 4 * 4
+    p = torch.zeros(npad, device=DEV); p[:n] = p0.to(DEV)
+    gg = torch.zeros(npad, device=DEV)
+    m, v = torch.zeros(npad, device=DEV), torch.zeros(npad, device=DEV)
+    for step in range(1, 4):
+        gs = g * step
+        ref.grad = gs.clone()
+        opt.step()
+        gg[:n] = gs.to(DEV)
+        be.adam_step(p, gg, m, v, n, 1e-4, 0.9, 0.999, 1e-8, 1e-5, 1.0, step)
+        assert rel_l2(p[:n].cpu() - p0, ref.detach() - p0) < 1e-5

@@ -1,7 +1,403 @@
-// Fused vertex head + loss + head backward (placeholder until the kernel lands; see include/a2f_hip.h).
+// Fused vertex head + VocaLoss + head backward in ONE pass over the (B, n) frame matrix (gfx950).
+//
+//   pred = H W^T + bias + template      (voca.py:48-49 / audio2face.py:65-66 / faceformer.py:181,187)
+//   rec, vel partial sums               (loss.py:29-40)
+//   G = dloss/dpred (registers only) -> dH = G W, dW = G^T H, dbias = colsum G
+//
+// HBM traffic is the algorithmic minimum: template and gt are read once, pred is written once
+// (3 x 60 276 B per frame); G is never materialised.  Everything else lives on chip:
+//
+//  * grid = CG column groups x RG row groups (<= one workgroup per CU); a workgroup = 4 waves owns 512 columns
+//    (128 per wave, four 32-column MFMA chunks) and walks its row range in blocks of 32 frames;
+//  * LDS: W slice [512][K|1] (both the forward B-operand and the dH B-operand, odd pitch = conflict-free),
+//    H^T tile [64][33], per-wave G^T staging [32][33] (also the cross-wave dH reduction buffer);
+//  * f32-input MFMA 32x32x2 (exact fp32 fma chains).  The forward accumulator tile (column on the lane, rows in
+//    the 16 registers) IS the A-operand of dW += G^T H with no data movement (k-step q takes register q; the
+//    B-operand supplies the matching frame rows); dH = G W needs G with the row on the lane: one LDS transpose
+//    per chunk inside the wave (no barrier);
+//  * dW (128 VGPR/lane) and dbias stay in registers for the whole row range; dH is reduced across the 4 waves in
+//    LDS and leaves as one partial slab per column group; slabs are folded by small reduce kernels;
+//  * template/gt for chunk i+1 are requested before the MFMAs of chunk i (one wave per SIMD: ILP hides HBM).
+//
+// n = 15069 is odd, so rows are 4-byte aligned only: global accesses are dword per lane, two 128-byte row
+// segments per wave-instruction.
 #include "a2f_common.h"
-extern "C" size_t a2f_head_fused_ws_bytes(int64_t B, int64_t n, int64_t K) { (void)B; (void)n; (void)K; return 16; }
-extern "C" int a2f_head_fused(const float*, const float*, const float*, const float*, int64_t, const float*, int64_t, int64_t, int64_t,
-                              int64_t, float, float, float*, float*, float*, float*, float*, void*, size_t, a2f_stream_t) {
-  return a2f::set_err(A2F_EINVAL, "a2f_head_fused: not implemented yet");
+
+namespace a2f {
+
+constexpr int HF_THREADS = 256;
+constexpr int HF_COLS = 512;          // columns per workgroup
+constexpr int HF_WCOLS = 128;         // columns per wave
+constexpr int HF_ROWS = 32;           // frames per row block
+constexpr int HF_KP = 64;             // K padded (two 32-wide MFMA tiles)
+constexpr int HF_HP = 33;             // pitch of the [k][row] and [col][row] LDS tiles
+
+struct HeadArgs {
+  const float* H; const float* W; const float* bias; const float* templ; const float* gt;
+  float* pred; float* dH_slab; float* dW_slab; float* db_slab; double* loss_part;
+  int64_t ldt;                         // template row stride: n, or 0 for one broadcast row
+  int B, Bloss, n, CG, RG, NRB;
+  float cr, cv;                        // 2 k_rec / (Bloss V), 2 k_vel / ((Bloss/2) V)
+};
+
+__device__ __forceinline__ int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Raw buffer access: the 128-bit resource (wave-uniform base, SGPRs) + a 32-bit per-lane byte offset.  An offset of
+// 0xFFFFFFFF is out of range for the resource: the load returns 0 and the store is dropped, which gives branch-free
+// predication on boundary tiles and keeps every address computation in 32 bits (no 64-bit pointers per element).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t tile_rsrc(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7FFFFFF0, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ void buf_store(rsrc_t r, int byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);
+}
+
+template <int K>
+__global__ __launch_bounds__(HF_THREADS, 1) void head_fused_kernel(const HeadArgs a) {
+  constexpr int PITCH = K | 1;
+  constexpr int WS_FLOATS = HF_COLS * PITCH + 64;
+  constexpr int HS_FLOATS = HF_KP * HF_HP;
+  constexpr int GS_FLOATS = HF_ROWS * HF_HP;          // per wave
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Ws = lds;
+  float* Hs = lds + WS_FLOATS;
+  float* Gs_all = Hs + HS_FLOATS;
+
+  const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);          // scalar: keeps tile base addresses in SGPRs
+  const int cg = blockIdx.x % a.CG, rg = blockIdx.x / a.CG;
+  const int c0 = cg * HF_COLS;
+  const int n = a.n, B = a.B;
+  float* Gs = Gs_all + wave * GS_FLOATS;
+
+  // ---- stage the W slice (rows = columns of pred) and clear the padding ----
+  for (int e = t; e < HF_COLS * K; e += HF_THREADS) {
+    const int col = e / K, k = e - col * K;
+    const int gc = c0 + col;
+    Ws[col * PITCH + k] = gc < n ? a.W[(int64_t)gc * K + k] : 0.f;
+  }
+  if (PITCH != K)
+    for (int col = t; col < HF_COLS; col += HF_THREADS) Ws[col * PITCH + K] = 0.f;
+  if (t < 64) Ws[HF_COLS * PITCH + t] = 0.f;
+  for (int e = t; e < HS_FLOATS; e += HF_THREADS) Hs[e] = 0.f;        // rows K..63 of H^T stay zero for ever
+
+  float bias_r[4];
+  int colg[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    colg[ct] = c0 + wave * HF_WCOLS + ct * 32 + l31;
+    bias_r[ct] = colg[ct] < n ? a.bias[colg[ct]] : 0.f;
+  }
+
+  f32x16 dW[4][2];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dW[ct][kt][r] = 0.f;
+  float db_acc[4] = {0.f, 0.f, 0.f, 0.f};
+  double rec_d = 0.0, vel_d = 0.0;                    // per-lane totals; fp32 partials are folded in once per row block
+
+  const int rb0 = (int)(((int64_t)rg * a.NRB) / a.RG);
+  const int rb1 = (int)(((int64_t)(rg + 1) * a.NRB) / a.RG);
+
+  // Tile addressing: wave-uniform tile base (SGPR pair) + 32-bit lane offset (4h*n + lane column) + r-dependent
+  // scalar row offset.  Out-of-range elements of boundary tiles read the tile's first element instead (always
+  // valid), so loads never branch; such elements are neutralised in the epilogue.
+  const int lane_off = 4 * h * n + l31;
+  const int lane_off_t = 4 * h * (int)a.ldt + l31;
+  float tc[16], gcur[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { tc[r] = 0.f; gcur[r] = 0.f; }
+  auto issue_loads = [&](int rb, int ct) {
+    const int cl = wave * HF_WCOLS + ct * 32;
+    {
+      const rsrc_t gb = tile_rsrc(a.gt + ((int64_t)rb * HF_ROWS * n + (c0 + cl)));
+      const rsrc_t tb = tile_rsrc(a.templ + ((int64_t)rb * HF_ROWS * a.ldt + (c0 + cl)));
+      const int rlim = B - rb * HF_ROWS;
+      // validity as integer masks (-1 valid / 0 invalid): pure ALU, so hipcc cannot turn the predication into branches
+      const int mcol = ((colg[ct] - n) >> 31) & ((rb - rb1) >> 31);
+      // opaque copies: stop LICM from hoisting 4 chunks x 16 rows x 3 arrays of per-lane offsets out of the row loop
+      // (that costs >200 VGPRs and spills); recomputing them is 2 VALU ops per element, hidden under the MFMAs
+      int lo = lane_off, lot = lane_off_t, h4 = 4 * h;
+      asm volatile("" : "+v"(lo), "+v"(lot), "+v"(h4));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2);         // compile-time part of the tile row; + 4h on the lane
+        const int inval = ~(mcol & ((rr + h4 - rlim) >> 31));             // -1 -> offset 0xFFFFFFFF -> load returns 0
+        tc[r] = buf_load(tb, (4 * (rr * (int)a.ldt + lot)) | inval);
+        gcur[r] = buf_load(gb, (4 * (rr * n + lo)) | inval);
+      }
+    }
+  };
+  issue_loads(rb0, 0);
+
+  for (int rb = rb0; rb < rb1; ++rb) {
+    __syncthreads();                                   // previous block's Hs / reduction-buffer readers are done
+    for (int e = t; e < HF_ROWS * K; e += HF_THREADS) {
+      const int row = e / K, k = e - row * K;
+      const int grow = rb * HF_ROWS + row;
+      Hs[k * HF_HP + row] = grow < B ? a.H[(int64_t)grow * K + k] : 0.f;
+    }
+    __syncthreads();
+
+    f32x16 dH[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dH[kt][r] = 0.f;
+    float rec = 0.f, vel = 0.f;
+
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int cl = wave * HF_WCOLS + ct * 32;        // first column of the chunk inside the slice
+      // (chunks that lie wholly beyond column n run on zeros: straight-line code keeps the 160 accumulator
+      //  registers free of control-flow copies; only the last column group has such chunks)
+      f32x16 acc;
+      {
+        // ---- forward tile: acc[row][col] = sum_k H[row][k] W[col][k] ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < K / 2; ++s) {
+          const float av = Hs[(2 * s + h) * HF_HP + l31];
+          const float bv = Ws[(cl + l31) * PITCH + 2 * s + h];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- epilogue: pred, loss partials, G (in place of acc) ----
+        const bool colok = colg[ct] < n;
+        const bool interior = ((rb + 1) * HF_ROWS <= B) && (c0 + cl + 32 <= n);     // wave-uniform
+        const int rlim = B - rb * HF_ROWS;
+        const int mint = interior ? -1 : 0;            // whole tile inside the matrix (wave-uniform)
+        const int mcolv = (colg[ct] - n) >> 31;        // -1 where this lane's column exists
+        const rsrc_t pb = tile_rsrc(a.pred + ((int64_t)rb * HF_ROWS * n + (c0 + cl)));
+        int lo = lane_off, h4 = 4 * h;
+        asm volatile("" : "+v"(lo), "+v"(h4));         // see issue_loads: keep store offsets local to the chunk
+        float gsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int rr = (r & 3) + 8 * (r >> 2);
+          const float p0 = acc[r] + bias_r[ct] + tc[r];
+          const float p1 = acc[r + 1] + bias_r[ct] + tc[r + 1];
+          buf_store(pb, (4 * (rr * n + lo)) | ~(mint | (mcolv & ((rr + h4 - rlim) >> 31))), p0);
+          buf_store(pb, (4 * ((rr + 1) * n + lo)) | ~(mint | (mcolv & ((rr + 1 + h4 - rlim) >> 31))), p1);
+          const bool in_loss = colok && (rb * HF_ROWS + rr + h4 + 1 < a.Bloss);
+          const float d0 = in_loss ? p0 - gcur[r] : 0.f;
+          const float d1 = in_loss ? p1 - gcur[r + 1] : 0.f;
+          const float dv = d1 - d0;
+          rec += d0 * d0 + d1 * d1;
+          vel += dv * dv;
+          const float g0 = a.cr * d0 - a.cv * dv;
+          const float g1 = a.cr * d1 + a.cv * dv;
+          acc[r] = g0;
+          acc[r + 1] = g1;
+          gsum += g0 + g1;
+        }
+        db_acc[ct] += gsum;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // template / gt registers are free again: request the next chunk's tile now, so the loads fly under the
+      // 64 backward MFMAs of this chunk (one wave per SIMD: ILP, not occupancy, hides HBM latency)
+      if (ct < 3) issue_loads(rb, ct + 1);
+      else issue_loads(rb + 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        // ---- dW[col][k] += sum_row G[row][col] H[row][k]: accumulator register q is the A operand of k-step q ----
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int rr = rho(q, h);
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            const float bv = Hs[(kt * 32 + l31) * HF_HP + rr];
+            dW[ct][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[q], bv, dW[ct][kt], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dH[row][k] += sum_col G[row][col] W[col][k]: transpose G through the wave's LDS tile ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Gs[l31 * HF_HP + rho(r, h)] = acc[r];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const float av = Gs[(2 * s + h) * HF_HP + l31];
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            const float bv = Ws[(cl + 2 * s + h) * PITCH + kt * 32 + l31];
+            dH[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, dH[kt], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+    rec_d += (double)rec;
+    vel_d += (double)vel;
+    // ---- fold the four waves' dH partials (two 32-wide halves) and emit this column group's slab rows ----
+    float* red = Gs_all;                                // [4][32][32] floats, reuses the staging tiles
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave * 1024 + rho(r, h) * 32 + l31] = dH[kt][r];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = t + i * HF_THREADS;               // 0..1023: row = e/32, k = e%32
+        const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+        const int row = rb * HF_ROWS + (e >> 5);
+        if (row < B) a.dH_slab[((int64_t)cg * B + row) * HF_KP + kt * 32 + (e & 31)] = v;
+      }
+    }
+  }
+
+  // ---- workgroup epilogue: dW / dbias slabs of this row group, loss partials ----
+  const int64_t ncols_pad = (int64_t)a.CG * HF_COLS;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const int cl = wave * HF_WCOLS + ct * 32;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        a.dW_slab[((int64_t)rg * ncols_pad + c0 + cl + rho(r, h)) * HF_KP + kt * 32 + l31] = dW[ct][kt][r];
+    const float s = db_acc[ct] + __shfl_xor(db_acc[ct], 32, 64);
+    if (h == 0) a.db_slab[(int64_t)rg * ncols_pad + c0 + cl + l31] = s;
+  }
+  __syncthreads();                                      // staging tiles are free: reuse them for the loss fold
+  double* lsum = reinterpret_cast<double*>(Gs_all);     // [2][4]; byte offset of Gs_all is a multiple of 8
+  const double rs = wave_sum_d(rec_d), vs = wave_sum_d(vel_d);
+  if (lane == 0) { lsum[wave] = rs; lsum[4 + wave] = vs; }
+  __syncthreads();
+  if (t == 0) {
+    a.loss_part[2 * blockIdx.x] = lsum[0] + lsum[1] + lsum[2] + lsum[3];
+    a.loss_part[2 * blockIdx.x + 1] = lsum[4] + lsum[5] + lsum[6] + lsum[7];
+  }
+}
+
+// out[r][k] = sum_s slab[s][r][k], k < K ; slab row pitch HF_KP, slab stride `sstride` floats
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nslabs, int64_t sstride, int64_t rows,
+                                                           int K, float* __restrict__ out) {
+  const int64_t total = rows * HF_KP;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int k = (int)(i & (HF_KP - 1));
+    if (k >= K) continue;
+    float v = 0.f;
+    for (int s = 0; s < nslabs; ++s) v += slab[(int64_t)s * sstride + i];
+    out[(i >> 6) * K + k] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void vec_reduce_kernel(const float* __restrict__ slab, int nslabs, int64_t sstride, int64_t len,
+                                                          float* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  float v = 0.f;
+  for (int s = 0; s < nslabs; ++s) v += slab[(int64_t)s * sstride + i];
+  out[i] = v;
+}
+
+__global__ void head_loss_finish_kernel(const double* __restrict__ part, int nparts, double inv_rec, double inv_vel, float k_rec,
+                                        float k_vel, float* __restrict__ out3) {
+  const int t = threadIdx.x;
+  double r = 0, v = 0;
+  for (int i = t; i < nparts; i += 64) { r += part[2 * i]; v += part[2 * i + 1]; }
+  r = wave_sum_d(r);
+  v = wave_sum_d(v);
+  if (t == 0) {
+    const float rec = (float)(r * inv_rec), vel = (float)(v * inv_vel);
+    out3[0] = rec * k_rec + vel * k_vel;
+    out3[1] = rec;
+    out3[2] = vel;
+  }
+}
+
+struct HeadPlan {
+  int CG, RG, NRB;
+  size_t off_dH, off_dW, off_db, off_loss, total;
+};
+
+static HeadPlan head_plan(int64_t B, int64_t n) {
+  HeadPlan p;
+  p.CG = (int)cdiv(n, HF_COLS);
+  p.NRB = (int)cdiv(B, HF_ROWS);
+  int rg = 256 / p.CG;
+  if (rg < 1) rg = 1;
+  if (rg > p.NRB) rg = p.NRB;
+  p.RG = rg;
+  size_t o = 0;
+  p.off_dH = o; o += (size_t)p.CG * (size_t)B * HF_KP * sizeof(float);
+  p.off_dW = o; o += (size_t)p.RG * (size_t)p.CG * HF_COLS * HF_KP * sizeof(float);
+  p.off_db = o; o += (size_t)p.RG * (size_t)p.CG * HF_COLS * sizeof(float);
+  o = (o + 15) & ~(size_t)15;
+  p.off_loss = o; o += (size_t)p.CG * p.RG * 2 * sizeof(double);
+  p.total = o;
+  return p;
+}
+
+template <int K>
+static int head_launch(const HeadArgs& a, const HeadPlan& p, hipStream_t s) {
+  constexpr int PITCH = K | 1;
+  const size_t lds_bytes = (size_t)(HF_COLS * PITCH + 64 + HF_KP * HF_HP + 4 * HF_ROWS * HF_HP) * sizeof(float);
+  static bool attr_set = false;       // idempotent; a benign race sets the same value
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes);
+    if (e != hipSuccess) return set_err(A2F_ELAUNCH, "head_fused: hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(head_fused_kernel<K>, dim3((unsigned)(p.CG * p.RG)), dim3(HF_THREADS), lds_bytes, s, a);
+  return A2F_OK;
+}
+
+}  // namespace a2f
+
+extern "C" size_t a2f_head_fused_ws_bytes(int64_t B, int64_t n, int64_t K) {
+  (void)K;
+  if (B <= 0 || n <= 0) return 16;
+  return a2f::head_plan(B, n).total;
+}
+
+extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias, const float* templ, int64_t template_rows,
+                              const float* gt, int64_t B, int64_t Bloss, int64_t n, int64_t K, float k_rec, float k_vel,
+                              float* pred, float* out3, float* dH, float* dW, float* dbias, void* ws, size_t ws_bytes,
+                              a2f_stream_t stream) {
+  using namespace a2f;
+  A2F_CHECK_ARG(H && W && bias && templ && gt && pred && out3 && dH && dW && dbias && ws, "head_fused: null pointer");
+  A2F_CHECK_ARG(K == 50 || K == 64, "head_fused: K=%lld unsupported (50: VOCA/Audio2Mesh bottleneck, 64: FaceFormer)", (long long)K);
+  A2F_CHECK_ARG(B >= 2 && B < (1 << 30), "head_fused: B=%lld", (long long)B);
+  A2F_CHECK_ARG(Bloss >= 2 && (Bloss % 2) == 0 && Bloss <= B, "head_fused: Bloss=%lld must be even, >= 2 and <= B (loss.py:13-15,33-35)", (long long)Bloss);
+  A2F_CHECK_ARG(n >= 3 && (n % 3) == 0 && n < (1 << 30), "head_fused: n=%lld must be a multiple of 3", (long long)n);
+  A2F_CHECK_ARG(template_rows == 1 || template_rows == B, "head_fused: template_rows must be 1 or B");
+  const HeadPlan p = head_plan(B, n);
+  if (ws_bytes < p.total) return set_err(A2F_EWORKSPACE, "head_fused: workspace %zu < %zu", ws_bytes, p.total);
+  hipStream_t s = (hipStream_t)stream;
+  char* w8 = (char*)ws;
+  HeadArgs a;
+  a.H = H; a.W = W; a.bias = bias; a.templ = templ; a.gt = gt; a.pred = pred;
+  a.dH_slab = (float*)(w8 + p.off_dH); a.dW_slab = (float*)(w8 + p.off_dW); a.db_slab = (float*)(w8 + p.off_db);
+  a.loss_part = (double*)(w8 + p.off_loss);
+  a.ldt = template_rows == 1 ? 0 : n;
+  a.B = (int)B; a.Bloss = (int)Bloss; a.n = (int)n; a.CG = p.CG; a.RG = p.RG; a.NRB = p.NRB;
+  const double V = (double)(n / 3);
+  a.cr = (float)(2.0 * k_rec / ((double)Bloss * V));
+  a.cv = (float)(2.0 * k_vel / ((double)(Bloss / 2) * V));
+  int rc = (K == 50) ? head_launch<50>(a, p, s) : head_launch<64>(a, p, s);
+  if (rc != A2F_OK) return rc;
+  const int64_t ncols_pad = (int64_t)p.CG * HF_COLS;
+  {
+    int64_t blocks = cdiv(B * HF_KP, 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.dH_slab, p.CG, (int64_t)B * HF_KP, B, (int)K, dH);
+    blocks = cdiv(n * HF_KP, 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.dW_slab, p.RG, ncols_pad * HF_KP, n, (int)K, dW);
+    hipLaunchKernelGGL(vec_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const float*)a.db_slab, p.RG, ncols_pad, n, dbias);
+    hipLaunchKernelGGL(head_loss_finish_kernel, dim3(1), dim3(64), 0, s, (const double*)a.loss_part, p.CG * p.RG,
+                       1.0 / ((double)Bloss * V), 1.0 / ((double)(Bloss / 2) * V), k_rec, k_vel, out3);
+  }
+  A2F_CHECK_LAUNCH("head_fused");
+  return A2F_OK;
 }

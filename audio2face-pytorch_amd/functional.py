@@ -303,3 +303,136 @@ class A2MTrunkFn(torch.autograd.Function):
             Wd *= 2
         ctx.sv = None
         return (None, None, None) + (None,) * 20 + tuple(g_conv) + tuple(g_bn) + tuple(g_fc)
+
+
+# =================================================================================================
+# Fused head + loss + head backward (single pass over the frame matrix; see csrc/head_fused.hip)
+# =================================================================================================
+class HeadLossFusedFn(torch.autograd.Function):
+    """(H (B,K), W (n,K), b (n), template (B,n)|(1,n), gt (B,n), Bloss, k_rec, k_vel) -> (pred (B,n), out3).
+
+    out3 = [loss, rec_loss, vel_loss].  The head gradients for d(loss) are produced by the same kernel pass that
+    writes pred (G = dloss/dpred never exists in memory); backward only scales them by the incoming d/d(loss).
+    pred is returned for metrics / prediction and is NOT differentiable on this path, nor are rec/vel separately
+    (use HeadFn + VocaLossFn for arbitrary graphs).
+    """
+
+    @staticmethod
+    def forward(ctx, H, W, b, template, gt, Bloss, k_rec, k_vel):
+        be = ops.backend()
+        B, K = H.shape
+        n = W.shape[0]
+        Hc, Wc, bc = _f32c(H), _f32c(W), _f32c(b)
+        tc, gc = _f32c(template).reshape(-1, n), _f32c(gt).reshape(B, n)
+        dev = Hc.device
+        pred = torch.empty(B, n, device=dev, dtype=torch.float32)
+        out3 = torch.empty(3, device=dev, dtype=torch.float32)
+        dH = torch.empty(B, K, device=dev, dtype=torch.float32)
+        dW = torch.empty(n, K, device=dev, dtype=torch.float32)
+        db = torch.empty(n, device=dev, dtype=torch.float32)
+        be.head_fused(Hc, Wc, bc, tc, tc.shape[0], gc, B, int(Bloss), n, K, float(k_rec), float(k_vel), pred, out3, dH, dW, db)
+        ctx.save_for_backward(dH, dW, db)
+        ctx.mark_non_differentiable(pred)
+        return pred, out3
+
+    @staticmethod
+    def backward(ctx, _gpred, g3):
+        dH, dW, db = ctx.saved_tensors
+        g = g3[0]                        # d/d(loss); stays on device
+        return dH * g, dW * g, db * g, None, None, None, None, None
+
+
+# =================================================================================================
+# Generic Linear / matmul on the HIP GEMM (FaceFormer projections, collapsed feedback matrix)
+# =================================================================================================
+class LinearFn(torch.autograd.Function):
+    """y = x W^T (+ b);  x (M,K), W (N,K), b (N) or None."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        be = ops.backend()
+        xc, Wc = _f32c(x), _f32c(W)
+        bc = _f32c(b) if b is not None else None
+        M, K = xc.shape
+        N = Wc.shape[0]
+        y = torch.empty(M, N, device=xc.device, dtype=torch.float32)
+        ops.linear_fwd(be, xc, Wc, bc, y, M, N, K)
+        ctx.save_for_backward(xc, Wc)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = ops.backend()
+        xc, Wc = ctx.saved_tensors
+        M, K = xc.shape
+        N = Wc.shape[0]
+        dy = _f32c(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+            ops.linear_bwd_input(be, dy, Wc, dx, M, N, K)
+        dW = torch.zeros(N, K, device=dy.device, dtype=torch.float32)
+        db = torch.zeros(N, device=dy.device, dtype=torch.float32)
+        ops.linear_bwd_weight(be, dy, xc, dW, db, M, N, K)
+        return dx, dW, (db if ctx.has_bias else None)
+
+
+class MatmulFn(torch.autograd.Function):
+    """C = A B;  A (M,K), B (K,N), both row-major."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        be = ops.backend()
+        Ac, Bc = _f32c(A), _f32c(B)
+        M, K = Ac.shape
+        N = Bc.shape[1]
+        Cm = torch.zeros(M, N, device=Ac.device, dtype=torch.float32)
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        be.gemm(Ac, Bc, Cm, M, N, K, (0, K, 1), (0, N, 1), N, split_k=ops.split_k_for(K, tiles))
+        ctx.save_for_backward(Ac, Bc)
+        return Cm
+
+    @staticmethod
+    def backward(ctx, dC):
+        be = ops.backend()
+        Ac, Bc = ctx.saved_tensors
+        M, K = Ac.shape
+        N = Bc.shape[1]
+        dC = _f32c(dC)
+        dA = torch.empty(M, K, device=dC.device, dtype=torch.float32)
+        be.gemm(dC, Bc, dA, M, K, N, (0, N, 1), (0, 1, N), K)                    # dA = dC B^T
+        dB = torch.empty(K, N, device=dC.device, dtype=torch.float32)
+        be.gemm(Ac, dC, dB, K, N, M, (0, 1, K), (0, N, 1), N)                    # dB = A^T dC
+        return dA, dB
+
+
+# =================================================================================================
+# FaceFormer decoder recurrence   (reference: src/model/faceformer.py:154-185, evaluated incrementally)
+# =================================================================================================
+class FFDecoderFn(torch.autograd.Function):
+    """(params block (A2F_FF_PARAM_FLOATS,), pe (period,64), cross (S,T,64), style (S,64)) -> y (S,T,64)."""
+
+    @staticmethod
+    def forward(ctx, params, pe, cross, style, period):
+        be = ops.backend()
+        pc, pec, cc, sc = _f32c(params), _f32c(pe), _f32c(cross), _f32c(style)
+        S, T, _ = cc.shape
+        y = torch.empty(S, T, 64, device=cc.device, dtype=torch.float32)
+        save = torch.empty(be.ff_save_floats(S, T), device=cc.device, dtype=torch.float32)
+        be.ff_decoder_fwd(pc, pec, cc, sc, S, T, int(period), y, save)
+        ctx.save_for_backward(pc, save)
+        ctx.dims = (S, T, int(period))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = ops.backend()
+        pc, save = ctx.saved_tensors
+        S, T, period = ctx.dims
+        dy = _f32c(dy)
+        dparams = torch.zeros_like(pc)
+        dcross = torch.empty(S, T, 64, device=dy.device, dtype=torch.float32)
+        dstyle = torch.empty(S, 64, device=dy.device, dtype=torch.float32)
+        be.ff_decoder_bwd(pc, dy, S, T, period, save, dparams, dcross, dstyle)
+        return dparams, None, dcross, dstyle, None

@@ -1,0 +1,124 @@
+"""Drop-in ``Faceformer`` (reference: /root/reference/src/model/faceformer.py:92-191) on the HIP hot path.
+
+Same constructor signature, sub-module / parameter names and shapes (``audio_encoder.*`` follows HF wav2vec2 keys,
+``transformer_decoder.layers.0.*`` follows nn.TransformerDecoderLayer), zero-initialised vertice maps, and
+``forward(audio, one_hot, template, **kwargs)`` -> (1, T, V, 3) / ``predict``.
+
+What differs is how the same function is evaluated: the reference re-runs the decoder and the
+64->15069 map on the growing prefix every step (O(T^3), faceformer.py:154-185); here the decoder is ONE persistent HIP
+kernel per sequence with a K/V cache, the diagonal cross-attention is a per-frame vector computed by two GEMMs, the
+feedback ``vertice_map(vertice_map_r(y))`` is the collapsed 64x64 map ``A y + c``, and the 15069-wide head runs once
+per frame (fused with the loss in training).  Closed forms replace the materialised (4,600,600) bias table and the
+660-row PPE buffer, so T is not limited to 600.  Dropout is not applied (the reference is stochastic in train mode;
+parity is defined for dropout off) - see DESIGN.md.
+
+The constructor does not download anything: the reference's ``from_pretrained`` calls need the network; load
+pretrained wav2vec2 weights with ``model.audio_encoder.load_state_dict(...)`` (HF key names).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from ..functional import FFDecoderFn, HeadFn, HeadLossFusedFn, LinearFn, MatmulFn
+from .wav2vec import Wav2Vec2Model, normalize_waveform
+
+
+class PeriodicPositionalEncoding(nn.Module):
+    """faceformer.py:70-88; kept as a module so the ``PPE.pe`` buffer exists under the reference's name."""
+
+    def __init__(self, d_model, dropout=0.1, period=25, max_seq_len=600):
+        super().__init__()
+        pe = torch.zeros(period, d_model)
+        position = torch.arange(0, period, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.period = period
+        self.register_buffer("pe", pe.unsqueeze(0).repeat(1, max_seq_len // period + 1, 1))
+
+    def table(self):
+        return self.pe[0, : self.period]          # one period; the kernel indexes it with i mod period
+
+
+class Faceformer(nn.Module):
+    def __init__(self, n_verts: int, n_onehot: int, audio_encoder: nn.Module | None = None):
+        super().__init__()
+        self.feature_dim = 64
+        self.n_onehot = n_onehot
+        self.dataset = "vocaset"
+        self.period = 60
+        self.vertice_dim = n_verts
+        self.audio_encoder = audio_encoder if audio_encoder is not None else Wav2Vec2Model()
+        self.audio_feature_map = nn.Linear(768, self.feature_dim)
+        self.vertice_map = nn.Linear(self.vertice_dim, self.feature_dim)
+        self.PPE = PeriodicPositionalEncoding(self.feature_dim, period=self.period)
+        decoder_layer = nn.TransformerDecoderLayer(d_model=self.feature_dim, nhead=4, dim_feedforward=2 * self.feature_dim,
+                                                   batch_first=True)
+        self.transformer_decoder = nn.TransformerDecoder(decoder_layer, num_layers=1)      # parameter container only
+        self.vertice_map_r = nn.Linear(self.feature_dim, self.vertice_dim)
+        self.obj_vector = nn.Linear(self.n_onehot, self.feature_dim, bias=False)
+        for lin in (self.vertice_map_r, self.vertice_map):                                  # faceformer.py:132-135
+            nn.init.constant_(lin.weight, 0)
+            nn.init.constant_(lin.bias, 0)
+
+    # ------------------------------------------------------------------ pieces
+    def _packed_decoder_params(self):
+        """Decoder weights + collapsed feedback in the C-ABI block layout (a2f_hip.h: A2F_FF_*); autograd flows through
+        the concatenation back to the individual parameters."""
+        L = self.transformer_decoder.layers[0]
+        Wm, bm = self.vertice_map.weight, self.vertice_map.bias
+        Wr, br = self.vertice_map_r.weight, self.vertice_map_r.bias
+        A = MatmulFn.apply(Wm, Wr)                                          # (64,64) = Wm Wr
+        c = MatmulFn.apply(Wm, br.reshape(-1, 1)).reshape(-1) + bm           # Wm br + bm
+        parts = [L.self_attn.in_proj_weight, L.self_attn.in_proj_bias, L.self_attn.out_proj.weight, L.self_attn.out_proj.bias,
+                 L.linear1.weight, L.linear1.bias, L.linear2.weight, L.linear2.bias,
+                 L.norm1.weight, L.norm1.bias, L.norm2.weight, L.norm2.bias, L.norm3.weight, L.norm3.bias, A, c]
+        return torch.cat([p.reshape(-1) for p in parts])
+
+    def encode(self, audio, frame_num):
+        wave = normalize_waveform(audio)                                     # audio_preprocessor, faceformer.py:142-144
+        return self.audio_encoder(wave, self.dataset, frame_num=frame_num).last_hidden_state
+
+    def decode_hidden(self, enc, one_hot):
+        """enc (S,T,768), one_hot (S,n_onehot) -> decoder rows y (S,T,64)."""
+        S, T, _ = enc.shape
+        L = self.transformer_decoder.layers[0]
+        d = self.feature_dim
+        mem = LinearFn.apply(enc.reshape(S * T, -1), self.audio_feature_map.weight, self.audio_feature_map.bias)     # :152
+        mw, mb = L.multihead_attn.in_proj_weight, L.multihead_attn.in_proj_bias
+        v = LinearFn.apply(mem, mw[2 * d:], mb[2 * d:])                      # diagonal enc-dec mask: softmax over one key
+        cross = LinearFn.apply(v, L.multihead_attn.out_proj.weight, L.multihead_attn.out_proj.bias).view(S, T, d)
+        style = LinearFn.apply(one_hot, self.obj_vector.weight, None)       # (S,64)  :148
+        return FFDecoderFn.apply(self._packed_decoder_params(), self.PPE.table(), cross, style, self.period)
+
+    # ------------------------------------------------------------------ reference surface
+    def forward(self, audio, one_hot, template, **kwargs):
+        frame_num = audio.shape[1] * 60 // 16000                             # faceformer.py:141
+        enc = kwargs.get("encoder_states")
+        if enc is None:
+            enc = self.encode(audio, frame_num)
+        y = self.decode_hidden(enc, one_hot)                                 # (1,T,64)
+        T = y.shape[1]
+        pred = HeadFn.apply(y.reshape(T, -1), self.vertice_map_r.weight, self.vertice_map_r.bias, template.reshape(1, -1))
+        return pred.view(1, T, -1, 3)
+
+    def predict(self, audio, one_hot, template, **kwargs):
+        return self(audio, one_hot, template, **kwargs)
+
+    def forward_with_loss(self, audio, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0, **kwargs):
+        """Training fast path = forward + FaceFormerLoss (loss.py:4-17) with the head, the loss and the head backward
+        fused into one pass; the odd tail frame is predicted but left out of the loss, as the reference does."""
+        frame_num = audio.shape[1] * 60 // 16000
+        enc = kwargs.get("encoder_states")
+        if enc is None:
+            enc = self.encode(audio, frame_num)
+        y = self.decode_hidden(enc, one_hot)
+        T = y.shape[1]
+        if T < 2:
+            raise RuntimeError("FaceFormerLoss needs at least 2 frames")
+        pred, out3 = HeadLossFusedFn.apply(y.reshape(T, -1), self.vertice_map_r.weight, self.vertice_map_r.bias,
+                                           template.reshape(1, -1), gt.reshape(T, -1), T - (T % 2), k_rec, k_vel)
+        return pred.view(1, T, -1, 3), {"loss": out3[0], "rec_loss": out3[1].detach(), "vel_loss": out3[2].detach()}

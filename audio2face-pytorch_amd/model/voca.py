@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..functional import HeadFn, VocaTrunkFn, VOCA_CONVS
+from ..functional import HeadFn, HeadLossFusedFn, VocaTrunkFn, VOCA_CONVS
 
 _FC = ((72, 72), (72, 128), None, (128, 50))        # decoder slots 0,1,(2 = Tanh),3; slot 4 is the vertex head
 
@@ -48,3 +48,17 @@ class Voca(nn.Module):
 
     def predict(self, x, one_hot, template, **kwargs):
         return self(x, one_hot, template, **kwargs)
+
+    def forward_with_loss(self, x, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0):
+        """Training fast path: model forward + VocaLoss + head backward fused into one pass over the frame matrix.
+
+        Returns (pred (B,V,3) detached, {"loss","rec_loss","vel_loss"}); only "loss" carries gradient.  Numerically the
+        same function as ``VocaLoss(k_rec,k_vel)(self(x, one_hot, template), gt)``.
+        """
+        bs = x.size(0)
+        if bs % 2 != 0:
+            raise RuntimeError(f"VocaLoss pairs consecutive frames (loss.py:33-35): batch {bs} must be even")
+        h3 = self.trunk(x, one_hot)
+        pred, out3 = HeadLossFusedFn.apply(h3, self.decoder[4].weight, self.decoder[4].bias, template.reshape(bs, -1),
+                                           gt.reshape(bs, -1), bs, k_rec, k_vel)
+        return pred.view(bs, -1, 3), {"loss": out3[0], "rec_loss": out3[1].detach(), "vel_loss": out3[2].detach()}

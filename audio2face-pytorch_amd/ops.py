@@ -144,16 +144,15 @@ class HipBackend:
     def ff_save_floats(self, S, T):
         return self.lib.a2f_ff_save_bytes(S, T) // 4
 
-    def ff_decoder_fwd(self, params, cross, style, S, T, period, y, save):
-        _chk(params, cross, style, y, save)
-        _lib.check(self.lib.a2f_ff_decoder_fwd(_ptr(params), _ptr(cross), _ptr(style), S, T, period, _ptr(y), _ptr(save),
+    def ff_decoder_fwd(self, params, pe, cross, style, S, T, period, y, save):
+        _chk(params, pe, cross, style, y, save)
+        _lib.check(self.lib.a2f_ff_decoder_fwd(_ptr(params), _ptr(pe), _ptr(cross), _ptr(style), S, T, period, _ptr(y), _ptr(save),
                                                save.numel() * 4, self._stream(y)), "a2f_ff_decoder_fwd")
 
-    def ff_decoder_bwd(self, params, cross, style, dy, S, T, period, save, dparams, dcross, dstyle):
-        _chk(params, cross, style, dy, save, dparams, dcross, dstyle)
-        _lib.check(self.lib.a2f_ff_decoder_bwd(_ptr(params), _ptr(cross), _ptr(style), _ptr(dy), S, T, period, _ptr(save),
-                                               save.numel() * 4, _ptr(dparams), _ptr(dcross), _ptr(dstyle),
-                                               self._stream(dy)), "a2f_ff_decoder_bwd")
+    def ff_decoder_bwd(self, params, dy, S, T, period, save, dparams, dcross, dstyle):
+        _chk(params, dy, save, dparams, dcross, dstyle)
+        _lib.check(self.lib.a2f_ff_decoder_bwd(_ptr(params), _ptr(dy), S, T, period, _ptr(save), save.numel() * 4,
+                                               _ptr(dparams), _ptr(dcross), _ptr(dstyle), self._stream(dy)), "a2f_ff_decoder_bwd")
 
     # ---- optimiser ----------------------------------------------------------------------------
     def adam_step(self, p, g, m, v, n, lr, b1, b2, eps, wd, grad_scale, step):

@@ -65,9 +65,11 @@ class FlatAdam:
 class TrainStep:
     """fwd -> loss -> bwd -> (all-reduce) -> Adam, mirroring Audio2FaceModel.training_step + configure_optimizers."""
 
-    def __init__(self, model: torch.nn.Module, loss_fn, lr: float, process_group=None):
+    def __init__(self, model: torch.nn.Module, loss_fn, lr: float, process_group=None, fused: bool = True):
         self.model = model
         self.loss_fn = loss_fn
+        # fused = head + loss + head-backward in one HIP pass when the model offers it and the loss is the stock VocaLoss
+        self.fused = fused and hasattr(model, "forward_with_loss") and type(loss_fn).__name__ in ("VocaLoss", "FaceFormerLoss")
         self.opt = FlatAdam(model.parameters(), lr=lr, weight_decay=lr / 10, process_group=process_group)
 
     @staticmethod
@@ -79,8 +81,12 @@ class TrainStep:
 
     def __call__(self, x, one_hot, gt, template) -> Dict[str, torch.Tensor]:
         self.opt.zero_grad()
-        pred = self.model(x, one_hot, template)
-        loss = self.loss_fn(pred, gt)
+        if self.fused:
+            lf = getattr(self.loss_fn, "loss", self.loss_fn)          # FaceFormerLoss wraps a VocaLoss
+            _pred, loss = self.model.forward_with_loss(x, one_hot, template, gt, lf.k_rec, lf.k_vel)
+        else:
+            pred = self.model(x, one_hot, template)
+            loss = self.loss_fn(pred, gt)
         loss["loss"].backward()
         self.opt.step()
         # mse_error (lightning_model.py:119-125) == rec_loss / 3 for 3-vectors: no extra pass over pred/gt

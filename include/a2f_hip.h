@@ -163,13 +163,14 @@ enum {
   A2F_FF_PARAM_FLOATS = A2F_FF_C + 64
 };
 size_t a2f_ff_save_bytes(int64_t S, int64_t T);
-int a2f_ff_decoder_fwd(const float* params, const float* cross, const float* style, int64_t S, int64_t T,
+/* pe: (period, 64) periodic positional-encoding table (faceformer.py:74-80), computed by the caller exactly as the
+ * reference builds it. */
+int a2f_ff_decoder_fwd(const float* params, const float* pe, const float* cross, const float* style, int64_t S, int64_t T,
                        int32_t period, float* y, void* save, size_t save_bytes, a2f_stream_t stream);
-/* dy (S,T,64) -> dparams (A2F_FF_PARAM_FLOATS, accumulated with atomics into a zeroed block),
- * dcross (S,T,64), dstyle (S,64). */
-int a2f_ff_decoder_bwd(const float* params, const float* cross, const float* style, const float* dy,
-                       int64_t S, int64_t T, int32_t period, const void* save, size_t save_bytes,
-                       float* dparams, float* dcross, float* dstyle, a2f_stream_t stream);
+/* dy (S,T,64) -> dparams (A2F_FF_PARAM_FLOATS, accumulated with atomics: the caller zeroes it), dcross (S,T,64),
+ * dstyle (S,64).  `save` is the forward's buffer; its dK/dV accumulator columns are scratch for this call. */
+int a2f_ff_decoder_bwd(const float* params, const float* dy, int64_t S, int64_t T, int32_t period, void* save,
+                       size_t save_bytes, float* dparams, float* dcross, float* dstyle, a2f_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused Adam step on flat fp32 buffers (torch.optim.Adam semantics as configured at

@@ -200,24 +200,19 @@ class EmuBackend:
         return Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, ln, A, c
 
     @classmethod
-    def ff_spec(cls, params, cross, style, period):
+    def ff_spec(cls, params, pe, cross, style, period):
         """Differentiable torch statement of the recurrence the HIP kernel implements (double precision)."""
         import torch.nn.functional as F
         Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, ln, A, c = cls._ff_unpack(params)
         S, T, D = cross.shape
         H, hd = 4, 16
         slopes = torch.tensor([2.0 ** (-2 * (h + 1)) for h in range(H)], dtype=params.dtype)
-        i2 = torch.arange(0, D, 2, dtype=params.dtype)
-        div = torch.exp(i2 * (-math.log(10000.0) / D))
         ys = []
         for s in range(S):
             ks, vs, rows = [], [], []
             emb = style[s]
             for i in range(T):
-                pos = float(i % period)
-                pe = torch.zeros(D, dtype=params.dtype)
-                pe[0::2] = torch.sin(pos * div); pe[1::2] = torch.cos(pos * div)
-                x = emb + pe
+                x = emb + pe[i % period]
                 qkv = F.linear(x, Wqkv, bqkv)
                 q = qkv[:D].view(H, hd) * 0.25
                 ks.append(qkv[D:2 * D]); vs.append(qkv[2 * D:])
@@ -236,19 +231,22 @@ class EmuBackend:
         return torch.stack(ys)
 
     def ff_save_floats(self, S, T):
-        return 1
+        return S * T * 64 * 2 + 8          # the emulator keeps (cross, style-free) inputs it needs for its autograd replay
 
-    def ff_decoder_fwd(self, params, cross, style, S, T, period, y, save):
+    def ff_decoder_fwd(self, params, pe, cross, style, S, T, period, y, save):
         with torch.no_grad():
-            out = self.ff_spec(params.double(), cross.reshape(S, T, 64).double(), style.reshape(S, 64).double(), period)
+            out = self.ff_spec(params.double(), pe.double(), cross.reshape(S, T, 64).double(), style.reshape(S, 64).double(), period)
         y.reshape(S, T, 64).copy_(out.float())
+        self._ff_ctx = (pe.clone(), cross.reshape(S, T, 64).clone(), style.reshape(S, 64).clone())
 
-    def ff_decoder_bwd(self, params, cross, style, dy, S, T, period, save, dparams, dcross, dstyle):
-        p = params.double().requires_grad_(True)
-        cr = cross.reshape(S, T, 64).double().requires_grad_(True)
-        st = style.reshape(S, 64).double().requires_grad_(True)
-        out = self.ff_spec(p, cr, st, period)
-        out.backward(dy.reshape(S, T, 64).double())
+    def ff_decoder_bwd(self, params, dy, S, T, period, save, dparams, dcross, dstyle):
+        pe, cross, style = self._ff_ctx
+        with torch.enable_grad():                       # we are called from inside an autograd backward
+            p = params.detach().double().requires_grad_(True)
+            cr = cross.detach().double().requires_grad_(True)
+            st = style.detach().double().requires_grad_(True)
+            out = self.ff_spec(p, pe.double(), cr, st, period)
+            out.backward(dy.reshape(S, T, 64).double())
         dparams.add_(p.grad.float()); dcross.reshape(S, T, 64).copy_(cr.grad.float()); dstyle.reshape(S, 64).copy_(st.grad.float())
 
     # ------------------------------------------------------------------ Adam

@@ -199,3 +199,87 @@ def test_adam_matches_torch_optim():
         gg[:n] = gs.to(DEV)
         be.adam_step(p, gg, m, v, n, 1e-4, 0.9, 0.999, 1e-8, 1e-5, 1.0, step)
         assert rel_l2(p[:n].cpu() - p0, ref.detach() - p0) < 1e-5
+
+
+@pytest.mark.parametrize("B_,n,K,trows,Bloss", [(4, 15069, 50, 4, 4), (70, 1536, 50, 70, 70), (64, 999, 64, 1, 64), (33, 600, 64, 1, 32),
+                                                 (2, 3, 50, 2, 2), (130, 15069, 64, 1, 130), (256, 15069, 50, 256, 256)])
+def test_head_fused_vs_contract(B_, n, K, trows, Bloss):
+    hip, emu = ops.HipBackend(), EmuBackend()
+    H, Wt, bias = rnd(B_, K, seed=50), rnd(n, K, seed=51, scale=0.3), rnd(n, seed=52)
+    templ = rnd(trows, n, seed=53, scale=5.0)
+    gt = (templ if trows == B_ else templ.expand(B_, n)) + rnd(B_, n, seed=54, scale=0.5)
+    outs = []
+    for be, dev in ((hip, DEV), (emu, "cpu")):
+        pred = torch.full((B_, n), float("nan"), device=dev)
+        out3 = torch.empty(3, device=dev)
+        dH, dW, db = torch.full((B_, K), float("nan"), device=dev), torch.full((n, K), float("nan"), device=dev), torch.full((n,), float("nan"), device=dev)
+        be.head_fused(H.to(dev), Wt.to(dev), bias.to(dev), templ.to(dev), trows, gt.contiguous().to(dev), B_, Bloss, n, K, 1.0, 10.0,
+                      pred, out3, dH, dW, db)
+        outs.append([t.cpu() for t in (pred, out3, dH, dW, db)])
+    (p_h, o_h, dH_h, dW_h, db_h), (p_e, o_e, dH_e, dW_e, db_e) = outs
+    assert rel_l2(p_h, p_e) < 2e-6
+    assert torch.allclose(o_h, o_e, rtol=2e-5, atol=0)
+    assert rel_l2(dH_h, dH_e) < 2e-5
+    assert rel_l2(dW_h, dW_e) < 2e-5
+    assert rel_l2(db_h, db_e) < 2e-5
+
+
+def test_head_fused_rejects_bad_arguments():
+    be = ops.HipBackend()
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    with pytest.raises(a2f_amd.A2FError):       # unsupported K
+        be.head_fused(z(4, 32), z(30, 32), z(30), z(4, 30), 4, z(4, 30), 4, 4, 30, 32, 1.0, 10.0, z(4, 30), z(3), z(4, 32), z(30, 32), z(30))
+    with pytest.raises(a2f_amd.A2FError):       # odd Bloss
+        be.head_fused(z(4, 50), z(30, 50), z(30), z(4, 30), 4, z(4, 30), 4, 3, 30, 50, 1.0, 10.0, z(4, 30), z(3), z(4, 50), z(30, 50), z(30))
+
+
+@pytest.mark.parametrize("R,C", [(7, 3), (1000, 72), (4096, 108), (333, 162), (2049, 243), (512, 256), (5, 1000)])
+@pytest.mark.parametrize("training,relu", [(True, True), (True, False), (False, True)])
+def test_batchnorm_fwd_bwd(R, C, training, relu):
+    hip, emu = ops.HipBackend(), EmuBackend()
+    x = rnd(R, C, seed=60, scale=2.0) + 0.5
+    gamma, beta = rnd(C, seed=61) * 0.1 + 1.0, rnd(C, seed=62) * 0.1
+    rm0, rv0 = rnd(C, seed=63) * 0.1, rnd(C, seed=64).abs() + 0.5
+    dy = rnd(R, C, seed=65)
+    res = []
+    for be, dev in ((hip, DEV), (emu, "cpu")):
+        rm, rv = rm0.clone().to(dev), rv0.clone().to(dev)
+        y, mu, istd = torch.empty(R, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+        be.bn_fwd(x.to(dev), R, C, gamma.to(dev), beta.to(dev), rm, rv, 0.1, 1e-5, training, relu, y, mu, istd)
+        dx, dg, dbt = torch.empty(R, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+        be.bn_bwd(x.to(dev), y, dy.to(dev), R, C, gamma.to(dev), mu, istd, training, relu, dx, dg, dbt)
+        res.append([t.cpu() for t in (y, rm, rv, dx, dg, dbt)])
+    for name, a, b in zip(("y", "running_mean", "running_var", "dx", "dgamma", "dbeta"), res[0], res[1]):
+        assert rel_l2(a, b) < 2e-5, name
+
+
+@pytest.mark.parametrize("S,T,period", [(1, 5, 60), (3, 70, 60), (2, 33, 7)])
+def test_ff_decoder_kernels_vs_spec(S, T, period):
+    """Recurrence forward + reverse-time backward against autograd on the float64 statement of the same recurrence."""
+    from a2f_amd._lib import load as _load
+    nP = 192 * 64 + 192 + 64 * 64 + 64 + 128 * 64 + 128 + 64 * 128 + 64 + 6 * 64 + 64 * 64 + 64
+    P = rnd(nP, seed=70, scale=0.12)
+    o_ln = 192 * 64 + 192 + 64 * 64 + 64 + 128 * 64 + 128 + 64 * 128 + 64
+    P[o_ln:o_ln + 64] += 1.0; P[o_ln + 128:o_ln + 192] += 1.0; P[o_ln + 256:o_ln + 320] += 1.0       # LayerNorm gains near 1
+    P[o_ln + 384:o_ln + 384 + 64 * 64] *= 0.3                                                           # contractive feedback
+    pe = rnd(period, 64, seed=71)
+    cross, style, dy = rnd(S, T, 64, seed=72), rnd(S, 64, seed=73), rnd(S, T, 64, seed=74)
+    hip, emu = ops.HipBackend(), EmuBackend()
+    y_h = torch.empty(S, T, 64, device=DEV)
+    save = torch.empty(hip.ff_save_floats(S, T), device=DEV)
+    hip.ff_decoder_fwd(P.to(DEV), pe.to(DEV), cross.to(DEV), style.to(DEV), S, T, period, y_h, save)
+    y_e = torch.empty(S, T, 64)
+    emu.ff_decoder_fwd(P, pe, cross, style, S, T, period, y_e, None)
+    assert rel_l2(y_h.cpu(), y_e) < 2e-5
+    dP_h, dc_h, ds_h = torch.zeros(nP, device=DEV), torch.empty(S, T, 64, device=DEV), torch.empty(S, 64, device=DEV)
+    hip.ff_decoder_bwd(P.to(DEV), dy.to(DEV), S, T, period, save, dP_h, dc_h, ds_h)
+    dP_e, dc_e, ds_e = torch.zeros(nP), torch.empty(S, T, 64), torch.empty(S, 64)
+    emu.ff_decoder_bwd(P, dy, S, T, period, None, dP_e, dc_e, ds_e)
+    assert rel_l2(dc_h.cpu(), dc_e) < 1e-4
+    assert rel_l2(ds_h.cpu(), ds_e) < 1e-4
+    names = [("Wqkv", 192 * 64), ("bqkv", 192), ("Wo", 4096), ("bo", 64), ("W1", 8192), ("b1", 128), ("W2", 8192), ("b2", 64),
+             ("ln", 384), ("A", 4096), ("c", 64)]
+    o = 0
+    for nm, sz_ in names:
+        assert rel_l2(dP_h.cpu()[o:o + sz_], dP_e[o:o + sz_]) < 1e-4, nm
+        o += sz_

@@ -87,3 +87,154 @@ def test_cpu_tensors_fail_loudly():
     m = a2f_amd.Voca(n_verts=NV, n_onehot=12)
     with pytest.raises(a2f_amd.A2FError):
         m(torch.zeros(2, 29, 16), torch.zeros(2, 12), torch.zeros(2, 5023, 3))
+
+
+def test_voca_fused_step_golden_g1():
+    g = load("g1_voca")
+    m, _ = _voca()
+    B = 4
+    x = W.formula_input("g1.x", (B, 29, 16)).to(DEV)
+    one_hot = torch.from_numpy(g["one_hot"]).to(DEV)
+    template = W.formula_input("g1.template", (B, 5023, 3), 5.0)
+    gt = (template + W.formula_input("g1.gt", (B, 5023, 3), 0.5)).to(DEV)
+    pred, loss = m.forward_with_loss(x, one_hot, template.to(DEV), gt)
+    assert packed_error(g, "pred", pred) < TOL
+    for k in ("loss", "rec_loss", "vel_loss"):
+        assert abs(float(loss[k].detach()) - float(g["loss::" + k])) <= 1e-5 * abs(float(g["loss::" + k]))
+    loss["loss"].backward()
+    for k, p in m.named_parameters():
+        assert packed_error(g, "grad::" + k, p.grad) < TOL, k
+
+
+def test_voca_fused_equals_unfused_large():
+    """Fused single-pass head+loss+backward vs the separate kernels at a bench-like shape (B = 2 x 600 frames)."""
+    torch.manual_seed(0)
+    m1, _ = _voca()
+    m2, _ = _voca()
+    B = 1200
+    x = torch.randn(B, 29, 16, device=DEV)
+    oh = torch.zeros(B, 12, device=DEV); oh[torch.arange(B), torch.arange(B) % 8] = 1
+    t = torch.randn(B, 5023, 3, device=DEV) * 5
+    gt = t + torch.randn(B, 5023, 3, device=DEV) * 0.5
+    l1 = a2f_amd.VocaLoss()(m1(x, oh, t), gt)
+    l1["loss"].backward()
+    p2, l2 = m2.forward_with_loss(x, oh, t, gt)
+    l2["loss"].backward()
+    for k in ("loss", "rec_loss", "vel_loss"):
+        assert abs(float(l1[k].detach()) - float(l2[k].detach())) <= 2e-5 * abs(float(l1[k].detach()))
+    for (k, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert rel_l2(b.grad, a.grad) < 5e-5, k
+
+
+BN_CANCELLED = {f"analysis_net.{3 * l}.bias" for l in range(5)} | {f"articulation_net.{i}.bias" for i in (0, 3, 6)}
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_audio2mesh_golden_g2(mode):
+    g = load("g2_audio2mesh")
+    m = a2f_amd.Audio2Mesh(n_verts=NV, n_onehot=12)
+    m.load_state_dict(W.formula_state_dict(W.audio2mesh_shapes(NV, 12), gains={"output_net.4": 4.0}))
+    m.to(DEV).train(mode == "train")
+    B = 4
+    x = W.formula_input("g2.x", (B, 52, 32)).to(DEV)
+    one_hot = torch.from_numpy(g["one_hot"]).to(DEV)
+    template = W.formula_input("g2.template", (B, 5023, 3), 5.0)
+    gt = (template + W.formula_input("g2.gt", (B, 5023, 3), 0.5)).to(DEV)
+    pred = m(x, one_hot, template.to(DEV))
+    assert packed_error(g, f"{mode}::pred", pred) < TOL
+    loss = a2f_amd.VocaLoss()(pred, gt)
+    for k in ("loss", "rec_loss", "vel_loss"):
+        assert abs(float(loss[k].detach()) - float(g[f"{mode}::loss::{k}"])) <= 2e-5 * abs(float(g[f"{mode}::loss::{k}"]))
+    loss["loss"].backward()
+    for k, p in m.named_parameters():
+        if mode == "train" and k in BN_CANCELLED:
+            # exact gradient is 0 (batch-stat BN removes the conv bias); what is left is fp32 cancellation noise
+            wgrad = dict(m.named_parameters())[k.replace(".bias", ".weight")].grad
+            assert float(p.grad.norm()) < 1e-3 * float(wgrad.norm()), k
+            continue
+        assert packed_error(g, f"{mode}::grad::{k}", p.grad) < 5e-4, k
+    if mode == "train":
+        for k, b in m.named_buffers():
+            if b.is_floating_point():
+                assert packed_error(g, "train::buffer::" + k, b) < 1e-5, k
+
+
+def test_audio2mesh_audio_sample_windows_g7():
+    """Config 1 plumbing: windows cut from assets/audio_sample.npy, batch = 1 per frame, eval mode."""
+    g = load("g7_audio_sample_audio2mesh")
+    m = a2f_amd.Audio2Mesh(n_verts=NV, n_onehot=12)
+    m.load_state_dict(W.formula_state_dict(W.audio2mesh_shapes(NV, 12), gains={"output_net.4": 4.0}))
+    m.to(DEV).eval()
+    x = torch.from_numpy(g["x"]).to(DEV)
+    one_hot = torch.from_numpy(g["one_hot"]).to(DEV)
+    template = W.formula_input("g7.template", (1, 5023, 3), 5.0).to(DEV)
+    with torch.no_grad():
+        pred = torch.cat([m(x[i:i + 1], one_hot, template) for i in range(x.shape[0])], 0)
+    assert packed_error(g, "pred", pred) < TOL
+
+
+FF_GAINS = {"vertice_map_r.weight": 4.0, "vertice_map.weight": 0.05, "obj_vector": 2.0, "in_proj_weight": 1.5}
+
+
+def _faceformer(stub=True):
+    m = a2f_amd.Faceformer(n_verts=NV, n_onehot=12, audio_encoder=torch.nn.Identity() if stub else None)
+    m.load_state_dict(W.formula_state_dict(W.faceformer_decoder_shapes(NV, 12, 64), gains=FF_GAINS), strict=False)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("T", [7, 61, 130])
+def test_faceformer_decoder_golden_g3(T):
+    """Decoder + head + FaceFormerLoss with a pinned encoder output (crosses the period-60 boundary, odd-T branch)."""
+    g = load("g3_faceformer_decoder")
+    m = _faceformer()
+    pre = f"T{T}::"
+    enc = W.formula_input(f"g3.enc{T}", (1, T, 768)).to(DEV).requires_grad_(True)
+    audio = torch.zeros(1, T * 16000 // 60 + 8, device=DEV)
+    one_hot = torch.from_numpy(g[pre + "one_hot"]).to(DEV)
+    template = W.formula_input(f"g3.template{T}", (1, 5023, 3), 5.0)
+    gt = (template.view(1, 1, 5023, 3) + W.formula_input(f"g3.gt{T}", (1, T, 5023, 3), 0.5)).to(DEV)
+    for fused in (False, True):
+        m.zero_grad()
+        enc.grad = None
+        if fused:
+            pred, loss = m.forward_with_loss(audio, one_hot, template.to(DEV), gt, encoder_states=enc)
+        else:
+            pred = m(audio, one_hot, template.to(DEV), encoder_states=enc)
+            loss = a2f_amd.FaceFormerLoss()(pred, gt)
+        assert packed_error(g, pre + "pred", pred) < TOL
+        import numpy as np
+        assert np.allclose(pred.detach().double().reshape(T, -1).norm(dim=1).cpu().numpy(), g[pre + "pred::frame_l2"], rtol=1e-5)
+        for k in ("loss", "rec_loss", "vel_loss"):
+            assert abs(float(loss[k].detach()) - float(g[pre + "loss::" + k])) <= 1e-4 * abs(float(g[pre + "loss::" + k]))
+        loss["loss"].backward()
+        for k, p in m.named_parameters():
+            if (pre + "nograd::" + k) in g:
+                continue
+            assert packed_error(g, pre + "grad::" + k, p.grad) < TOL, (fused, k)
+        assert packed_error(g, pre + "grad::enc", enc.grad) < TOL
+
+
+def test_faceformer_end_to_end_golden_g8():
+    g = load("g8_faceformer_e2e")
+    m = _faceformer(stub=False)
+    m.audio_encoder.load_state_dict(W.formula_state_dict(W.wav2vec2_shapes(), gains={"original0": 40.0}))
+    m.to(DEV).eval()
+    T = 30
+    audio = W.formula_input("g8.audio", (1, T * 16000 // 60 + 5), 0.1).to(DEV)
+    one_hot = torch.from_numpy(g["one_hot"]).to(DEV)
+    template = W.formula_input("g8.template", (1, 5023, 3), 5.0).to(DEV)
+    with torch.no_grad():
+        pred = m(audio, one_hot, template)
+    assert packed_error(g, "pred", pred) < TOL
+
+
+def test_faceformer_long_sequence_beyond_reference_limit():
+    """T = 700 > 600: the reference's materialised mask/PPE tables stop at 600 frames; closed forms do not."""
+    m = _faceformer()
+    T = 700
+    enc = torch.randn(1, T, 768, device=DEV)
+    audio = torch.zeros(1, T * 16000 // 60 + 8, device=DEV)
+    oh = torch.zeros(1, 12, device=DEV); oh[0, 3] = 1
+    with torch.no_grad():
+        pred = m(audio, oh, torch.zeros(1, 5023, 3, device=DEV), encoder_states=enc)
+    assert pred.shape == (1, T, 5023, 3) and bool(torch.isfinite(pred).all())

@@ -1,0 +1,102 @@
+"""CPU, world_size 2 (gloo): the data-parallel step = one all-reduce of the flat gradient buffer + fused Adam with the
+1/world averaging folded in.  Two ranks on disjoint even-sized shards must land on the same parameters as one process on
+the concatenated batch (VocaLoss means over equal shards average exactly; velocity pairs never straddle a shard).
+The C ABI is emulated on CPU (tests/emu_backend.py); the HIP kernels themselves are covered by the -m gpu tests."""
+import os
+import socket
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+NV = 33
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_batch(B):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 29, 16, generator=g)
+    oh = torch.zeros(B, 12); oh[torch.arange(B), torch.arange(B) % 8] = 1
+    t = torch.randn(B, NV // 3, 3, generator=g)
+    gt = t + 0.3 * torch.randn(B, NV // 3, 3, generator=g)
+    return x, oh, gt, t
+
+
+def _run(rank, world, port, out_path, fused):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import a2f_amd
+    from a2f_amd import ops
+    from a2f_amd.trainer import TrainStep
+    from emu_backend import EmuBackend
+    torch.set_num_threads(1)
+    ops.set_backend(EmuBackend())
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(11)
+    model = a2f_amd.Voca(n_verts=NV, n_onehot=12)
+    step = TrainStep(model, a2f_amd.VocaLoss(), lr=1e-3, fused=fused)
+    x, oh, gt, t = _make_batch(8)
+    per = 8 // world
+    sl = slice(rank * per, (rank + 1) * per)
+    for _ in range(2):
+        out = step(x[sl], oh[sl], gt[sl], t[sl])
+    if rank == 0:
+        torch.save({"flat": step.opt.flat_p.clone(), "loss": float(out["loss"].detach())}, out_path)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_dp2_gloo_matches_single_process():
+    with tempfile.TemporaryDirectory() as d:
+        p1, p2 = os.path.join(d, "w1.pt"), os.path.join(d, "w2.pt")
+        _run(0, 1, 0, p1, False)
+        from a2f_amd import ops
+        ops.set_backend(None)
+        mp.spawn(_run, args=(2, _free_port(), p2, False), nprocs=2, join=True)
+        a, b = torch.load(p1), torch.load(p2)
+        rel = float((a["flat"] - b["flat"]).norm() / a["flat"].norm())
+        assert rel < 1e-5, rel
+
+
+def test_flat_adam_aliases_parameters_and_matches_torch_adam():
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import a2f_amd  # noqa: F401
+    from a2f_amd import ops
+    from a2f_amd.trainer import FlatAdam
+    from emu_backend import EmuBackend
+    old = ops.set_backend(EmuBackend())
+    try:
+        torch.manual_seed(3)
+        m = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+        ref = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+        ref.load_state_dict(m.state_dict())
+        opt = FlatAdam(m.parameters(), lr=1e-2, weight_decay=1e-3)
+        ropt = torch.optim.Adam(ref.parameters(), lr=1e-2, weight_decay=1e-3)
+        x = torch.randn(4, 5)
+        for _ in range(3):
+            opt.zero_grad(); ropt.zero_grad()
+            m(x).pow(2).sum().backward(); ref(x).pow(2).sum().backward()
+            opt.step(); ropt.step()
+        for a, b in zip(m.parameters(), ref.parameters()):
+            assert a.data_ptr() >= opt.flat_p.data_ptr() and torch.allclose(a, b, atol=1e-6)
+    finally:
+        ops.set_backend(old)

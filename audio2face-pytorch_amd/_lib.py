@@ -30,6 +30,7 @@ class GemmDesc(C.Structure):
         ("act", i32), ("aux_mode", i32), ("accumulate", i32), ("split_k", i32),
         ("mask_operand", i32), ("mask_period", i32), ("mask_phase", i32), ("mask_lo", i32), ("mask_hi", i32),
         ("reserved", i32),
+        ("splitk_ws", c_f32p),
     ]
 
 
@@ -70,7 +71,7 @@ def load(path: str | None = None):
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = path or LIB_PATH
+    path = path or os.environ.get("A2F_LIB_PATH") or LIB_PATH        # A2F_LIB_PATH: tooling hook for ablation builds
     if not os.path.exists(path):
         raise A2FError(f"HIP extension not built: {path} is missing. Run `python __graft_entry__.py` (build()) "
                        f"or `python audio2face-pytorch_amd/_build.py`. There is no CPU fallback.")

@@ -151,6 +151,20 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const a2f_gemm_desc
 
   // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const bool atomic = d.split_k > 1;
+  if (atomic && d.splitk_ws) {            // slab mode: this split's partial tile -> ws[z][row][col], pitch Neff
+    float* slab = d.splitk_ws + (int64_t)blockIdx.z * M * Neff;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + j * 32 + (lane & 31);
+      if (col >= Neff) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M) slab[(int64_t)row * Neff + col] = acc[j][r];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + j * 32 + (lane & 31);
@@ -183,6 +197,19 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const a2f_gemm_desc
   }
 }
 
+// fold split-K slabs in fixed order: C[row][col] = sum_z slab[z][row][col]; virtual ones column -> ones_out
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, int Neff, float* __restrict__ C,
+                                                             int64_t ldc, float* __restrict__ ones_out) {
+  const int64_t total = (int64_t)M * Neff;
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  float v = 0.f;
+  for (int z = 0; z < splits; ++z) v += ws[(int64_t)z * total + i];
+  const int row = (int)(i / Neff), col = (int)(i - (int64_t)row * Neff);
+  if (col < N) C[(int64_t)row * ldc + col] = v;
+  else ones_out[row] = v;
+}
+
 }  // namespace a2f
 
 extern "C" int a2f_gemm_f32(const a2f_gemm_desc* dp, a2f_stream_t stream) {
@@ -212,6 +239,15 @@ extern "C" int a2f_gemm_f32(const a2f_gemm_desc* dp, a2f_stream_t stream) {
     case 64: hipLaunchKernelGGL(gemm_f32_kernel<64>, grid, dim3(G_THREADS), 0, s, d); break;
     case 96: hipLaunchKernelGGL(gemm_f32_kernel<96>, grid, dim3(G_THREADS), 0, s, d); break;
     default: hipLaunchKernelGGL(gemm_f32_kernel<128>, grid, dim3(G_THREADS), 0, s, d); break;
+  }
+  if (split > 1 && d.splitk_ws) {
+    // a split whose K range is empty stores nothing: clamp the fold to the splits that exist
+    const int ktiles = (int)cdiv(d.K, G_BK);
+    const int per = (ktiles + split - 1) / split;
+    const int live = (ktiles + per - 1) / per;
+    const int64_t total = d.M * neff;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, (const float*)d.splitk_ws, live, (int)d.M,
+                       (int)d.N, (int)neff, d.C, d.ldc, d.ones_out);
   }
   A2F_CHECK_LAUNCH("gemm_f32");
   return A2F_OK;

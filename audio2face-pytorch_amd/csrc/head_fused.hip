@@ -22,12 +22,11 @@
 // n = 15069 is odd, so rows are 4-byte aligned only: global accesses are dword per lane, two 128-byte row
 // segments per wave-instruction.
 #include "a2f_common.h"
+#include <stdlib.h>
 
 namespace a2f {
 
-constexpr int HF_THREADS = 256;
-constexpr int HF_COLS = 512;          // columns per workgroup
-constexpr int HF_WCOLS = 128;         // columns per wave
+constexpr int HF_MAXCOLS = 512;       // widest column group (workspace sizing)
 constexpr int HF_ROWS = 32;           // frames per row block
 constexpr int HF_KP = 64;             // K padded (two 32-wide MFMA tiles)
 constexpr int HF_HP = 33;             // pitch of the [k][row] and [col][row] LDS tiles
@@ -56,8 +55,17 @@ __device__ __forceinline__ void buf_store(rsrc_t r, int byte_off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);
 }
 
-template <int K>
-__global__ __launch_bounds__(HF_THREADS, 1) void head_fused_kernel(const HeadArgs a) {
+// NW waves per workgroup, each owning CPW = 16/NW chunks of 32 columns.  NW = 8 (two waves per SIMD, <= 256 registers
+// each: 64 dW accumulators) hides LDS / HBM latency behind the partner wave's MFMAs and is used when the LDS budget
+// allows (K = 50); NW = 4 (one wave per SIMD, 128 dW accumulators) is the K = 64 configuration.
+// COLS columns per workgroup (512: one workgroup per CU; 256: half the LDS, two independent workgroups per CU whose
+// memory stalls and MFMA phases overlap each other), WPS = resident waves per SIMD the register budget is sized for.
+template <int K, int NW, int COLS, int WPS>
+__global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs a) {
+  constexpr int HF_COLS = COLS;
+  constexpr int HF_THREADS = 64 * NW;
+  constexpr int CPW = COLS / (32 * NW);
+  constexpr int HF_WCOLS = 32 * CPW;
   constexpr int PITCH = K | 1;
   constexpr int WS_FLOATS = HF_COLS * PITCH + 64;
   constexpr int HS_FLOATS = HF_KP * HF_HP;
@@ -85,22 +93,24 @@ __global__ __launch_bounds__(HF_THREADS, 1) void head_fused_kernel(const HeadArg
   if (t < 64) Ws[HF_COLS * PITCH + t] = 0.f;
   for (int e = t; e < HS_FLOATS; e += HF_THREADS) Hs[e] = 0.f;        // rows K..63 of H^T stay zero for ever
 
-  float bias_r[4];
-  int colg[4];
+  float bias_r[CPW];
+  int colg[CPW];
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct) {
+  for (int ct = 0; ct < CPW; ++ct) {
     colg[ct] = c0 + wave * HF_WCOLS + ct * 32 + l31;
     bias_r[ct] = colg[ct] < n ? a.bias[colg[ct]] : 0.f;
   }
 
-  f32x16 dW[4][2];
+  f32x16 dW[CPW][2];
+  float db_acc[CPW];
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct)
+  for (int ct = 0; ct < CPW; ++ct) {
+    db_acc[ct] = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dW[ct][kt][r] = 0.f;
-  float db_acc[4] = {0.f, 0.f, 0.f, 0.f};
+  }
   double rec_d = 0.0, vel_d = 0.0;                    // per-lane totals; fp32 partials are folded in once per row block
 
   const int rb0 = (int)(((int64_t)rg * a.NRB) / a.RG);
@@ -109,12 +119,26 @@ __global__ __launch_bounds__(HF_THREADS, 1) void head_fused_kernel(const HeadArg
   // Tile addressing: wave-uniform tile base (SGPR pair) + 32-bit lane offset (4h*n + lane column) + r-dependent
   // scalar row offset.  Out-of-range elements of boundary tiles read the tile's first element instead (always
   // valid), so loads never branch; such elements are neutralised in the epilogue.
+  // LDS lane bases: every tile index below is (lane base) + (compile-time constant), so the constant lands in the
+  // ds_read/ds_write immediate-offset field instead of a per-row address register
+  const int lb_rowmajor = h * HF_HP + l31;             // [k or col][row]-tiles read along rows:   + 2*s*HF_HP
+  const int lb_colmajor = l31 * HF_HP + 4 * h;         // same tiles addressed by (lane column, row 4h + rr)
+  const int lb_wfwd = l31 * PITCH + h;                 // W slice as forward B operand:           + cl*PITCH + 2*s
+  const int lb_wbwd = h * PITCH + l31;                 // W slice as dH B operand:                + (cl + 2*s)*PITCH + 32*kt
   const int lane_off = 4 * h * n + l31;
   const int lane_off_t = 4 * h * (int)a.ldt + l31;
-  float tc[16], gcur[16];
+  // register sets: (tc, gcur) = tile consumed by the current epilogue; (tn, gn) = next chunk (requested two chunks
+  // ago); DEPTH2 adds (tf, gf) = the chunk after next, so a request has two chunks of MFMA time (~5 us) to land
+  constexpr bool DEPTH2 = false;                      // two-deep prefetch measured slower (register spills), kept as a knob
+#ifdef HF_EARLY_ISSUE
+  constexpr bool EARLY = true;                        // request chunk c+1 at the START of chunk c (second register set)
+#else
+  constexpr bool EARLY = false;
+#endif
+  float tc[16], gcur[16], tn[16], gn[16], tf[16], gf[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { tc[r] = 0.f; gcur[r] = 0.f; }
-  auto issue_loads = [&](int rb, int ct) {
+  for (int r = 0; r < 16; ++r) { tc[r] = 0.f; gcur[r] = 0.f; tn[r] = 0.f; gn[r] = 0.f; tf[r] = 0.f; gf[r] = 0.f; }
+  auto issue_loads = [&](int rb, int ct, float* tc, float* gcur) {
     const int cl = wave * HF_WCOLS + ct * 32;
     {
       const rsrc_t gb = tile_rsrc(a.gt + ((int64_t)rb * HF_ROWS * n + (c0 + cl)));
@@ -130,12 +154,26 @@ __global__ __launch_bounds__(HF_THREADS, 1) void head_fused_kernel(const HeadArg
       for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2);         // compile-time part of the tile row; + 4h on the lane
         const int inval = ~(mcol & ((rr + h4 - rlim) >> 31));             // -1 -> offset 0xFFFFFFFF -> load returns 0
+#ifdef HF_ABL_NOLOAD      // timing ablation only (wrong results): no template / gt traffic
+        tc[r] = __int_as_float(inval & 0x3f800000); gcur[r] = __int_as_float(lo & 0x3f000000);
+#else
         tc[r] = buf_load(tb, (4 * (rr * (int)a.ldt + lot)) | inval);
         gcur[r] = buf_load(gb, (4 * (rr * n + lo)) | inval);
+#endif
       }
     }
   };
-  issue_loads(rb0, 0);
+  // linear chunk index -> (row block, chunk)
+  auto issue_at = [&](int rb, int ct, int ahead, float* tt, float* gg) {
+    const int lin = ct + ahead;
+    issue_loads(rb + lin / CPW, lin % CPW, tt, gg);
+  };
+  issue_loads(rb0, 0, tc, gcur);
+  if (DEPTH2) issue_at(rb0, 0, 1, tn, gn);
+  if (EARLY) {                                        // tn/gn double as "next" set: current tile goes straight to tc/gcur
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { tn[r] = tc[r]; gn[r] = gcur[r]; }
+  }
 
   for (int rb = rb0; rb < rb1; ++rb) {
     __syncthreads();                                   // previous block's Hs / reduction-buffer readers are done
@@ -154,19 +192,31 @@ __global__ __launch_bounds__(HF_THREADS, 1) void head_fused_kernel(const HeadArg
     float rec = 0.f, vel = 0.f;
 
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
+    for (int ct = 0; ct < CPW; ++ct) {
       const int cl = wave * HF_WCOLS + ct * 32;        // first column of the chunk inside the slice
       // (chunks that lie wholly beyond column n run on zeros: straight-line code keeps the 160 accumulator
       //  registers free of control-flow copies; only the last column group has such chunks)
+      if (EARLY) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { tc[r] = tn[r]; gcur[r] = gn[r]; }
+        issue_at(rb, ct, 1, tn, gn);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       f32x16 acc;
+      // opaque zero: keeps hipcc from caching this row block's H fragments (57 VGPRs) across the chunks of the wave;
+      // re-reading them from LDS per chunk is free (the LDS pipe is far from saturated)
+      int hz = 0;
+      asm volatile("" : "+v"(hz));
+      const float* Hq = Hs + hz;
+      const float* Wc = Ws + cl * PITCH + hz;           // this chunk's rows of the W slice
       {
         // ---- forward tile: acc[row][col] = sum_k H[row][k] W[col][k] ----
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < K / 2; ++s) {
-          const float av = Hs[(2 * s + h) * HF_HP + l31];
-          const float bv = Ws[(cl + l31) * PITCH + 2 * s + h];
+          const float av = Hq[lb_rowmajor + 2 * s * HF_HP];
+          const float bv = Wc[lb_wfwd + 2 * s];
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -185,8 +235,12 @@ __global__ __launch_bounds__(HF_THREADS, 1) void head_fused_kernel(const HeadArg
           const int rr = (r & 3) + 8 * (r >> 2);
           const float p0 = acc[r] + bias_r[ct] + tc[r];
           const float p1 = acc[r + 1] + bias_r[ct] + tc[r + 1];
+#ifdef HF_ABL_NOSTORE     // timing ablation only: pred is not written
+          asm volatile("" :: "v"(p0), "v"(p1));
+#else
           buf_store(pb, (4 * (rr * n + lo)) | ~(mint | (mcolv & ((rr + h4 - rlim) >> 31))), p0);
           buf_store(pb, (4 * ((rr + 1) * n + lo)) | ~(mint | (mcolv & ((rr + 1 + h4 - rlim) >> 31))), p1);
+#endif
           const bool in_loss = colok && (rb * HF_ROWS + rr + h4 + 1 < a.Bloss);
           const float d0 = in_loss ? p0 - gcur[r] : 0.f;
           const float d1 = in_loss ? p1 - gcur[r + 1] : 0.f;
@@ -204,50 +258,64 @@ __global__ __launch_bounds__(HF_THREADS, 1) void head_fused_kernel(const HeadArg
       }
       // template / gt registers are free again: request the next chunk's tile now, so the loads fly under the
       // 64 backward MFMAs of this chunk (one wave per SIMD: ILP, not occupancy, hides HBM latency)
-      if (ct < 3) issue_loads(rb, ct + 1);
-      else issue_loads(rb + 1, 0);
+      if (DEPTH2) issue_at(rb, ct, 2, tf, gf);
+      else if (!EARLY) issue_at(rb, ct, 1, tn, gn);
       __builtin_amdgcn_sched_barrier(0);
       {
         // ---- dW[col][k] += sum_row G[row][col] H[row][k]: accumulator register q is the A operand of k-step q ----
+#ifdef HF_ABL_NODW        // timing ablation only: no dW product
+        asm volatile("" :: "v"(acc[0]), "v"(acc[5]), "v"(acc[10]), "v"(acc[15]));
+#else
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const int rr = rho(q, h);
+          const int rrc = (q & 3) + 8 * (q >> 2);
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt) {
-            const float bv = Hs[(kt * 32 + l31) * HF_HP + rr];
+            const float bv = Hq[lb_colmajor + kt * 32 * HF_HP + rrc];
             dW[ct][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[q], bv, dW[ct][kt], 0, 0, 0);
           }
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // ---- dH[row][k] += sum_col G[row][col] W[col][k]: transpose G through the wave's LDS tile ----
+#ifndef HF_ABL_NODH       // timing ablation only: no dH product
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Gs[l31 * HF_HP + rho(r, h)] = acc[r];
+        for (int r = 0; r < 16; ++r) Gs[lb_colmajor + (r & 3) + 8 * (r >> 2)] = acc[r];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-          const float av = Gs[(2 * s + h) * HF_HP + l31];
+          const float av = Gs[lb_rowmajor + 2 * s * HF_HP];
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt) {
-            const float bv = Ws[(cl + 2 * s + h) * PITCH + kt * 32 + l31];
+            const float bv = Wc[lb_wbwd + 2 * s * PITCH + kt * 32];
             dH[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, dH[kt], 0, 0, 0);
           }
         }
+#endif
+      }
+      // rotate the prefetch sets
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (!EARLY) { tc[r] = tn[r]; gcur[r] = gn[r]; }
+        if (DEPTH2) { tn[r] = tf[r]; gn[r] = gf[r]; }
       }
     }
 
     rec_d += (double)rec;
     vel_d += (double)vel;
     // ---- fold the four waves' dH partials (two 32-wide halves) and emit this column group's slab rows ----
-    float* red = Gs_all;                                // [4][32][32] floats, reuses the staging tiles
+    float* red = Gs_all;                                // [NW][32][32] floats, reuses the staging tiles
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[wave * 1024 + rho(r, h) * 32 + l31] = dH[kt][r];
+      for (int r = 0; r < 16; ++r) red[(wave * 1024 + 4 * h * 32 + l31) + ((r & 3) + 8 * (r >> 2)) * 32] = dH[kt][r];
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 1024 / HF_THREADS; ++i) {
         const int e = t + i * HF_THREADS;               // 0..1023: row = e/32, k = e%32
-        const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w * 1024 + e];
         const int row = rb * HF_ROWS + (e >> 5);
         if (row < B) a.dH_slab[((int64_t)cg * B + row) * HF_KP + kt * 32 + (e & 31)] = v;
       }
@@ -257,7 +325,7 @@ __global__ __launch_bounds__(HF_THREADS, 1) void head_fused_kernel(const HeadArg
   // ---- workgroup epilogue: dW / dbias slabs of this row group, loss partials ----
   const int64_t ncols_pad = (int64_t)a.CG * HF_COLS;
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct) {
+  for (int ct = 0; ct < CPW; ++ct) {
     const int cl = wave * HF_WCOLS + ct * 32;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -270,11 +338,13 @@ __global__ __launch_bounds__(HF_THREADS, 1) void head_fused_kernel(const HeadArg
   __syncthreads();                                      // staging tiles are free: reuse them for the loss fold
   double* lsum = reinterpret_cast<double*>(Gs_all);     // [2][4]; byte offset of Gs_all is a multiple of 8
   const double rs = wave_sum_d(rec_d), vs = wave_sum_d(vel_d);
-  if (lane == 0) { lsum[wave] = rs; lsum[4 + wave] = vs; }
+  if (lane == 0) { lsum[wave] = rs; lsum[NW + wave] = vs; }
   __syncthreads();
   if (t == 0) {
-    a.loss_part[2 * blockIdx.x] = lsum[0] + lsum[1] + lsum[2] + lsum[3];
-    a.loss_part[2 * blockIdx.x + 1] = lsum[4] + lsum[5] + lsum[6] + lsum[7];
+    double r = 0.0, v = 0.0;
+    for (int w = 0; w < NW; ++w) { r += lsum[w]; v += lsum[NW + w]; }
+    a.loss_part[2 * blockIdx.x] = r;
+    a.loss_part[2 * blockIdx.x + 1] = v;
   }
 }
 
@@ -321,11 +391,12 @@ struct HeadPlan {
   size_t off_dH, off_dW, off_db, off_loss, total;
 };
 
-static HeadPlan head_plan(int64_t B, int64_t n) {
+static HeadPlan head_plan(int64_t B, int64_t n, int cols, int wg_slots) {
   HeadPlan p;
+  const int HF_COLS = cols;
   p.CG = (int)cdiv(n, HF_COLS);
   p.NRB = (int)cdiv(B, HF_ROWS);
-  int rg = 256 / p.CG;
+  int rg = wg_slots / p.CG;
   if (rg < 1) rg = 1;
   if (rg > p.NRB) rg = p.NRB;
   p.RG = rg;
@@ -339,27 +410,39 @@ static HeadPlan head_plan(int64_t B, int64_t n) {
   return p;
 }
 
-template <int K>
+template <int K, int NW, int COLS, int WPS>
 static int head_launch(const HeadArgs& a, const HeadPlan& p, hipStream_t s) {
   constexpr int PITCH = K | 1;
-  const size_t lds_bytes = (size_t)(HF_COLS * PITCH + 64 + HF_KP * HF_HP + 4 * HF_ROWS * HF_HP) * sizeof(float);
+  const size_t lds_bytes = (size_t)(COLS * PITCH + 64 + HF_KP * HF_HP + NW * HF_ROWS * HF_HP) * sizeof(float);
   static bool attr_set = false;       // idempotent; a benign race sets the same value
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<K, NW, COLS, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds_bytes);
     if (e != hipSuccess) return set_err(A2F_ELAUNCH, "head_fused: hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL(head_fused_kernel<K>, dim3((unsigned)(p.CG * p.RG)), dim3(HF_THREADS), lds_bytes, s, a);
+  hipLaunchKernelGGL((head_fused_kernel<K, NW, COLS, WPS>), dim3((unsigned)(p.CG * p.RG)), dim3(64 * NW), lds_bytes, s, a);
   return A2F_OK;
 }
 
 }  // namespace a2f
 
+namespace a2f {
+// kernel configuration per K: 0 = 512 columns x 8 waves (1 workgroup/CU), 1 = 512 x 4, 2 = 256 columns x 4 waves (2 workgroups/CU)
+static int head_cfg(int64_t K) {
+  static const int env = [] { const char* e = getenv("A2F_HEAD_CFG"); return e ? atoi(e) : -1; }();
+  if (K == 64) return (env == 2) ? 2 : 1;
+  return env >= 0 && env <= 2 ? env : 1;          // measured on MI355X (B=19200): cfg1 1.71 ms, cfg0 2.02 ms, cfg2 2.39 ms
+}
+static HeadPlan head_plan_for(int64_t B, int64_t n, int64_t K) {
+  const int cfg = head_cfg(K);
+  return cfg == 2 ? head_plan(B, n, 256, (K == 64) ? 256 : 512) : head_plan(B, n, 512, 256);
+}
+}  // namespace a2f
+
 extern "C" size_t a2f_head_fused_ws_bytes(int64_t B, int64_t n, int64_t K) {
-  (void)K;
   if (B <= 0 || n <= 0) return 16;
-  return a2f::head_plan(B, n).total;
+  return a2f::head_plan_for(B, n, K).total;
 }
 
 extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias, const float* templ, int64_t template_rows,
@@ -373,7 +456,7 @@ extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias,
   A2F_CHECK_ARG(Bloss >= 2 && (Bloss % 2) == 0 && Bloss <= B, "head_fused: Bloss=%lld must be even, >= 2 and <= B (loss.py:13-15,33-35)", (long long)Bloss);
   A2F_CHECK_ARG(n >= 3 && (n % 3) == 0 && n < (1 << 30), "head_fused: n=%lld must be a multiple of 3", (long long)n);
   A2F_CHECK_ARG(template_rows == 1 || template_rows == B, "head_fused: template_rows must be 1 or B");
-  const HeadPlan p = head_plan(B, n);
+  const HeadPlan p = head_plan_for(B, n, K);
   if (ws_bytes < p.total) return set_err(A2F_EWORKSPACE, "head_fused: workspace %zu < %zu", ws_bytes, p.total);
   hipStream_t s = (hipStream_t)stream;
   char* w8 = (char*)ws;
@@ -386,9 +469,12 @@ extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias,
   const double V = (double)(n / 3);
   a.cr = (float)(2.0 * k_rec / ((double)Bloss * V));
   a.cv = (float)(2.0 * k_vel / ((double)(Bloss / 2) * V));
-  int rc = (K == 50) ? head_launch<50>(a, p, s) : head_launch<64>(a, p, s);
+  const int cfg = head_cfg(K);
+  int rc;
+  if (K == 50) rc = cfg == 0 ? head_launch<50, 8, 512, 2>(a, p, s) : cfg == 1 ? head_launch<50, 4, 512, 1>(a, p, s) : head_launch<50, 4, 256, 2>(a, p, s);
+  else rc = cfg == 2 ? head_launch<64, 4, 256, 1>(a, p, s) : head_launch<64, 4, 512, 1>(a, p, s);
   if (rc != A2F_OK) return rc;
-  const int64_t ncols_pad = (int64_t)p.CG * HF_COLS;
+  const int64_t ncols_pad = (int64_t)p.CG * (cfg == 2 ? 256 : 512);
   {
     int64_t blocks = cdiv(B * HF_KP, 256); if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.dH_slab, p.CG, (int64_t)B * HF_KP, B, (int)K, dH);

@@ -70,8 +70,8 @@ class HeadFn(torch.autograd.Function):
         G = _f32c(G)
         dH = torch.zeros(B, K, device=G.device, dtype=torch.float32)
         be.gemm(G, Wc, dH, B, K, n, (0, n, 1), (0, K, 1), K, split_k=2, tag="head_dH")
-        dW = torch.zeros(n, K, device=G.device, dtype=torch.float32)
-        db = torch.zeros(n, device=G.device, dtype=torch.float32)
+        dW = torch.empty(n, K, device=G.device, dtype=torch.float32)
+        db = torch.empty(n, device=G.device, dtype=torch.float32)
         ops.linear_bwd_weight(be, G, Hc, dW, db, B, n, K, tag="head_dW")
         dT = None
         if ctx.needs_input_grad[3]:
@@ -85,78 +85,89 @@ class HeadFn(torch.autograd.Function):
 VOCA_CONVS = ((37, 32, 8), (32, 32, 4), (32, 64, 2), (64, 64, 1))      # (Cin, Cout, positions out); input has 16 positions
 
 
+def voca_trunk_fwd(be, x, one_hot, params):
+    """x (B,29,16), one_hot (B,>=8), params = 8 conv tensors + 6 decoder tensors -> (h3 (B,50), saved tuple)."""
+    cw = params[0:8]                  # time_conv.{0,2,4,6}.{weight,bias}
+    fw0, fb0, fw1, fb1, fw3, fb3 = (_f32c(p) for p in params[8:14])
+    B = x.shape[0]
+    dev = x.device
+    new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+    xc, oh = _f32c(x), _f32c(one_hot)
+    a0, cat = new(B, 16, 37), new(B, 72)
+    be.voca_pack(xc, oh, B, oh.shape[1], a0, cat)
+    acts, wgs = [a0], []
+    for li, (ci, co, pout) in enumerate(VOCA_CONVS):
+        w, b = _f32c(cw[2 * li]), _f32c(cw[2 * li + 1])
+        wg = new(co, 3 * ci)
+        be.conv_weight_pack(w, wg, co, ci, 3, 0)
+        last = pout == 1
+        out = cat if last else new(B, pout, co)
+        ops.conv_fwd(be, acts[-1], wg, b, out, B * pout, pout, ci, co, ldc=72 if last else co)
+        acts.append(out)
+        wgs.append(wg)
+    z1, z2, h3 = new(B, 72), new(B, 128), new(B, 50)
+    ops.linear_fwd(be, cat, fw0, fb0, z1, B, 72, 72)                      # decoder.0
+    ops.linear_fwd(be, z1, fw1, fb1, z2, B, 128, 72, act=ACT_TANH)        # decoder.1 + Tanh
+    ops.linear_fwd(be, z2, fw3, fb3, h3, B, 50, 128)                      # decoder.3
+    return h3, (a0, acts[1], acts[2], acts[3], cat, z1, z2, fw0, fw1, fw3, *wgs)
+
+
+def voca_trunk_bwd(be, saved, dh3, out=None):
+    """Gradients of the 14 trunk parameters (same order as ``params``).  ``out``: optional list of 14 preallocated
+    tensors (e.g. the trainer's flat-gradient views) that are OVERWRITTEN in place; otherwise new tensors are returned."""
+    a0, a1, a2, a3, cat, z1, z2, fw0, fw1, fw3, wg1, wg2, wg3, wg4 = saved
+    B = cat.shape[0]
+    dev = cat.device
+    new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+    tgt = (lambda i, *s: out[i]) if out is not None else (lambda i, *s: new(*s))
+    dh3 = _f32c(dh3)
+    grads = [None] * 14
+    # decoder.3 (128 -> 50)
+    dW3, db3 = tgt(12, 50, 128), tgt(13, 50)
+    ops.linear_bwd_weight(be, dh3, z2, dW3, db3, B, 50, 128)
+    dz2 = new(B, 128)
+    ops.linear_bwd_input(be, dh3, fw3, dz2, B, 50, 128, aux=z2, ldaux=128, aux_mode=AUX_TANH_BWD)
+    # decoder.1 (72 -> 128)
+    dW1, db1 = tgt(10, 128, 72), tgt(11, 128)
+    ops.linear_bwd_weight(be, dz2, z1, dW1, db1, B, 128, 72)
+    dz1 = new(B, 72)
+    ops.linear_bwd_input(be, dz2, fw1, dz1, B, 128, 72)
+    # decoder.0 (72 -> 72); only the 64 conv features need an input gradient (ReLU of conv 4 applied here)
+    dW0, db0 = tgt(8, 72, 72), tgt(9, 72)
+    ops.linear_bwd_weight(be, dz1, cat, dW0, db0, B, 72, 72)
+    d_act = new(B, 64)
+    ops.linear_bwd_input(be, dz1, fw0, d_act, B, 72, 72, n_cols=64, aux=cat, ldaux=72, aux_mode=AUX_RELU_BWD)
+    grads[8:14] = [dW0, db0, dW1, db1, dW3, db3]
+    # temporal conv stack, last to first
+    acts = (a0, a1, a2, a3)
+    wgs = (wg1, wg2, wg3, wg4)
+    for li in (3, 2, 1, 0):
+        ci, co, pout = VOCA_CONVS[li]
+        R = B * pout
+        dwg, dbias = new(co, 3 * ci), tgt(2 * li + 1, co)
+        ops.conv_bwd_weight(be, acts[li], d_act, dwg, dbias, R, pout, ci, co)
+        dw = tgt(2 * li, co, ci, 3, 1)
+        be.conv_weight_pack(dwg, dw, co, ci, 3, 1)
+        grads[2 * li], grads[2 * li + 1] = dw, dbias
+        if li > 0:
+            d_in = new(B, 2 * pout, ci)
+            ops.conv_k3s2_bwd_input(be, d_act, wgs[li], d_in, R, pout, ci, co, relu_of=acts[li])
+            d_act = d_in
+    return grads
+
+
 class VocaTrunkFn(torch.autograd.Function):
     """x (B,29,16), one_hot (B,>=8), 8 conv tensors, 6 decoder tensors -> h3 (B,50)."""
 
     @staticmethod
     def forward(ctx, x, one_hot, *params):
-        be = ops.backend()
-        cw = params[0:8]                  # time_conv.{0,2,4,6}.{weight,bias}
-        fw0, fb0, fw1, fb1, fw3, fb3 = (_f32c(p) for p in params[8:14])
-        B = x.shape[0]
-        dev = x.device
-        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
-        xc, oh = _f32c(x), _f32c(one_hot)
-        a0, cat = new(B, 16, 37), new(B, 72)
-        be.voca_pack(xc, oh, B, oh.shape[1], a0, cat)
-        acts, wgs = [a0], []
-        for li, (ci, co, pout) in enumerate(VOCA_CONVS):
-            w, b = _f32c(cw[2 * li]), _f32c(cw[2 * li + 1])
-            wg = new(co, 3 * ci)
-            be.conv_weight_pack(w, wg, co, ci, 3, 0)
-            last = pout == 1
-            out = cat if last else new(B, pout, co)
-            ops.conv_fwd(be, acts[-1], wg, b, out, B * pout, pout, ci, co, ldc=72 if last else co)
-            acts.append(out)
-            wgs.append(wg)
-        z1, z2, h3 = new(B, 72), new(B, 128), new(B, 50)
-        ops.linear_fwd(be, cat, fw0, fb0, z1, B, 72, 72)                      # decoder.0
-        ops.linear_fwd(be, z1, fw1, fb1, z2, B, 128, 72, act=ACT_TANH)        # decoder.1 + Tanh
-        ops.linear_fwd(be, z2, fw3, fb3, h3, B, 50, 128)                      # decoder.3
-        ctx.save_for_backward(a0, acts[1], acts[2], acts[3], cat, z1, z2, fw0, fw1, fw3, *wgs)
+        h3, saved = voca_trunk_fwd(ops.backend(), x, one_hot, params)
+        ctx.save_for_backward(*saved)
         return h3
 
     @staticmethod
     def backward(ctx, dh3):
-        be = ops.backend()
-        a0, a1, a2, a3, cat, z1, z2, fw0, fw1, fw3, wg1, wg2, wg3, wg4 = ctx.saved_tensors
-        B = cat.shape[0]
-        dev = cat.device
-        zeros = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
-        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
-        dh3 = _f32c(dh3)
-        # decoder.3 (128 -> 50)
-        dW3, db3 = zeros(50, 128), zeros(50)
-        ops.linear_bwd_weight(be, dh3, z2, dW3, db3, B, 50, 128)
-        dz2 = new(B, 128)
-        ops.linear_bwd_input(be, dh3, fw3, dz2, B, 50, 128, aux=z2, ldaux=128, aux_mode=AUX_TANH_BWD)
-        # decoder.1 (72 -> 128)
-        dW1, db1 = zeros(128, 72), zeros(128)
-        ops.linear_bwd_weight(be, dz2, z1, dW1, db1, B, 128, 72)
-        dz1 = new(B, 72)
-        ops.linear_bwd_input(be, dz2, fw1, dz1, B, 128, 72)
-        # decoder.0 (72 -> 72); only the 64 conv features need an input gradient (ReLU of conv 4 applied here)
-        dW0, db0 = zeros(72, 72), zeros(72)
-        ops.linear_bwd_weight(be, dz1, cat, dW0, db0, B, 72, 72)
-        d_act = new(B, 64)
-        ops.linear_bwd_input(be, dz1, fw0, d_act, B, 72, 72, n_cols=64, aux=cat, ldaux=72, aux_mode=AUX_RELU_BWD)
-        # temporal conv stack, last to first
-        acts = (a0, a1, a2, a3)
-        wgs = (wg1, wg2, wg3, wg4)
-        conv_grads = [None] * 8
-        for li in (3, 2, 1, 0):
-            ci, co, pout = VOCA_CONVS[li]
-            R = B * pout
-            dwg, dbias = zeros(co, 3 * ci), zeros(co)
-            ops.conv_bwd_weight(be, acts[li], d_act, dwg, dbias, R, pout, ci, co)
-            dw = new(co, ci, 3, 1)
-            be.conv_weight_pack(dwg, dw, co, ci, 3, 1)
-            conv_grads[2 * li], conv_grads[2 * li + 1] = dw, dbias
-            if li > 0:
-                d_in = new(B, 2 * pout, ci)
-                ops.conv_k3s2_bwd_input(be, d_act, wgs[li], d_in, R, pout, ci, co, relu_of=acts[li])
-                d_act = d_in
-        return (None, None, *conv_grads, dW0, db0, dW1, db1, dW3, db3)
+        return (None, None, *voca_trunk_bwd(ops.backend(), ctx.saved_tensors, dh3))
 
 
 # =================================================================================================
@@ -242,21 +253,21 @@ class A2MTrunkFn(torch.autograd.Function):
         dh3 = _f32c(dh3)
         g_conv, g_bn, g_fc = [None] * 20, [None] * 20, [None] * 6
         # output_net.3, .1, .0
-        dW, db = zeros(50, 128), zeros(50)
+        dW, db = new(50, 128), new(50)
         ops.linear_bwd_weight(be, dh3, z2, dW, db, B, 50, 128); g_fc[4], g_fc[5] = dW, db
         dz2 = new(B, 128)
         ops.linear_bwd_input(be, dh3, fw[2], dz2, B, 50, 128, aux=z2, ldaux=128, aux_mode=AUX_TANH_BWD)
-        dW, db = zeros(128, 72), zeros(128)
+        dW, db = new(128, 72), new(128)
         ops.linear_bwd_weight(be, dz2, z1, dW, db, B, 128, 72); g_fc[2], g_fc[3] = dW, db
         dz1 = new(B, 72)
         ops.linear_bwd_input(be, dz2, fw[1], dz1, B, 128, 72)
-        dW, db = zeros(72, ncat), zeros(72)
+        dW, db = new(72, ncat), new(72)
         ops.linear_bwd_weight(be, dz1, cat, dW, db, B, 72, ncat); g_fc[0], g_fc[1] = dW, db
         d = new(B, 256)                                       # grad w.r.t. conv-9 pre-activation (ReLU mask of cat fused)
         ops.linear_bwd_input(be, dz1, fw[0], d, B, 72, ncat, n_cols=256, aux=cat, ldaux=ncat, aux_mode=AUX_RELU_BWD)
 
         def conv_wgrad(i, dout, R, P_out, Ci, Co, KH=3, stride=2, pad=1):
-            dwg, dbias = zeros(Co, KH * Ci), zeros(Co)
+            dwg, dbias = new(Co, KH * Ci), new(Co)
             ops.conv_bwd_weight(be, sv["conv_in"][i], dout, dwg, dbias, R, P_out, Ci, Co, KH=KH, stride=stride, pad=pad)
             shape = (Co, Ci, 1, KH) if i < 5 else (Co, Ci, KH, 1)
             dw = new(*shape)
@@ -318,8 +329,10 @@ class HeadLossFusedFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, H, W, b, template, gt, Bloss, k_rec, k_vel):
+    def forward(ctx, H, W, b, template, gt, Bloss, k_rec, k_vel, unit_grad=False):
         be = ops.backend()
+        ctx.set_materialize_grads(False)          # pred is not differentiable: never build a (B,n) zero gradient for it
+        ctx.unit_grad = bool(unit_grad)           # caller promises d/d(loss) == 1 (loss["loss"].backward()): skip the rescale
         B, K = H.shape
         n = W.shape[0]
         Hc, Wc, bc = _f32c(H), _f32c(W), _f32c(b)
@@ -338,8 +351,12 @@ class HeadLossFusedFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _gpred, g3):
         dH, dW, db = ctx.saved_tensors
+        if g3 is None:
+            return (None,) * 9
+        if ctx.unit_grad:
+            return dH, dW, db, None, None, None, None, None, None
         g = g3[0]                        # d/d(loss); stays on device
-        return dH * g, dW * g, db * g, None, None, None, None, None
+        return dH * g, dW * g, db * g, None, None, None, None, None, None
 
 
 # =================================================================================================
@@ -372,8 +389,8 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
             ops.linear_bwd_input(be, dy, Wc, dx, M, N, K)
-        dW = torch.zeros(N, K, device=dy.device, dtype=torch.float32)
-        db = torch.zeros(N, device=dy.device, dtype=torch.float32)
+        dW = torch.empty(N, K, device=dy.device, dtype=torch.float32)
+        db = torch.empty(N, device=dy.device, dtype=torch.float32)
         ops.linear_bwd_weight(be, dy, xc, dW, db, M, N, K)
         return dx, dW, (db if ctx.has_bias else None)
 
@@ -387,9 +404,10 @@ class MatmulFn(torch.autograd.Function):
         Ac, Bc = _f32c(A), _f32c(B)
         M, K = Ac.shape
         N = Bc.shape[1]
-        Cm = torch.zeros(M, N, device=Ac.device, dtype=torch.float32)
+        Cm = torch.empty(M, N, device=Ac.device, dtype=torch.float32)
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        be.gemm(Ac, Bc, Cm, M, N, K, (0, K, 1), (0, N, 1), N, split_k=ops.split_k_for(K, tiles))
+        sk = ops.split_k_for(K, tiles)
+        be.gemm(Ac, Bc, Cm, M, N, K, (0, K, 1), (0, N, 1), N, split_k=sk, splitk_ws=ops._splitk_ws(Cm, sk, M, N))
         ctx.save_for_backward(Ac, Bc)
         return Cm
 

@@ -108,7 +108,7 @@ class Faceformer(nn.Module):
     def predict(self, audio, one_hot, template, **kwargs):
         return self(audio, one_hot, template, **kwargs)
 
-    def forward_with_loss(self, audio, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0, **kwargs):
+    def forward_with_loss(self, audio, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0, unit_grad: bool = False, **kwargs):
         """Training fast path = forward + FaceFormerLoss (loss.py:4-17) with the head, the loss and the head backward
         fused into one pass; the odd tail frame is predicted but left out of the loss, as the reference does."""
         frame_num = audio.shape[1] * 60 // 16000
@@ -120,5 +120,5 @@ class Faceformer(nn.Module):
         if T < 2:
             raise RuntimeError("FaceFormerLoss needs at least 2 frames")
         pred, out3 = HeadLossFusedFn.apply(y.reshape(T, -1), self.vertice_map_r.weight, self.vertice_map_r.bias,
-                                           template.reshape(1, -1), gt.reshape(T, -1), T - (T % 2), k_rec, k_vel)
+                                           template.reshape(1, -1), gt.reshape(T, -1), T - (T % 2), k_rec, k_vel, unit_grad)
         return pred.view(1, T, -1, 3), {"loss": out3[0], "rec_loss": out3[1].detach(), "vel_loss": out3[2].detach()}

@@ -10,7 +10,8 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..functional import HeadFn, HeadLossFusedFn, VocaTrunkFn, VOCA_CONVS
+from .. import ops
+from ..functional import HeadFn, HeadLossFusedFn, VocaTrunkFn, VOCA_CONVS, voca_trunk_bwd, voca_trunk_fwd
 
 _FC = ((72, 72), (72, 128), None, (128, 50))        # decoder slots 0,1,(2 = Tanh),3; slot 4 is the vertex head
 
@@ -49,7 +50,7 @@ class Voca(nn.Module):
     def predict(self, x, one_hot, template, **kwargs):
         return self(x, one_hot, template, **kwargs)
 
-    def forward_with_loss(self, x, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0):
+    def forward_with_loss(self, x, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0, unit_grad: bool = False):
         """Training fast path: model forward + VocaLoss + head backward fused into one pass over the frame matrix.
 
         Returns (pred (B,V,3) detached, {"loss","rec_loss","vel_loss"}); only "loss" carries gradient.  Numerically the
@@ -60,5 +61,31 @@ class Voca(nn.Module):
             raise RuntimeError(f"VocaLoss pairs consecutive frames (loss.py:33-35): batch {bs} must be even")
         h3 = self.trunk(x, one_hot)
         pred, out3 = HeadLossFusedFn.apply(h3, self.decoder[4].weight, self.decoder[4].bias, template.reshape(bs, -1),
-                                           gt.reshape(bs, -1), bs, k_rec, k_vel)
+                                           gt.reshape(bs, -1), bs, k_rec, k_vel, unit_grad)
         return pred.view(bs, -1, 3), {"loss": out3[0], "rec_loss": out3[1].detach(), "vel_loss": out3[2].detach()}
+
+    @torch.no_grad()
+    def train_step_direct(self, x, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0):
+        """Autograd-free training pass for the trainer: forward + VocaLoss + backward as one fixed launch sequence that
+        OVERWRITES every parameter's preallocated ``.grad`` (the flat-gradient views of ``FlatAdam``) - no autograd
+        graph, no gradient-accumulation kernels, no zero fill, hipGraph-capturable.  Same arithmetic as
+        ``forward_with_loss(...)["loss"].backward()``.  Returns (pred (B,V,3), out3 = [loss, rec, vel])."""
+        be = ops.backend()
+        bs = x.size(0)
+        if bs % 2 != 0:
+            raise RuntimeError(f"VocaLoss pairs consecutive frames (loss.py:33-35): batch {bs} must be even")
+        tp = self._trunk_params()
+        head_w, head_b = self.decoder[4].weight, self.decoder[4].bias
+        for p in tp + [head_w, head_b]:
+            if p.grad is None or not p.grad.is_contiguous():
+                raise RuntimeError("train_step_direct needs preallocated contiguous .grad tensors (see trainer.FlatAdam)")
+        h3, saved = voca_trunk_fwd(be, x, one_hot, [p.data for p in tp])
+        n, K = head_w.shape
+        dev = h3.device
+        pred = torch.empty(bs, n, device=dev, dtype=torch.float32)
+        out3 = torch.empty(3, device=dev, dtype=torch.float32)
+        dH = torch.empty(bs, K, device=dev, dtype=torch.float32)
+        be.head_fused(h3, head_w.data, head_b.data, template.reshape(bs, n).contiguous(), bs, gt.reshape(bs, n).contiguous(), bs, bs, n, K,
+                      float(k_rec), float(k_vel), pred, out3, dH, head_w.grad, head_b.grad)
+        voca_trunk_bwd(be, saved, dH, out=[p.grad for p in tp])
+        return pred.view(bs, -1, 3), out3

@@ -65,8 +65,8 @@ class HipBackend:
     # ---- a2f_gemm_f32 -------------------------------------------------------------------------
     def gemm(self, A, B, Cout, M, N, K, a: Tuple[int, int, int], b: Tuple[int, int, int], ldc, *, c_off=0, bias=None,
              act=ACT_NONE, aux=None, aux_off=0, ldaux=0, aux_mode=AUX_NONE, accumulate=False, split_k=1, ones_out=None,
-             mask: Optional[Tuple[int, int, int, int, int]] = None, tag: Optional[str] = None):
-        _chk(A, B, Cout, bias, aux, ones_out)
+             mask: Optional[Tuple[int, int, int, int, int]] = None, tag: Optional[str] = None, splitk_ws=None):
+        _chk(A, B, Cout, bias, aux, ones_out, splitk_ws)
         d = GemmDesc()
         d.A, d.a_off, d.a_rs, d.a_cs = _ptr(A), a[0], a[1], a[2]
         d.B, d.b_off, d.b_rs, d.b_cs = _ptr(B), b[0], b[1], b[2]
@@ -78,6 +78,10 @@ class HipBackend:
         d.act, d.aux_mode, d.accumulate, d.split_k = act, aux_mode, int(accumulate), split_k
         if mask is not None:
             d.mask_operand, d.mask_period, d.mask_phase, d.mask_lo, d.mask_hi = mask
+        if splitk_ws is not None:
+            if splitk_ws.numel() < split_k * M * (N + 1):
+                raise A2FError("gemm: split-K workspace too small")
+            d.splitk_ws = _ptr(splitk_ws)
         ev = self._prof_begin(tag)
         _lib.check(self.lib.a2f_gemm_f32(C.byref(d), self._stream(Cout)), "a2f_gemm_f32")
         self._prof_end(tag, ev)
@@ -189,6 +193,13 @@ def split_k_for(rows: int, tiles: int = 1) -> int:
     return max(1, min(want, max(1, 1024 // max(tiles, 1))))
 
 
+def _splitk_ws(ref: torch.Tensor, split: int, M: int, N: int):
+    """Slab workspace for deterministic split-K (None when a single split does the whole contraction)."""
+    if split <= 1:
+        return None
+    return torch.empty(split * M * (N + 1), device=ref.device, dtype=torch.float32)
+
+
 def linear_fwd(be, x, W, bias, out, M, N, K, *, ldx=None, ldc=None, act=ACT_NONE, aux=None, ldaux=0, aux_mode=AUX_NONE, tag=None):
     """out[M,N] = act(x[M,K] W[N,K]^T + bias)  (torch.nn.Linear layout)."""
     be.gemm(x, W, out, M, N, K, (0, ldx or K, 1), (0, 1, K), ldc or N, bias=bias, act=act, aux=aux, ldaux=ldaux, aux_mode=aux_mode, tag=tag)
@@ -201,9 +212,11 @@ def linear_bwd_input(be, dy, W, dx, M, N, K, *, ld_dy=None, n_cols=None, ldc=Non
 
 
 def linear_bwd_weight(be, dy, x, dW, db, M, N, K, *, ld_dy=None, ldx=None, tag=None):
-    """dW[N,K] = dy[M,N]^T x[M,K];  db[N] = colsum(dy).  dW/db must be zero on entry (split-K atomics)."""
+    """dW[N,K] = dy[M,N]^T x[M,K];  db[N] = colsum(dy).  Overwrites dW/db (slab split-K, deterministic)."""
     tiles = ((N + 127) // 128) * ((K + 1 + 127) // 128)
-    be.gemm(dy, x, dW, N, K, M, (0, 1, ld_dy or N), (0, ldx or K, 1), K, ones_out=db, split_k=split_k_for(M, tiles), tag=tag)
+    sk = split_k_for(M, tiles)
+    be.gemm(dy, x, dW, N, K, M, (0, 1, ld_dy or N), (0, ldx or K, 1), K, ones_out=db, split_k=sk, tag=tag,
+            splitk_ws=_splitk_ws(dW, sk, N, K))
 
 
 def conv_fwd(be, act_in, wg, bias, out, R, P_out, Cin, Co, *, KH=3, stride=2, pad=1, ldc=None, c_off=0, relu=True):
@@ -223,8 +236,9 @@ def conv_bwd_weight(be, act_in, dout, dwg, dbias, R, P_out, Cin, Co, *, KH=3, st
     """dwg[Co, KH*Cin] = dout[R,Co]^T windows(act_in);  dbias = colsum(dout).  Outputs zeroed by the caller."""
     mask = (2, P_out, 0, 0, pad * Cin) if pad else None
     tiles = ((Co + 127) // 128) * ((KH * Cin + 1 + 127) // 128)
+    sk = split_k_for(R, tiles)
     be.gemm(dout, act_in, dwg, Co, KH * Cin, R, (0, 1, ld_dout or Co), (-pad * Cin, stride * Cin, 1), KH * Cin,
-            ones_out=dbias, split_k=split_k_for(R, tiles), mask=mask)
+            ones_out=dbias, split_k=sk, mask=mask, splitk_ws=_splitk_ws(dwg, sk, Co, KH * Cin))
 
 
 def conv_k3s2_bwd_input(be, dout, wg, d_in, R, P_out, Cin, Co, *, relu_of=None):

@@ -65,9 +65,18 @@ class FlatAdam:
 class TrainStep:
     """fwd -> loss -> bwd -> (all-reduce) -> Adam, mirroring Audio2FaceModel.training_step + configure_optimizers."""
 
-    def __init__(self, model: torch.nn.Module, loss_fn, lr: float, process_group=None, fused: bool = True):
+    def __init__(self, model: torch.nn.Module, loss_fn, lr: float, process_group=None, fused: bool = True,
+                 use_graph: bool = False):
         self.model = model
         self.loss_fn = loss_fn
+        # use_graph: capture zero_grad + forward + loss + backward (~90 launches) into one hipGraph after a warm-up and
+        # replay it every step; the all-reduce and the Adam launch stay eager.  The caller must then pass the SAME
+        # input tensors every step (copy each new batch into them) - the usual static-buffer contract of graph replay.
+        self.use_graph = use_graph
+        self._graph = None
+        self._graph_inputs = None
+        self._graph_out = None
+        self._warm = 0
         # fused = head + loss + head-backward in one HIP pass when the model offers it and the loss is the stock VocaLoss
         self.fused = fused and hasattr(model, "forward_with_loss") and type(loss_fn).__name__ in ("VocaLoss", "FaceFormerLoss")
         self.opt = FlatAdam(model.parameters(), lr=lr, weight_decay=lr / 10, process_group=process_group)
@@ -80,15 +89,46 @@ class TrainStep:
         return batch["audio"], batch["one_hot"], batch["verts"], batch["template_vert"]
 
     def __call__(self, x, one_hot, gt, template) -> Dict[str, torch.Tensor]:
+        if self.use_graph and x.is_cuda:
+            return self._graph_step(x, one_hot, gt, template)
+        loss = self._fwd_bwd(x, one_hot, gt, template)
+        self.opt.step()
+        return loss
+
+    def _graph_step(self, x, one_hot, gt, template):
+        ins = (x, one_hot, gt, template)
+        if self._graph is None:
+            if self._warm < 2:                                  # eager warm-up: allocator pools, LDS attributes, autotune-free
+                self._warm += 1
+                loss = self._fwd_bwd(*ins)
+                self.opt.step()
+                return loss
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._fwd_bwd(*ins)
+            self._graph, self._graph_inputs, self._graph_out = g, ins, out
+        else:
+            if any(a.data_ptr() != b.data_ptr() for a, b in zip(ins, self._graph_inputs)):
+                raise RuntimeError("TrainStep(use_graph=True) replays a captured graph: pass the same input tensors each step")
+        self._graph.replay()
+        self.opt.step()
+        return self._graph_out
+
+    def _fwd_bwd(self, x, one_hot, gt, template) -> Dict[str, torch.Tensor]:
+        if self.fused and hasattr(self.model, "train_step_direct"):
+            # autograd-free launch sequence that overwrites the flat gradient views (no zero fill, no accumulation kernels)
+            lf = getattr(self.loss_fn, "loss", self.loss_fn)
+            _pred, out3 = self.model.train_step_direct(x, one_hot, template, gt, lf.k_rec, lf.k_vel)
+            return {"loss": out3[0], "rec_loss": out3[1], "vel_loss": out3[2], "err": out3[1] / 3.0}
         self.opt.zero_grad()
         if self.fused:
             lf = getattr(self.loss_fn, "loss", self.loss_fn)          # FaceFormerLoss wraps a VocaLoss
-            _pred, loss = self.model.forward_with_loss(x, one_hot, template, gt, lf.k_rec, lf.k_vel)
+            _pred, loss = self.model.forward_with_loss(x, one_hot, template, gt, lf.k_rec, lf.k_vel, unit_grad=True)
         else:
             pred = self.model(x, one_hot, template)
             loss = self.loss_fn(pred, gt)
         loss["loss"].backward()
-        self.opt.step()
         # mse_error (lightning_model.py:119-125) == rec_loss / 3 for 3-vectors: no extra pass over pred/gt
         loss["err"] = loss["rec_loss"].detach() / 3.0
         return loss

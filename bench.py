@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--frames", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the ~90 kernels of a step eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,7 +134,7 @@ def main():
 
     torch.manual_seed(1234)                                  # identical initial weights on every rank
     model = a2f_amd.Voca(n_verts=NV3, n_onehot=12).to(device)
-    step = TrainStep(model, a2f_amd.VocaLoss(), lr=1e-4)
+    step = TrainStep(model, a2f_amd.VocaLoss(), lr=1e-4, use_graph=not args.no_graph)
     x, one_hot, gt, templ = make_voca_batch(args.seqs, args.frames, rank, device)
     B = x.shape[0]
 
@@ -142,7 +143,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 3)):                      # >= 3: two eager warm-up steps + the graph capture step
         out = step(x, one_hot, gt, templ)
     barrier()
     t0 = time.perf_counter()
@@ -167,15 +168,19 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"VOCA train step (fwd+VocaLoss+bwd+Adam), {args.seqs} seq x {args.frames} frames = {B} windows "
                                f"(29,16) per GPU per step, 5023-vertex meshes, BASELINE configs[1]",
-                   "frames_per_gpu_step": B, "parallelism": f"dp{world}", "final_loss": round(loss_val, 6)},
+                   "frames_per_gpu_step": B, "parallelism": f"dp{world}", "final_loss": round(loss_val, 6),
+                   "launch": "eager" if args.no_graph else "hipGraph replay (fwd+loss+bwd) + eager all-reduce/Adam"},
     }
 
     if rank == 0 and not args.no_roofline:
         be = ops.backend()
         be.prof = {}
         nprof = max(3, min(args.steps, 10))
+        eager = TrainStep.__new__(TrainStep)                   # same model/optimizer, eager launches so events bracket kernels
+        eager.__dict__.update(step.__dict__)
+        eager.use_graph = False
         for _ in range(nprof):
-            step(x, one_hot, gt, templ)
+            eager(x, one_hot, gt, templ)
         torch.cuda.synchronize()
         per = {tag: sum(a.elapsed_time(b) for a, b in evs) / len(evs) for tag, evs in be.prof.items()}   # ms per launch
         be.prof = None

@@ -53,8 +53,11 @@ const char* a2f_last_error(void);
  *      aux_mode 3: v += aux                       (template add, voca.py:49)
  * ones_out != NULL appends a virtual all-ones column n == N to B and routes it to ones_out[m]
  * (bias gradients as part of the weight-gradient GEMM).
- * split_k > 1 partitions K over grid.z and accumulates with fp32 atomics into a C (and ones_out)
- * that the caller has zeroed; only valid with act = aux_mode = 0, bias = NULL.
+ * split_k > 1 partitions K over grid.z; only valid with act = aux_mode = 0, bias = NULL, accumulate = 0.
+ *   splitk_ws == NULL: partial tiles are added with fp32 atomics into a C (and ones_out) the caller has zeroed;
+ *   splitk_ws != NULL: (>= split_k*M*(N+1) floats) every split stores its partial tile there and a second
+ *   kernel folds the splits in fixed order into C / ones_out (overwrite): deterministic, and free of the atomic
+ *   contention that dominates when the output is tiny (weight gradients).
  * Replaces torch.nn.Linear / Conv2d forward+backward as dispatched by the reference models.
  */
 typedef struct a2f_gemm_desc {
@@ -68,6 +71,7 @@ typedef struct a2f_gemm_desc {
   int32_t act, aux_mode, accumulate, split_k;
   int32_t mask_operand, mask_period, mask_phase, mask_lo, mask_hi;
   int32_t reserved;
+  float* splitk_ws;
 } a2f_gemm_desc;
 
 int a2f_gemm_f32(const a2f_gemm_desc* d, a2f_stream_t stream);

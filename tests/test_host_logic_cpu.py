@@ -102,7 +102,8 @@ def test_audio2mesh_module_matches_reference_golden(emu, mode):
     for k, p in m.named_parameters():
         assert p.grad is not None, k
         if mode == "train" and k in BN_CANCELLED_BIASES:
-            assert float(p.grad.norm()) < 1e-4, k       # exact gradient is 0: batch-stat BN removes the conv bias
+            wg = dict(m.named_parameters())[k.replace(".bias", ".weight")].grad
+            assert float(p.grad.norm()) < 1e-3 * float(wg.norm()), k       # exact gradient is 0: batch-stat BN removes the conv bias
             continue
         assert packed_error(g, f"{mode}::grad::{k}", p.grad) < 5e-4, k
     if mode == "train":

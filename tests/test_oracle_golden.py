@@ -60,8 +60,12 @@ def test_g2_audio2mesh(mode):
     for k in ("loss", "rec_loss", "vel_loss"):
         assert abs(float(loss[k].detach()) - float(g[f"{mode}::loss::{k}"])) <= 1e-5 * abs(float(g[f"{mode}::loss::{k}"]))
     loss["loss"].backward()
+    cancelled = {f"analysis_net.{3 * l}.bias" for l in range(5)} | {f"articulation_net.{i}.bias" for i in (0, 3, 6)}
     for k, v in P.items():
         if v.is_floating_point() and v.requires_grad:
+            if mode == "train" and k in cancelled:       # exact gradient is 0 (batch-stat BN cancels the conv bias): noise only
+                assert float(v.grad.norm()) < 1e-3 * float(P[k.replace(".bias", ".weight")].grad.norm()), k
+                continue
             assert packed_error(g, f"{mode}::grad::{k}", v.grad) < 5e-4, k
     if mode == "train":
         for k, v in P.items():

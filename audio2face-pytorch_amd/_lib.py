@@ -39,6 +39,9 @@ SIGNATURES = {
     "a2f_version": (C.c_int, []),
     "a2f_last_error": (C.c_char_p, []),
     "a2f_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "a2f_wgrad_supported": (C.c_int, [i64, i64]),
+    "a2f_wgrad_ws_floats": (sz, [i64, i64, i64]),
+    "a2f_wgrad_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "a2f_vocaloss_ws_bytes": (sz, [i64, i64]),
     "a2f_vocaloss_fwd": (C.c_int, [c_f32p, c_f32p, i64, i64, f32, f32, c_f32p, C.c_void_p, sz, C.c_void_p]),
     "a2f_vocaloss_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, i64, i64, f32, f32, c_f32p, C.c_void_p]),

@@ -86,6 +86,28 @@ class HipBackend:
         _lib.check(self.lib.a2f_gemm_f32(C.byref(d), self._stream(Cout)), "a2f_gemm_f32")
         self._prof_end(tag, ev)
 
+    # ---- a2f_wgrad_f32 ------------------------------------------------------------------------
+    def wgrad_supported(self, M, N):
+        return bool(self.lib.a2f_wgrad_supported(M, N))
+
+    def wgrad(self, A, B, Cout, M, N, K, a, b, ldc, *, ones_out=None, mask=None, tag=None):
+        """C[M,N] = sum_k A(m,k) B(k,n) for tiny outputs (see a2f_hip.h); overwrites C / ones_out, deterministic."""
+        _chk(A, B, Cout, ones_out)
+        ws = torch.empty(self.lib.a2f_wgrad_ws_floats(M, N, K), device=Cout.device, dtype=torch.float32)
+        d = GemmDesc()
+        d.A, d.a_off, d.a_rs, d.a_cs = _ptr(A), a[0], a[1], a[2]
+        d.B, d.b_off, d.b_rs, d.b_cs = _ptr(B), b[0], b[1], b[2]
+        d.C, d.ldc = _ptr(Cout), ldc
+        d.M, d.N, d.K = M, N, K
+        d.ones_out = _ptr(ones_out)
+        d.split_k = 1
+        if mask is not None:
+            d.mask_operand, d.mask_period, d.mask_phase, d.mask_lo, d.mask_hi = mask
+        d.splitk_ws = _ptr(ws)
+        ev = self._prof_begin(tag)
+        _lib.check(self.lib.a2f_wgrad_f32(C.byref(d), self._stream(Cout)), "a2f_wgrad_f32")
+        self._prof_end(tag, ev)
+
     # ---- loss ---------------------------------------------------------------------------------
     def vocaloss_fwd(self, pred, gt, B, n, k_rec, k_vel, out3):
         _chk(pred, gt, out3)
@@ -213,6 +235,9 @@ def linear_bwd_input(be, dy, W, dx, M, N, K, *, ld_dy=None, n_cols=None, ldc=Non
 
 def linear_bwd_weight(be, dy, x, dW, db, M, N, K, *, ld_dy=None, ldx=None, tag=None):
     """dW[N,K] = dy[M,N]^T x[M,K];  db[N] = colsum(dy).  Overwrites dW/db (slab split-K, deterministic)."""
+    if be.wgrad_supported(N, K):
+        be.wgrad(dy, x, dW, N, K, M, (0, 1, ld_dy or N), (0, ldx or K, 1), K, ones_out=db, tag=tag)
+        return
     tiles = ((N + 127) // 128) * ((K + 1 + 127) // 128)
     sk = split_k_for(M, tiles)
     be.gemm(dy, x, dW, N, K, M, (0, 1, ld_dy or N), (0, ldx or K, 1), K, ones_out=db, split_k=sk, tag=tag,
@@ -235,6 +260,10 @@ def conv_fwd(be, act_in, wg, bias, out, R, P_out, Cin, Co, *, KH=3, stride=2, pa
 def conv_bwd_weight(be, act_in, dout, dwg, dbias, R, P_out, Cin, Co, *, KH=3, stride=2, pad=1, ld_dout=None):
     """dwg[Co, KH*Cin] = dout[R,Co]^T windows(act_in);  dbias = colsum(dout).  Outputs zeroed by the caller."""
     mask = (2, P_out, 0, 0, pad * Cin) if pad else None
+    if be.wgrad_supported(Co, KH * Cin):
+        be.wgrad(dout, act_in, dwg, Co, KH * Cin, R, (0, 1, ld_dout or Co), (-pad * Cin, stride * Cin, 1), KH * Cin,
+                 ones_out=dbias, mask=mask)
+        return
     tiles = ((Co + 127) // 128) * ((KH * Cin + 1 + 127) // 128)
     sk = split_k_for(R, tiles)
     be.gemm(dout, act_in, dwg, Co, KH * Cin, R, (0, 1, ld_dout or Co), (-pad * Cin, stride * Cin, 1), KH * Cin,

@@ -76,6 +76,15 @@ typedef struct a2f_gemm_desc {
 
 int a2f_gemm_f32(const a2f_gemm_desc* d, a2f_stream_t stream);
 
+/* Weight-gradient specialisation of the same contract for tiny outputs and huge contractions (dW = dY^T X of the
+ * Linear / implicit-GEMM convolution layers, voca.py:19-36): M <= 128, N+1 <= 224 (a2f_wgrad_supported), A stored (K,M)
+ * with a_rs == 1, B stored (K,N) with b_cs == 1, optional B window mask and ones column, linear epilogue, C (and
+ * ones_out) OVERWRITTEN.  One register tile set per wave, operands read from global memory in MFMA layout, per-wave
+ * partial slabs in d->splitk_ws (>= a2f_wgrad_ws_floats(M,N,K) floats) folded in fixed order (deterministic). */
+int a2f_wgrad_supported(int64_t M, int64_t N);
+size_t a2f_wgrad_ws_floats(int64_t M, int64_t N, int64_t K);
+int a2f_wgrad_f32(const a2f_gemm_desc* d, a2f_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * VocaLoss (src/loss/loss.py:24-55); FaceFormerLoss (loss.py:4-17) is the same call on the
  * even-length prefix of the (T, n) frame matrix.

@@ -93,6 +93,15 @@ class EmuBackend:
             s = Am.sum(dim=1).float()
             ones_out[:M] = ones_out[:M] + s if accumulate else s
 
+    def wgrad_supported(self, M, N):
+        mt, nt = (M + 31) // 32, (N + 1 + 31) // 32
+        return (nt <= 7) if mt in (1, 2) else (nt <= 4) if mt == 3 else (nt <= 3) if mt == 4 else False
+
+    def wgrad(self, A, B, Cout, M, N, K, a, b, ldc, *, ones_out=None, mask=None, tag=None):
+        assert a[1] == 1 and b[2] == 1 and self.wgrad_supported(M, N)
+        ws = torch.empty(2 * M * (N + 1))
+        self.gemm(A, B, Cout, M, N, K, a, b, ldc, ones_out=ones_out, mask=mask, split_k=2, splitk_ws=ws)
+
     # ------------------------------------------------------------------ loss
     def vocaloss_fwd(self, pred, gt, B, n, k_rec, k_vel, out3):
         d = (pred.reshape(B, n) - gt.reshape(B, n)).double()

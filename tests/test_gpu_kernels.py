@@ -283,3 +283,26 @@ def test_ff_decoder_kernels_vs_spec(S, T, period):
     for nm, sz_ in names:
         assert rel_l2(dP_h.cpu()[o:o + sz_], dP_e[o:o + sz_]) < 1e-4, nm
         o += sz_
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 111, 5000), (32, 96, 777), (64, 96, 3001), (64, 192, 1200), (72, 72, 640), (128, 72, 19), (50, 128, 2048), (1, 1, 3)])
+def test_wgrad_kernel_vs_contract(M, N, K):
+    """dW = dY^T X with the ones column and a conv padding mask, against the float64 emulation of the contract."""
+    dy, x = rnd(K, M, seed=80), rnd(K + 2, N, seed=81)
+    period = 4
+    hip, emu = ops.HipBackend(), EmuBackend()
+    assert hip.wgrad_supported(M, N)
+    outs = []
+    for be, dev in ((hip, DEV), (emu, "cpu")):
+        Cc = torch.full((M, N + 2), float("nan"), device=dev)
+        db = torch.full((M,), float("nan"), device=dev)
+        # B is a window view starting one element before row 0 (offset -1 masked by the padding rule on phase-0 rows)
+        be.wgrad(dy.to(dev), x.to(dev), Cc, M, N, K, (0, 1, M), (0, N, 1), N + 2, ones_out=db, mask=(2, period, 0, 0, min(5, N)))
+        outs.append((Cc.cpu(), db.cpu()))
+    (c_h, d_h), (c_e, d_e) = outs
+    assert rel_l2(c_h[:, :N], c_e[:, :N]) < 2e-5 and rel_l2(d_h, d_e) < 2e-5
+    assert bool(torch.isnan(c_h[:, N:]).all())               # columns beyond N untouched
+    # determinism (fixed fold order)
+    Cc2 = torch.empty(M, N + 2, device=DEV); db2 = torch.empty(M, device=DEV)
+    hip.wgrad(dy.to(DEV), x.to(DEV), Cc2, M, N, K, (0, 1, M), (0, N, 1), N + 2, ones_out=db2, mask=(2, period, 0, 0, min(5, N)))
+    assert torch.equal(Cc2[:, :N].cpu(), c_h[:, :N])

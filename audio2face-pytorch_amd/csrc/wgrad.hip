@@ -82,22 +82,25 @@ __global__ __launch_bounds__(WG_THREADS, 1) void wgrad_kernel(const a2f_gemm_des
     }
 }
 
-// out[i] = sum_z slab[z][i]: 16 outputs x 16 z-lanes per workgroup, fixed summation order
+// out[i] = sum_z slab[z][i]: one wave per output element (4 per workgroup), 64 z-lanes with 4 independent partial sums
+// each (loads in flight together), butterfly fold: fixed summation order, ~20 dependent steps instead of slabs/16.
 __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* __restrict__ ws, int slabs, int M, int N, int Neff,
                                                           float* __restrict__ C, int64_t ldc, float* __restrict__ ones_out) {
-  __shared__ float sh[16][17];
-  const int t = threadIdx.x, o = t & 15, zg = t >> 4;
+  const int t = threadIdx.x, lane = t & 63;
   const int64_t total = (int64_t)M * Neff;
-  const int64_t i = (int64_t)blockIdx.x * 16 + o;
-  float v = 0.f;
-  if (i < total)
-    for (int z = zg; z < slabs; z += 16) v += ws[(int64_t)z * total + i];
-  sh[zg][o] = v;
-  __syncthreads();
-  if (t < 16 && i < total) {
-    float s = 0.f;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) s += sh[g][t];
+  const int64_t i = (int64_t)blockIdx.x * 4 + (t >> 6);
+  if (i >= total) return;                                   // wave-uniform
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+  int z = lane;
+  for (; z + 192 < slabs; z += 256) {
+    v0 += ws[(int64_t)z * total + i];
+    v1 += ws[(int64_t)(z + 64) * total + i];
+    v2 += ws[(int64_t)(z + 128) * total + i];
+    v3 += ws[(int64_t)(z + 192) * total + i];
+  }
+  for (; z < slabs; z += 64) v0 += ws[(int64_t)z * total + i];
+  const float s = wave_sum((v0 + v1) + (v2 + v3));
+  if (lane == 0) {
     const int row = (int)(i / Neff), col = (int)(i - (int64_t)row * Neff);
     if (col < N) C[(int64_t)row * ldc + col] = s;
     else ones_out[row] = s;
@@ -159,7 +162,7 @@ extern "C" int a2f_wgrad_f32(const a2f_gemm_desc* dp, a2f_stream_t stream) {
   else return set_err(A2F_EINVAL, "wgrad: no tile set for %d x %d tiles", mt, nt);
   const int64_t neff = d.N + (d.ones_out ? 1 : 0);
   const int64_t total = d.M * neff;
-  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)cdiv(total, 16)), dim3(256), 0, s, (const float*)d.splitk_ws, p.slabs, (int)d.M, (int)d.N,
+  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)cdiv(total, 4)), dim3(256), 0, s, (const float*)d.splitk_ws, p.slabs, (int)d.M, (int)d.N,
                      (int)neff, d.C, d.ldc, d.ones_out);
   A2F_CHECK_LAUNCH("wgrad_f32");
   return A2F_OK;

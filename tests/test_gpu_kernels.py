@@ -306,3 +306,44 @@ def test_wgrad_kernel_vs_contract(M, N, K):
     Cc2 = torch.empty(M, N + 2, device=DEV); db2 = torch.empty(M, device=DEV)
     hip.wgrad(dy.to(DEV), x.to(DEV), Cc2, M, N, K, (0, 1, M), (0, N, 1), N + 2, ones_out=db2, mask=(2, period, 0, 0, min(5, N)))
     assert torch.equal(Cc2[:, :N].cpu(), c_h[:, :N])
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 32, 111), (777, 64, 96), (1500, 128, 72), (640, 50, 128), (3000, 64, 192), (513, 72, 72), (900, 37, 33)])
+@pytest.mark.parametrize("layout", ["nt", "nn"])
+def test_gemm_tall_skinny_shapes(M, N, K, layout):
+    """The trunk's tall-skinny products (M >= 512, K <= 192, N <= 128): all epilogues, ldc > N, accumulate."""
+    A = rnd(M, K, seed=90)
+    if layout == "nt":
+        B, b = rnd(N, K, seed=91), (0, 1, K)
+    else:
+        B, b = rnd(K, N + 3, seed=91), (0, N + 3, 1)
+    bias, aux, C0 = rnd(N, seed=92), rnd(M, N, seed=93), rnd(M, N + 2, seed=94)
+    for kw in (dict(), dict(bias=bias, act=1), dict(act=2), dict(aux=aux, ldaux=N, aux_mode=1), dict(aux=aux, ldaux=N, aux_mode=2, accumulate=True),
+               dict(bias=bias, aux=aux, ldaux=N, aux_mode=3)):
+        (c_hip, _), (c_emu, _) = run_gemm_both(A, B, C0, M, N, K, (0, K, 1), b, N + 2, **kw)
+        assert rel_l2(c_hip, c_emu) < 2e-5, kw.keys()
+        assert torch.equal(c_hip[:, N:], C0[:, N:])
+
+
+def test_conv_window_masks_large():
+    """Implicit-GEMM conv forward / shifted dgrad windows at M = 1600 rows against torch conv1d."""
+    B_, P_out, Cin, Co = 200, 8, 37, 32
+    P_in = 2 * P_out
+    act = rnd(B_, P_in, Cin, seed=95)
+    w = rnd(Co, Cin, 3, seed=96, scale=0.2)
+    bias = rnd(Co, seed=97)
+    x = act.permute(0, 2, 1).clone().requires_grad_(True)
+    y = torch.relu(torch.nn.functional.conv1d(x, w, bias, stride=2, padding=1))
+    dy = rnd(B_, P_out, Co, seed=98)
+    y.backward(dy.permute(0, 2, 1))
+    be = ops.HipBackend()
+    wg = torch.empty(Co, 3 * Cin, device=DEV)
+    be.conv_weight_pack(w.to(DEV), wg, Co, Cin, 3, 0)
+    out = torch.empty(B_, P_out, Co, device=DEV)
+    R = B_ * P_out
+    ops.conv_fwd(be, act.to(DEV), wg, bias.to(DEV), out, R, P_out, Cin, Co)
+    assert rel_l2(out.cpu(), y.detach().permute(0, 2, 1)) < 2e-5
+    d_pre = (dy * (out.cpu() > 0)).to(DEV).contiguous()
+    d_in = torch.full((B_, P_in, Cin), float("nan"), device=DEV)
+    ops.conv_k3s2_bwd_input(be, d_pre, wg, d_in, R, P_out, Cin, Co)
+    assert rel_l2(d_in.cpu(), x.grad.permute(0, 2, 1)) < 5e-5

@@ -122,3 +122,22 @@ class Faceformer(nn.Module):
         pred, out3 = HeadLossFusedFn.apply(y.reshape(T, -1), self.vertice_map_r.weight, self.vertice_map_r.bias,
                                            template.reshape(1, -1), gt.reshape(T, -1), T - (T % 2), k_rec, k_vel, unit_grad)
         return pred.view(1, T, -1, 3), {"loss": out3[0], "rec_loss": out3[1].detach(), "vel_loss": out3[2].detach()}
+
+    def forward_with_loss_batch(self, audio, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0):
+        """S independent batch-1 problems in one step (the reference trains batch = 1, train.py:33):
+        audio (S,N), one_hot (S,n_onehot), template (S,V,3), gt (S,T,V,3).  The encoder runs batched, the decoder
+        recurrence launches one workgroup per sequence, the fused head runs once per sequence (its template is per
+        sequence).  Returns (pred (S,T,V,3), mean loss dict)."""
+        S = audio.shape[0]
+        frame_num = audio.shape[1] * 60 // 16000
+        enc = self.encode(audio, frame_num)
+        y = self.decode_hidden(enc, one_hot)                                  # (S,T,64)
+        T = y.shape[1]
+        preds, tot = [], None
+        for s in range(S):
+            p, o3 = HeadLossFusedFn.apply(y[s], self.vertice_map_r.weight, self.vertice_map_r.bias, template[s].reshape(1, -1),
+                                          gt[s].reshape(T, -1), T - (T % 2), k_rec, k_vel)
+            preds.append(p)
+            tot = o3 if tot is None else tot + o3
+        tot = tot / S
+        return torch.stack(preds).view(S, T, -1, 3), {"loss": tot[0], "rec_loss": tot[1].detach(), "vel_loss": tot[2].detach()}

@@ -1,0 +1,68 @@
+"""Config surface and registries of the reference training harness (reference:
+/root/reference/src/model/lightning_model.py:20-73 and /root/reference/config.yaml), Lightning-free.
+
+``ExpConfig`` keeps every key of config.yaml - including the reference's spelling ``percision`` - and
+``get_model`` / ``get_loss_fn`` return the HIP-backed drop-in classes for the three models on the hot path.
+Song2Face / af_model are not on the accelerated path and raise a clear error.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import yaml
+from pydantic import BaseModel
+
+from .loss import FaceFormerLoss, VocaLoss
+from .model.audio2face import Audio2Mesh
+from .model.faceformer import Faceformer
+from .model.voca import Voca
+
+
+class ExpConfig(BaseModel):
+    # dataset
+    batch_size: int
+    # model
+    modelname: str
+    one_hot_size: int
+    feature_extractor: Optional[str] = None
+    sample_rate: int
+    vertex_count: int
+    split_frame: bool
+    n_feature: int
+    out_dim: int
+    win_length: int
+    hop_length: Optional[int] = None
+    # training
+    percision: str
+    lr: float
+    # loss
+    loss: Optional[str] = None
+
+    @classmethod
+    def from_yaml(cls, path: str):
+        with open(path, "r") as f:
+            return cls(**yaml.safe_load(f))
+
+    def name(self):
+        return f"{self.modelname}_{self.feature_extractor}_{self.lr}_{self.loss}_{self.percision}"
+
+
+_MODELS = {"voca": Voca, "audio2mesh": Audio2Mesh, "faceformer": Faceformer}
+
+
+def get_model(modelname: str):
+    try:
+        return _MODELS[modelname]
+    except KeyError:
+        raise KeyError(f"model '{modelname}' is not on the MI355X hot path (available: {sorted(_MODELS)}); "
+                       f"use the reference implementation for it") from None
+
+
+def get_loss_fn(modelname: str):
+    return FaceFormerLoss() if modelname == "faceformer" else VocaLoss()
+
+
+def build_from_config(config: ExpConfig):
+    """(model, loss_fn) exactly as Audio2FaceModel.__init__ builds them (lightning_model.py:96-99)."""
+    model = get_model(config.modelname)(n_verts=config.vertex_count, n_onehot=config.one_hot_size)
+    return model, get_loss_fn(config.modelname)

@@ -1,0 +1,42 @@
+"""CPU: config.yaml surface and registries mirror the reference harness (lightning_model.py:20-73, config.yaml:1-12)."""
+import os
+import tempfile
+
+import pytest
+
+import a2f_amd
+from a2f_amd.registry import ExpConfig, build_from_config, get_loss_fn, get_model
+
+REFERENCE_CONFIG = """batch_size: 128
+modelname: "audio2mesh"
+vertex_count: 15069 #5023 * 3
+one_hot_size: 12
+split_frame: True
+percision: "16-mixed"
+lr: 1e-4
+feature_extractor: "mfcc"
+sample_rate: 22000
+n_feature: 32
+out_dim: 52
+win_length: 440 #220*2
+"""
+
+
+def test_expconfig_parses_reference_yaml_keys():
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "config.yaml")
+        open(p, "w").write(REFERENCE_CONFIG)
+        cfg = ExpConfig.from_yaml(p)
+    assert cfg.modelname == "audio2mesh" and cfg.vertex_count == 15069 and cfg.percision == "16-mixed" and cfg.lr == 1e-4
+    assert cfg.hop_length is None and cfg.loss is None
+    assert cfg.name() == "audio2mesh_mfcc_0.0001_None_16-mixed"
+    model, loss = build_from_config(cfg)
+    assert isinstance(model, a2f_amd.Audio2Mesh) and model.n_verts == 15069 and model.n_onehot == 12
+    assert isinstance(loss, a2f_amd.VocaLoss)
+
+
+def test_registries():
+    assert get_model("voca") is a2f_amd.Voca and get_model("faceformer") is a2f_amd.Faceformer
+    assert isinstance(get_loss_fn("faceformer"), a2f_amd.FaceFormerLoss) and isinstance(get_loss_fn("voca"), a2f_amd.VocaLoss)
+    with pytest.raises(KeyError):
+        get_model("song2face")

@@ -34,6 +34,7 @@ constexpr int HF_HP = 33;             // pitch of the [k][row] and [col][row] LD
 struct HeadArgs {
   const float* H; const float* W; const float* bias; const float* templ; const float* gt;
   float* pred; float* dH_slab; float* dW_slab; float* db_slab; double* loss_part;
+  unsigned long long* dbg;             // diagnostic build only (HF_STAMPS): per-wave phase cycle totals
   int64_t ldt;                         // template row stride: n, or 0 for one broadcast row
   int B, Bloss, n, CG, RG, NRB;
   float cr, cv;                        // 2 k_rec / (Bloss V), 2 k_vel / ((Bloss/2) V)
@@ -48,11 +49,13 @@ using rsrc_t = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ rsrc_t tile_rsrc(const float* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7FFFFFF0, 0x00020000);
 }
-__device__ __forceinline__ float buf_load(rsrc_t r, int byte_off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+// soff: wave-uniform byte offset (SGPR) added by the hardware: interior tiles address every row with ONE lane-offset
+// register and a scalar row offset, i.e. zero vector ALU work per load / store.
+__device__ __forceinline__ float buf_load(rsrc_t r, int byte_off, int soff = 0) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, soff, 0));
 }
-__device__ __forceinline__ void buf_store(rsrc_t r, int byte_off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);
+__device__ __forceinline__ void buf_store(rsrc_t r, int byte_off, float v, int soff = 0) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, soff, 0);
 }
 
 // NW waves per workgroup, each owning CPW = 16/NW chunks of 32 columns.  NW = 8 (two waves per SIMD, <= 256 registers
@@ -60,6 +63,17 @@ __device__ __forceinline__ void buf_store(rsrc_t r, int byte_off, float v) {
 // allows (K = 50); NW = 4 (one wave per SIMD, 128 dW accumulators) is the K = 64 configuration.
 // COLS columns per workgroup (512: one workgroup per CU; 256: half the LDS, two independent workgroups per CU whose
 // memory stalls and MFMA phases overlap each other), WPS = resident waves per SIMD the register budget is sized for.
+#ifdef HF_STAMPS
+#define HF_STAMP(var)                                                            \
+  do {                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+  } while (0)
+#else
+#define HF_STAMP(var) do { } while (0)
+#endif
+
 template <int K, int NW, int COLS, int WPS>
 __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs a) {
   constexpr int HF_COLS = COLS;
@@ -111,7 +125,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
 #pragma unroll
       for (int r = 0; r < 16; ++r) dW[ct][kt][r] = 0.f;
   }
-  double rec_d = 0.0, vel_d = 0.0;                    // per-lane totals; fp32 partials are folded in once per row block
+  double rec_d = 0.0, vel_d = 0.0;
+  unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, acc_t[6] = {0, 0, 0, 0, 0, 0};
+  (void)st0; (void)st1; (void)st2; (void)st3; (void)st4; (void)st5; (void)acc_t;                    // per-lane totals; fp32 partials are folded in once per row block
 
   const int rb0 = (int)(((int64_t)rg * a.NRB) / a.RG);
   const int rb1 = (int)(((int64_t)(rg + 1) * a.NRB) / a.RG);
@@ -127,17 +143,33 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
   const int lb_wbwd = h * PITCH + l31;                 // W slice as dH B operand:                + (cl + 2*s)*PITCH + 32*kt
   const int lane_off = 4 * h * n + l31;
   const int lane_off_t = 4 * h * (int)a.ldt + l31;
-  // register sets: (tc, gcur) = tile consumed by the current epilogue; (tn, gn) = next chunk (requested two chunks
-  // ago); DEPTH2 adds (tf, gf) = the chunk after next, so a request has two chunks of MFMA time (~5 us) to land
-  constexpr bool DEPTH2 = false;                      // two-deep prefetch measured slower (register spills), kept as a knob
-#ifdef HF_EARLY_ISSUE
-  constexpr bool EARLY = true;                        // request chunk c+1 at the START of chunk c (second register set)
-#else
-  constexpr bool EARLY = false;
-#endif
-  float tc[16], gcur[16], tn[16], gn[16], tf[16], gf[16];
+  // (tc, gcur): template / gt tile of the chunk whose epilogue runs next.  They are refilled row-register by
+  // row-register during the backward MFMAs of the current chunk (their previous contents died in its epilogue).
+  float tc[16], gcur[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { tc[r] = 0.f; gcur[r] = 0.f; tn[r] = 0.f; gn[r] = 0.f; tf[r] = 0.f; gf[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) { tc[r] = 0.f; gcur[r] = 0.f; }
+  // one row-register (r) of a tile: the forms below interleave these with the MFMA stream so the vector-memory queue
+  // never backs up (32 back-to-back tile loads stall the issuing wave until the queue drains: measured, the memory time
+  // then ADDS to the matrix time instead of hiding under it)
+  auto issue_row = [&](int rb, int ct, int r, float* tt, float* gg) {
+    const int cl = wave * HF_WCOLS + ct * 32;
+    const rsrc_t gb = tile_rsrc(a.gt + ((int64_t)rb * HF_ROWS * n + (c0 + cl)));
+    const rsrc_t tb = tile_rsrc(a.templ + ((int64_t)rb * HF_ROWS * a.ldt + (c0 + cl)));
+    const int rlim = B - rb * HF_ROWS;
+    const int mcol = ((colg[ct] - n) >> 31) & ((rb - rb1) >> 31);
+    int lo = lane_off, lot = lane_off_t, h4 = 4 * h;
+    asm volatile("" : "+v"(lo), "+v"(lot), "+v"(h4));
+    const int rr = (r & 3) + 8 * (r >> 2);
+    const int inval = ~(mcol & ((rr + h4 - rlim) >> 31));
+    // (a scalar-soffset form - zero VALU per access on interior tiles - was measured 30 % SLOWER end to end: the uniform
+    //  interior/boundary branch per row splits the scheduling region; keep the branch-free per-lane offsets)
+#ifdef HF_ABL_NOLOAD
+    tt[r] = __int_as_float(inval & 0x3f800000); gg[r] = __int_as_float(lo & 0x3f000000);
+#else
+    tt[r] = buf_load(tb, (4 * (rr * (int)a.ldt + lot)) | inval);
+    gg[r] = buf_load(gb, (4 * (rr * n + lo)) | inval);
+#endif
+  };
   auto issue_loads = [&](int rb, int ct, float* tc, float* gcur) {
     const int cl = wave * HF_WCOLS + ct * 32;
     {
@@ -163,26 +195,52 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
       }
     }
   };
-  // linear chunk index -> (row block, chunk)
-  auto issue_at = [&](int rb, int ct, int ahead, float* tt, float* gg) {
-    const int lin = ct + ahead;
-    issue_loads(rb + lin / CPW, lin % CPW, tt, gg);
-  };
   issue_loads(rb0, 0, tc, gcur);
-  if (DEPTH2) issue_at(rb0, 0, 1, tn, gn);
-  if (EARLY) {                                        // tn/gn double as "next" set: current tile goes straight to tc/gcur
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { tn[r] = tc[r]; gn[r] = gcur[r]; }
-  }
 
-  for (int rb = rb0; rb < rb1; ++rb) {
-    __syncthreads();                                   // previous block's Hs / reduction-buffer readers are done
-    for (int e = t; e < HF_ROWS * K; e += HF_THREADS) {
+  // H tile of the NEXT row block travels in registers: requested at the top of a row block (older than every tile
+  // prefetch, so consuming it never drains the in-order vmcnt queue behind younger tile loads), written to LDS at the
+  // bottom.  A synchronous stage here cost a full HBM round trip per row block behind the tile prefetches.
+  constexpr bool LEAN = (WPS >= 2);                    // two waves per SIMD: 256 registers each -> no deferred stores, no H registers
+  constexpr int HPT = LEAN ? 1 : (HF_ROWS * K + HF_THREADS - 1) / HF_THREADS;
+  float hreg[HPT];
+  auto h_request = [&](int rb) {
+    if (LEAN) return;
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+      const int e = t + i * HF_THREADS;
       const int row = e / K, k = e - row * K;
       const int grow = rb * HF_ROWS + row;
-      Hs[k * HF_HP + row] = grow < B ? a.H[(int64_t)grow * K + k] : 0.f;
+      hreg[i] = (e < HF_ROWS * K && grow < B && rb < rb1) ? a.H[(int64_t)grow * K + k] : 0.f;
     }
-    __syncthreads();
+  };
+  auto h_commit = [&](int rb) {
+    if (LEAN) {                                        // synchronous stage of row block rb (partner wave covers the latency)
+      for (int e = t; e < HF_ROWS * K; e += HF_THREADS) {
+        const int row = e / K, k = e - row * K;
+        const int grow = rb * HF_ROWS + row;
+        Hs[k * HF_HP + row] = (grow < B && rb < rb1) ? a.H[(int64_t)grow * K + k] : 0.f;
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+      const int e = t + i * HF_THREADS;
+      const int row = e / K, k = e - row * K;
+      if (e < HF_ROWS * K) Hs[k * HF_HP + row] = hreg[i];
+    }
+  };
+  h_request(rb0);
+  __syncthreads();                                     // W slice staged, Hs zeroed
+  h_commit(rb0);
+
+  for (int rb = rb0; rb < rb1; ++rb) {
+    HF_STAMP(st5);
+    __syncthreads();                                   // Hs of this row block is complete; reduction buffer is free
+    h_request(rb + 1);
+    HF_STAMP(st0);
+#ifdef HF_STAMPS
+    acc_t[4] += st0 - st5;
+#endif
 
     f32x16 dH[2];
 #pragma unroll
@@ -196,19 +254,17 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
       const int cl = wave * HF_WCOLS + ct * 32;        // first column of the chunk inside the slice
       // (chunks that lie wholly beyond column n run on zeros: straight-line code keeps the 160 accumulator
       //  registers free of control-flow copies; only the last column group has such chunks)
-      if (EARLY) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { tc[r] = tn[r]; gcur[r] = gn[r]; }
-        issue_at(rb, ct, 1, tn, gn);
-        __builtin_amdgcn_sched_barrier(0);
-      }
       f32x16 acc;
+      float pv[16];                                     // pred values / store offsets of this chunk, stored during the dH MFMAs
+      int so[16];
+      rsrc_t pbuf;
       // opaque zero: keeps hipcc from caching this row block's H fragments (57 VGPRs) across the chunks of the wave;
       // re-reading them from LDS per chunk is free (the LDS pipe is far from saturated)
       int hz = 0;
       asm volatile("" : "+v"(hz));
       const float* Hq = Hs + hz;
       const float* Wc = Ws + cl * PITCH + hz;           // this chunk's rows of the W slice
+      HF_STAMP(st0);
       {
         // ---- forward tile: acc[row][col] = sum_k H[row][k] W[col][k] ----
 #pragma unroll
@@ -219,6 +275,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
           const float bv = Wc[lb_wfwd + 2 * s];
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
         }
+        HF_STAMP(st1);
         __builtin_amdgcn_sched_barrier(0);
         // ---- epilogue: pred, loss partials, G (in place of acc) ----
         const bool colok = colg[ct] < n;
@@ -226,7 +283,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
         const int rlim = B - rb * HF_ROWS;
         const int mint = interior ? -1 : 0;            // whole tile inside the matrix (wave-uniform)
         const int mcolv = (colg[ct] - n) >> 31;        // -1 where this lane's column exists
-        const rsrc_t pb = tile_rsrc(a.pred + ((int64_t)rb * HF_ROWS * n + (c0 + cl)));
+        pbuf = tile_rsrc(a.pred + ((int64_t)rb * HF_ROWS * n + (c0 + cl)));
         int lo = lane_off, h4 = 4 * h;
         asm volatile("" : "+v"(lo), "+v"(h4));         // see issue_loads: keep store offsets local to the chunk
         float gsum = 0.f;
@@ -235,12 +292,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
           const int rr = (r & 3) + 8 * (r >> 2);
           const float p0 = acc[r] + bias_r[ct] + tc[r];
           const float p1 = acc[r + 1] + bias_r[ct] + tc[r + 1];
-#ifdef HF_ABL_NOSTORE     // timing ablation only: pred is not written
-          asm volatile("" :: "v"(p0), "v"(p1));
-#else
-          buf_store(pb, (4 * (rr * n + lo)) | ~(mint | (mcolv & ((rr + h4 - rlim) >> 31))), p0);
-          buf_store(pb, (4 * ((rr + 1) * n + lo)) | ~(mint | (mcolv & ((rr + 1 + h4 - rlim) >> 31))), p1);
-#endif
+          const int so0 = (4 * (rr * n + lo)) | ~(mint | (mcolv & ((rr + h4 - rlim) >> 31)));
+          const int so1 = (4 * ((rr + 1) * n + lo)) | ~(mint | (mcolv & ((rr + 1 + h4 - rlim) >> 31)));
+          if (!LEAN) { pv[r] = p0; pv[r + 1] = p1; so[r] = so0; so[r + 1] = so1; }
+          else { buf_store(pbuf, so0, p0); buf_store(pbuf, so1, p1); }
+
           const bool in_loss = colok && (rb * HF_ROWS + rr + h4 + 1 < a.Bloss);
           const float d0 = in_loss ? p0 - gcur[r] : 0.f;
           const float d1 = in_loss ? p1 - gcur[r + 1] : 0.f;
@@ -258,9 +314,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
       }
       // template / gt registers are free again: request the next chunk's tile now, so the loads fly under the
       // 64 backward MFMAs of this chunk (one wave per SIMD: ILP, not occupancy, hides HBM latency)
-      if (DEPTH2) issue_at(rb, ct, 2, tf, gf);
-      else if (!EARLY) issue_at(rb, ct, 1, tn, gn);
-      __builtin_amdgcn_sched_barrier(0);
+      HF_STAMP(st2);
+      const int lin1 = ct + 1;                          // next chunk in linear order
+      const int rbn = rb + lin1 / CPW, ctn = lin1 % CPW;
       {
         // ---- dW[col][k] += sum_row G[row][col] H[row][k]: accumulator register q is the A operand of k-step q ----
 #ifdef HF_ABL_NODW        // timing ablation only: no dW product
@@ -274,8 +330,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
             const float bv = Hq[lb_colmajor + kt * 32 * HF_HP + rrc];
             dW[ct][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[q], bv, dW[ct][kt], 0, 0, 0);
           }
+          issue_row(rbn, ctn, q, tc, gcur);             // two tile loads ride behind each pair of MFMAs
         }
 #endif
+        HF_STAMP(st3);
         __builtin_amdgcn_sched_barrier(0);
         // ---- dH[row][k] += sum_col G[row][col] W[col][k]: transpose G through the wave's LDS tile ----
 #ifndef HF_ABL_NODH       // timing ablation only: no dH product
@@ -289,17 +347,21 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
             const float bv = Wc[lb_wbwd + 2 * s * PITCH + kt * 32];
             dH[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, dH[kt], 0, 0, 0);
           }
+#ifdef HF_ABL_NOSTORE
+          if (!LEAN) asm volatile("" :: "v"(pv[s]), "v"(so[s]));
+#else
+          if (!LEAN) buf_store(pbuf, so[s], pv[s]);     // one pred row-register per k-step
+#endif
         }
 #endif
       }
-      // rotate the prefetch sets
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (!EARLY) { tc[r] = tn[r]; gcur[r] = gn[r]; }
-        if (DEPTH2) { tn[r] = tf[r]; gn[r] = gf[r]; }
-      }
+      HF_STAMP(st4);
+#ifdef HF_STAMPS
+      acc_t[0] += st1 - st0; acc_t[1] += st2 - st1; acc_t[2] += st3 - st2; acc_t[3] += st4 - st3;
+#endif
     }
 
+    HF_STAMP(st5);
     rec_d += (double)rec;
     vel_d += (double)vel;
     // ---- fold the four waves' dH partials (two 32-wide halves) and emit this column group's slab rows ----
@@ -320,8 +382,17 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
         if (row < B) a.dH_slab[((int64_t)cg * B + row) * HF_KP + kt * 32 + (e & 31)] = v;
       }
     }
+    h_commit(rb + 1);                                  // every wave passed a barrier after its last Hs read of this block
+    HF_STAMP(st0);
+#ifdef HF_STAMPS
+    acc_t[5] += st0 - st5;
+#endif
   }
 
+#ifdef HF_STAMPS
+  if (lane == 0 && a.dbg)
+    for (int i = 0; i < 6; ++i) a.dbg[((int64_t)blockIdx.x * NW + wave) * 8 + i] = acc_t[i];
+#endif
   // ---- workgroup epilogue: dW / dbias slabs of this row group, loss partials ----
   const int64_t ncols_pad = (int64_t)a.CG * HF_COLS;
 #pragma unroll
@@ -388,7 +459,7 @@ __global__ void head_loss_finish_kernel(const double* __restrict__ part, int npa
 
 struct HeadPlan {
   int CG, RG, NRB;
-  size_t off_dH, off_dW, off_db, off_loss, total;
+  size_t off_dH, off_dW, off_db, off_loss, off_dbg, total;
 };
 
 static HeadPlan head_plan(int64_t B, int64_t n, int cols, int wg_slots) {
@@ -406,6 +477,7 @@ static HeadPlan head_plan(int64_t B, int64_t n, int cols, int wg_slots) {
   p.off_db = o; o += (size_t)p.RG * (size_t)p.CG * HF_COLS * sizeof(float);
   o = (o + 15) & ~(size_t)15;
   p.off_loss = o; o += (size_t)p.CG * p.RG * 2 * sizeof(double);
+  p.off_dbg = o; o += (size_t)p.CG * p.RG * 8 * 8 * sizeof(unsigned long long);
   p.total = o;
   return p;
 }
@@ -428,15 +500,18 @@ static int head_launch(const HeadArgs& a, const HeadPlan& p, hipStream_t s) {
 }  // namespace a2f
 
 namespace a2f {
-// kernel configuration per K: 0 = 512 columns x 8 waves (1 workgroup/CU), 1 = 512 x 4, 2 = 256 columns x 4 waves (2 workgroups/CU)
+// kernel configuration: 0 = 512 columns x 8 waves, 1 = 512 x 4 waves, 2 = 256 x 4 (two workgroups per CU),
+// 3 = 384 x 4 (no spills at one wave per SIMD), 4 = 256 x 8 (two waves per SIMD, 183 VGPRs, no spills; K = 50 only)
 static int head_cfg(int64_t K) {
   static const int env = [] { const char* e = getenv("A2F_HEAD_CFG"); return e ? atoi(e) : -1; }();
-  if (K == 64) return (env == 2) ? 2 : 1;
-  return env >= 0 && env <= 2 ? env : 1;          // measured on MI355X (B=19200): cfg1 1.71 ms, cfg0 2.02 ms, cfg2 2.39 ms
+  if (K == 64) return (env >= 1 && env <= 3) ? env : 3;
+  // measured on MI355X (B = 19200, K = 50, kernel + slab folds): cfg4 1.55 ms, cfg3 1.61, cfg1 1.71-1.79, cfg0 2.0+, cfg2 2.4
+  return env >= 0 && env <= 4 ? env : 4;
 }
 static HeadPlan head_plan_for(int64_t B, int64_t n, int64_t K) {
   const int cfg = head_cfg(K);
-  return cfg == 2 ? head_plan(B, n, 256, (K == 64) ? 256 : 512) : head_plan(B, n, 512, 256);
+  return cfg == 2 ? head_plan(B, n, 256, (K == 64) ? 256 : 512) : cfg == 3 ? head_plan(B, n, 384, 256)
+       : cfg == 4 ? head_plan(B, n, 256, 256) : head_plan(B, n, 512, 256);
 }
 }  // namespace a2f
 
@@ -464,6 +539,7 @@ extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias,
   a.H = H; a.W = W; a.bias = bias; a.templ = templ; a.gt = gt; a.pred = pred;
   a.dH_slab = (float*)(w8 + p.off_dH); a.dW_slab = (float*)(w8 + p.off_dW); a.db_slab = (float*)(w8 + p.off_db);
   a.loss_part = (double*)(w8 + p.off_loss);
+  a.dbg = (unsigned long long*)(w8 + p.off_dbg);
   a.ldt = template_rows == 1 ? 0 : n;
   a.B = (int)B; a.Bloss = (int)Bloss; a.n = (int)n; a.CG = p.CG; a.RG = p.RG; a.NRB = p.NRB;
   const double V = (double)(n / 3);
@@ -471,10 +547,12 @@ extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias,
   a.cv = (float)(2.0 * k_vel / ((double)(Bloss / 2) * V));
   const int cfg = head_cfg(K);
   int rc;
-  if (K == 50) rc = cfg == 0 ? head_launch<50, 8, 512, 2>(a, p, s) : cfg == 1 ? head_launch<50, 4, 512, 1>(a, p, s) : head_launch<50, 4, 256, 2>(a, p, s);
-  else rc = cfg == 2 ? head_launch<64, 4, 256, 1>(a, p, s) : head_launch<64, 4, 512, 1>(a, p, s);
+  if (K == 50) rc = cfg == 0 ? head_launch<50, 8, 512, 2>(a, p, s) : cfg == 1 ? head_launch<50, 4, 512, 1>(a, p, s)
+                  : cfg == 2 ? head_launch<50, 4, 256, 2>(a, p, s) : cfg == 4 ? head_launch<50, 8, 256, 2>(a, p, s)
+                  : head_launch<50, 4, 384, 1>(a, p, s);
+  else rc = cfg == 2 ? head_launch<64, 4, 256, 1>(a, p, s) : cfg == 3 ? head_launch<64, 4, 384, 1>(a, p, s) : head_launch<64, 4, 512, 1>(a, p, s);
   if (rc != A2F_OK) return rc;
-  const int64_t ncols_pad = (int64_t)p.CG * (cfg == 2 ? 256 : 512);
+  const int64_t ncols_pad = (int64_t)p.CG * ((cfg == 2 || cfg == 4) ? 256 : cfg == 3 ? 384 : 512);
   {
     int64_t blocks = cdiv(B * HF_KP, 256); if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.dH_slab, p.CG, (int64_t)B * HF_KP, B, (int)K, dH);

@@ -125,10 +125,11 @@ class HipBackend:
                                              self._stream(pred)), "a2f_vocaloss_bwd")
         self._prof_end("loss_bwd", ev)
 
-    def head_fused(self, H, W, bias, templ, template_rows, gt, B, Bloss, n, K, k_rec, k_vel, pred, out3, dH, dW, dbias):
+    def head_fused(self, H, W, bias, templ, template_rows, gt, B, Bloss, n, K, k_rec, k_vel, pred, out3, dH, dW, dbias, ws=None):
         _chk(H, W, bias, templ, gt, pred, out3, dH, dW, dbias)
         nb = self.lib.a2f_head_fused_ws_bytes(B, n, K)
-        ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=H.device)
+        if ws is None:
+            ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=H.device)
         ev = self._prof_begin("head_fused")
         _lib.check(self.lib.a2f_head_fused(_ptr(H), _ptr(W), _ptr(bias), _ptr(templ), template_rows, _ptr(gt), B, Bloss, n, K,
                                            k_rec, k_vel, _ptr(pred), _ptr(out3), _ptr(dH), _ptr(dW), _ptr(dbias),

@@ -5,16 +5,16 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-template <int MODE, int WRITE>
-__global__ __launch_bounds__(512) void k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int B, int n, int NRB, int RG, int CG) {
+template <int MODE, int WRITE, int NW>
+__global__ __launch_bounds__(64 * NW) void k(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int B, int n, int NRB, int RG, int CG) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
   const int cg = blockIdx.x % CG, rg = blockIdx.x / CG;
   const int rb0 = rg * NRB / RG, rb1 = (rg + 1) * NRB / RG;
   float acc = 0.f;
   for (int rb = rb0; rb < rb1; ++rb) {
     if (MODE == 0) {
-      for (int ct = 0; ct < 2; ++ct) {
-        const int col = cg * 512 + wave * 64 + ct * 32 + l31;
+      for (int ct = 0; ct < 16 / NW; ++ct) {
+        const int col = cg * 512 + wave * (512 / NW) + ct * 32 + l31;
         float va[16], vb[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -30,7 +30,8 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ a, const floa
         }
       }
     } else {
-      const int col = cg * 512 + wave * 64 + lane;
+      for (int cc = 0; cc < 8 / NW; ++cc) {
+      const int col = cg * 512 + wave * (512 / NW) + cc * 64 + lane;
       float va[32], vb[32];
 #pragma unroll
       for (int r = 0; r < 32; ++r) {
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ a, const floa
         acc += va[r] * vb[r];
         if (WRITE) { const int row = rb * 32 + r; if (col < n && row < B) o[(long)row * n + col] = va[r] + vb[r]; }
       }
+      }
     }
   }
   if (acc == 12345.678f) o[0] = acc;
@@ -55,17 +57,20 @@ int main() {
   hipMalloc(&a, bytes); hipMalloc(&b, bytes); hipMalloc(&o, bytes);
   hipMemset(a, 0, bytes); hipMemset(b, 0, bytes);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  auto run = [&](auto kern, const char* name, int wr) {
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(CG * RG), dim3(512), 0, 0, a, b, o, B, n, NRB, RG, CG);
+  auto run = [&](auto kern, const char* name, int wr, int nw = 8) {
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(CG * RG), dim3(64 * nw), 0, 0, a, b, o, B, n, NRB, RG, CG);
     hipEventRecord(e0);
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(CG * RG), dim3(512), 0, 0, a, b, o, B, n, NRB, RG, CG);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(CG * RG), dim3(64 * nw), 0, 0, a, b, o, B, n, NRB, RG, CG);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
-    printf("%-28s %.3f ms  %.0f GB/s\n", name, ms, (2 + wr) * (double)bytes / ms / 1e6);
+    printf("%-36s %.3f ms  %.0f GB/s\n", name, ms, (2 + wr) * (double)bytes / ms / 1e6);
   };
-  run(k<0, 0>, "tile 2x128B read-only", 0);
-  run(k<1, 0>, "row 256B read-only", 0);
-  run(k<0, 1>, "tile 2x128B read+write", 1);
-  run(k<1, 1>, "row 256B read+write", 1);
+  run(k<0, 0, 8>, "8 waves tile 2x128B read-only", 0, 8);
+  run(k<1, 0, 8>, "8 waves row 256B read-only", 0, 8);
+  run(k<0, 1, 8>, "8 waves tile 2x128B read+write", 1, 8);
+  run(k<1, 1, 8>, "8 waves row 256B read+write", 1, 8);
+  run(k<0, 0, 4>, "4 waves tile 2x128B read-only", 0, 4);
+  run(k<0, 1, 4>, "4 waves tile 2x128B read+write", 1, 4);
+  run(k<1, 1, 4>, "4 waves row 256B read+write", 1, 4);
   return 0;
 }

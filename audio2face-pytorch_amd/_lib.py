@@ -48,6 +48,8 @@ SIGNATURES = {
     "a2f_head_fused_ws_bytes": (sz, [i64, i64, i64]),
     "a2f_head_fused": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, c_f32p, i64, i64, i64, i64, f32, f32,
                                  c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
+    "a2f_profile_enable": (C.c_int, [i32]),
+    "a2f_profile_head_ms": (C.c_int, [C.POINTER(C.c_float), C.POINTER(i32)]),
     "a2f_voca_pack": (C.c_int, [c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, C.c_void_p]),
     "a2f_a2m_pack": (C.c_int, [c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, i64, i64, C.c_void_p]),
     "a2f_conv_weight_pack": (C.c_int, [c_f32p, c_f32p, i64, i64, i64, i32, C.c_void_p]),

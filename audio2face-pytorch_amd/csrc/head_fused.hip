@@ -88,6 +88,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
   float* Ws = lds;
   float* Hs = lds + WS_FLOATS;
   float* Gs_all = Hs + HS_FLOATS;
+  // dedicated [NW][32][64] dH fold buffer when LDS allows: the fold then needs one barrier per row block instead of four
+  constexpr bool BIGRED = (WS_FLOATS + HS_FLOATS + NW * GS_FLOATS + NW * 2048) * 4 <= 160 * 1024;
+  float* redbig = Gs_all + NW * GS_FLOATS;
 
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);          // scalar: keeps tile base addresses in SGPRs
@@ -201,10 +204,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
   // prefetch, so consuming it never drains the in-order vmcnt queue behind younger tile loads), written to LDS at the
   // bottom.  A synchronous stage here cost a full HBM round trip per row block behind the tile prefetches.
   constexpr bool LEAN = (WPS >= 2);                    // two waves per SIMD: 256 registers each -> no deferred stores, no H registers
-  constexpr int HPT = LEAN ? 1 : (HF_ROWS * K + HF_THREADS - 1) / HF_THREADS;
+  constexpr int HPT = (HF_ROWS * K + HF_THREADS - 1) / HF_THREADS;
   float hreg[HPT];
   auto h_request = [&](int rb) {
-    if (LEAN) return;
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {
       const int e = t + i * HF_THREADS;
@@ -214,14 +216,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
     }
   };
   auto h_commit = [&](int rb) {
-    if (LEAN) {                                        // synchronous stage of row block rb (partner wave covers the latency)
-      for (int e = t; e < HF_ROWS * K; e += HF_THREADS) {
-        const int row = e / K, k = e - row * K;
-        const int grow = rb * HF_ROWS + row;
-        Hs[k * HF_HP + row] = (grow < B && rb < rb1) ? a.H[(int64_t)grow * K + k] : 0.f;
-      }
-      return;
-    }
+    (void)rb;
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {
       const int e = t + i * HF_THREADS;
@@ -365,21 +360,38 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
     rec_d += (double)rec;
     vel_d += (double)vel;
     // ---- fold the four waves' dH partials (two 32-wide halves) and emit this column group's slab rows ----
-    float* red = Gs_all;                                // [NW][32][32] floats, reuses the staging tiles
+    if (BIGRED) {
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) redbig[(wave * 2048 + 4 * h * 64 + kt * 32 + l31) + ((r & 3) + 8 * (r >> 2)) * 64] = dH[kt][r];
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[(wave * 1024 + 4 * h * 32 + l31) + ((r & 3) + 8 * (r >> 2)) * 32] = dH[kt][r];
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 1024 / HF_THREADS; ++i) {
-        const int e = t + i * HF_THREADS;               // 0..1023: row = e/32, k = e%32
+      for (int i = 0; i < 2048 / HF_THREADS; ++i) {
+        const int e = t + i * HF_THREADS;               // 0..2047: row = e/64, k = e%64
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) v += red[w * 1024 + e];
-        const int row = rb * HF_ROWS + (e >> 5);
-        if (row < B) a.dH_slab[((int64_t)cg * B + row) * HF_KP + kt * 32 + (e & 31)] = v;
+        for (int w = 0; w < NW; ++w) v += redbig[w * 2048 + e];
+        const int row = rb * HF_ROWS + (e >> 6);
+        if (row < B) a.dH_slab[((int64_t)cg * B + row) * HF_KP + (e & 63)] = v;
+      }
+    } else {
+      float* red = Gs_all;                              // [NW][32][32] floats, reuses the staging tiles
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 1024 + 4 * h * 32 + l31) + ((r & 3) + 8 * (r >> 2)) * 32] = dH[kt][r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 1024 / HF_THREADS; ++i) {
+          const int e = t + i * HF_THREADS;             // 0..1023: row = e/32, k = e%32
+          float v = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) v += red[w * 1024 + e];
+          const int row = rb * HF_ROWS + (e >> 5);
+          if (row < B) a.dH_slab[((int64_t)cg * B + row) * HF_KP + kt * 32 + (e & 31)] = v;
+        }
       }
     }
     h_commit(rb + 1);                                  // every wave passed a barrier after its last Hs read of this block
@@ -482,10 +494,20 @@ static HeadPlan head_plan(int64_t B, int64_t n, int cols, int wg_slots) {
   return p;
 }
 
+// ---- optional HIP-event timing of the main kernel alone (bench.py roofline leg) ------------------------------------
+// Off by default: the library then has no mutable global state.  When enabled, a ring of event pairs is recorded on the
+// launch stream right around head_fused_kernel (not around the slab folds that follow it).
+static bool g_prof_on = false;
+static int g_prof_n = 0;
+static hipEvent_t g_prof_ev[64][2];
+static bool g_prof_init = false;
+
 template <int K, int NW, int COLS, int WPS>
 static int head_launch(const HeadArgs& a, const HeadPlan& p, hipStream_t s) {
   constexpr int PITCH = K | 1;
-  const size_t lds_bytes = (size_t)(COLS * PITCH + 64 + HF_KP * HF_HP + NW * HF_ROWS * HF_HP) * sizeof(float);
+  size_t lds_floats = (size_t)(COLS * PITCH + 64 + HF_KP * HF_HP + NW * HF_ROWS * HF_HP);
+  if ((lds_floats + NW * 2048) * 4 <= 160 * 1024) lds_floats += NW * 2048;          // BIGRED (see kernel)
+  const size_t lds_bytes = lds_floats * sizeof(float);
   static bool attr_set = false;       // idempotent; a benign race sets the same value
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<K, NW, COLS, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -493,7 +515,10 @@ static int head_launch(const HeadArgs& a, const HeadPlan& p, hipStream_t s) {
     if (e != hipSuccess) return set_err(A2F_ELAUNCH, "head_fused: hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e));
     attr_set = true;
   }
+  const bool prof = g_prof_on && g_prof_n < 64;
+  if (prof) hipEventRecord(g_prof_ev[g_prof_n][0], s);
   hipLaunchKernelGGL((head_fused_kernel<K, NW, COLS, WPS>), dim3((unsigned)(p.CG * p.RG)), dim3(64 * NW), lds_bytes, s, a);
+  if (prof) { hipEventRecord(g_prof_ev[g_prof_n][1], s); ++g_prof_n; }
   return A2F_OK;
 }
 
@@ -514,6 +539,35 @@ static HeadPlan head_plan_for(int64_t B, int64_t n, int64_t K) {
        : cfg == 4 ? head_plan(B, n, 256, 256) : head_plan(B, n, 512, 256);
 }
 }  // namespace a2f
+
+extern "C" int a2f_profile_enable(int32_t on) {
+  using namespace a2f;
+  if (on && !g_prof_init) {
+    for (int i = 0; i < 64; ++i)
+      for (int j = 0; j < 2; ++j)
+        if (hipEventCreate(&g_prof_ev[i][j]) != hipSuccess) return set_err(A2F_ELAUNCH, "profile_enable: hipEventCreate failed");
+    g_prof_init = true;
+  }
+  g_prof_on = on != 0;
+  g_prof_n = 0;
+  return A2F_OK;
+}
+
+extern "C" int a2f_profile_head_ms(float* mean_ms, int32_t* launches) {
+  using namespace a2f;
+  A2F_CHECK_ARG(mean_ms && launches, "profile_head_ms: null pointer");
+  double tot = 0.0;
+  for (int i = 0; i < g_prof_n; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]) != hipSuccess)
+      return set_err(A2F_ELAUNCH, "profile_head_ms: events not complete (synchronize the device first)");
+    tot += ms;
+  }
+  *launches = g_prof_n;
+  *mean_ms = g_prof_n ? (float)(tot / g_prof_n) : 0.f;
+  g_prof_n = 0;
+  return A2F_OK;
+}
 
 extern "C" size_t a2f_head_fused_ws_bytes(int64_t B, int64_t n, int64_t K) {
   if (B <= 0 || n <= 0) return 16;

@@ -7,7 +7,8 @@
 // set per WAVE (MT x NT accumulators of the 32x32x2 f32 MFMA), every wave of every workgroup owns a slice of K, and both
 // operands are read from global memory directly in MFMA operand layout - A is stored (K, M) with M contiguous and B is
 // stored (K, N) with N contiguous, so a wave-instruction fetches two full 128-byte row segments: coalesced, no LDS, no
-// barriers.  Each wave leaves one partial slab; `wgrad_fold_kernel` folds the slabs in fixed order (deterministic).
+// barriers in the K loop.  The four waves fold through LDS into one partial slab per workgroup; `wgrad_fold_kernel` sums the
+// slabs in fixed order (deterministic).
 #include "a2f_common.h"
 
 namespace a2f {
@@ -21,8 +22,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void wgrad_kernel(const a2f_gemm_des
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int M = (int)d.M, N = (int)d.N, K = (int)d.K;
   const int Neff = N + (d.ones_out ? 1 : 0);
-  const int slab_id = blockIdx.x * 4 + wave;
-  const int kbeg = slab_id * rows_per_wave;
+  const int kbeg = (blockIdx.x * 4 + wave) * rows_per_wave;
   const int kend = min(K, kbeg + rows_per_wave);
   const float* __restrict__ Ap = d.A + d.a_off;
   const float* __restrict__ Bp = d.B + d.b_off;
@@ -66,41 +66,52 @@ __global__ __launch_bounds__(WG_THREADS, 1) void wgrad_kernel(const a2f_gemm_des
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
   }
 
-  // partial slab of this wave: [m][n], pitch Neff.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  float* slab = d.splitk_ws + (int64_t)slab_id * M * Neff;
+  // fold the four waves of the workgroup through LDS, tile by tile, and leave ONE partial slab per workgroup:
+  // [m][n], pitch Neff.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  __shared__ float red[4][1024];
+  float* slab = d.splitk_ws + (int64_t)blockIdx.x * M * Neff;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int n = j * 32 + l31;
-      if (n >= Neff) continue;
+      __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < M) slab[(int64_t)m * Neff + n] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[i][j][r];
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = t + q * WG_THREADS;                  // 0..1023: row = e / 32, col = e % 32
+        const int m = i * 32 + (e >> 5), n = j * 32 + (e & 31);
+        if (m < M && n < Neff) slab[(int64_t)m * Neff + n] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
       }
     }
 }
 
-// out[i] = sum_z slab[z][i]: one wave per output element (4 per workgroup), 64 z-lanes with 4 independent partial sums
-// each (loads in flight together), butterfly fold: fixed summation order, ~20 dependent steps instead of slabs/16.
+// out[i] = sum_z slab[z][i]: 16 consecutive outputs x 16 z-lanes per workgroup (64-byte coalesced segments), every lane
+// keeps 4 independent partial sums so its loads are in flight together; fixed summation order (deterministic).
 __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* __restrict__ ws, int slabs, int M, int N, int Neff,
                                                           float* __restrict__ C, int64_t ldc, float* __restrict__ ones_out) {
-  const int t = threadIdx.x, lane = t & 63;
+  __shared__ float sh[16][17];
+  const int t = threadIdx.x, o = t & 15, zg = t >> 4;
   const int64_t total = (int64_t)M * Neff;
-  const int64_t i = (int64_t)blockIdx.x * 4 + (t >> 6);
-  if (i >= total) return;                                   // wave-uniform
+  const int64_t i = (int64_t)blockIdx.x * 16 + o;
   float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-  int z = lane;
-  for (; z + 192 < slabs; z += 256) {
-    v0 += ws[(int64_t)z * total + i];
-    v1 += ws[(int64_t)(z + 64) * total + i];
-    v2 += ws[(int64_t)(z + 128) * total + i];
-    v3 += ws[(int64_t)(z + 192) * total + i];
+  if (i < total) {
+    int z = zg;
+    for (; z + 48 < slabs; z += 64) {
+      v0 += ws[(int64_t)z * total + i];
+      v1 += ws[(int64_t)(z + 16) * total + i];
+      v2 += ws[(int64_t)(z + 32) * total + i];
+      v3 += ws[(int64_t)(z + 48) * total + i];
+    }
+    for (; z < slabs; z += 16) v0 += ws[(int64_t)z * total + i];
   }
-  for (; z < slabs; z += 64) v0 += ws[(int64_t)z * total + i];
-  const float s = wave_sum((v0 + v1) + (v2 + v3));
-  if (lane == 0) {
+  sh[zg][o] = (v0 + v1) + (v2 + v3);
+  __syncthreads();
+  if (t < 16 && i < total) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += sh[g][t];
     const int row = (int)(i / Neff), col = (int)(i - (int64_t)row * Neff);
     if (col < N) C[(int64_t)row * ldc + col] = s;
     else ones_out[row] = s;
@@ -115,7 +126,7 @@ static WgradPlan wgrad_plan(int64_t K) {
   WgradPlan p;
   p.rows_per_wave = (int)rpw;
   p.blocks = (int)cdiv(K, rpw * 4);
-  p.slabs = p.blocks * 4;
+  p.slabs = p.blocks;                 // one slab per workgroup (waves folded in LDS)
   return p;
 }
 
@@ -162,7 +173,7 @@ extern "C" int a2f_wgrad_f32(const a2f_gemm_desc* dp, a2f_stream_t stream) {
   else return set_err(A2F_EINVAL, "wgrad: no tile set for %d x %d tiles", mt, nt);
   const int64_t neff = d.N + (d.ones_out ? 1 : 0);
   const int64_t total = d.M * neff;
-  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)cdiv(total, 4)), dim3(256), 0, s, (const float*)d.splitk_ws, p.slabs, (int)d.M, (int)d.N,
+  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)cdiv(total, 16)), dim3(256), 0, s, (const float*)d.splitk_ws, p.slabs, (int)d.M, (int)d.N,
                      (int)neff, d.C, d.ldc, d.ones_out);
   A2F_CHECK_LAUNCH("wgrad_f32");
   return A2F_OK;

@@ -136,6 +136,15 @@ class HipBackend:
                                            _ptr(ws), nb, self._stream(H)), "a2f_head_fused")
         self._prof_end("head_fused", ev)
 
+    def profile_head(self, on: bool):
+        _lib.check(self.lib.a2f_profile_enable(int(on)), "a2f_profile_enable")
+
+    def profile_head_ms(self):
+        """(mean ms, launches) of head_fused_kernel alone since profile_head(True); call after torch.cuda.synchronize()."""
+        ms, n = C.c_float(0), C.c_int32(0)
+        _lib.check(self.lib.a2f_profile_head_ms(C.byref(ms), C.byref(n)), "a2f_profile_head_ms")
+        return ms.value, n.value
+
     # ---- packing ------------------------------------------------------------------------------
     def voca_pack(self, x, one_hot, B, n_onehot, a0, cat72):
         _chk(x, one_hot, a0, cat72)

@@ -118,6 +118,12 @@ int a2f_head_fused(const float* H, const float* W, const float* bias, const floa
                    float* pred, float* out3, float* dH, float* dW, float* dbias,
                    void* ws, size_t ws_bytes, a2f_stream_t stream);
 
+/* Measurement hook (off by default; the only mutable global state of the library, and only while enabled): records
+ * HIP events on the launch stream right around the main kernel of a2f_head_fused (not its slab folds) for up to 64
+ * launches; a2f_profile_head_ms returns their mean duration and resets the ring (synchronise the device first). */
+int a2f_profile_enable(int32_t on);
+int a2f_profile_head_ms(float* mean_ms, int32_t* launches);
+
 /* ------------------------------------------------------------------------------------------------
  * VOCA input packing (voca.py:40-45): x (B,29,16), one_hot (B,n_onehot>=8) ->
  *   a0 (B,16,37) channels-last window [h][c]: c<29: x[b,c,h]; c>=29: one_hot[b, h%8]  (repeat(1,16).view quirk)

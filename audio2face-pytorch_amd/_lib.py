@@ -51,6 +51,8 @@ SIGNATURES = {
     "a2f_profile_enable": (C.c_int, [i32]),
     "a2f_profile_head_ms": (C.c_int, [C.POINTER(C.c_float), C.POINTER(i32)]),
     "a2f_voca_pack": (C.c_int, [c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, C.c_void_p]),
+    "a2f_voca_trunk_fwd": (C.c_int, [c_f32p, c_f32p, i64, i64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_void_p), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "a2f_a2m_pack": (C.c_int, [c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, i64, i64, C.c_void_p]),
     "a2f_conv_weight_pack": (C.c_int, [c_f32p, c_f32p, i64, i64, i64, i32, C.c_void_p]),
     "a2f_bn_ws_bytes": (sz, [i64, i64]),

@@ -1,0 +1,255 @@
+// Fused VOCA trunk forward (gfx950): one-hot tiling + concat -> 4 x (Conv(3,1)/s2 + ReLU) -> Linear 72->72 -> Linear
+// 72->128 + tanh -> Linear 128->50, all for a block of 32 frames inside one workgroup
+// (/root/reference/src/model/voca.py:40-48, everything except the 15069-wide head).
+//
+// The per-layer implicit-GEMM launches of this stack (8 + 7 kernels, 0.25 ms at 19 200 frames) are latency bound: every
+// layer is a tiny tall-skinny product.  Here the activations of a frame block never leave the CU: they live in LDS in
+// channels-last rows with ONE leading zero row per frame (the left zero padding of the k=3/s=2/p=1 convolution), so the
+// im2col row of output position p is the contiguous window starting at row 2p - no masks, no im2col.  Each layer is a set
+// of 32x32 f32-MFMA tiles (A fragment = window row, B fragment = weight row, both conflict-free ds_read_b32 thanks to odd
+// pitches) distributed over the 4 waves.  Every activation is also written to global memory once
+// (channels-last, exactly the buffers the backward kernels read) - 3.8 KB per frame.
+//
+// LDS (117 504 B): R0 = input windows [32][17][37] (later: conv2/conv3 outputs, concat, fc activations),
+//                  R1 = conv1 output [32][9][32] (+1).
+// The weights never touch LDS: each wave keeps the B fragments of every tile it is responsible for (288 floats per
+// lane) in REGISTERS for the life of the persistent kernel - one wave per SIMD owns the full 512-entry register file -
+// so a layer is nothing but A-fragment LDS reads feeding back-to-back MFMAs, with one barrier per layer.
+#include "a2f_common.h"
+
+namespace a2f {
+
+constexpr int VT_THREADS = 256;
+constexpr int VT_F = 32;                                   // frames per block
+constexpr int VT_S0 = 17 * 37;                             // 629: frame stride of the input windows (odd)
+constexpr int VT_S1 = 9 * 32 + 1;                          // 289
+constexpr int VT_S2 = 5 * 32 + 1;                          // 161
+constexpr int VT_S3 = 3 * 64 + 1;                          // 193
+constexpr int VT_SC = 73, VT_SZ2 = 129;
+constexpr int VT_R0 = VT_F * VT_S0;                        // 20128 floats
+constexpr int VT_A2 = 0, VT_A3 = VT_A2 + VT_F * VT_S2, VT_CAT = VT_A3 + VT_F * VT_S3, VT_Z1 = VT_CAT + VT_F * VT_SC,
+              VT_Z2 = VT_Z1 + VT_F * VT_SC;                // ends at exactly VT_R0
+static_assert(VT_Z2 + VT_F * VT_SZ2 == VT_R0, "R0 carve");
+constexpr int VT_R1 = VT_F * VT_S1;                        // 9248
+constexpr size_t VT_LDS_BYTES = (size_t)(VT_R0 + VT_R1) * sizeof(float);
+
+struct TrunkArgs {
+  const float* x; const float* one_hot;
+  const float* cw[4]; const float* cb[4];                  // time_conv.{0,2,4,6} weight (Co,Ci,3[,1]) / bias
+  const float* fw[3]; const float* fb[3];                  // decoder.{0,1,3}
+  float* a0; float* a1; float* a2; float* a3; float* cat; float* z1; float* z2; float* h3;
+  int B, no, NB;
+};
+
+// B-operand fragments of one 32-column weight tile, kept in REGISTERS for the whole (persistent) kernel:
+//   bw[s] = W(n = n0 + lane&31, k = 2s + (lane>>5)),  zero beyond N / K.
+// conv weights are read in the reference layout w[n][ci][kh] with k = kh*Ci + ci (TAP0 = first tap staged).
+template <int KS, int K, int CI, int TAP0, bool CONV>
+__device__ __forceinline__ void vt_load_frags(const float* __restrict__ w, int N, int n0, int lane, float (&bw)[KS]) {
+  const int n = n0 + (lane & 31), h = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 2 * s + h;
+    float v = 0.f;
+    if (n < N && k < K) {
+      if (CONV) { const int kh = TAP0 + k / CI, ci = k % CI; v = w[(n * CI + ci) * 3 + kh]; }
+      else v = w[n * K + k];
+    }
+    bw[s] = v;
+  }
+}
+
+// one 32-row x 32-col tile: A fragment from LDS (row of this lane at ap[0..2*KS)), B fragments from registers
+template <int KS>
+__device__ __forceinline__ f32x16 vt_tile(const float* ap, const float (&bw)[KS]) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bw[s], acc, 0, 0, 0);
+  return acc;
+}
+
+__global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const TrunkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* R0 = lds;
+  float* R1 = lds + VT_R0;
+  const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int B = a.B;
+
+  // ---- every weight this wave will ever need, as MFMA B fragments in registers (one wave per SIMD) ----
+  // conv4 runs on waves 0,1 and decoder.3 on waves 2,3: their 64 fragments share one array (w47), 288 VGPRs in all
+  float w1[56], w2[48], w3[48], w47[64], w5[36], w6[36];
+  vt_load_frags<56, 111, 37, 0, true>(a.cw[0], 32, 0, lane, w1);
+  vt_load_frags<48, 96, 32, 0, true>(a.cw[1], 32, 0, lane, w2);
+  vt_load_frags<48, 96, 32, 0, true>(a.cw[2], 64, (wave & 1) * 32, lane, w3);
+  if (wave < 2) vt_load_frags<64, 128, 64, 1, true>(a.cw[3], 64, wave * 32, lane, w47);   // taps 1,2: tap 0 always meets the padding
+  else vt_load_frags<64, 128, 1, 0, false>(a.fw[2], 50, (wave - 2) * 32, lane, w47);
+  vt_load_frags<36, 72, 1, 0, false>(a.fw[0], 72, (wave < 3 ? wave : 0) * 32, lane, w5);
+  vt_load_frags<36, 72, 1, 0, false>(a.fw[1], 128, wave * 32, lane, w6);
+  const float cb1 = a.cb[0][l31], cb2 = a.cb[1][l31], cb3 = a.cb[2][(wave & 1) * 32 + l31], cb4 = a.cb[3][(wave & 1) * 32 + l31];
+  const int c5 = (wave < 3 ? wave : 0) * 32 + l31, c7 = (wave & 1) * 32 + l31;
+  const float fb5 = c5 < 72 ? a.fb[0][c5] : 0.f, fb6 = a.fb[1][wave * 32 + l31], fb7 = c7 < 50 ? a.fb[2][c7] : 0.f;
+
+  // zero rows of R1 (never overwritten)
+  for (int e = t; e < VT_F * 33; e += VT_THREADS) { const int f = e / 33, c = e - f * 33; R1[f * VT_S1 + (c < 32 ? c : 288)] = 0.f; }
+
+  for (int blk = blockIdx.x; blk < a.NB; blk += gridDim.x) {
+    const int f0 = blk * VT_F;
+    __syncthreads();                                       // previous block finished with R0
+    // ---- stage the input windows: R0[f][1+h][c] = x[f][c][h] (c<29) | one_hot[f][h%8] ; row 0 = zeros ----
+    for (int e0 = t; e0 < VT_F * 464; e0 += 8 * VT_THREADS) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * VT_THREADS, f = e / 464;
+        v[u] = (e < VT_F * 464 && f0 + f < B) ? a.x[(int64_t)f0 * 464 + e] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * VT_THREADS;
+        if (e < VT_F * 464) { const int f = e / 464, r = e - f * 464, c = r >> 4, hh = r & 15; R0[f * VT_S0 + (1 + hh) * 37 + c] = v[u]; }
+      }
+    }
+    for (int e = t; e < VT_F * 16 * 8; e += VT_THREADS) {
+      const int f = e >> 7, r = e & 127, hh = r >> 3, q = r & 7;
+      const int fr = f0 + f;
+      R0[f * VT_S0 + (1 + hh) * 37 + 29 + q] = fr < B ? a.one_hot[(int64_t)fr * a.no + (hh & 7)] : 0.f;
+    }
+    for (int e = t; e < VT_F * 37; e += VT_THREADS) { const int f = e / 37, c = e - f * 37; R0[f * VT_S0 + c] = 0.f; }
+    __syncthreads();
+    // a0 to global (B,16,37), coalesced along (h,c)
+    for (int e = t; e < VT_F * 592; e += VT_THREADS) {
+      const int f = e / 592, r = e - f * 592;
+      if (f0 + f < B) a.a0[(int64_t)(f0 + f) * 592 + r] = R0[f * VT_S0 + 37 + r];
+    }
+    // ---- conv1: rows (f,p<8) = 256 = 8 tiles, 2 per wave; window = R0[f*629 + 2p*37 ..+111) ----
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int mt = wave + 4 * it;
+      const int row = mt * 32 + l31, f = row >> 3, p = row & 7;
+      const f32x16 acc = vt_tile<56>(R0 + f * VT_S0 + 2 * p * 37 + h, w1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int orow = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 3, op = orow & 7;
+        const float v = fmaxf(acc[r] + cb1, 0.f);
+        R1[of * VT_S1 + (1 + op) * 32 + l31] = v;
+        if (f0 + of < B) a.a1[((int64_t)(f0 + of) * 8 + op) * 32 + l31] = v;
+      }
+    }
+    __syncthreads();                                       // R0 (input windows) is dead; conv1 output complete
+    for (int e = t; e < VT_F * 33; e += VT_THREADS) { const int f = e / 33, c = e - f * 33; R0[VT_A2 + f * VT_S2 + (c < 32 ? c : 160)] = 0.f; }
+    for (int e = t; e < VT_F * 65; e += VT_THREADS) { const int f = e / 65, c = e - f * 65; R0[VT_A3 + f * VT_S3 + (c < 64 ? c : 192)] = 0.f; }
+    // one-hot tail of the concat vector (voca.py:47): cat[f][64+q] = one_hot[f][q]
+    for (int e = t; e < VT_F * 8; e += VT_THREADS) {
+      const int f = e >> 3, q = e & 7, fr = f0 + f;
+      const float v = fr < B ? a.one_hot[(int64_t)fr * a.no + q] : 0.f;
+      R0[VT_CAT + f * VT_SC + 64 + q] = v;
+      if (fr < B) a.cat[(int64_t)fr * 72 + 64 + q] = v;
+    }
+    // ---- conv2: rows (f,p<4) = 128 = 4 tiles, 1 per wave (reads R1, writes the A2 area of R0: no hazard with the zeroing) ----
+    {
+      const int row = wave * 32 + l31, f = row >> 2, p = row & 3;
+      const f32x16 acc = vt_tile<48>(R1 + f * VT_S1 + 2 * p * 32 + h, w2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int orow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 2, op = orow & 3;
+        const float v = fmaxf(acc[r] + cb2, 0.f);
+        R0[VT_A2 + of * VT_S2 + (1 + op) * 32 + l31] = v;
+        if (f0 + of < B) a.a2[((int64_t)(f0 + of) * 4 + op) * 32 + l31] = v;
+      }
+    }
+    __syncthreads();
+    // ---- conv3: rows (f,p<2) = 64 = 2 M-tiles x 2 N-tiles ----
+    {
+      const int mt = wave >> 1, nt = wave & 1;
+      const int row = mt * 32 + l31, f = row >> 1, p = row & 1;
+      const f32x16 acc = vt_tile<48>(R0 + VT_A2 + f * VT_S2 + 2 * p * 32 + h, w3);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int orow = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 1, op = orow & 1;
+        const float v = fmaxf(acc[r] + cb3, 0.f);
+        R0[VT_A3 + of * VT_S3 + (1 + op) * 64 + nt * 32 + l31] = v;
+        if (f0 + of < B) a.a3[((int64_t)(f0 + of) * 2 + op) * 64 + nt * 32 + l31] = v;
+      }
+    }
+    __syncthreads();
+    // ---- conv4: rows f = 32 = 1 M-tile x 2 N-tiles (waves 0,1); window = positions 0,1 (taps 1,2) ----
+    if (wave < 2) {
+      const f32x16 acc = vt_tile<64>(R0 + VT_A3 + l31 * VT_S3 + 64 + h, w47);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = fmaxf(acc[r] + cb4, 0.f);
+        R0[VT_CAT + of * VT_SC + wave * 32 + l31] = v;
+        if (f0 + of < B) a.cat[(int64_t)(f0 + of) * 72 + wave * 32 + l31] = v;
+      }
+    }
+    __syncthreads();
+    // ---- decoder.0: 72 -> 72 (3 N-tiles, waves 0..2), no activation ----
+    if (wave < 3) {
+      const f32x16 acc = vt_tile<36>(R0 + VT_CAT + l31 * VT_SC + h, w5);
+      if (c5 < 72) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float v = acc[r] + fb5;
+          R0[VT_Z1 + of * VT_SC + c5] = v;
+          if (f0 + of < B) a.z1[(int64_t)(f0 + of) * 72 + c5] = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- decoder.1: 72 -> 128 + tanh (4 N-tiles) ----
+    {
+      const f32x16 acc = vt_tile<36>(R0 + VT_Z1 + l31 * VT_SC + h, w6);
+      const int col = wave * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = tanhf(acc[r] + fb6);
+        R0[VT_Z2 + of * VT_SZ2 + col] = v;
+        if (f0 + of < B) a.z2[(int64_t)(f0 + of) * 128 + col] = v;
+      }
+    }
+    __syncthreads();
+    // ---- decoder.3: 128 -> 50 (2 N-tiles, waves 2,3), output to global only ----
+    if (wave >= 2) {
+      const f32x16 acc = vt_tile<64>(R0 + VT_Z2 + l31 * VT_SZ2 + h, w47);
+      if (c7 < 50) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (f0 + of < B) a.h3[(int64_t)(f0 + of) * 50 + c7] = acc[r] + fb7;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace a2f
+
+extern "C" int a2f_voca_trunk_fwd(const float* x, const float* one_hot, int64_t B, int64_t n_onehot, const float* const* conv_w,
+                                  const float* const* conv_b, const float* const* fc_w, const float* const* fc_b, float* a0, float* a1,
+                                  float* a2, float* a3, float* cat72, float* z1, float* z2, float* h3, a2f_stream_t stream) {
+  using namespace a2f;
+  A2F_CHECK_ARG(x && one_hot && conv_w && conv_b && fc_w && fc_b && a0 && a1 && a2 && a3 && cat72 && z1 && z2 && h3, "voca_trunk_fwd: null pointer");
+  A2F_CHECK_ARG(B > 0 && B < (1ll << 30) && n_onehot >= 8, "voca_trunk_fwd: B=%lld n_onehot=%lld", (long long)B, (long long)n_onehot);
+  TrunkArgs a;
+  a.x = x; a.one_hot = one_hot;
+  for (int i = 0; i < 4; ++i) { A2F_CHECK_ARG(conv_w[i] && conv_b[i], "voca_trunk_fwd: null conv parameter"); a.cw[i] = conv_w[i]; a.cb[i] = conv_b[i]; }
+  for (int i = 0; i < 3; ++i) { A2F_CHECK_ARG(fc_w[i] && fc_b[i], "voca_trunk_fwd: null decoder parameter"); a.fw[i] = fc_w[i]; a.fb[i] = fc_b[i]; }
+  a.a0 = a0; a.a1 = a1; a.a2 = a2; a.a3 = a3; a.cat = cat72; a.z1 = z1; a.z2 = z2; a.h3 = h3;
+  a.B = (int)B; a.no = (int)n_onehot; a.NB = (int)cdiv(B, VT_F);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&voca_trunk_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VT_LDS_BYTES);
+    if (e != hipSuccess) return set_err(A2F_ELAUNCH, "voca_trunk_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int grid = a.NB < 256 ? a.NB : 256;
+  hipLaunchKernelGGL(voca_trunk_fwd_kernel, dim3(grid), dim3(VT_THREADS), VT_LDS_BYTES, (hipStream_t)stream, a);
+  A2F_CHECK_LAUNCH("voca_trunk_fwd");
+  return A2F_OK;
+}

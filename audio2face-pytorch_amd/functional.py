@@ -86,7 +86,27 @@ VOCA_CONVS = ((37, 32, 8), (32, 32, 4), (32, 64, 2), (64, 64, 1))      # (Cin, C
 
 
 def voca_trunk_fwd(be, x, one_hot, params):
-    """x (B,29,16), one_hot (B,>=8), params = 8 conv tensors + 6 decoder tensors -> (h3 (B,50), saved tuple)."""
+    """x (B,29,16), one_hot (B,>=8), params = 8 conv tensors + 6 decoder tensors -> (h3 (B,50), saved tuple).
+
+    One fused launch (csrc/voca_trunk.hip): the activations of a 32-frame block stay in LDS through all seven layers.
+    ``layerwise=True`` in ``voca_trunk_fwd_layerwise`` keeps the per-layer implicit-GEMM sequence (used by tests to
+    cross-check the fused kernel)."""
+    if not hasattr(be, "voca_trunk_fwd"):
+        return voca_trunk_fwd_layerwise(be, x, one_hot, params)
+    cw = [_f32c(p) for p in params[0:8]]
+    fw0, fb0, fw1, fb1, fw3, fb3 = (_f32c(p) for p in params[8:14])
+    B = x.shape[0]
+    dev = x.device
+    new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+    xc, oh = _f32c(x), _f32c(one_hot)
+    a0, a1, a2, a3 = new(B, 16, 37), new(B, 8, 32), new(B, 4, 32), new(B, 2, 64)
+    cat, z1, z2, h3 = new(B, 72), new(B, 72), new(B, 128), new(B, 50)
+    be.voca_trunk_fwd(xc, oh, B, oh.shape[1], cw[0::2], cw[1::2], [fw0, fw1, fw3], [fb0, fb1, fb3], a0, a1, a2, a3, cat, z1, z2, h3)
+    return h3, (a0, a1, a2, a3, cat, z1, z2, fw0, fw1, fw3, cw[0], cw[2], cw[4], cw[6])
+
+
+def voca_trunk_fwd_layerwise(be, x, one_hot, params):
+    """Same function as voca_trunk_fwd, one implicit-GEMM launch per layer (reference sequence for the fused kernel)."""
     cw = params[0:8]                  # time_conv.{0,2,4,6}.{weight,bias}
     fw0, fb0, fw1, fb1, fw3, fb3 = (_f32c(p) for p in params[8:14])
     B = x.shape[0]
@@ -95,7 +115,7 @@ def voca_trunk_fwd(be, x, one_hot, params):
     xc, oh = _f32c(x), _f32c(one_hot)
     a0, cat = new(B, 16, 37), new(B, 72)
     be.voca_pack(xc, oh, B, oh.shape[1], a0, cat)
-    acts, wgs = [a0], []
+    acts = [a0]
     for li, (ci, co, pout) in enumerate(VOCA_CONVS):
         w, b = _f32c(cw[2 * li]), _f32c(cw[2 * li + 1])
         wg = new(co, 3 * ci)
@@ -104,21 +124,27 @@ def voca_trunk_fwd(be, x, one_hot, params):
         out = cat if last else new(B, pout, co)
         ops.conv_fwd(be, acts[-1], wg, b, out, B * pout, pout, ci, co, ldc=72 if last else co)
         acts.append(out)
-        wgs.append(wg)
     z1, z2, h3 = new(B, 72), new(B, 128), new(B, 50)
     ops.linear_fwd(be, cat, fw0, fb0, z1, B, 72, 72)                      # decoder.0
     ops.linear_fwd(be, z1, fw1, fb1, z2, B, 128, 72, act=ACT_TANH)        # decoder.1 + Tanh
     ops.linear_fwd(be, z2, fw3, fb3, h3, B, 50, 128)                      # decoder.3
-    return h3, (a0, acts[1], acts[2], acts[3], cat, z1, z2, fw0, fw1, fw3, *wgs)
+    return h3, (a0, acts[1], acts[2], acts[3], cat, z1, z2, fw0, fw1, fw3, _f32c(cw[0]), _f32c(cw[2]), _f32c(cw[4]), _f32c(cw[6]))
 
 
 def voca_trunk_bwd(be, saved, dh3, out=None):
     """Gradients of the 14 trunk parameters (same order as ``params``).  ``out``: optional list of 14 preallocated
     tensors (e.g. the trainer's flat-gradient views) that are OVERWRITTEN in place; otherwise new tensors are returned."""
-    a0, a1, a2, a3, cat, z1, z2, fw0, fw1, fw3, wg1, wg2, wg3, wg4 = saved
+    a0, a1, a2, a3, cat, z1, z2, fw0, fw1, fw3, cw1, cw2, cw3, cw4 = saved
     B = cat.shape[0]
     dev = cat.device
     new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+    wgs = []                                              # packed (Co, 3*Ci) conv weights for the data gradients
+    for li, w in enumerate((cw1, cw2, cw3, cw4)):
+        ci, co, _ = VOCA_CONVS[li]
+        wg = new(co, 3 * ci)
+        if li > 0:                                        # conv 1 needs no data gradient
+            be.conv_weight_pack(w, wg, co, ci, 3, 0)
+        wgs.append(wg)
     tgt = (lambda i, *s: out[i]) if out is not None else (lambda i, *s: new(*s))
     dh3 = _f32c(dh3)
     grads = [None] * 14
@@ -140,7 +166,6 @@ def voca_trunk_bwd(be, saved, dh3, out=None):
     grads[8:14] = [dW0, db0, dW1, db1, dW3, db3]
     # temporal conv stack, last to first
     acts = (a0, a1, a2, a3)
-    wgs = (wg1, wg2, wg3, wg4)
     for li in (3, 2, 1, 0):
         ci, co, pout = VOCA_CONVS[li]
         R = B * pout

@@ -150,6 +150,13 @@ class HipBackend:
         _chk(x, one_hot, a0, cat72)
         _lib.check(self.lib.a2f_voca_pack(_ptr(x), _ptr(one_hot), B, n_onehot, _ptr(a0), _ptr(cat72), self._stream(x)), "a2f_voca_pack")
 
+    def voca_trunk_fwd(self, x, one_hot, B, n_onehot, conv_w, conv_b, fc_w, fc_b, a0, a1, a2, a3, cat72, z1, z2, h3):
+        _chk(x, one_hot, *conv_w, *conv_b, *fc_w, *fc_b, a0, a1, a2, a3, cat72, z1, z2, h3)
+        arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        _lib.check(self.lib.a2f_voca_trunk_fwd(_ptr(x), _ptr(one_hot), B, n_onehot, arr(conv_w), arr(conv_b), arr(fc_w), arr(fc_b),
+                                               _ptr(a0), _ptr(a1), _ptr(a2), _ptr(a3), _ptr(cat72), _ptr(z1), _ptr(z2), _ptr(h3),
+                                               self._stream(x)), "a2f_voca_trunk_fwd")
+
     def a2m_pack(self, x, one_hot, B, n_onehot, a0, cat, cat_ld, cat_off):
         _chk(x, one_hot, a0, cat)
         _lib.check(self.lib.a2f_a2m_pack(_ptr(x), _ptr(one_hot), B, n_onehot, _ptr(a0), _ptr(cat), cat_ld, cat_off,

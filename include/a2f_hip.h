@@ -136,6 +136,16 @@ int a2f_voca_pack(const float* x, const float* one_hot, int64_t B, int64_t n_one
 int a2f_a2m_pack(const float* x, const float* one_hot, int64_t B, int64_t n_onehot, float* a0, float* cat,
                  int64_t cat_ld, int64_t cat_off, a2f_stream_t stream);
 
+/* Fused VOCA trunk forward (voca.py:40-48 up to the 50-wide bottleneck) for all B frames in one launch: activations of a
+ * 32-frame block stay in LDS across the four temporal convolutions and the three Linear layers; every activation is
+ * also stored once, channels-last, in exactly the layout the backward entry points read:
+ *   a0 (B,16,37) a1 (B,8,32) a2 (B,4,32) a3 (B,2,64) cat72 (B,72) z1 (B,72) z2 (B,128, post-tanh) h3 (B,50).
+ * conv_w[i]: time_conv.{0,2,4,6}.weight (Co,Ci,3,1) in the reference layout, conv_b[i] its bias; fc_w/fc_b: decoder.{0,1,3}.
+ * The four pointer arrays are HOST arrays of device pointers. */
+int a2f_voca_trunk_fwd(const float* x, const float* one_hot, int64_t B, int64_t n_onehot, const float* const* conv_w,
+                       const float* const* conv_b, const float* const* fc_w, const float* const* fc_b, float* a0, float* a1,
+                       float* a2, float* a3, float* cat72, float* z1, float* z2, float* h3, a2f_stream_t stream);
+
 /* Conv weight re-layout  w (Co,Ci,KH) <-> wg (Co, KH*Ci) [k = kh*Ci+ci]; dir 0: w->wg, 1: wg->w(+=0 overwrite) */
 int a2f_conv_weight_pack(const float* src, float* dst, int64_t Co, int64_t Ci, int64_t KH, int32_t dir, a2f_stream_t stream);
 

@@ -238,3 +238,23 @@ def test_faceformer_long_sequence_beyond_reference_limit():
     with torch.no_grad():
         pred = m(audio, oh, torch.zeros(1, 5023, 3, device=DEV), encoder_states=enc)
     assert pred.shape == (1, T, 5023, 3) and bool(torch.isfinite(pred).all())
+
+
+@pytest.mark.parametrize("B", [1, 31, 32, 33, 700])
+def test_voca_fused_trunk_kernel_equals_layerwise(B):
+    """csrc/voca_trunk.hip (one launch, activations in LDS) against the per-layer implicit-GEMM sequence: every saved
+    activation and the 50-wide bottleneck."""
+    from a2f_amd import ops
+    from a2f_amd.functional import voca_trunk_fwd, voca_trunk_fwd_layerwise
+    m, _ = _voca()
+    gen = torch.Generator().manual_seed(B)
+    x = torch.randn(B, 29, 16, generator=gen).to(DEV)
+    oh = torch.zeros(B, 12); oh[torch.arange(B), torch.randint(0, 12, (B,), generator=gen)] = 1.0
+    oh = oh.to(DEV)
+    params = [p.data for p in m._trunk_params()]
+    be = ops.backend()
+    h_f, s_f = voca_trunk_fwd(be, x, oh, params)
+    h_l, s_l = voca_trunk_fwd_layerwise(be, x, oh, params)
+    assert rel_l2(h_f, h_l) < 2e-6
+    for name, a, b in zip(("a0", "a1", "a2", "a3", "cat", "z1", "z2"), s_f[:7], s_l[:7]):
+        assert rel_l2(a, b) < 2e-6, name

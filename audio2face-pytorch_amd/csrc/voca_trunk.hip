@@ -228,6 +228,186 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
   }
 }
 
+// =====================================================================================================================
+// Fused data-gradient chain of the trunk (backward of voca.py:46-48 w.r.t. activations): from d(h3) down to the gradient
+// of conv1's pre-activation, for a block of 32 frames per workgroup, same machinery as the forward kernel: gradients of a
+// frame block stay in LDS, every weight is an MFMA B fragment in registers (269 VGPRs per lane), one barrier per layer.
+// The k=3/s=2/p=1 data gradient in gather form: even input rows take tap 1 of one output row; odd input rows take tap 2 of
+// output row p and tap 0 of output row p+1 - with ONE trailing zero row per frame in the LDS tile that is the contiguous
+// window [row p | row p+1] times the stacked weights [tap 2; tap 0].  Activation-function derivatives (tanh', ReLU masks
+// of the saved forward activations) are applied in the epilogues.  Outputs are the pre-activation gradients the weight
+// gradient kernels (wgrad.hip) contract with the saved activations.
+constexpr int VB_DH = 0;                                   // [32][51]
+constexpr int VB_Z2 = VB_DH + VT_F * 51;                   // [32][129]
+constexpr int VB_Z1 = VB_Z2 + VT_F * 129;                  // [32][73]
+constexpr int VB_C4 = VB_Z1 + VT_F * 73;                   // [32][65]
+constexpr int VB_C3 = VB_C4 + VT_F * 65;                   // [32][3][64] + 1  (rows 0,1 + trailing zero row)
+constexpr int VB_C2 = VB_C3 + VT_F * 193;                  // [32][5][32] + 1  (rows 0..3 + trailing zero row)
+constexpr int VB_END = VB_C2 + VT_F * 161;
+constexpr size_t VB_LDS_BYTES = (size_t)VB_END * sizeof(float);
+
+struct TrunkBwdArgs {
+  const float* dh3; const float* z2; const float* cat; const float* a3; const float* a2; const float* a1;
+  const float* fw3; const float* fw1; const float* fw0; const float* cw4; const float* cw3; const float* cw2;
+  float* g_z2; float* g_z1; float* g_c4; float* g_c3; float* g_c2; float* g_c1;
+  int B, NB;
+};
+
+__global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(const TrunkBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int B = a.B;
+
+  // ---- weight fragments (B operand: lane -> output column n, lane>>5 -> contraction parity) ----
+  float q3[25], q1[64], q0[36], q4[32], q5[64], q6e[16], q6o[32];
+  {
+    const int n = wave * 32 + l31;                                           // fc3': n < 128, k = j < 50: W3[j][n]
+#pragma unroll
+    for (int s = 0; s < 25; ++s) q3[s] = a.fw3[(2 * s + h) * 128 + n];
+  }
+  {
+    const int n = (wave < 3 ? wave : 0) * 32 + l31;                          // fc1': n < 72, k < 128: W1[k][n]
+#pragma unroll
+    for (int s = 0; s < 64; ++s) q1[s] = n < 72 ? a.fw1[(2 * s + h) * 72 + n] : 0.f;
+  }
+  {
+    const int n = (wave & 1) * 32 + l31;                                     // fc0': n < 64 (conv features only), k < 72: W0[k][n]
+#pragma unroll
+    for (int s = 0; s < 36; ++s) q0[s] = a.fw0[(2 * s + h) * 72 + n];
+  }
+  {
+    const int hp = wave >> 1, ci = (wave & 1) * 32 + l31;                    // conv4': column (h', ci), k = co: w4[co][ci][h'+1]
+#pragma unroll
+    for (int s = 0; s < 32; ++s) q4[s] = a.cw4[((2 * s + h) * 64 + ci) * 3 + hp + 1];
+  }
+  if (wave < 2) {                                                            // conv3' even rows: tap 1, k = co < 64
+#pragma unroll
+    for (int s = 0; s < 32; ++s) q5[s] = a.cw3[((2 * s + h) * 32 + l31) * 3 + 1];
+#pragma unroll
+    for (int s = 32; s < 64; ++s) q5[s] = 0.f;
+  } else {                                                                   // conv3' odd rows: [tap 2 ; tap 0], k < 128
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+      const int k = 2 * s + h;
+      q5[s] = k < 64 ? a.cw3[(k * 32 + l31) * 3 + 2] : a.cw3[((k - 64) * 32 + l31) * 3 + 0];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 16; ++s) q6e[s] = a.cw2[((2 * s + h) * 32 + l31) * 3 + 1];       // conv2' even: tap 1, k = co < 32
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {                                                       // conv2' odd: [tap 2 ; tap 0], k < 64
+    const int k = 2 * s + h;
+    q6o[s] = k < 32 ? a.cw2[(k * 32 + l31) * 3 + 2] : a.cw2[((k - 32) * 32 + l31) * 3 + 0];
+  }
+  // trailing zero rows of the two convolution-gradient tiles (never overwritten)
+  for (int e = t; e < VT_F * 65; e += VT_THREADS) { const int f = e / 65, c = e - f * 65; lds[VB_C3 + f * 193 + 128 + c] = 0.f; }
+  for (int e = t; e < VT_F * 33; e += VT_THREADS) { const int f = e / 33, c = e - f * 33; lds[VB_C2 + f * 161 + 128 + c] = 0.f; }
+
+  for (int blk = blockIdx.x; blk < a.NB; blk += gridDim.x) {
+    const int f0 = blk * VT_F;
+    __syncthreads();
+    for (int e = t; e < VT_F * 50; e += VT_THREADS) {
+      const int f = e / 50, j = e - f * 50;
+      lds[VB_DH + f * 51 + j] = f0 + f < B ? a.dh3[(int64_t)f0 * 50 + e] : 0.f;
+    }
+    __syncthreads();
+    // ---- decoder.3 backward: dz2pre = (dh3 W3) * (1 - z2^2) ----
+    {
+      const f32x16 acc = vt_tile<25>(lds + VB_DH + l31 * 51 + h, q3);
+      const int col = wave * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool ok = f0 + of < B;
+        const float z = ok ? a.z2[(int64_t)(f0 + of) * 128 + col] : 0.f;
+        const float v = acc[r] * (1.f - z * z);
+        lds[VB_Z2 + of * 129 + col] = v;
+        if (ok) a.g_z2[(int64_t)(f0 + of) * 128 + col] = v;
+      }
+    }
+    __syncthreads();
+    // ---- decoder.1 backward: dz1 = dz2pre W1 ----
+    if (wave < 3) {
+      const f32x16 acc = vt_tile<64>(lds + VB_Z2 + l31 * 129 + h, q1);
+      const int col = wave * 32 + l31;
+      if (col < 72) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
+          lds[VB_Z1 + of * 73 + col] = acc[r];
+          if (f0 + of < B) a.g_z1[(int64_t)(f0 + of) * 72 + col] = acc[r];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- decoder.0 backward (conv features only) + ReLU mask of conv4's output ----
+    if (wave < 2) {
+      const f32x16 acc = vt_tile<36>(lds + VB_Z1 + l31 * 73 + h, q0);
+      const int col = wave * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool ok = f0 + of < B;
+        const float c = ok ? a.cat[(int64_t)(f0 + of) * 72 + col] : 0.f;
+        const float v = c > 0.f ? acc[r] : 0.f;
+        lds[VB_C4 + of * 65 + col] = v;
+        if (ok) a.g_c4[(int64_t)(f0 + of) * 64 + col] = v;
+      }
+    }
+    __syncthreads();
+    // ---- conv4 data gradient: d3[f][h'][ci] = sum_co g4[f][co] w4[co][ci][h'+1], masked by a3 > 0 ----
+    {
+      const f32x16 acc = vt_tile<32>(lds + VB_C4 + l31 * 65 + h, q4);
+      const int hp = wave >> 1, ci = (wave & 1) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool ok = f0 + of < B;
+        const float m = ok ? a.a3[((int64_t)(f0 + of) * 2 + hp) * 64 + ci] : 0.f;
+        const float v = m > 0.f ? acc[r] : 0.f;
+        lds[VB_C3 + of * 193 + hp * 64 + ci] = v;
+        if (ok) a.g_c3[((int64_t)(f0 + of) * 2 + hp) * 64 + ci] = v;
+      }
+    }
+    __syncthreads();
+    // ---- conv3 data gradient: rows (f, p<2); waves 0,1: even input rows 2p (tap 1); waves 2,3: odd rows 2p+1 ----
+    {
+      const int mt = wave & 1, odd = wave >> 1;
+      const int row = mt * 32 + l31, f = row >> 1, p = row & 1;
+      const float* ap = lds + VB_C3 + f * 193 + p * 64 + h;
+      const f32x16 acc = odd ? vt_tile<64>(ap, q5) : vt_tile<32>(ap, reinterpret_cast<const float(&)[32]>(q5));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int orow = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 1, hin = 2 * (orow & 1) + odd;
+        const bool ok = f0 + of < B;
+        const float m = ok ? a.a2[((int64_t)(f0 + of) * 4 + hin) * 32 + l31] : 0.f;
+        const float v = m > 0.f ? acc[r] : 0.f;
+        lds[VB_C2 + of * 161 + hin * 32 + l31] = v;
+        if (ok) a.g_c2[((int64_t)(f0 + of) * 4 + hin) * 32 + l31] = v;
+      }
+    }
+    __syncthreads();
+    // ---- conv2 data gradient: rows (f, p<4) = 4 tiles, one per wave: even rows 2p, then odd rows 2p+1 ----
+    {
+      const int row = wave * 32 + l31, f = row >> 2, p = row & 3;
+      const float* ap = lds + VB_C2 + f * 161 + p * 32 + h;
+#pragma unroll
+      for (int odd = 0; odd < 2; ++odd) {
+        const f32x16 acc = odd ? vt_tile<32>(ap, q6o) : vt_tile<16>(ap, q6e);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int orow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 2, hin = 2 * (orow & 3) + odd;
+          if (f0 + of < B) {
+            const int64_t o = ((int64_t)(f0 + of) * 8 + hin) * 32 + l31;
+            a.g_c1[o] = a.a1[o] > 0.f ? acc[r] : 0.f;
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace a2f
 
 extern "C" int a2f_voca_trunk_fwd(const float* x, const float* one_hot, int64_t B, int64_t n_onehot, const float* const* conv_w,
@@ -251,5 +431,30 @@ extern "C" int a2f_voca_trunk_fwd(const float* x, const float* one_hot, int64_t 
   const int grid = a.NB < 256 ? a.NB : 256;
   hipLaunchKernelGGL(voca_trunk_fwd_kernel, dim3(grid), dim3(VT_THREADS), VT_LDS_BYTES, (hipStream_t)stream, a);
   A2F_CHECK_LAUNCH("voca_trunk_fwd");
+  return A2F_OK;
+}
+
+extern "C" int a2f_voca_trunk_bwd_data(const float* dh3, const float* z2, const float* cat72, const float* a3, const float* a2,
+                                       const float* a1, const float* fw3, const float* fw1, const float* fw0, const float* cw4,
+                                       const float* cw3, const float* cw2, int64_t B, float* g_z2, float* g_z1, float* g_c4,
+                                       float* g_c3, float* g_c2, float* g_c1, a2f_stream_t stream) {
+  using namespace a2f;
+  A2F_CHECK_ARG(dh3 && z2 && cat72 && a3 && a2 && a1 && fw3 && fw1 && fw0 && cw4 && cw3 && cw2 && g_z2 && g_z1 && g_c4 && g_c3 && g_c2 && g_c1,
+                "voca_trunk_bwd_data: null pointer");
+  A2F_CHECK_ARG(B > 0 && B < (1ll << 30), "voca_trunk_bwd_data: B=%lld", (long long)B);
+  TrunkBwdArgs a;
+  a.dh3 = dh3; a.z2 = z2; a.cat = cat72; a.a3 = a3; a.a2 = a2; a.a1 = a1;
+  a.fw3 = fw3; a.fw1 = fw1; a.fw0 = fw0; a.cw4 = cw4; a.cw3 = cw3; a.cw2 = cw2;
+  a.g_z2 = g_z2; a.g_z1 = g_z1; a.g_c4 = g_c4; a.g_c3 = g_c3; a.g_c2 = g_c2; a.g_c1 = g_c1;
+  a.B = (int)B; a.NB = (int)cdiv(B, VT_F);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&voca_trunk_bwd_data_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VB_LDS_BYTES);
+    if (e != hipSuccess) return set_err(A2F_ELAUNCH, "voca_trunk_bwd_data: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int grid = a.NB < 256 ? a.NB : 256;
+  hipLaunchKernelGGL(voca_trunk_bwd_data_kernel, dim3(grid), dim3(VT_THREADS), VB_LDS_BYTES, (hipStream_t)stream, a);
+  A2F_CHECK_LAUNCH("voca_trunk_bwd_data");
   return A2F_OK;
 }

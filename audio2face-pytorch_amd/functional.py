@@ -133,7 +133,40 @@ def voca_trunk_fwd_layerwise(be, x, one_hot, params):
 
 def voca_trunk_bwd(be, saved, dh3, out=None):
     """Gradients of the 14 trunk parameters (same order as ``params``).  ``out``: optional list of 14 preallocated
-    tensors (e.g. the trainer's flat-gradient views) that are OVERWRITTEN in place; otherwise new tensors are returned."""
+    tensors (e.g. the trainer's flat-gradient views) that are OVERWRITTEN in place; otherwise new tensors are returned.
+
+    One fused launch for the whole data-gradient chain (csrc/voca_trunk.hip) + one register-tile weight-gradient
+    contraction per layer (csrc/wgrad.hip)."""
+    if not hasattr(be, "voca_trunk_bwd_data"):
+        return voca_trunk_bwd_layerwise(be, saved, dh3, out)
+    a0, a1, a2, a3, cat, z1, z2, fw0, fw1, fw3, cw1, cw2, cw3, cw4 = saved
+    B = cat.shape[0]
+    dev = cat.device
+    new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+    tgt = (lambda i, *s: out[i]) if out is not None else (lambda i, *s: new(*s))
+    dh3 = _f32c(dh3)
+    g_z2, g_z1, g_c4, g_c3, g_c2, g_c1 = new(B, 128), new(B, 72), new(B, 64), new(B, 2, 64), new(B, 4, 32), new(B, 8, 32)
+    be.voca_trunk_bwd_data(dh3, z2, cat, a3, a2, a1, fw3, fw1, fw0, cw4, cw3, cw2, B, g_z2, g_z1, g_c4, g_c3, g_c2, g_c1)
+    grads = [None] * 14
+    dW3, db3 = tgt(12, 50, 128), tgt(13, 50)
+    ops.linear_bwd_weight(be, dh3, z2, dW3, db3, B, 50, 128)
+    dW1, db1 = tgt(10, 128, 72), tgt(11, 128)
+    ops.linear_bwd_weight(be, g_z2, z1, dW1, db1, B, 128, 72)
+    dW0, db0 = tgt(8, 72, 72), tgt(9, 72)
+    ops.linear_bwd_weight(be, g_z1, cat, dW0, db0, B, 72, 72)
+    grads[8:14] = [dW0, db0, dW1, db1, dW3, db3]
+    for li, (act_in, g) in enumerate(((a0, g_c1), (a1, g_c2), (a2, g_c3), (a3, g_c4))):
+        ci, co, pout = VOCA_CONVS[li]
+        dwg, dbias = new(co, 3 * ci), tgt(2 * li + 1, co)
+        ops.conv_bwd_weight(be, act_in, g, dwg, dbias, B * pout, pout, ci, co)
+        dw = tgt(2 * li, co, ci, 3, 1)
+        be.conv_weight_pack(dwg, dw, co, ci, 3, 1)
+        grads[2 * li], grads[2 * li + 1] = dw, dbias
+    return grads
+
+
+def voca_trunk_bwd_layerwise(be, saved, dh3, out=None):
+    """Same gradients, one implicit-GEMM launch per layer and direction (reference sequence for the fused kernel)."""
     a0, a1, a2, a3, cat, z1, z2, fw0, fw1, fw3, cw1, cw2, cw3, cw4 = saved
     B = cat.shape[0]
     dev = cat.device

@@ -157,6 +157,13 @@ class HipBackend:
                                                _ptr(a0), _ptr(a1), _ptr(a2), _ptr(a3), _ptr(cat72), _ptr(z1), _ptr(z2), _ptr(h3),
                                                self._stream(x)), "a2f_voca_trunk_fwd")
 
+    def voca_trunk_bwd_data(self, dh3, z2, cat, a3, a2, a1, fw3, fw1, fw0, cw4, cw3, cw2, B, g_z2, g_z1, g_c4, g_c3, g_c2, g_c1):
+        ts = (dh3, z2, cat, a3, a2, a1, fw3, fw1, fw0, cw4, cw3, cw2)
+        outs = (g_z2, g_z1, g_c4, g_c3, g_c2, g_c1)
+        _chk(*ts, *outs)
+        _lib.check(self.lib.a2f_voca_trunk_bwd_data(*[_ptr(x) for x in ts], B, *[_ptr(x) for x in outs], self._stream(dh3)),
+                   "a2f_voca_trunk_bwd_data")
+
     def a2m_pack(self, x, one_hot, B, n_onehot, a0, cat, cat_ld, cat_off):
         _chk(x, one_hot, a0, cat)
         _lib.check(self.lib.a2f_a2m_pack(_ptr(x), _ptr(one_hot), B, n_onehot, _ptr(a0), _ptr(cat), cat_ld, cat_off,

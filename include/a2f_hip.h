@@ -146,6 +146,16 @@ int a2f_voca_trunk_fwd(const float* x, const float* one_hot, int64_t B, int64_t 
                        const float* const* conv_b, const float* const* fc_w, const float* const* fc_b, float* a0, float* a1,
                        float* a2, float* a3, float* cat72, float* z1, float* z2, float* h3, a2f_stream_t stream);
 
+/* Fused data-gradient chain of the same trunk: d(h3) (B,50) -> pre-activation gradients of every layer, one launch:
+ *   g_z2 (B,128) = d(decoder.1 pre-tanh), g_z1 (B,72) = d(decoder.0 output), g_c4 (B,64), g_c3 (B,2,64), g_c2 (B,4,32),
+ *   g_c1 (B,8,32) = d(conv pre-ReLU outputs).  Reads the forward's saved activations for the tanh' / ReLU masks and the
+ *   weights in the reference layouts.  The weight gradients are then a2f_wgrad_f32 contractions of these with the saved
+ *   activations (dW3 = dh3^T z2, dW1 = g_z2^T z1, dW0 = g_z1^T cat, conv l: g_cl^T windows(a_{l-1})). */
+int a2f_voca_trunk_bwd_data(const float* dh3, const float* z2, const float* cat72, const float* a3, const float* a2,
+                            const float* a1, const float* fw3, const float* fw1, const float* fw0, const float* cw4,
+                            const float* cw3, const float* cw2, int64_t B, float* g_z2, float* g_z1, float* g_c4,
+                            float* g_c3, float* g_c2, float* g_c1, a2f_stream_t stream);
+
 /* Conv weight re-layout  w (Co,Ci,KH) <-> wg (Co, KH*Ci) [k = kh*Ci+ci]; dir 0: w->wg, 1: wg->w(+=0 overwrite) */
 int a2f_conv_weight_pack(const float* src, float* dst, int64_t Co, int64_t Ci, int64_t KH, int32_t dir, a2f_stream_t stream);
 

@@ -258,3 +258,22 @@ def test_voca_fused_trunk_kernel_equals_layerwise(B):
     assert rel_l2(h_f, h_l) < 2e-6
     for name, a, b in zip(("a0", "a1", "a2", "a3", "cat", "z1", "z2"), s_f[:7], s_l[:7]):
         assert rel_l2(a, b) < 2e-6, name
+
+
+@pytest.mark.parametrize("B", [2, 33, 700])
+def test_voca_fused_trunk_backward_equals_layerwise(B):
+    """Fused data-gradient chain + wgrad contractions against the per-layer implicit-GEMM backward."""
+    from a2f_amd import ops
+    from a2f_amd.functional import voca_trunk_bwd, voca_trunk_bwd_layerwise, voca_trunk_fwd
+    m, _ = _voca()
+    gen = torch.Generator().manual_seed(100 + B)
+    x = torch.randn(B, 29, 16, generator=gen).to(DEV)
+    oh = torch.zeros(B, 12); oh[torch.arange(B), torch.randint(0, 12, (B,), generator=gen)] = 1.0
+    oh = oh.to(DEV)
+    dh3 = torch.randn(B, 50, generator=gen).to(DEV)
+    be = ops.backend()
+    _, saved = voca_trunk_fwd(be, x, oh, [p.data for p in m._trunk_params()])
+    g_f = voca_trunk_bwd(be, saved, dh3)
+    g_l = voca_trunk_bwd_layerwise(be, saved, dh3)
+    for i, (a, b) in enumerate(zip(g_f, g_l)):
+        assert rel_l2(a, b) < 2e-5, i

@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
         ("ones_out", c_f32p),
         ("act", i32), ("aux_mode", i32), ("accumulate", i32), ("split_k", i32),
         ("mask_operand", i32), ("mask_period", i32), ("mask_phase", i32), ("mask_lo", i32), ("mask_hi", i32),
-        ("reserved", i32),
+        ("c_unpack_kh", i32),
         ("splitk_ws", c_f32p),
     ]
 
@@ -42,6 +42,7 @@ SIGNATURES = {
     "a2f_wgrad_supported": (C.c_int, [i64, i64]),
     "a2f_wgrad_ws_floats": (sz, [i64, i64, i64]),
     "a2f_wgrad_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "a2f_wgrad_batch_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int32, C.c_void_p]),
     "a2f_vocaloss_ws_bytes": (sz, [i64, i64]),
     "a2f_vocaloss_fwd": (C.c_int, [c_f32p, c_f32p, i64, i64, f32, f32, c_f32p, C.c_void_p, sz, C.c_void_p]),
     "a2f_vocaloss_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, i64, i64, f32, f32, c_f32p, C.c_void_p]),

@@ -1,4 +1,4 @@
-// Weight-gradient GEMM for tiny outputs and huge contractions (gfx950):
+// Weight-gradient GEMMs for tiny outputs and huge contractions (gfx950):
 //     C[M,N] = sum_k A(m,k) B(k,n),  M <= 128, N+1 <= 224, K = frames x positions (1e4 .. 2e5)
 // i.e. dW = dY^T X (+ dbias through a virtual ones column) of every Linear / implicit-GEMM convolution of the VOCA trunk.
 //
@@ -7,25 +7,86 @@
 // set per WAVE (MT x NT accumulators of the 32x32x2 f32 MFMA), every wave of every workgroup owns a slice of K, and both
 // operands are read from global memory directly in MFMA operand layout - A is stored (K, M) with M contiguous and B is
 // stored (K, N) with N contiguous, so a wave-instruction fetches two full 128-byte row segments: coalesced, no LDS, no
-// barriers in the K loop.  The four waves fold through LDS into one partial slab per workgroup; `wgrad_fold_kernel` sums the
-// slabs in fixed order (deterministic).
+// barriers in the K loop.  The loop is latency-bound (one wave per SIMD), so operand loads are double-buffered in
+// registers: 2 x WG_U k-steps are in flight while the previous set feeds the matrix pipe; loads are raw buffer loads whose
+// out-of-range offset (-1) returns 0, which is the K tail, the M/N edge and the convolution's left zero padding at once.
+// The four waves fold through LDS into one partial slab per workgroup; the fold kernel sums the slabs in fixed order
+// (deterministic) and can store a convolution gradient directly in nn.Conv2d's (Co, Ci, KH, 1) layout.
+//
+// Up to A2F_WGRAD_BATCH_MAX problems run in ONE launch pair (all seven trunk layers of a VOCA step): the workgroup index
+// selects its problem from a table in the kernel arguments.
 #include "a2f_common.h"
+
+#include <string.h>
+
+#include <algorithm>
 
 namespace a2f {
 
 constexpr int WG_THREADS = 256;
-constexpr int WG_UNROLL = 4;          // k-steps (of 2 rows) whose loads are in flight together
+constexpr int WG_U = 8;               // k-steps (of 2 rows) per register set; two sets are in flight
+
+using wrsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ wrsrc_t wg_rsrc(const float* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float wg_load(wrsrc_t r, int byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+
+// one problem of a batch, as the kernels see it (offsets folded into the pointers)
+struct WgradProb {
+  const float* A;                     // (K, M): element (k, m) at A[k * a_cs + m]
+  const float* B;                     // (K, N): element (k, n) at B[k * b_rs + n]
+  float* ws;                          // slabs [blocks][M][Neff]
+  float* C;
+  float* ones_out;
+  int a_cs, b_rs, ldc;
+  int M, N, K, Neff;
+  int mask_period, mask_phase, mask_lo, mask_hi;   // mask_period == 0: no window mask
+  int rows_per_wave, blocks, shape;                // shape = MT * 8 + NT of the instantiated tile set
+  int unpack_kh;                                   // > 0: column kh*Ci+ci is stored at ci*KH+kh (Conv2d weight layout)
+  int blk_beg, fold_beg;                           // first workgroup of this problem in the GEMM / fold launch
+};
+
+struct WgradBatch {
+  int count;
+  WgradProb p[A2F_WGRAD_BATCH_MAX];
+};
+
+// the problem a workgroup belongs to: wave-uniform select chain over the kernel arguments (no scratch copy)
+__device__ __forceinline__ WgradProb pick_problem(const WgradBatch& b, int blk, bool fold) {
+  WgradProb pr = b.p[0];
+#pragma unroll
+  for (int i = 1; i < A2F_WGRAD_BATCH_MAX; ++i)
+    if (i < b.count && blk >= (fold ? b.p[i].fold_beg : b.p[i].blk_beg)) pr = b.p[i];
+  return pr;
+}
 
 template <int MT, int NT>
-__global__ __launch_bounds__(WG_THREADS, 1) void wgrad_kernel(const a2f_gemm_desc d, int rows_per_wave) {
+__device__ __forceinline__ void wgrad_body(const WgradProb& pr, int blk, float (*red)[1024]) {
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int M = (int)d.M, N = (int)d.N, K = (int)d.K;
-  const int Neff = N + (d.ones_out ? 1 : 0);
-  const int kbeg = (blockIdx.x * 4 + wave) * rows_per_wave;
-  const int kend = min(K, kbeg + rows_per_wave);
-  const float* __restrict__ Ap = d.A + d.a_off;
-  const float* __restrict__ Bp = d.B + d.b_off;
+  const int M = pr.M, N = pr.N, Neff = pr.Neff;
+  const int kbeg = (blk * 4 + wave) * pr.rows_per_wave;
+  const int kend = kbeg + pr.rows_per_wave;              // a multiple of one register-set pair; rows >= K read as 0
+  // exact operand spans: rows >= K (the tail of the last wave) and bytes past the last row read as 0; columns >= M / N
+  // of an interior row read the neighbouring row - finite garbage that only reaches output rows / columns never stored
+  const wrsrc_t ra = wg_rsrc(pr.A, ((pr.K - 1) * pr.a_cs + M) * 4), rb = wg_rsrc(pr.B, ((pr.K - 1) * pr.b_rs + N) * 4);
+  const bool ones = Neff > N;
+  const int lane_a = (h * pr.a_cs + l31) * 4, lane_b = (h * pr.b_rs + l31) * 4;   // + (k0 + 2u) * stride: row k0+2u+h
+  const int step_a = 2 * pr.a_cs * 4, step_b = 2 * pr.b_rs * 4;
+  // left zero padding of the convolution window: rows with (k % period) == phase drop columns [mask_lo, mask_hi)
+  const bool masked = pr.mask_period > 0;
+  const int period = masked ? pr.mask_period : 1, step_pos = 2 % period;
+  int pos = (kbeg + h) % period;                           // advanced by 2 rows per k-step, in load order
+  bool bmask[NT], bone[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = j * 32 + l31;
+    bmask[j] = masked && n >= pr.mask_lo && n < pr.mask_hi;
+    bone[j] = ones && n == N;
+  }
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -35,41 +96,45 @@ __global__ __launch_bounds__(WG_THREADS, 1) void wgrad_kernel(const a2f_gemm_des
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  for (int k0 = kbeg; k0 < kend; k0 += 2 * WG_UNROLL) {
-    float av[WG_UNROLL][MT], bv[WG_UNROLL][NT];
+  auto load_set = [&](int k0, float (&av)[WG_U][MT], float (&bv)[WG_U][NT]) {
+    const int va0 = lane_a + k0 * pr.a_cs * 4, vb0 = lane_b + k0 * pr.b_rs * 4;
 #pragma unroll
-    for (int u = 0; u < WG_UNROLL; ++u) {
-      const int k = k0 + 2 * u + h;                        // this lane's contraction row of k-step u
-      const bool kok = k < kend;
-      const bool pad = (d.mask_operand == 2) && (k % d.mask_period == d.mask_phase);
+    for (int u = 0; u < WG_U; ++u) {
+      const int va = va0 + u * step_a, vb = vb0 + u * step_b;
+      const bool padrow = masked && pos == pr.mask_phase;
+      const bool inside = k0 + 2 * u + h < pr.K;
+      pos += step_pos;
+      if (pos >= period) pos -= period;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int m = i * 32 + l31;
-        av[u][i] = (kok && m < M) ? Ap[(int64_t)k * d.a_cs + m] : 0.f;
-      }
+      for (int i = 0; i < MT; ++i) av[u][i] = wg_load(ra, va + i * 128);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int n = j * 32 + l31;
-        float v = 0.f;
-        if (kok) {
-          if (n < N) { if (!(pad && n >= d.mask_lo && n < d.mask_hi)) v = Bp[(int64_t)k * d.b_rs + n]; }
-          else if (n == N && d.ones_out) v = 1.f;
-        }
-        bv[u][j] = v;
+        const float v = wg_load(rb, (padrow && bmask[j]) ? -1 : vb + j * 128);
+        bv[u][j] = (bone[j] && inside) ? 1.f : v;
       }
     }
+  };
+  auto mfma_set = [&](float (&av)[WG_U][MT], float (&bv)[WG_U][NT]) {
 #pragma unroll
-    for (int u = 0; u < WG_UNROLL; ++u)
+    for (int u = 0; u < WG_U; ++u)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+  };
+
+  float a0[WG_U][MT], b0[WG_U][NT], a1[WG_U][MT], b1[WG_U][NT];
+  load_set(kbeg, a0, b0);
+  for (int k0 = kbeg; k0 < kend; k0 += 4 * WG_U) {
+    load_set(k0 + 2 * WG_U, a1, b1);
+    mfma_set(a0, b0);
+    if (k0 + 4 * WG_U < kend) load_set(k0 + 4 * WG_U, a0, b0);
+    mfma_set(a1, b1);
   }
 
   // fold the four waves of the workgroup through LDS, tile by tile, and leave ONE partial slab per workgroup:
   // [m][n], pitch Neff.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  __shared__ float red[4][1024];
-  float* slab = d.splitk_ws + (int64_t)blockIdx.x * M * Neff;
+  float* slab = pr.ws + (int64_t)blk * M * Neff;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -87,14 +152,32 @@ __global__ __launch_bounds__(WG_THREADS, 1) void wgrad_kernel(const a2f_gemm_des
     }
 }
 
+__global__ __launch_bounds__(WG_THREADS, 1) void wgrad_batch_kernel(const WgradBatch b) {
+  __shared__ float red[4][1024];
+  const WgradProb pr = pick_problem(b, blockIdx.x, false);
+  const int blk = blockIdx.x - pr.blk_beg;
+  switch (pr.shape) {
+    case 1 * 8 + 4: wgrad_body<1, 4>(pr, blk, red); break;
+    case 1 * 8 + 7: wgrad_body<1, 7>(pr, blk, red); break;
+    case 2 * 8 + 4: wgrad_body<2, 4>(pr, blk, red); break;
+    case 2 * 8 + 5: wgrad_body<2, 5>(pr, blk, red); break;
+    case 2 * 8 + 7: wgrad_body<2, 7>(pr, blk, red); break;
+    case 3 * 8 + 3: wgrad_body<3, 3>(pr, blk, red); break;
+    case 3 * 8 + 4: wgrad_body<3, 4>(pr, blk, red); break;
+    default: wgrad_body<4, 3>(pr, blk, red); break;
+  }
+}
+
 // out[i] = sum_z slab[z][i]: 16 consecutive outputs x 16 z-lanes per workgroup (64-byte coalesced segments), every lane
 // keeps 4 independent partial sums so its loads are in flight together; fixed summation order (deterministic).
-__global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* __restrict__ ws, int slabs, int M, int N, int Neff,
-                                                          float* __restrict__ C, int64_t ldc, float* __restrict__ ones_out) {
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(const WgradBatch b) {
   __shared__ float sh[16][17];
+  const WgradProb pr = pick_problem(b, blockIdx.x, true);
+  const float* __restrict__ ws = pr.ws;
+  const int slabs = pr.blocks;
   const int t = threadIdx.x, o = t & 15, zg = t >> 4;
-  const int64_t total = (int64_t)M * Neff;
-  const int64_t i = (int64_t)blockIdx.x * 16 + o;
+  const int64_t total = (int64_t)pr.M * pr.Neff;
+  const int64_t i = (int64_t)(blockIdx.x - pr.fold_beg) * 16 + o;
   float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
   if (i < total) {
     int z = zg;
@@ -112,69 +195,101 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* __restrict
     float s = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) s += sh[g][t];
-    const int row = (int)(i / Neff), col = (int)(i - (int64_t)row * Neff);
-    if (col < N) C[(int64_t)row * ldc + col] = s;
-    else ones_out[row] = s;
+    const int row = (int)(i / pr.Neff), col = (int)(i - (int64_t)row * pr.Neff);
+    if (col < pr.N) {
+      int c = col;
+      if (pr.unpack_kh > 0) { const int ci_n = pr.N / pr.unpack_kh, kh = col / ci_n; c = (col - kh * ci_n) * pr.unpack_kh + kh; }
+      pr.C[(int64_t)row * pr.ldc + c] = s;
+    } else {
+      pr.ones_out[row] = s;
+    }
   }
 }
 
-struct WgradPlan { int rows_per_wave, blocks, slabs; };
-static WgradPlan wgrad_plan(int64_t K) {
-  // aim at ~300 workgroups (256 CUs, one 512-register wave per SIMD), at least 32 rows per wave
-  int64_t rpw = cdiv(cdiv(K, 300 * 4), 8) * 8;
-  if (rpw < 32) rpw = 32;
+struct WgradPlan { int rows_per_wave, blocks; };
+
+// smallest instantiated tile set that covers (mt, nt); 0 if none
+static int wgrad_shape(int mt, int nt) {
+  if (mt == 1) return nt <= 4 ? 1 * 8 + 4 : nt <= 7 ? 1 * 8 + 7 : 0;
+  if (mt == 2) return nt <= 4 ? 2 * 8 + 4 : nt <= 5 ? 2 * 8 + 5 : nt <= 7 ? 2 * 8 + 7 : 0;
+  if (mt == 3) return nt <= 3 ? 3 * 8 + 3 : nt <= 4 ? 3 * 8 + 4 : 0;
+  if (mt == 4) return nt <= 3 ? 4 * 8 + 3 : 0;
+  return 0;
+}
+
+// The loop moves (MT+NT) x 256 B per k-step and wave, so a workgroup that owns ~800/(MT+NT) rows per wave moves ~0.4 MB:
+// the seven trunk problems of a 19 200-frame step then make ~600 equally heavy workgroups (one 512-register workgroup per
+// CU).  Short contractions are cut into at least ~64 workgroups; a wave's slice is a multiple of one register set pair.
+static WgradPlan wgrad_plan(int64_t M, int64_t N, int64_t K) {
+  const int shape = wgrad_shape((int)((M + 31) / 32), (int)((N + 1 + 31) / 32));
+  const int64_t tiles = shape ? (shape / 8 + shape % 8) : 8;
+  int64_t rpw = std::min<int64_t>(800 / tiles, cdiv(K, 4 * 64));
+  rpw = std::max<int64_t>(4 * WG_U, cdiv(rpw, 4 * WG_U) * (4 * WG_U));
   WgradPlan p;
   p.rows_per_wave = (int)rpw;
   p.blocks = (int)cdiv(K, rpw * 4);
-  p.slabs = p.blocks;                 // one slab per workgroup (waves folded in LDS)
   return p;
-}
-
-template <int MT, int NT>
-static void wgrad_launch(const a2f_gemm_desc& d, const WgradPlan& p, hipStream_t s) {
-  hipLaunchKernelGGL((wgrad_kernel<MT, NT>), dim3(p.blocks), dim3(WG_THREADS), 0, s, d, p.rows_per_wave);
 }
 
 }  // namespace a2f
 
 extern "C" size_t a2f_wgrad_ws_floats(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 1;
-  return (size_t)a2f::wgrad_plan(K).slabs * (size_t)M * (size_t)(N + 1);
+  return (size_t)a2f::wgrad_plan(M, N, K).blocks * (size_t)M * (size_t)(N + 1);
 }
 
 extern "C" int a2f_wgrad_supported(int64_t M, int64_t N) {
-  const int mt = (int)((M + 31) / 32), nt = (int)((N + 1 + 31) / 32);
-  return ((mt == 1 || mt == 2) ? nt <= 7 : mt == 3 ? nt <= 4 : mt == 4 ? nt <= 3 : false) ? 1 : 0;
+  if (M <= 0 || N <= 0) return 0;
+  return a2f::wgrad_shape((int)((M + 31) / 32), (int)((N + 1 + 31) / 32)) ? 1 : 0;
+}
+
+extern "C" int a2f_wgrad_batch_f32(const a2f_gemm_desc* descs, int32_t count, a2f_stream_t stream) {
+  using namespace a2f;
+  A2F_CHECK_ARG(descs != nullptr && count >= 1 && count <= A2F_WGRAD_BATCH_MAX, "wgrad: 1..%d descriptors per batch", A2F_WGRAD_BATCH_MAX);
+  WgradBatch b;
+  memset(&b, 0, sizeof(b));
+  b.count = count;
+  int blk = 0, fold = 0;
+  for (int i = 0; i < count; ++i) {
+    const a2f_gemm_desc& d = descs[i];
+    A2F_CHECK_ARG(d.A && d.B && d.C && d.splitk_ws, "wgrad[%d]: null pointer (A, B, C and splitk_ws are required)", i);
+    A2F_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0 && d.K < (1ll << 30), "wgrad[%d]: bad shape", i);
+    A2F_CHECK_ARG(a2f_wgrad_supported(d.M, d.N), "wgrad[%d]: output %lld x %lld too large for the register-tile kernel", i, (long long)d.M,
+                  (long long)d.N);
+    A2F_CHECK_ARG(d.a_rs == 1 && d.b_cs == 1, "wgrad[%d]: needs A stored (K,M) with M contiguous and B stored (K,N) with N contiguous", i);
+    A2F_CHECK_ARG(d.a_cs > 0 && d.b_rs > 0 && (d.K * d.a_cs + d.M) * 4 < 0x7FFFFFF0ll && (d.K * d.b_rs + d.N) * 4 < 0x7FFFFFF0ll,
+                  "wgrad[%d]: operand spans 2 GB or more (use a2f_gemm_f32)", i);
+    A2F_CHECK_ARG(d.act == 0 && d.aux_mode == 0 && d.bias == nullptr && !d.accumulate, "wgrad[%d]: linear epilogue only", i);
+    A2F_CHECK_ARG(d.mask_operand == 0 || (d.mask_operand == 2 && d.mask_period > 0), "wgrad[%d]: only a B-operand window mask is supported", i);
+    A2F_CHECK_ARG(d.ldc >= d.N, "wgrad[%d]: ldc < N", i);
+    A2F_CHECK_ARG(d.c_unpack_kh >= 0 && (d.c_unpack_kh == 0 || d.N % d.c_unpack_kh == 0), "wgrad[%d]: c_unpack_kh must divide N", i);
+    const WgradPlan pl = wgrad_plan(d.M, d.N, d.K);
+    WgradProb& p = b.p[i];
+    p.A = d.A + d.a_off;
+    p.B = d.B + d.b_off;
+    p.ws = d.splitk_ws;
+    p.C = d.C;
+    p.ones_out = d.ones_out;
+    p.a_cs = (int)d.a_cs; p.b_rs = (int)d.b_rs; p.ldc = (int)d.ldc;
+    p.M = (int)d.M; p.N = (int)d.N; p.K = (int)d.K; p.Neff = (int)d.N + (d.ones_out ? 1 : 0);
+    if (d.mask_operand == 2) { p.mask_period = d.mask_period; p.mask_phase = d.mask_phase; p.mask_lo = d.mask_lo; p.mask_hi = d.mask_hi; }
+    p.rows_per_wave = pl.rows_per_wave;
+    p.blocks = pl.blocks;
+    p.shape = wgrad_shape((int)((d.M + 31) / 32), (p.Neff + 31) / 32);
+    p.unpack_kh = d.c_unpack_kh;
+    p.blk_beg = blk;
+    p.fold_beg = fold;
+    blk += pl.blocks;
+    fold += (int)cdiv((int64_t)p.M * p.Neff, 16);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(wgrad_batch_kernel, dim3(blk), dim3(WG_THREADS), 0, s, b);
+  hipLaunchKernelGGL(wgrad_fold_kernel, dim3(fold), dim3(256), 0, s, b);
+  A2F_CHECK_LAUNCH("wgrad_batch_f32");
+  return A2F_OK;
 }
 
 extern "C" int a2f_wgrad_f32(const a2f_gemm_desc* dp, a2f_stream_t stream) {
-  using namespace a2f;
   A2F_CHECK_ARG(dp != nullptr, "wgrad: null descriptor");
-  const a2f_gemm_desc d = *dp;
-  A2F_CHECK_ARG(d.A && d.B && d.C && d.splitk_ws, "wgrad: null pointer (A, B, C and splitk_ws are required)");
-  A2F_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0 && d.K < (1ll << 30), "wgrad: bad shape");
-  A2F_CHECK_ARG(a2f_wgrad_supported(d.M, d.N), "wgrad: output %lld x %lld too large for the register-tile kernel", (long long)d.M, (long long)d.N);
-  A2F_CHECK_ARG(d.a_rs == 1 && d.b_cs == 1, "wgrad: needs A stored (K,M) with M contiguous and B stored (K,N) with N contiguous");
-  A2F_CHECK_ARG(d.act == 0 && d.aux_mode == 0 && d.bias == nullptr && !d.accumulate, "wgrad: linear epilogue only");
-  A2F_CHECK_ARG(d.mask_operand == 0 || (d.mask_operand == 2 && d.mask_period > 0), "wgrad: only a B-operand window mask is supported");
-  A2F_CHECK_ARG(d.ldc >= d.N, "wgrad: ldc < N");
-  const WgradPlan p = wgrad_plan(d.K);
-  hipStream_t s = (hipStream_t)stream;
-  const int mt = (int)((d.M + 31) / 32), nt = (int)((d.N + (d.ones_out ? 1 : 0) + 31) / 32);
-  // smallest instantiated tile set that covers (mt, nt)
-  if (mt == 1 && nt <= 4) wgrad_launch<1, 4>(d, p, s);
-  else if (mt == 1) wgrad_launch<1, 7>(d, p, s);
-  else if (mt == 2 && nt <= 4) wgrad_launch<2, 4>(d, p, s);
-  else if (mt == 2 && nt <= 5) wgrad_launch<2, 5>(d, p, s);
-  else if (mt == 2) wgrad_launch<2, 7>(d, p, s);
-  else if (mt == 3 && nt <= 3) wgrad_launch<3, 3>(d, p, s);
-  else if (mt == 3) wgrad_launch<3, 4>(d, p, s);
-  else if (nt <= 3) wgrad_launch<4, 3>(d, p, s);
-  else return set_err(A2F_EINVAL, "wgrad: no tile set for %d x %d tiles", mt, nt);
-  const int64_t neff = d.N + (d.ones_out ? 1 : 0);
-  const int64_t total = d.M * neff;
-  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)cdiv(total, 16)), dim3(256), 0, s, (const float*)d.splitk_ws, p.slabs, (int)d.M, (int)d.N,
-                     (int)neff, d.C, d.ldc, d.ones_out);
-  A2F_CHECK_LAUNCH("wgrad_f32");
-  return A2F_OK;
+  return a2f_wgrad_batch_f32(dp, 1, stream);
 }

@@ -147,21 +147,21 @@ def voca_trunk_bwd(be, saved, dh3, out=None):
     dh3 = _f32c(dh3)
     g_z2, g_z1, g_c4, g_c3, g_c2, g_c1 = new(B, 128), new(B, 72), new(B, 64), new(B, 2, 64), new(B, 4, 32), new(B, 8, 32)
     be.voca_trunk_bwd_data(dh3, z2, cat, a3, a2, a1, fw3, fw1, fw0, cw4, cw3, cw2, B, g_z2, g_z1, g_c4, g_c3, g_c2, g_c1)
+    # all seven weight gradients (+ bias gradients through the ones column) in one launch pair; the heavy convolution
+    # problems first so the light ones fill the tail
     grads = [None] * 14
-    dW3, db3 = tgt(12, 50, 128), tgt(13, 50)
-    ops.linear_bwd_weight(be, dh3, z2, dW3, db3, B, 50, 128)
-    dW1, db1 = tgt(10, 128, 72), tgt(11, 128)
-    ops.linear_bwd_weight(be, g_z2, z1, dW1, db1, B, 128, 72)
-    dW0, db0 = tgt(8, 72, 72), tgt(9, 72)
-    ops.linear_bwd_weight(be, g_z1, cat, dW0, db0, B, 72, 72)
-    grads[8:14] = [dW0, db0, dW1, db1, dW3, db3]
+    items = []
     for li, (act_in, g) in enumerate(((a0, g_c1), (a1, g_c2), (a2, g_c3), (a3, g_c4))):
         ci, co, pout = VOCA_CONVS[li]
-        dwg, dbias = new(co, 3 * ci), tgt(2 * li + 1, co)
-        ops.conv_bwd_weight(be, act_in, g, dwg, dbias, B * pout, pout, ci, co)
-        dw = tgt(2 * li, co, ci, 3, 1)
-        be.conv_weight_pack(dwg, dw, co, ci, 3, 1)
+        dw, dbias = tgt(2 * li, co, ci, 3, 1), tgt(2 * li + 1, co)
+        items.append(ops.conv_wgrad_item(be, act_in, g, dw, dbias, B * pout, pout, ci, co))
         grads[2 * li], grads[2 * li + 1] = dw, dbias
+    dW0, db0, dW1, db1, dW3, db3 = tgt(8, 72, 72), tgt(9, 72), tgt(10, 128, 72), tgt(11, 128), tgt(12, 50, 128), tgt(13, 50)
+    items.append(ops.linear_wgrad_item(be, g_z1, cat, dW0, db0, B, 72, 72))
+    items.append(ops.linear_wgrad_item(be, g_z2, z1, dW1, db1, B, 128, 72))
+    items.append(ops.linear_wgrad_item(be, dh3, z2, dW3, db3, B, 50, 128))
+    be.wgrad_batch(items)
+    grads[8:14] = [dW0, db0, dW1, db1, dW3, db3]
     return grads
 
 

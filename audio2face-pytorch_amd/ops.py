@@ -90,8 +90,9 @@ class HipBackend:
     def wgrad_supported(self, M, N):
         return bool(self.lib.a2f_wgrad_supported(M, N))
 
-    def wgrad(self, A, B, Cout, M, N, K, a, b, ldc, *, ones_out=None, mask=None, tag=None):
-        """C[M,N] = sum_k A(m,k) B(k,n) for tiny outputs (see a2f_hip.h); overwrites C / ones_out, deterministic."""
+    def wgrad_item(self, A, B, Cout, M, N, K, a, b, ldc, *, ones_out=None, mask=None, unpack_kh=0):
+        """One problem of ``wgrad_batch``: C[M,N] = sum_k A(m,k) B(k,n) for tiny outputs (see a2f_hip.h); overwrites C /
+        ones_out, deterministic.  ``unpack_kh``: store column kh*Ci+ci at ci*KH+kh (nn.Conv2d weight layout)."""
         _chk(A, B, Cout, ones_out)
         ws = torch.empty(self.lib.a2f_wgrad_ws_floats(M, N, K), device=Cout.device, dtype=torch.float32)
         d = GemmDesc()
@@ -101,12 +102,23 @@ class HipBackend:
         d.M, d.N, d.K = M, N, K
         d.ones_out = _ptr(ones_out)
         d.split_k = 1
+        d.c_unpack_kh = unpack_kh
         if mask is not None:
             d.mask_operand, d.mask_period, d.mask_phase, d.mask_lo, d.mask_hi = mask
         d.splitk_ws = _ptr(ws)
-        ev = self._prof_begin(tag)
-        _lib.check(self.lib.a2f_wgrad_f32(C.byref(d), self._stream(Cout)), "a2f_wgrad_f32")
-        self._prof_end(tag, ev)
+        return d, (ws, Cout)
+
+    def wgrad_batch(self, items, tag=None):
+        """Run up to 8 ``wgrad_item`` problems per launch pair (a2f_wgrad_batch_f32)."""
+        for i in range(0, len(items), 8):
+            chunk = items[i:i + 8]
+            arr = (GemmDesc * len(chunk))(*[it[0] for it in chunk])
+            ev = self._prof_begin(tag)
+            _lib.check(self.lib.a2f_wgrad_batch_f32(arr, len(chunk), self._stream(chunk[0][1][1])), "a2f_wgrad_batch_f32")
+            self._prof_end(tag, ev)
+
+    def wgrad(self, A, B, Cout, M, N, K, a, b, ldc, *, ones_out=None, mask=None, tag=None, unpack_kh=0):
+        self.wgrad_batch([self.wgrad_item(A, B, Cout, M, N, K, a, b, ldc, ones_out=ones_out, mask=mask, unpack_kh=unpack_kh)], tag=tag)
 
     # ---- loss ---------------------------------------------------------------------------------
     def vocaloss_fwd(self, pred, gt, B, n, k_rec, k_vel, out3):
@@ -255,6 +267,19 @@ def linear_bwd_input(be, dy, W, dx, M, N, K, *, ld_dy=None, n_cols=None, ldc=Non
     """dx[M,:n_cols] = (dy[M,N] W[N,K])[:, :n_cols], optionally times an activation derivative (aux)."""
     nc = n_cols or K
     be.gemm(dy, W, dx, M, nc, N, (0, ld_dy or N, 1), (0, K, 1), ldc or nc, aux=aux, ldaux=ldaux, aux_mode=aux_mode)
+
+
+def linear_wgrad_item(be, dy, x, dW, db, M, N, K, *, ld_dy=None, ldx=None):
+    """``wgrad_batch`` item for dW[N,K] = dy[M,N]^T x[M,K], db[N] = colsum(dy)."""
+    return be.wgrad_item(dy, x, dW, N, K, M, (0, 1, ld_dy or N), (0, ldx or K, 1), K, ones_out=db)
+
+
+def conv_wgrad_item(be, act_in, dout, dw, dbias, R, P_out, Cin, Co, *, KH=3, stride=2, pad=1, ld_dout=None):
+    """``wgrad_batch`` item for the weight gradient of the strided implicit-GEMM convolution, stored straight into the
+    nn.Conv2d layout dw (Co, Cin, KH, 1); dbias = colsum(dout)."""
+    mask = (2, P_out, 0, 0, pad * Cin) if pad else None
+    return be.wgrad_item(dout, act_in, dw, Co, KH * Cin, R, (0, 1, ld_dout or Co), (-pad * Cin, stride * Cin, 1), KH * Cin,
+                         ones_out=dbias, mask=mask, unpack_kh=KH)
 
 
 def linear_bwd_weight(be, dy, x, dW, db, M, N, K, *, ld_dy=None, ldx=None, tag=None):

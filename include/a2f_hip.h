@@ -70,7 +70,7 @@ typedef struct a2f_gemm_desc {
   float* ones_out;
   int32_t act, aux_mode, accumulate, split_k;
   int32_t mask_operand, mask_period, mask_phase, mask_lo, mask_hi;
-  int32_t reserved;
+  int32_t c_unpack_kh;   /* a2f_wgrad_* only: > 0 stores column kh*Ci+ci (Ci = N/c_unpack_kh) at ci*KH+kh, i.e. C in nn.Conv2d's (Co,Ci,KH,1) layout */
   float* splitk_ws;
 } a2f_gemm_desc;
 
@@ -80,10 +80,14 @@ int a2f_gemm_f32(const a2f_gemm_desc* d, a2f_stream_t stream);
  * Linear / implicit-GEMM convolution layers, voca.py:19-36): M <= 128, N+1 <= 224 (a2f_wgrad_supported), A stored (K,M)
  * with a_rs == 1, B stored (K,N) with b_cs == 1, optional B window mask and ones column, linear epilogue, C (and
  * ones_out) OVERWRITTEN.  One register tile set per wave, operands read from global memory in MFMA layout, per-wave
- * partial slabs in d->splitk_ws (>= a2f_wgrad_ws_floats(M,N,K) floats) folded in fixed order (deterministic). */
+ * partial slabs in d->splitk_ws (>= a2f_wgrad_ws_floats(M,N,K) floats) folded in fixed order (deterministic).
+ * a2f_wgrad_batch_f32 runs up to A2F_WGRAD_BATCH_MAX independent problems (e.g. all seven trunk layers of a VOCA step)
+ * in one launch pair; each descriptor carries its own workspace.  Operands must span less than 2 GB each. */
+#define A2F_WGRAD_BATCH_MAX 8
 int a2f_wgrad_supported(int64_t M, int64_t N);
 size_t a2f_wgrad_ws_floats(int64_t M, int64_t N, int64_t K);
 int a2f_wgrad_f32(const a2f_gemm_desc* d, a2f_stream_t stream);
+int a2f_wgrad_batch_f32(const a2f_gemm_desc* descs, int32_t count, a2f_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * VocaLoss (src/loss/loss.py:24-55); FaceFormerLoss (loss.py:4-17) is the same call on the

@@ -97,10 +97,25 @@ class EmuBackend:
         mt, nt = (M + 31) // 32, (N + 1 + 31) // 32
         return (nt <= 7) if mt in (1, 2) else (nt <= 4) if mt == 3 else (nt <= 3) if mt == 4 else False
 
-    def wgrad(self, A, B, Cout, M, N, K, a, b, ldc, *, ones_out=None, mask=None, tag=None):
+    def wgrad(self, A, B, Cout, M, N, K, a, b, ldc, *, ones_out=None, mask=None, tag=None, unpack_kh=0):
         assert a[1] == 1 and b[2] == 1 and self.wgrad_supported(M, N)
         ws = torch.empty(2 * M * (N + 1))
-        self.gemm(A, B, Cout, M, N, K, a, b, ldc, ones_out=ones_out, mask=mask, split_k=2, splitk_ws=ws)
+        if unpack_kh:
+            assert ldc == N and N % unpack_kh == 0
+            tmp = torch.empty(M, N)
+            self.gemm(A, B, tmp, M, N, K, a, b, N, ones_out=ones_out, mask=mask, split_k=2, splitk_ws=ws)
+            ci = N // unpack_kh                                     # column kh*Ci+ci -> ci*KH+kh
+            Cout.reshape(M, ci, unpack_kh).copy_(tmp.reshape(M, unpack_kh, ci).transpose(1, 2))
+        else:
+            self.gemm(A, B, Cout, M, N, K, a, b, ldc, ones_out=ones_out, mask=mask, split_k=2, splitk_ws=ws)
+
+    def wgrad_item(self, *args, **kw):
+        return (args, kw), None
+
+    def wgrad_batch(self, items, tag=None):
+        assert 1 <= len(items)
+        for (args, kw), _ in items:
+            self.wgrad(*args, **kw)
 
     # ------------------------------------------------------------------ loss
     def vocaloss_fwd(self, pred, gt, B, n, k_rec, k_vel, out3):

@@ -308,6 +308,39 @@ def test_wgrad_kernel_vs_contract(M, N, K):
     assert torch.equal(Cc2[:, :N].cpu(), c_h[:, :N])
 
 
+def test_wgrad_batch_conv_layout_and_linears():
+    """One launch pair for several problems: conv weight gradients stored straight in nn.Conv2d layout (c_unpack_kh) next
+    to Linear weight gradients, against torch autograd; frame counts that leave ragged K tails."""
+    be = ops.HipBackend()
+    items, checks = [], []
+    for li, (B_, P_out, Cin, Co) in enumerate([(37, 8, 37, 32), (21, 4, 32, 32), (13, 2, 32, 64), (45, 1, 64, 64)]):
+        act = rnd(B_, 2 * P_out, Cin, seed=300 + li)
+        dy = rnd(B_, P_out, Co, seed=310 + li)
+        x = act.permute(0, 2, 1).clone()
+        w = torch.zeros(Co, Cin, 3, requires_grad=True)
+        bias = torch.zeros(Co, requires_grad=True)
+        torch.nn.functional.conv1d(x, w, bias, stride=2, padding=1).backward(dy.permute(0, 2, 1))
+        dw = torch.full((Co, Cin, 3, 1), float("nan"), device=DEV)
+        db = torch.full((Co,), float("nan"), device=DEV)
+        keep = (act.to(DEV), dy.to(DEV))
+        items.append(ops.conv_wgrad_item(be, keep[0], keep[1], dw, db, B_ * P_out, P_out, Cin, Co))
+        checks.append((dw, w.grad.unsqueeze(-1), db, bias.grad, keep))
+    for li, (M, N, K) in enumerate([(333, 72, 72), (65, 128, 72), (1001, 50, 128)]):
+        dy, xx = rnd(M, N, seed=320 + li), rnd(M, K, seed=330 + li)
+        dW = torch.full((N, K), float("nan"), device=DEV)
+        db = torch.full((N,), float("nan"), device=DEV)
+        keep = (dy.to(DEV), xx.to(DEV))
+        items.append(ops.linear_wgrad_item(be, keep[0], keep[1], dW, db, M, N, K))
+        checks.append((dW, dy.double().t() @ xx.double(), db, dy.double().sum(0), keep))
+    be.wgrad_batch(items)
+    for got_w, ref_w, got_b, ref_b, _ in checks:
+        assert rel_l2(got_w.cpu(), ref_w) < 2e-5 and rel_l2(got_b.cpu(), ref_b) < 2e-5
+    with pytest.raises(a2f_amd.A2FError):                           # more than one batch worth in a single C call
+        arr = (type(items[0][0]) * 9)(*[it[0] for it in (items + items)[:9]])
+        from a2f_amd import _lib
+        _lib.check(be.lib.a2f_wgrad_batch_f32(arr, 9, None), "a2f_wgrad_batch_f32")
+
+
 @pytest.mark.parametrize("M,N,K", [(512, 32, 111), (777, 64, 96), (1500, 128, 72), (640, 50, 128), (3000, 64, 192), (513, 72, 72), (900, 37, 33)])
 @pytest.mark.parametrize("layout", ["nt", "nn"])
 def test_gemm_tall_skinny_shapes(M, N, K, layout):

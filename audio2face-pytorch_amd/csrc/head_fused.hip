@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += redbig[w * 2048 + e];
         const int row = rb * HF_ROWS + (e >> 6);
-        if (row < B) a.dH_slab[((int64_t)cg * B + row) * HF_KP + (e & 63)] = v;
+        if (row < B && (e & 63) < ((K + 3) & ~3)) a.dH_slab[((int64_t)cg * B + row) * HF_KP + (e & 63)] = v;   // quads the fold reads
       }
     } else {
       float* red = Gs_all;                              // [NW][32][32] floats, reuses the staging tiles
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
 #pragma unroll
           for (int w = 0; w < NW; ++w) v += red[w * 1024 + e];
           const int row = rb * HF_ROWS + (e >> 5);
-          if (row < B) a.dH_slab[((int64_t)cg * B + row) * HF_KP + kt * 32 + (e & 31)] = v;
+          if (row < B && kt * 32 + (e & 31) < ((K + 3) & ~3)) a.dH_slab[((int64_t)cg * B + row) * HF_KP + kt * 32 + (e & 31)] = v;
         }
       }
     }
@@ -431,41 +431,71 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
   }
 }
 
-// out[r][k] = sum_s slab[s][r][k], k < K ; slab row pitch HF_KP, slab stride `sstride` floats
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nslabs, int64_t sstride, int64_t rows,
-                                                           int K, float* __restrict__ out) {
-  const int64_t total = rows * HF_KP;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int k = (int)(i & (HF_KP - 1));
-    if (k >= K) continue;
-    float v = 0.f;
-    for (int s = 0; s < nslabs; ++s) v += slab[(int64_t)s * sstride + i];
-    out[(i >> 6) * K + k] = v;
+// ONE launch folds everything the main kernel left behind, in fixed order (deterministic):
+//   workgroups [0, nH)        dH[r][k]  = sum over CG column-group slabs   (290 MB at B = 19 200: the only part that matters)
+//   workgroups [nH, nH+nW)    dW[c][k]  = sum over RG row-group slabs
+//   workgroups [.., +nb)      db[c]     = sum over RG row-group slabs
+//   last workgroup            loss scalars from the per-workgroup double partials
+// Slab rows have pitch HF_KP = 64 floats (256 B): a lane owns one float4 of a row, quads with k >= K are skipped, and four
+// slabs are in flight per lane at a time.
+struct HeadFoldArgs {
+  const float* dH_slab; const float* dW_slab; const float* db_slab; const double* loss_part;
+  float* dH; float* dW; float* db; float* out3;
+  int64_t sH, sW, sb;                 // slab strides (floats)
+  int64_t rowsH, rowsW, lenb;
+  int nslabH, nslabW, nparts, K;
+  int nH, nW, nb;                     // workgroup counts of the three ranges
+  double inv_rec, inv_vel;
+  float k_rec, k_vel;
+};
+
+__device__ __forceinline__ void fold_rows(const float* __restrict__ slab, int nslabs, int64_t sstride, int64_t rows, int K,
+                                          float* __restrict__ out, int64_t blk) {
+  const int64_t q = blk * 256 + threadIdx.x;               // float4 index: row = q / 16, k = 4 * (q % 16)
+  const int64_t row = q >> 4;
+  const int k = (int)(q & 15) * 4;
+  if (row >= rows || k >= K) return;
+  const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(slab) + q;
+  const int64_t st4 = sstride >> 2;
+  f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
+  int s = 0;
+  for (; s + 4 <= nslabs; s += 4) {
+    const f32x4 x0 = p[(int64_t)s * st4], x1 = p[(int64_t)(s + 1) * st4], x2 = p[(int64_t)(s + 2) * st4], x3 = p[(int64_t)(s + 3) * st4];
+    v0 += x0; v1 += x1; v2 += x2; v3 += x3;
   }
+  for (; s < nslabs; ++s) v0 += p[(int64_t)s * st4];
+  const f32x4 v = (v0 + v1) + (v2 + v3);
+  float* o = out + row * K + k;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (k + e < K) o[e] = v[e];
 }
 
-__global__ __launch_bounds__(256) void vec_reduce_kernel(const float* __restrict__ slab, int nslabs, int64_t sstride, int64_t len,
-                                                          float* __restrict__ out) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= len) return;
-  float v = 0.f;
-  for (int s = 0; s < nslabs; ++s) v += slab[(int64_t)s * sstride + i];
-  out[i] = v;
-}
-
-__global__ void head_loss_finish_kernel(const double* __restrict__ part, int nparts, double inv_rec, double inv_vel, float k_rec,
-                                        float k_vel, float* __restrict__ out3) {
-  const int t = threadIdx.x;
-  double r = 0, v = 0;
-  for (int i = t; i < nparts; i += 64) { r += part[2 * i]; v += part[2 * i + 1]; }
-  r = wave_sum_d(r);
-  v = wave_sum_d(v);
-  if (t == 0) {
-    const float rec = (float)(r * inv_rec), vel = (float)(v * inv_vel);
-    out3[0] = rec * k_rec + vel * k_vel;
-    out3[1] = rec;
-    out3[2] = vel;
+__global__ __launch_bounds__(256) void head_fold_kernel(const HeadFoldArgs f) {
+  const int b = blockIdx.x;
+  if (b < f.nH) {
+    fold_rows(f.dH_slab, f.nslabH, f.sH, f.rowsH, f.K, f.dH, b);
+  } else if (b < f.nH + f.nW) {
+    fold_rows(f.dW_slab, f.nslabW, f.sW, f.rowsW, f.K, f.dW, b - f.nH);
+  } else if (b < f.nH + f.nW + f.nb) {
+    const int64_t i = (int64_t)(b - f.nH - f.nW) * 256 + threadIdx.x;
+    if (i < f.lenb) {
+      float v = 0.f;
+      for (int s = 0; s < f.nslabW; ++s) v += f.db_slab[(int64_t)s * f.sb + i];
+      f.db[i] = v;
+    }
+  } else if (threadIdx.x < 64) {
+    const int t = threadIdx.x;
+    double r = 0, v = 0;
+    for (int i = t; i < f.nparts; i += 64) { r += f.loss_part[2 * i]; v += f.loss_part[2 * i + 1]; }
+    r = wave_sum_d(r);
+    v = wave_sum_d(v);
+    if (t == 0) {
+      const float rec = (float)(r * f.inv_rec), vel = (float)(v * f.inv_vel);
+      f.out3[0] = rec * f.k_rec + vel * f.k_vel;
+      f.out3[1] = rec;
+      f.out3[2] = vel;
+    }
   }
 }
 
@@ -608,13 +638,16 @@ extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias,
   if (rc != A2F_OK) return rc;
   const int64_t ncols_pad = (int64_t)p.CG * ((cfg == 2 || cfg == 4) ? 256 : cfg == 3 ? 384 : 512);
   {
-    int64_t blocks = cdiv(B * HF_KP, 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.dH_slab, p.CG, (int64_t)B * HF_KP, B, (int)K, dH);
-    blocks = cdiv(n * HF_KP, 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.dW_slab, p.RG, ncols_pad * HF_KP, n, (int)K, dW);
-    hipLaunchKernelGGL(vec_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, (const float*)a.db_slab, p.RG, ncols_pad, n, dbias);
-    hipLaunchKernelGGL(head_loss_finish_kernel, dim3(1), dim3(64), 0, s, (const double*)a.loss_part, p.CG * p.RG,
-                       1.0 / ((double)Bloss * V), 1.0 / ((double)(Bloss / 2) * V), k_rec, k_vel, out3);
+    HeadFoldArgs f;
+    f.dH_slab = a.dH_slab; f.dW_slab = a.dW_slab; f.db_slab = a.db_slab; f.loss_part = a.loss_part;
+    f.dH = dH; f.dW = dW; f.db = dbias; f.out3 = out3;
+    f.sH = (int64_t)B * HF_KP; f.sW = ncols_pad * HF_KP; f.sb = ncols_pad;
+    f.rowsH = B; f.rowsW = n; f.lenb = n;
+    f.nslabH = p.CG; f.nslabW = p.RG; f.nparts = p.CG * p.RG; f.K = (int)K;
+    f.nH = (int)cdiv(B * 16, 256); f.nW = (int)cdiv(n * 16, 256); f.nb = (int)cdiv(n, 256);
+    f.inv_rec = 1.0 / ((double)Bloss * V); f.inv_vel = 1.0 / ((double)(Bloss / 2) * V);
+    f.k_rec = k_rec; f.k_vel = k_vel;
+    hipLaunchKernelGGL(head_fold_kernel, dim3((unsigned)(f.nH + f.nW + f.nb + 1)), dim3(256), 0, s, f);
   }
   A2F_CHECK_LAUNCH("head_fused");
   return A2F_OK;

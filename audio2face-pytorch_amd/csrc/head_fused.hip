@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
 //   workgroups [nH, nH+nW)    dW[c][k]  = sum over RG row-group slabs
 //   workgroups [.., +nb)      db[c]     = sum over RG row-group slabs
 //   last workgroup            loss scalars from the per-workgroup double partials
-// Slab rows have pitch HF_KP = 64 floats (256 B): a lane owns one float4 of a row, quads with k >= K are skipped, and four
+// Slab rows have pitch HF_KP = 64 floats (256 B): a lane owns one float4 of a row, quads with k >= K are skipped, and eight
 // slabs are in flight per lane at a time.
 struct HeadFoldArgs {
   const float* dH_slab; const float* dW_slab; const float* db_slab; const double* loss_part;
@@ -459,6 +459,12 @@ __device__ __forceinline__ void fold_rows(const float* __restrict__ slab, int ns
   const int64_t st4 = sstride >> 2;
   f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
   int s = 0;
+  for (; s + 8 <= nslabs; s += 8) {
+    const f32x4 x0 = p[(int64_t)s * st4], x1 = p[(int64_t)(s + 1) * st4], x2 = p[(int64_t)(s + 2) * st4], x3 = p[(int64_t)(s + 3) * st4];
+    const f32x4 x4 = p[(int64_t)(s + 4) * st4], x5 = p[(int64_t)(s + 5) * st4], x6 = p[(int64_t)(s + 6) * st4], x7 = p[(int64_t)(s + 7) * st4];
+    v0 += x0; v1 += x1; v2 += x2; v3 += x3;
+    v0 += x4; v1 += x5; v2 += x6; v3 += x7;
+  }
   for (; s + 4 <= nslabs; s += 4) {
     const f32x4 x0 = p[(int64_t)s * st4], x1 = p[(int64_t)(s + 1) * st4], x2 = p[(int64_t)(s + 2) * st4], x3 = p[(int64_t)(s + 3) * st4];
     v0 += x0; v1 += x1; v2 += x2; v3 += x3;

@@ -95,23 +95,35 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
   // zero rows of R1 (never overwritten)
   for (int e = t; e < VT_F * 33; e += VT_THREADS) { const int f = e / 33, c = e - f * 33; R1[f * VT_S1 + (c < 32 ? c : 288)] = 0.f; }
 
+  // the x tile of a block (32 frames x 464 floats = 58 per lane) is fetched one block ahead into registers, so its HBM
+  // latency hides under the previous block's layers
+  constexpr int XR = VT_F * 464 / VT_THREADS;              // 58
+  static_assert(XR * VT_THREADS == VT_F * 464, "x tile must divide evenly");
+  float px[XR];
+  // raw buffer loads: frames >= B are out of range for the resource and read as 0 (no per-element predicate)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, B * 464 * 4, 0x00020000);
+  auto fetch_x = [&](int blk) {
+    int voff = (blk * VT_F * 464 + t) * 4;
+    asm volatile("" : "+v"(voff));                         // keep ONE address register, the rest are immediates / adds
+#pragma unroll
+    for (int u = 0; u < XR; ++u) px[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff + u * VT_THREADS * 4, 0, 0));
+  };
+  if ((int)blockIdx.x < a.NB) fetch_x(blockIdx.x);
+
   for (int blk = blockIdx.x; blk < a.NB; blk += gridDim.x) {
     const int f0 = blk * VT_F;
     __syncthreads();                                       // previous block finished with R0
     // ---- stage the input windows: R0[f][1+h][c] = x[f][c][h] (c<29) | one_hot[f][h%8] ; row 0 = zeros ----
-    for (int e0 = t; e0 < VT_F * 464; e0 += 8 * VT_THREADS) {
-      float v[8];
+    {
+      int to = t;
+      asm volatile("" : "+v"(to));                         // recompute the 58 scatter addresses per block instead of keeping them live
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = e0 + u * VT_THREADS, f = e / 464;
-        v[u] = (e < VT_F * 464 && f0 + f < B) ? a.x[(int64_t)f0 * 464 + e] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = e0 + u * VT_THREADS;
-        if (e < VT_F * 464) { const int f = e / 464, r = e - f * 464, c = r >> 4, hh = r & 15; R0[f * VT_S0 + (1 + hh) * 37 + c] = v[u]; }
+      for (int u = 0; u < XR; ++u) {
+        const int e = to + u * VT_THREADS, f = e / 464, r = e - f * 464, c = r >> 4, hh = r & 15;
+        R0[f * VT_S0 + (1 + hh) * 37 + c] = px[u];
       }
     }
+    if (blk + (int)gridDim.x < a.NB) fetch_x(blk + gridDim.x);
     for (int e = t; e < VT_F * 16 * 8; e += VT_THREADS) {
       const int f = e >> 7, r = e & 127, hh = r >> 3, q = r & 7;
       const int fr = f0 + f;
@@ -304,13 +316,49 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
   for (int e = t; e < VT_F * 65; e += VT_THREADS) { const int f = e / 65, c = e - f * 65; lds[VB_C3 + f * 193 + 128 + c] = 0.f; }
   for (int e = t; e < VT_F * 33; e += VT_THREADS) { const int f = e / 33, c = e - f * 33; lds[VB_C2 + f * 161 + 128 + c] = 0.f; }
 
+  // d(h3) of a block (32 x 50 floats) is fetched one block ahead; the saved forward activations that gate the gradients
+  // (tanh', ReLU masks: 96 floats per lane) are all requested at the top of the block, so one HBM latency is paid per
+  // block instead of one per layer
+  float pdh[7];
+  auto fetch_dh = [&](int blk) {
+    const int f0n = blk * VT_F;
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int e = t + u * VT_THREADS;
+      pdh[u] = (e < VT_F * 50 && f0n + e / 50 < B) ? a.dh3[(int64_t)f0n * 50 + e] : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < a.NB) fetch_dh(blockIdx.x);
+
   for (int blk = blockIdx.x; blk < a.NB; blk += gridDim.x) {
     const int f0 = blk * VT_F;
     __syncthreads();
-    for (int e = t; e < VT_F * 50; e += VT_THREADS) {
-      const int f = e / 50, j = e - f * 50;
-      lds[VB_DH + f * 51 + j] = f0 + f < B ? a.dh3[(int64_t)f0 * 50 + e] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int e = t + u * VT_THREADS;
+      if (e < VT_F * 50) { const int f = e / 50, j = e - f * 50; lds[VB_DH + f * 51 + j] = pdh[u]; }
     }
+    float mz[16], mc[16], m3[16], m2[16], m1[2][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;       // accumulator row of register r
+      {
+        const bool ok = f0 + rr < B;
+        mz[r] = ok ? a.z2[(int64_t)(f0 + rr) * 128 + wave * 32 + l31] : 0.f;
+        mc[r] = (ok && wave < 2) ? a.cat[(int64_t)(f0 + rr) * 72 + wave * 32 + l31] : 0.f;
+        m3[r] = ok ? a.a3[((int64_t)(f0 + rr) * 2 + (wave >> 1)) * 64 + (wave & 1) * 32 + l31] : 0.f;
+      }
+      {
+        const int orow = (wave & 1) * 32 + rr, of = orow >> 1, hin = 2 * (orow & 1) + (wave >> 1);
+        m2[r] = f0 + of < B ? a.a2[((int64_t)(f0 + of) * 4 + hin) * 32 + l31] : 0.f;
+      }
+#pragma unroll
+      for (int odd = 0; odd < 2; ++odd) {
+        const int orow = wave * 32 + rr, of = orow >> 2, hin = 2 * (orow & 3) + odd;
+        m1[odd][r] = f0 + of < B ? a.a1[((int64_t)(f0 + of) * 8 + hin) * 32 + l31] : 0.f;
+      }
+    }
+    if (blk + (int)gridDim.x < a.NB) fetch_dh(blk + gridDim.x);
     __syncthreads();
     // ---- decoder.3 backward: dz2pre = (dh3 W3) * (1 - z2^2) ----
     {
@@ -320,7 +368,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
       for (int r = 0; r < 16; ++r) {
         const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
         const bool ok = f0 + of < B;
-        const float z = ok ? a.z2[(int64_t)(f0 + of) * 128 + col] : 0.f;
+        const float z = mz[r];
         const float v = acc[r] * (1.f - z * z);
         lds[VB_Z2 + of * 129 + col] = v;
         if (ok) a.g_z2[(int64_t)(f0 + of) * 128 + col] = v;
@@ -349,8 +397,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
       for (int r = 0; r < 16; ++r) {
         const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
         const bool ok = f0 + of < B;
-        const float c = ok ? a.cat[(int64_t)(f0 + of) * 72 + col] : 0.f;
-        const float v = c > 0.f ? acc[r] : 0.f;
+        const float v = mc[r] > 0.f ? acc[r] : 0.f;
         lds[VB_C4 + of * 65 + col] = v;
         if (ok) a.g_c4[(int64_t)(f0 + of) * 64 + col] = v;
       }
@@ -364,8 +411,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
       for (int r = 0; r < 16; ++r) {
         const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
         const bool ok = f0 + of < B;
-        const float m = ok ? a.a3[((int64_t)(f0 + of) * 2 + hp) * 64 + ci] : 0.f;
-        const float v = m > 0.f ? acc[r] : 0.f;
+        const float v = m3[r] > 0.f ? acc[r] : 0.f;
         lds[VB_C3 + of * 193 + hp * 64 + ci] = v;
         if (ok) a.g_c3[((int64_t)(f0 + of) * 2 + hp) * 64 + ci] = v;
       }
@@ -381,8 +427,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
       for (int r = 0; r < 16; ++r) {
         const int orow = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 1, hin = 2 * (orow & 1) + odd;
         const bool ok = f0 + of < B;
-        const float m = ok ? a.a2[((int64_t)(f0 + of) * 4 + hin) * 32 + l31] : 0.f;
-        const float v = m > 0.f ? acc[r] : 0.f;
+        const float v = m2[r] > 0.f ? acc[r] : 0.f;
         lds[VB_C2 + of * 161 + hin * 32 + l31] = v;
         if (ok) a.g_c2[((int64_t)(f0 + of) * 4 + hin) * 32 + l31] = v;
       }
@@ -400,7 +445,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
           const int orow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 2, hin = 2 * (orow & 3) + odd;
           if (f0 + of < B) {
             const int64_t o = ((int64_t)(f0 + of) * 8 + hin) * 32 + l31;
-            a.g_c1[o] = a.a1[o] > 0.f ? acc[r] : 0.f;
+            a.g_c1[o] = m1[odd][r] > 0.f ? acc[r] : 0.f;
           }
         }
       }
@@ -415,7 +460,7 @@ extern "C" int a2f_voca_trunk_fwd(const float* x, const float* one_hot, int64_t 
                                   float* a2, float* a3, float* cat72, float* z1, float* z2, float* h3, a2f_stream_t stream) {
   using namespace a2f;
   A2F_CHECK_ARG(x && one_hot && conv_w && conv_b && fc_w && fc_b && a0 && a1 && a2 && a3 && cat72 && z1 && z2 && h3, "voca_trunk_fwd: null pointer");
-  A2F_CHECK_ARG(B > 0 && B < (1ll << 30) && n_onehot >= 8, "voca_trunk_fwd: B=%lld n_onehot=%lld", (long long)B, (long long)n_onehot);
+  A2F_CHECK_ARG(B > 0 && B <= 1000000 && n_onehot >= 8, "voca_trunk_fwd: B=%lld (1..1e6 frames per call) n_onehot=%lld", (long long)B, (long long)n_onehot);
   TrunkArgs a;
   a.x = x; a.one_hot = one_hot;
   for (int i = 0; i < 4; ++i) { A2F_CHECK_ARG(conv_w[i] && conv_b[i], "voca_trunk_fwd: null conv parameter"); a.cw[i] = conv_w[i]; a.cb[i] = conv_b[i]; }

@@ -24,7 +24,20 @@
 namespace a2f {
 
 constexpr int WG_THREADS = 256;
-constexpr int WG_U = 8;               // k-steps (of 2 rows) per register set; two sets are in flight
+#ifdef WG_FOLD_ROW
+constexpr int WG_NT_MAX = 7;
+#elif defined(WG_LDS_BIG)
+constexpr int WG_NT_MAX = 7;
+#else
+constexpr int WG_NT_MAX = 1;
+#endif
+#ifndef WG_U_SET
+#define WG_U_SET 8
+#endif
+#ifndef WG_TARGET
+#define WG_TARGET 800
+#endif
+constexpr int WG_U = WG_U_SET;               // k-steps (of 2 rows) per register set; two sets are in flight
 
 using wrsrc_t = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ wrsrc_t wg_rsrc(const float* base, int bytes) {
@@ -64,7 +77,7 @@ __device__ __forceinline__ WgradProb pick_problem(const WgradBatch& b, int blk, 
 }
 
 template <int MT, int NT>
-__device__ __forceinline__ void wgrad_body(const WgradProb& pr, int blk, float (*red)[1024]) {
+__device__ __forceinline__ void wgrad_body(const WgradProb& pr, int blk, float (*red)[WG_NT_MAX * 1024]) {
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int M = pr.M, N = pr.N, Neff = pr.Neff;
@@ -132,9 +145,26 @@ __device__ __forceinline__ void wgrad_body(const WgradProb& pr, int blk, float (
     mfma_set(a1, b1);
   }
 
-  // fold the four waves of the workgroup through LDS, tile by tile, and leave ONE partial slab per workgroup:
-  // [m][n], pitch Neff.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // fold the four waves of the workgroup through LDS and leave ONE partial slab per workgroup: [m][n], pitch Neff.
+  // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* slab = pr.ws + (int64_t)blk * M * Neff;
+#ifdef WG_FOLD_ROW
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave][j * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4 * NT; ++q) {
+      const int e = t + q * WG_THREADS;                    // tile j = e / 1024, row = (e % 1024) / 32, col = e % 32
+      const int m = i * 32 + ((e & 1023) >> 5), n = (e >> 10) * 32 + (e & 31);
+      if (m < M && n < Neff) slab[(int64_t)m * Neff + n] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    }
+  }
+#else
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -150,10 +180,11 @@ __device__ __forceinline__ void wgrad_body(const WgradProb& pr, int blk, float (
         if (m < M && n < Neff) slab[(int64_t)m * Neff + n] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
       }
     }
+#endif
 }
 
 __global__ __launch_bounds__(WG_THREADS, 1) void wgrad_batch_kernel(const WgradBatch b) {
-  __shared__ float red[4][1024];
+  __shared__ float red[4][WG_NT_MAX * 1024];             // 112 KB: one row of accumulator tiles per wave
   const WgradProb pr = pick_problem(b, blockIdx.x, false);
   const int blk = blockIdx.x - pr.blk_beg;
   switch (pr.shape) {
@@ -223,7 +254,7 @@ static int wgrad_shape(int mt, int nt) {
 static WgradPlan wgrad_plan(int64_t M, int64_t N, int64_t K) {
   const int shape = wgrad_shape((int)((M + 31) / 32), (int)((N + 1 + 31) / 32));
   const int64_t tiles = shape ? (shape / 8 + shape % 8) : 8;
-  int64_t rpw = std::min<int64_t>(800 / tiles, cdiv(K, 4 * 64));
+  int64_t rpw = std::min<int64_t>(WG_TARGET / tiles, cdiv(K, 4 * 64));
   rpw = std::max<int64_t>(4 * WG_U, cdiv(rpw, 4 * WG_U) * (4 * WG_U));
   WgradPlan p;
   p.rows_per_wave = (int)rpw;

@@ -19,6 +19,41 @@
 
 namespace a2f {
 
+// diagnostic build only (-DVT_STAMPS): s_memtime totals per phase of wave 0 of workgroup 0, read by a2f_debug_trunk_stamps
+#ifdef VT_STAMPS
+__device__ unsigned long long vt_dbg[2][16];
+#define VT_STAMP(k, i)                                                              \
+  do {                                                                              \
+    unsigned long long now__;                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now__)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    if (blockIdx.x == 0 && threadIdx.x == 0) vt_dbg[k][i] += now__ - last__;        \
+    last__ = now__;                                                                 \
+  } while (0)
+#define VT_STAMP_INIT()                                                             \
+  unsigned long long last__;                                                        \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last__)::"memory")
+#else
+#define VT_STAMP(k, i) do { } while (0)
+#define VT_STAMP_INIT() do { } while (0)
+#endif
+
+// Global memory is touched only through raw buffer instructions whose resource covers exactly the B frames of a tensor:
+// a frame >= B (tail block) is out of range, so loads return 0 and stores are dropped - no per-element predicate.  (With
+// ordinary predicated loads hipcc wraps every load in a branch and waits for it at the join: 96 serialised latencies.)
+using vt_rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ vt_rsrc_t vt_rsrc(const float* p, int frames, int floats_per_frame) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, frames * floats_per_frame * 4, 0x00020000);
+}
+__device__ __forceinline__ float vt_ld(vt_rsrc_t r, int float_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, float_off * 4, 0, 0));
+}
+__device__ __forceinline__ void vt_st(vt_rsrc_t r, int float_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, float_off * 4, 0, 0);
+}
+constexpr int VT_MAX_FRAMES = 800000;                      // keeps every byte offset below 2^31
+
 constexpr int VT_THREADS = 256;
 constexpr int VT_F = 32;                                   // frames per block
 constexpr int VT_S0 = 17 * 37;                             // 629: frame stride of the input windows (odd)
@@ -100,19 +135,24 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
   constexpr int XR = VT_F * 464 / VT_THREADS;              // 58
   static_assert(XR * VT_THREADS == VT_F * 464, "x tile must divide evenly");
   float px[XR];
-  // raw buffer loads: frames >= B are out of range for the resource and read as 0 (no per-element predicate)
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, B * 464 * 4, 0x00020000);
+  float poh;                                               // one_hot[f0 + t/8][t%8] of the same block
+  const vt_rsrc_t rx = vt_rsrc(a.x, B, 464), roh = vt_rsrc(a.one_hot, B, a.no);
+  const vt_rsrc_t ra0 = vt_rsrc(a.a0, B, 592), ra1 = vt_rsrc(a.a1, B, 256), ra2 = vt_rsrc(a.a2, B, 128), ra3 = vt_rsrc(a.a3, B, 128);
+  const vt_rsrc_t rcat = vt_rsrc(a.cat, B, 72), rz1 = vt_rsrc(a.z1, B, 72), rz2 = vt_rsrc(a.z2, B, 128), rh3 = vt_rsrc(a.h3, B, 50);
   auto fetch_x = [&](int blk) {
-    int voff = (blk * VT_F * 464 + t) * 4;
+    int voff = blk * VT_F * 464 + t;
     asm volatile("" : "+v"(voff));                         // keep ONE address register, the rest are immediates / adds
 #pragma unroll
-    for (int u = 0; u < XR; ++u) px[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff + u * VT_THREADS * 4, 0, 0));
+    for (int u = 0; u < XR; ++u) px[u] = vt_ld(rx, voff + u * VT_THREADS);
+    poh = vt_ld(roh, (blk * VT_F + (t >> 3)) * a.no + (t & 7));
   };
   if ((int)blockIdx.x < a.NB) fetch_x(blockIdx.x);
+  VT_STAMP_INIT();
 
   for (int blk = blockIdx.x; blk < a.NB; blk += gridDim.x) {
     const int f0 = blk * VT_F;
     __syncthreads();                                       // previous block finished with R0
+    VT_STAMP(0, 0);
     // ---- stage the input windows: R0[f][1+h][c] = x[f][c][h] (c<29) | one_hot[f][h%8] ; row 0 = zeros ----
     {
       int to = t;
@@ -123,18 +163,35 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
         R0[f * VT_S0 + (1 + hh) * 37 + c] = px[u];
       }
     }
-    if (blk + (int)gridDim.x < a.NB) fetch_x(blk + gridDim.x);
-    for (int e = t; e < VT_F * 16 * 8; e += VT_THREADS) {
-      const int f = e >> 7, r = e & 127, hh = r >> 3, q = r & 7;
-      const int fr = f0 + f;
-      R0[f * VT_S0 + (1 + hh) * 37 + 29 + q] = fr < B ? a.one_hot[(int64_t)fr * a.no + (hh & 7)] : 0.f;
+    // one-hot channels (voca.py:40-45 repeat/view quirk): window row h carries one_hot[f][h % 8] in its 8 trailing
+    // channels; lane (f = t/8, j = t%8) owns that value and fills rows j and j+8
+    const float ohv = poh;
+    {
+      const int f = t >> 3, j = t & 7;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) R0[f * VT_S0 + (1 + j + 8 * b) * 37 + 29 + q] = ohv;
     }
+    if (blk + (int)gridDim.x < a.NB) fetch_x(blk + gridDim.x);
     for (int e = t; e < VT_F * 37; e += VT_THREADS) { const int f = e / 37, c = e - f * 37; R0[f * VT_S0 + c] = 0.f; }
     __syncthreads();
-    // a0 to global (B,16,37), coalesced along (h,c)
-    for (int e = t; e < VT_F * 592; e += VT_THREADS) {
-      const int f = e / 592, r = e - f * 592;
-      if (f0 + f < B) a.a0[(int64_t)(f0 + f) * 592 + r] = R0[f * VT_S0 + 37 + r];
+    VT_STAMP(0, 1);
+    // a0 to global (B,16,37): a frame is 592 contiguous floats in LDS and in HBM -> 148 float4 stores per frame
+    {
+      int to = t;
+      asm volatile("" : "+v"(to));
+#pragma unroll
+      for (int i = 0; i < (VT_F * 148 + VT_THREADS - 1) / VT_THREADS; ++i) {
+        const int e4 = to + i * VT_THREADS;
+        if (e4 < VT_F * 148) {
+          const int f = e4 / 148, q = e4 - f * 148;
+          const float* src = R0 + f * VT_S0 + 37 + 4 * q;
+          const f32x4 v = {src[0], src[1], src[2], src[3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ra0,
+                                                 ((f0 + f) * 592 + 4 * q) * 4, 0, 0);
+        }
+      }
     }
     // ---- conv1: rows (f,p<8) = 256 = 8 tiles, 2 per wave; window = R0[f*629 + 2p*37 ..+111) ----
 #pragma unroll
@@ -147,18 +204,18 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
         const int orow = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 3, op = orow & 7;
         const float v = fmaxf(acc[r] + cb1, 0.f);
         R1[of * VT_S1 + (1 + op) * 32 + l31] = v;
-        if (f0 + of < B) a.a1[((int64_t)(f0 + of) * 8 + op) * 32 + l31] = v;
+        vt_st(ra1, ((f0 + of) * 8 + op) * 32 + l31, v);
       }
     }
     __syncthreads();                                       // R0 (input windows) is dead; conv1 output complete
+    VT_STAMP(0, 2);
     for (int e = t; e < VT_F * 33; e += VT_THREADS) { const int f = e / 33, c = e - f * 33; R0[VT_A2 + f * VT_S2 + (c < 32 ? c : 160)] = 0.f; }
     for (int e = t; e < VT_F * 65; e += VT_THREADS) { const int f = e / 65, c = e - f * 65; R0[VT_A3 + f * VT_S3 + (c < 64 ? c : 192)] = 0.f; }
     // one-hot tail of the concat vector (voca.py:47): cat[f][64+q] = one_hot[f][q]
-    for (int e = t; e < VT_F * 8; e += VT_THREADS) {
-      const int f = e >> 3, q = e & 7, fr = f0 + f;
-      const float v = fr < B ? a.one_hot[(int64_t)fr * a.no + q] : 0.f;
-      R0[VT_CAT + f * VT_SC + 64 + q] = v;
-      if (fr < B) a.cat[(int64_t)fr * 72 + 64 + q] = v;
+    {
+      const int f = t >> 3, q = t & 7;
+      R0[VT_CAT + f * VT_SC + 64 + q] = ohv;
+      vt_st(rcat, (f0 + f) * 72 + 64 + q, ohv);
     }
     // ---- conv2: rows (f,p<4) = 128 = 4 tiles, 1 per wave (reads R1, writes the A2 area of R0: no hazard with the zeroing) ----
     {
@@ -169,10 +226,11 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
         const int orow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 2, op = orow & 3;
         const float v = fmaxf(acc[r] + cb2, 0.f);
         R0[VT_A2 + of * VT_S2 + (1 + op) * 32 + l31] = v;
-        if (f0 + of < B) a.a2[((int64_t)(f0 + of) * 4 + op) * 32 + l31] = v;
+        vt_st(ra2, ((f0 + of) * 4 + op) * 32 + l31, v);
       }
     }
     __syncthreads();
+    VT_STAMP(0, 3);
     // ---- conv3: rows (f,p<2) = 64 = 2 M-tiles x 2 N-tiles ----
     {
       const int mt = wave >> 1, nt = wave & 1;
@@ -183,10 +241,11 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
         const int orow = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 1, op = orow & 1;
         const float v = fmaxf(acc[r] + cb3, 0.f);
         R0[VT_A3 + of * VT_S3 + (1 + op) * 64 + nt * 32 + l31] = v;
-        if (f0 + of < B) a.a3[((int64_t)(f0 + of) * 2 + op) * 64 + nt * 32 + l31] = v;
+        vt_st(ra3, ((f0 + of) * 2 + op) * 64 + nt * 32 + l31, v);
       }
     }
     __syncthreads();
+    VT_STAMP(0, 4);
     // ---- conv4: rows f = 32 = 1 M-tile x 2 N-tiles (waves 0,1); window = positions 0,1 (taps 1,2) ----
     if (wave < 2) {
       const f32x16 acc = vt_tile<64>(R0 + VT_A3 + l31 * VT_S3 + 64 + h, w47);
@@ -195,10 +254,11 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
         const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
         const float v = fmaxf(acc[r] + cb4, 0.f);
         R0[VT_CAT + of * VT_SC + wave * 32 + l31] = v;
-        if (f0 + of < B) a.cat[(int64_t)(f0 + of) * 72 + wave * 32 + l31] = v;
+        vt_st(rcat, (f0 + of) * 72 + wave * 32 + l31, v);
       }
     }
     __syncthreads();
+    VT_STAMP(0, 5);
     // ---- decoder.0: 72 -> 72 (3 N-tiles, waves 0..2), no activation ----
     if (wave < 3) {
       const f32x16 acc = vt_tile<36>(R0 + VT_CAT + l31 * VT_SC + h, w5);
@@ -208,11 +268,12 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
           const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
           const float v = acc[r] + fb5;
           R0[VT_Z1 + of * VT_SC + c5] = v;
-          if (f0 + of < B) a.z1[(int64_t)(f0 + of) * 72 + c5] = v;
+          vt_st(rz1, (f0 + of) * 72 + c5, v);
         }
       }
     }
     __syncthreads();
+    VT_STAMP(0, 6);
     // ---- decoder.1: 72 -> 128 + tanh (4 N-tiles) ----
     {
       const f32x16 acc = vt_tile<36>(R0 + VT_Z1 + l31 * VT_SC + h, w6);
@@ -222,10 +283,11 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
         const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
         const float v = tanhf(acc[r] + fb6);
         R0[VT_Z2 + of * VT_SZ2 + col] = v;
-        if (f0 + of < B) a.z2[(int64_t)(f0 + of) * 128 + col] = v;
+        vt_st(rz2, (f0 + of) * 128 + col, v);
       }
     }
     __syncthreads();
+    VT_STAMP(0, 7);
     // ---- decoder.3: 128 -> 50 (2 N-tiles, waves 2,3), output to global only ----
     if (wave >= 2) {
       const f32x16 acc = vt_tile<64>(R0 + VT_Z2 + l31 * VT_SZ2 + h, w47);
@@ -233,10 +295,11 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (f0 + of < B) a.h3[(int64_t)(f0 + of) * 50 + c7] = acc[r] + fb7;
+          vt_st(rh3, (f0 + of) * 50 + c7, acc[r] + fb7);
         }
       }
     }
+    VT_STAMP(0, 8);
   }
 }
 
@@ -320,46 +383,61 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
   // (tanh', ReLU masks: 96 floats per lane) are all requested at the top of the block, so one HBM latency is paid per
   // block instead of one per layer
   float pdh[7];
+  const vt_rsrc_t rdh = vt_rsrc(a.dh3, B, 50), rz2 = vt_rsrc(a.z2, B, 128), rcat = vt_rsrc(a.cat, B, 72), ra3 = vt_rsrc(a.a3, B, 128),
+                  ra2 = vt_rsrc(a.a2, B, 128), ra1 = vt_rsrc(a.a1, B, 256);
+  const vt_rsrc_t rgz2 = vt_rsrc(a.g_z2, B, 128), rgz1 = vt_rsrc(a.g_z1, B, 72), rgc4 = vt_rsrc(a.g_c4, B, 64), rgc3 = vt_rsrc(a.g_c3, B, 128),
+                  rgc2 = vt_rsrc(a.g_c2, B, 128), rgc1 = vt_rsrc(a.g_c1, B, 256);
   auto fetch_dh = [&](int blk) {
-    const int f0n = blk * VT_F;
 #pragma unroll
     for (int u = 0; u < 7; ++u) {
       const int e = t + u * VT_THREADS;
-      pdh[u] = (e < VT_F * 50 && f0n + e / 50 < B) ? a.dh3[(int64_t)f0n * 50 + e] : 0.f;
+      pdh[u] = vt_ld(rdh, e < VT_F * 50 ? blk * VT_F * 50 + e : -1);
     }
   };
   if ((int)blockIdx.x < a.NB) fetch_dh(blockIdx.x);
+  VT_STAMP_INIT();
 
   for (int blk = blockIdx.x; blk < a.NB; blk += gridDim.x) {
     const int f0 = blk * VT_F;
     __syncthreads();
+    VT_STAMP(1, 0);
 #pragma unroll
     for (int u = 0; u < 7; ++u) {
       const int e = t + u * VT_THREADS;
       if (e < VT_F * 50) { const int f = e / 50, j = e - f * 50; lds[VB_DH + f * 51 + j] = pdh[u]; }
     }
+    // activation masks of this block, requested up front (accumulator row of register r: rho(r) + 4h).  One opaque base
+    // offset per tensor keeps the 96 addresses out of registers (each load adds a constant).
     float mz[16], mc[16], m3[16], m2[16], m1[2][16];
+    {
+      int bz = (f0 + 4 * h) * 128 + wave * 32 + l31;
+      int bc = wave < 2 ? (f0 + 4 * h) * 72 + wave * 32 + l31 : -0x20000000;   // waves 2,3: far out of range -> 0
+      int b3 = ((f0 + 4 * h) * 2 + (wave >> 1)) * 64 + (wave & 1) * 32 + l31;
+      asm volatile("" : "+v"(bz), "+v"(bc), "+v"(b3));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;       // accumulator row of register r
-      {
-        const bool ok = f0 + rr < B;
-        mz[r] = ok ? a.z2[(int64_t)(f0 + rr) * 128 + wave * 32 + l31] : 0.f;
-        mc[r] = (ok && wave < 2) ? a.cat[(int64_t)(f0 + rr) * 72 + wave * 32 + l31] : 0.f;
-        m3[r] = ok ? a.a3[((int64_t)(f0 + rr) * 2 + (wave >> 1)) * 64 + (wave & 1) * 32 + l31] : 0.f;
+      for (int r = 0; r < 16; ++r) {
+        const int r0 = (r & 3) + 8 * (r >> 2);
+        mz[r] = vt_ld(rz2, bz + r0 * 128);
+        mc[r] = vt_ld(rcat, bc + r0 * 72);
+        m3[r] = vt_ld(ra3, b3 + r0 * 128);
       }
-      {
-        const int orow = (wave & 1) * 32 + rr, of = orow >> 1, hin = 2 * (orow & 1) + (wave >> 1);
-        m2[r] = f0 + of < B ? a.a2[((int64_t)(f0 + of) * 4 + hin) * 32 + l31] : 0.f;
-      }
+      // conv3' rows: orow = (wave&1)*32 + rho + 4h -> frame of = orow/2, input row hin = 2*(orow&1) + (wave>>1)
+      // conv2' rows: orow = wave*32 + rho + 4h     -> frame of = orow/4, input row hin = 2*(orow&3) + odd
+      // both are affine in orow: a2 offset = (f0*4 + 2*orow + (wave>>1))*32 + l31 ; a1 offset = (f0*8 + 2*orow + odd)*32 + l31
+      int b2 = (f0 * 4 + 2 * ((wave & 1) * 32 + 4 * h) + (wave >> 1)) * 32 + l31;
+      int b1 = (f0 * 8 + 2 * (wave * 32 + 4 * h)) * 32 + l31;
+      asm volatile("" : "+v"(b2), "+v"(b1));
 #pragma unroll
-      for (int odd = 0; odd < 2; ++odd) {
-        const int orow = wave * 32 + rr, of = orow >> 2, hin = 2 * (orow & 3) + odd;
-        m1[odd][r] = f0 + of < B ? a.a1[((int64_t)(f0 + of) * 8 + hin) * 32 + l31] : 0.f;
+      for (int r = 0; r < 16; ++r) {
+        const int r0 = (r & 3) + 8 * (r >> 2);
+        m2[r] = vt_ld(ra2, b2 + 2 * r0 * 32);
+        m1[0][r] = vt_ld(ra1, b1 + 2 * r0 * 32);
+        m1[1][r] = vt_ld(ra1, b1 + 2 * r0 * 32 + 32);
       }
     }
     if (blk + (int)gridDim.x < a.NB) fetch_dh(blk + gridDim.x);
     __syncthreads();
+    VT_STAMP(1, 1);
     // ---- decoder.3 backward: dz2pre = (dh3 W3) * (1 - z2^2) ----
     {
       const f32x16 acc = vt_tile<25>(lds + VB_DH + l31 * 51 + h, q3);
@@ -367,14 +445,14 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const bool ok = f0 + of < B;
         const float z = mz[r];
         const float v = acc[r] * (1.f - z * z);
         lds[VB_Z2 + of * 129 + col] = v;
-        if (ok) a.g_z2[(int64_t)(f0 + of) * 128 + col] = v;
+        vt_st(rgz2, (f0 + of) * 128 + col, v);
       }
     }
     __syncthreads();
+    VT_STAMP(1, 2);
     // ---- decoder.1 backward: dz1 = dz2pre W1 ----
     if (wave < 3) {
       const f32x16 acc = vt_tile<64>(lds + VB_Z2 + l31 * 129 + h, q1);
@@ -384,11 +462,12 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
         for (int r = 0; r < 16; ++r) {
           const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
           lds[VB_Z1 + of * 73 + col] = acc[r];
-          if (f0 + of < B) a.g_z1[(int64_t)(f0 + of) * 72 + col] = acc[r];
+          vt_st(rgz1, (f0 + of) * 72 + col, acc[r]);
         }
       }
     }
     __syncthreads();
+    VT_STAMP(1, 3);
     // ---- decoder.0 backward (conv features only) + ReLU mask of conv4's output ----
     if (wave < 2) {
       const f32x16 acc = vt_tile<36>(lds + VB_Z1 + l31 * 73 + h, q0);
@@ -396,13 +475,13 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const bool ok = f0 + of < B;
         const float v = mc[r] > 0.f ? acc[r] : 0.f;
         lds[VB_C4 + of * 65 + col] = v;
-        if (ok) a.g_c4[(int64_t)(f0 + of) * 64 + col] = v;
+        vt_st(rgc4, (f0 + of) * 64 + col, v);
       }
     }
     __syncthreads();
+    VT_STAMP(1, 4);
     // ---- conv4 data gradient: d3[f][h'][ci] = sum_co g4[f][co] w4[co][ci][h'+1], masked by a3 > 0 ----
     {
       const f32x16 acc = vt_tile<32>(lds + VB_C4 + l31 * 65 + h, q4);
@@ -410,13 +489,13 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const bool ok = f0 + of < B;
         const float v = m3[r] > 0.f ? acc[r] : 0.f;
         lds[VB_C3 + of * 193 + hp * 64 + ci] = v;
-        if (ok) a.g_c3[((int64_t)(f0 + of) * 2 + hp) * 64 + ci] = v;
+        vt_st(rgc3, ((f0 + of) * 2 + hp) * 64 + ci, v);
       }
     }
     __syncthreads();
+    VT_STAMP(1, 5);
     // ---- conv3 data gradient: rows (f, p<2); waves 0,1: even input rows 2p (tap 1); waves 2,3: odd rows 2p+1 ----
     {
       const int mt = wave & 1, odd = wave >> 1;
@@ -426,13 +505,13 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int orow = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 1, hin = 2 * (orow & 1) + odd;
-        const bool ok = f0 + of < B;
         const float v = m2[r] > 0.f ? acc[r] : 0.f;
         lds[VB_C2 + of * 161 + hin * 32 + l31] = v;
-        if (ok) a.g_c2[((int64_t)(f0 + of) * 4 + hin) * 32 + l31] = v;
+        vt_st(rgc2, ((f0 + of) * 4 + hin) * 32 + l31, v);
       }
     }
     __syncthreads();
+    VT_STAMP(1, 6);
     // ---- conv2 data gradient: rows (f, p<4) = 4 tiles, one per wave: even rows 2p, then odd rows 2p+1 ----
     {
       const int row = wave * 32 + l31, f = row >> 2, p = row & 3;
@@ -443,13 +522,11 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int orow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 2, hin = 2 * (orow & 3) + odd;
-          if (f0 + of < B) {
-            const int64_t o = ((int64_t)(f0 + of) * 8 + hin) * 32 + l31;
-            a.g_c1[o] = m1[odd][r] > 0.f ? acc[r] : 0.f;
-          }
+          vt_st(rgc1, ((f0 + of) * 8 + hin) * 32 + l31, m1[odd][r] > 0.f ? acc[r] : 0.f);
         }
       }
     }
+    VT_STAMP(1, 7);
   }
 }
 
@@ -460,7 +537,7 @@ extern "C" int a2f_voca_trunk_fwd(const float* x, const float* one_hot, int64_t 
                                   float* a2, float* a3, float* cat72, float* z1, float* z2, float* h3, a2f_stream_t stream) {
   using namespace a2f;
   A2F_CHECK_ARG(x && one_hot && conv_w && conv_b && fc_w && fc_b && a0 && a1 && a2 && a3 && cat72 && z1 && z2 && h3, "voca_trunk_fwd: null pointer");
-  A2F_CHECK_ARG(B > 0 && B <= 1000000 && n_onehot >= 8, "voca_trunk_fwd: B=%lld (1..1e6 frames per call) n_onehot=%lld", (long long)B, (long long)n_onehot);
+  A2F_CHECK_ARG(B > 0 && B <= VT_MAX_FRAMES && n_onehot >= 8 && n_onehot <= 512, "voca_trunk_fwd: B=%lld (1..%d frames per call) n_onehot=%lld", (long long)B, VT_MAX_FRAMES, (long long)n_onehot);
   TrunkArgs a;
   a.x = x; a.one_hot = one_hot;
   for (int i = 0; i < 4; ++i) { A2F_CHECK_ARG(conv_w[i] && conv_b[i], "voca_trunk_fwd: null conv parameter"); a.cw[i] = conv_w[i]; a.cb[i] = conv_b[i]; }
@@ -486,7 +563,7 @@ extern "C" int a2f_voca_trunk_bwd_data(const float* dh3, const float* z2, const 
   using namespace a2f;
   A2F_CHECK_ARG(dh3 && z2 && cat72 && a3 && a2 && a1 && fw3 && fw1 && fw0 && cw4 && cw3 && cw2 && g_z2 && g_z1 && g_c4 && g_c3 && g_c2 && g_c1,
                 "voca_trunk_bwd_data: null pointer");
-  A2F_CHECK_ARG(B > 0 && B < (1ll << 30), "voca_trunk_bwd_data: B=%lld", (long long)B);
+  A2F_CHECK_ARG(B > 0 && B <= VT_MAX_FRAMES, "voca_trunk_bwd_data: B=%lld (1..%d frames per call)", (long long)B, VT_MAX_FRAMES);
   TrunkBwdArgs a;
   a.dh3 = dh3; a.z2 = z2; a.cat = cat72; a.a3 = a3; a.a2 = a2; a.a1 = a1;
   a.fw3 = fw3; a.fw1 = fw1; a.fw0 = fw0; a.cw4 = cw4; a.cw3 = cw3; a.cw2 = cw2;
@@ -503,3 +580,13 @@ extern "C" int a2f_voca_trunk_bwd_data(const float* dh3, const float* z2, const 
   A2F_CHECK_LAUNCH("voca_trunk_bwd_data");
   return A2F_OK;
 }
+
+#ifdef VT_STAMPS
+// diagnostic build only: copy and clear the phase totals (cycles of the 100 MHz s_memtime counter)
+extern "C" int a2f_debug_trunk_stamps(unsigned long long* out32) {
+  unsigned long long z[2][16] = {};
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(a2f::vt_dbg), sizeof(z)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(a2f::vt_dbg), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif

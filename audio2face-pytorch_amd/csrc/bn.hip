@@ -42,7 +42,23 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float* __r
     if (ro < rpp) {
       float mu = 0.f, is = 0.f;
       if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
-      for (int64_t r = r0 + ro; r < r1; r += rpp) {
+      // four rows per trip: the loads are independent, the double accumulation order stays fixed
+      int64_t r = r0 + ro;
+      for (; r + 3 * rpp < r1; r += 4 * rpp) {
+        float xv[4], gv[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t i = (r + (int64_t)u * rpp) * C + c;
+          xv[u] = x[i];
+          if (MODE == 1) { gv[u] = dy[i]; yv[u] = relu ? y[i] : 1.f; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (MODE == 0) { s0 += xv[u]; s1 += (double)xv[u] * xv[u]; }
+          else { const float g = yv[u] > 0.f ? gv[u] : 0.f; s0 += g; s1 += (double)g * ((xv[u] - mu) * is); }
+        }
+      }
+      for (; r < r1; r += rpp) {
         const int64_t i = r * C + c;
         if (MODE == 0) {
           const float v = x[i];
@@ -80,13 +96,38 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float* __r
   }
 }
 
-__global__ void bn_finish_stats_kernel(const double* __restrict__ part, int nblk, int64_t R, int C, float momentum, float eps,
-                                       float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ save_mean,
-                                       float* __restrict__ save_invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) { s += part[((int64_t)b * 2 + 0) * C + c]; q += part[((int64_t)b * 2 + 1) * C + c]; }
+// Fold of the per-block double partials: 16 channels x 16 block-lanes per workgroup (a lane sums every 16th block, the 16
+// lane sums are added in fixed order through LDS) - deterministic, and ~nblk/16 dependent loads deep instead of nblk.
+__device__ __forceinline__ void bn_fold_partials(const double* __restrict__ part, int nblk, int C, int c, int zg, bool valid,
+                                                 double (&sh)[2][16][17], double& s, double& q) {
+  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+  if (valid) {
+    int b = zg;
+    for (; b + 16 < nblk; b += 32) {
+      a0 += part[((int64_t)b * 2 + 0) * C + c]; b0 += part[((int64_t)b * 2 + 1) * C + c];
+      a1 += part[((int64_t)(b + 16) * 2 + 0) * C + c]; b1 += part[((int64_t)(b + 16) * 2 + 1) * C + c];
+    }
+    if (b < nblk) { a0 += part[((int64_t)b * 2 + 0) * C + c]; b0 += part[((int64_t)b * 2 + 1) * C + c]; }
+  }
+  const int o = threadIdx.x & 15;
+  sh[0][zg][o] = a0 + a1;
+  sh[1][zg][o] = b0 + b1;
+  __syncthreads();
+  s = 0.0; q = 0.0;
+  if (zg == 0) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { s += sh[0][g][o]; q += sh[1][g][o]; }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finish_stats_kernel(const double* __restrict__ part, int nblk, int64_t R, int C, float momentum,
+                                                               float eps, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                               float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  __shared__ double sh[2][16][17];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), zg = threadIdx.x >> 4;
+  double s, q;
+  bn_fold_partials(part, nblk, C, c, zg, c < C, sh, s, q);
+  if (zg != 0 || c >= C) return;
   const double mean = s / (double)R;
   double var = q / (double)R - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -105,11 +146,13 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const floa
   save_invstd[c] = (float)(1.0 / sqrt((double)rvar[c] + (double)eps));
 }
 
-__global__ void bn_finish_bwd_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) { s += part[((int64_t)b * 2 + 0) * C + c]; q += part[((int64_t)b * 2 + 1) * C + c]; }
+__global__ __launch_bounds__(256) void bn_finish_bwd_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+  __shared__ double sh[2][16][17];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), zg = threadIdx.x >> 4;
+  double s, q;
+  bn_fold_partials(part, nblk, C, c, zg, c < C, sh, s, q);
+  if (zg != 0 || c >= C) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)q;
 }
@@ -182,7 +225,7 @@ extern "C" int a2f_bn_fwd(const float* x, int64_t R, int64_t C, const float* gam
     const int nblk = bn_blocks(R, (int)C);
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblk), dim3(BN_THREADS), 0, s, x, (const float*)nullptr, (const float*)nullptr, R,
                        (int)C, (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
-    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(cb), dim3(256), 0, s, (const double*)ws, nblk, R, (int)C, momentum, eps,
+    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, s, (const double*)ws, nblk, R, (int)C, momentum, eps,
                        running_mean, running_var, save_mean, save_invstd);
   } else {
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cb), dim3(256), 0, s, running_mean, running_var, (int)C, eps, save_mean, save_invstd);
@@ -208,7 +251,7 @@ extern "C" int a2f_bn_bwd(const float* x, const float* y, const float* dy, int64
   const int nblk = bn_blocks(R, (int)C);
   hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(BN_THREADS), 0, s, x, y, dy, R, (int)C, save_mean, save_invstd, (int)relu,
                      (double*)ws);
-  hipLaunchKernelGGL(bn_finish_bwd_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, s, (const double*)ws, nblk, (int)C, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_finish_bwd_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, s, (const double*)ws, nblk, (int)C, dgamma, dbeta);
   const int64_t total = R * C;
   int64_t blocks = cdiv(total, BN_THREADS * 4);
   if (blocks > 4096) blocks = 4096;

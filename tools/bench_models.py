@@ -75,6 +75,12 @@ def faceformer(S, T, encoder=True):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) >= 3 and sys.argv[1] == "audio2mesh":      # e.g. under rocprofv3: one configuration only
+        audio2mesh(int(sys.argv[2]))
+        sys.exit(0)
+    if len(sys.argv) >= 3 and sys.argv[1] == "faceformer":
+        faceformer(int(sys.argv[2]), 600, encoder=len(sys.argv) < 4)
+        sys.exit(0)
     audio2mesh(128)
     audio2mesh(1024)
     faceformer(8, 600, encoder=False)

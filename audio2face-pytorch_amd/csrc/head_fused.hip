@@ -290,7 +290,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
           const int so0 = (4 * (rr * n + lo)) | ~(mint | (mcolv & ((rr + h4 - rlim) >> 31)));
           const int so1 = (4 * ((rr + 1) * n + lo)) | ~(mint | (mcolv & ((rr + 1 + h4 - rlim) >> 31)));
           if (!LEAN) { pv[r] = p0; pv[r + 1] = p1; so[r] = so0; so[r + 1] = so1; }
+#ifdef HF_ABL_NOSTORE
+          else { asm volatile("" :: "v"(p0), "v"(p1), "v"(so0), "v"(so1)); }
+#else
           else { buf_store(pbuf, so0, p0); buf_store(pbuf, so1, p1); }
+#endif
 
           const bool in_loss = colok && (rb * HF_ROWS + rr + h4 + 1 < a.Bloss);
           const float d0 = in_loss ? p0 - gcur[r] : 0.f;
@@ -431,6 +435,332 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
   }
 }
 
+// =====================================================================================================================
+// Split-precision variant (configuration 5): the same pass with every product on the bf16 matrix pipe.
+//
+// The ablation builds show the fp32-MFMA kernel is bound by the matrix pipe (compute-only 1.10 ms of 1.31 ms at
+// B = 19 200): v_mfma_f32_32x32x2_f32 retires 2 k per 64 cycles, v_mfma_f32_32x32x16_bf16 16 k per 32 cycles.  Every fp32
+// operand x is split as x = hi + lo with hi = bf16(x) (round to nearest even) and lo = bf16(x - hi), and a product is
+// evaluated as lo*hi' + hi*lo' + hi*hi' with fp32 accumulation: three MFMAs, 5.3x less matrix time than the fp32 form,
+// relative error of a product <= 2^-16 (the dropped lo*lo' term and the bf16 rounding of lo), i.e. ~1e-5 relative on
+// pred / dH / dW / db - inside the 1e-4 parity bar, with the loss and every elementwise step still in fp32.
+//
+// Layout differences from the fp32 kernel: the W slice lives in REGISTERS (each wave owns one 32-column chunk for the
+// whole kernel: forward B fragments and dH B fragments, hi and lo, 64 VGPRs), H tiles are kept in LDS as bf16 hi/lo in
+// two images (row-major for the forward A operand, k-major with the accumulator row permutation for the dW B operand) so
+// every fragment is ONE ds_read_b128, and the only fp32 LDS traffic left is the G transpose and the dH fold.
+using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
+using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
+
+// (a, b) -> packed bf16 pairs: hi = RNE(x), lo = RNE(x - hi)   (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ void x3_split2(float a, float b, unsigned& hi, unsigned& lo) {
+  const f32x2_t v = {a, b};
+  const bf16x2_t hb = __builtin_convertvector(v, bf16x2_t);
+  const f32x2_t r = v - __builtin_convertvector(hb, f32x2_t);
+  hi = __builtin_bit_cast(unsigned, hb);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+}
+__device__ __forceinline__ f32x16 x3_mfma(u32x4_t a, u32x4_t b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// c += (ah + al) * (bh + bl) without the lo*lo term; small terms first
+__device__ __forceinline__ f32x16 x3_mac(u32x4_t ah, u32x4_t al, u32x4_t bh, u32x4_t bl, f32x16 c) {
+  c = x3_mfma(al, bh, c);
+  c = x3_mfma(ah, bl, c);
+  return x3_mfma(ah, bh, c);
+}
+
+constexpr int X3_NW = 8, X3_COLS = 256, X3_THREADS = 64 * X3_NW;
+constexpr int X3_HROW_PITCH = 72 * 2;                 // bytes per row of the row-major H image   [split][row][k]   (k padded to 72)
+constexpr int X3_HCOL_PITCH = 40 * 2;                 // bytes per k of the k-major H image        [split][k][p(row)] (rows padded to 40)
+constexpr int X3_HROW_BYTES = 2 * HF_ROWS * X3_HROW_PITCH;      // 9216
+constexpr int X3_HCOL_BYTES = 2 * HF_KP * X3_HCOL_PITCH;        // 10240
+constexpr int X3_RED_FLOATS = X3_NW * HF_ROWS * HF_KP;          // [wave][32][64] fp32 dH partials; a wave's slice doubles as its G transpose tile
+constexpr int X3_WB_BYTES = X3_NW * 8 * 64 * 16;               // per wave: dH B fragments [kt][s][split][lane] x 16 B (lane-linear)
+constexpr size_t X3_LDS_BYTES = X3_HROW_BYTES + X3_HCOL_BYTES + (size_t)X3_RED_FLOATS * 4 + X3_WB_BYTES;
+
+template <int K>
+__global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* Hrow = reinterpret_cast<char*>(lds);
+  char* Hcol = Hrow + X3_HROW_BYTES;
+  float* red = reinterpret_cast<float*>(Hcol + X3_HCOL_BYTES);
+
+  const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int cg = blockIdx.x % a.CG, rg = blockIdx.x / a.CG;
+  const int c0 = cg * X3_COLS, cl = wave * 32;
+  const int n = a.n, B = a.B;
+  float* Gt = red + wave * (HF_ROWS * HF_KP);           // [32 cols][33] fp32 inside this wave's fold slice
+  u32x4_t* wbl = reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(red + X3_RED_FLOATS) + wave * (8 * 64 * 16)) + lane;   // + 64 * ((kt*2 + s)*2 + split)
+
+  // both H images start as zeros: k >= K and rows >= B never get written
+  for (int e = t; e < (X3_HROW_BYTES + X3_HCOL_BYTES) / 4; e += X3_THREADS) reinterpret_cast<unsigned*>(Hrow)[e] = 0u;
+
+  // ---- this wave's 32 rows of W as MFMA fragments in registers (range-checked buffer loads: col >= n reads 0) ----
+  const rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W), 0, n * K * 4, 0x00020000);
+  const int colg = c0 + cl + l31;
+  u32x4_t wf_h[4], wf_l[4];                             // forward B operand: W[colg][16s + 8h + j]
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const int k = 16 * s + 8 * h + j;
+      const float v0 = buf_load(wres, k < K ? (colg * K + k) * 4 : -1), v1 = buf_load(wres, k + 1 < K ? (colg * K + k + 1) * 4 : -1);
+      unsigned hi, lo;
+      x3_split2(v0, v1, hi, lo);
+      wf_h[s][j >> 1] = hi; wf_l[s][j >> 1] = lo;
+    }
+  // dH B operand [kt][s]: W[c0 + cl + 16s + 8h + j][32kt + l31]; parked in this wave's private LDS region (lane-linear
+  // 16-byte fragments: one conflict-free ds_read_b128 each) - 32 fewer live registers than keeping them next to wf
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4_t fh, fl;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const int k = 32 * kt + l31, col = c0 + cl + 16 * s + 8 * h + j;
+        const float v0 = buf_load(wres, k < K ? (col * K + k) * 4 : -1), v1 = buf_load(wres, k < K ? ((col + 1) * K + k) * 4 : -1);
+        unsigned hi, lo;
+        x3_split2(v0, v1, hi, lo);
+        fh[j >> 1] = hi; fl[j >> 1] = lo;
+      }
+      wbl[64 * ((kt * 2 + s) * 2 + 0)] = fh;
+      wbl[64 * ((kt * 2 + s) * 2 + 1)] = fl;
+    }
+  const float bias_r = colg < n ? a.bias[colg] : 0.f;
+
+  f32x16 dW[2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dW[kt][r] = 0.f;
+  float db_acc = 0.f;
+  double rec_d = 0.0, vel_d = 0.0;
+
+  const int rb0 = (int)(((int64_t)rg * a.NRB) / a.RG);
+  const int rb1 = (int)(((int64_t)(rg + 1) * a.NRB) / a.RG);
+  const int lane_off = 4 * h * n + l31;
+  const int lane_off_t = 4 * h * (int)a.ldt + l31;
+
+  // template / gt tile of the row block whose epilogue runs next, refilled row-register by row-register between the
+  // backward MFMAs of the current one (same scheme and the same branch-free predication as the fp32 kernel)
+  float tc[16], gcur[16];
+  auto issue_row = [&](int rb, int r) {
+    const rsrc_t gb = tile_rsrc(a.gt + ((int64_t)rb * HF_ROWS * n + (c0 + cl)));
+    const rsrc_t tb = tile_rsrc(a.templ + ((int64_t)rb * HF_ROWS * a.ldt + (c0 + cl)));
+    const int rlim = B - rb * HF_ROWS;
+    const int mcol = ((colg - n) >> 31) & ((rb - rb1) >> 31);
+    int lo = lane_off, lot = lane_off_t, h4 = 4 * h;
+    asm volatile("" : "+v"(lo), "+v"(lot), "+v"(h4));
+    const int rr = (r & 3) + 8 * (r >> 2);
+    const int inval = ~(mcol & ((rr + h4 - rlim) >> 31));
+    tc[r] = buf_load(tb, (4 * (rr * (int)a.ldt + lot)) | inval);
+    gcur[r] = buf_load(gb, (4 * (rr * n + lo)) | inval);
+  };
+#pragma unroll
+  for (int r = 0; r < 16; ++r) issue_row(rb0, r);
+
+  // H tile of the NEXT row block travels in registers (requested at the top of a row block, split and written to the two
+  // bf16 images at the bottom)
+  constexpr int HPT = (HF_ROWS * K + X3_THREADS - 1) / X3_THREADS;
+  const rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.H), 0, B * K * 4, 0x00020000);
+  float hreg[HPT];
+  auto h_request = [&](int rb) {
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+      const int e = t + i * X3_THREADS;
+      hreg[i] = buf_load(hres, (e < HF_ROWS * K && rb < rb1) ? (rb * HF_ROWS * K + e) * 4 : -1);     // rows >= B are out of range -> 0
+    }
+  };
+  auto h_commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+      const int e = t + i * X3_THREADS;
+      if (e < HF_ROWS * K) {
+        const int row = e / K, k = e - row * K;
+        // accumulator-order position of a tile row: row = 16s + 4h' + (j&3) + 8(j>>2)  ->  p = 16s + 8h' + j
+        const int p = (row & 16) + 8 * ((row >> 2) & 1) + (row & 3) + 4 * ((row >> 3) & 1);
+        unsigned hi, lo;
+        x3_split2(hreg[i], 0.f, hi, lo);
+        *reinterpret_cast<unsigned short*>(Hrow + row * X3_HROW_PITCH + k * 2) = (unsigned short)hi;
+        *reinterpret_cast<unsigned short*>(Hrow + HF_ROWS * X3_HROW_PITCH + row * X3_HROW_PITCH + k * 2) = (unsigned short)lo;
+        *reinterpret_cast<unsigned short*>(Hcol + k * X3_HCOL_PITCH + p * 2) = (unsigned short)hi;
+        *reinterpret_cast<unsigned short*>(Hcol + HF_KP * X3_HCOL_PITCH + k * X3_HCOL_PITCH + p * 2) = (unsigned short)lo;
+      }
+    }
+  };
+  h_request(rb0);
+  __syncthreads();                                      // images zeroed
+  h_commit();
+
+  const char* hrow_l = Hrow + l31 * X3_HROW_PITCH + 16 * h;           // forward A fragment s: + 32 s   (+ split image)
+  const char* hcol_l = Hcol + l31 * X3_HCOL_PITCH + 16 * h;           // dW B fragment (s, kt): + 32 kt * pitch + 32 s
+
+  for (int rb = rb0; rb < rb1; ++rb) {
+    __syncthreads();                                    // H images of this row block complete; fold buffer free
+    h_request(rb + 1);
+
+    // ---- forward tile: acc[row][col] = sum_k H[row][k] W[col][k] ----
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const u32x4_t ah = *reinterpret_cast<const u32x4_t*>(hrow_l + 32 * s);
+      const u32x4_t al = *reinterpret_cast<const u32x4_t*>(hrow_l + HF_ROWS * X3_HROW_PITCH + 32 * s);
+      acc = x3_mac(ah, al, wf_h[s], wf_l[s], acc);
+    }
+    // ---- epilogue: pred, loss partials, G (in place of acc), all fp32 ----
+    float rec = 0.f, vel = 0.f;
+    {
+      const bool colok = colg < n;
+      const bool interior = ((rb + 1) * HF_ROWS <= B) && (c0 + cl + 32 <= n);       // wave-uniform
+      const int rlim = B - rb * HF_ROWS;
+      const int mint = interior ? -1 : 0;
+      const int mcolv = (colg - n) >> 31;
+      const rsrc_t pbuf = tile_rsrc(a.pred + ((int64_t)rb * HF_ROWS * n + (c0 + cl)));
+      int lo = lane_off, h4 = 4 * h;
+      asm volatile("" : "+v"(lo), "+v"(h4));
+      float gsum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int rr = (r & 3) + 8 * (r >> 2);
+        const float p0 = acc[r] + bias_r + tc[r];
+        const float p1 = acc[r + 1] + bias_r + tc[r + 1];
+        const int so0 = (4 * (rr * n + lo)) | ~(mint | (mcolv & ((rr + h4 - rlim) >> 31)));
+        const int so1 = (4 * ((rr + 1) * n + lo)) | ~(mint | (mcolv & ((rr + 1 + h4 - rlim) >> 31)));
+        buf_store(pbuf, so0, p0);
+        buf_store(pbuf, so1, p1);
+        const bool in_loss = colok && (rb * HF_ROWS + rr + h4 + 1 < a.Bloss);
+        const float d0 = in_loss ? p0 - gcur[r] : 0.f;
+        const float d1 = in_loss ? p1 - gcur[r + 1] : 0.f;
+        const float dv = d1 - d0;
+        rec += d0 * d0 + d1 * d1;
+        vel += dv * dv;
+        const float g0 = a.cr * d0 - a.cv * dv;
+        const float g1 = a.cr * d1 + a.cv * dv;
+        acc[r] = g0;
+        acc[r + 1] = g1;
+        gsum += g0 + g1;
+      }
+      db_acc += gsum;
+    }
+    rec_d += (double)rec;
+    vel_d += (double)vel;
+
+#ifdef X3_ABL_NODW
+    asm volatile("" :: "v"(acc[0]), "v"(acc[5]), "v"(acc[10]), "v"(acc[15]));
+#pragma unroll
+    for (int q = 0; q < 16; ++q) issue_row(rb + 1, q);
+#else
+    // ---- G as bf16 fragments, column on the lane: k-step s of dW takes accumulator registers 8s .. 8s+7 ----
+    u32x4_t gc_h[2], gc_l[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        unsigned hi, lo;
+        x3_split2(acc[8 * s + j], acc[8 * s + j + 1], hi, lo);
+        gc_h[s][j >> 1] = hi; gc_l[s][j >> 1] = lo;
+      }
+#endif
+#ifndef X3_ABL_NODH
+    // the G transpose tile (for dH) is written now so its reads can overlap the dW products
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Gt[l31 * HF_HP + 4 * h + (r & 3) + 8 * (r >> 2)] = acc[r];
+#endif
+#ifndef X3_ABL_NODW
+
+    // ---- dW[col][k] += sum_row G[row][col] H[row][k]; the next row block's tile loads ride between the products ----
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const u32x4_t bh = *reinterpret_cast<const u32x4_t*>(hcol_l + 32 * kt * X3_HCOL_PITCH + 32 * s);
+        const u32x4_t bl = *reinterpret_cast<const u32x4_t*>(hcol_l + HF_KP * X3_HCOL_PITCH + 32 * kt * X3_HCOL_PITCH + 32 * s);
+        dW[kt] = x3_mac(gc_h[s], gc_l[s], bh, bl, dW[kt]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_row(rb + 1, (2 * s + kt) * 4 + q);
+      }
+#endif
+
+    // ---- dH[row][k] += sum_col G[row][col] W[col][k]: G with the row on the lane, through the wave's LDS tile ----
+    f32x16 dH[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dH[kt][r] = 0.f;
+#ifndef X3_ABL_NODH
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4_t gh, gl;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const float v0 = Gt[(16 * s + 8 * h + j) * HF_HP + l31], v1 = Gt[(16 * s + 8 * h + j + 1) * HF_HP + l31];
+        unsigned hi, lo;
+        x3_split2(v0, v1, hi, lo);
+        gh[j >> 1] = hi; gl[j >> 1] = lo;
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) dH[kt] = x3_mac(gh, gl, wbl[64 * ((kt * 2 + s) * 2 + 0)], wbl[64 * ((kt * 2 + s) * 2 + 1)], dH[kt]);
+    }
+#endif
+#ifndef X3_ABL_NOFOLD
+
+    // ---- fold the eight waves' dH partials and emit this column group's slab rows ----
+    // (a wave's fold slice holds its own G tile: its reads above are complete, nobody else touches it before the barrier)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave * 2048 + 4 * h * 64 + kt * 32 + l31) + ((r & 3) + 8 * (r >> 2)) * 64] = dH[kt][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2048 / X3_THREADS; ++i) {
+      const int e = t + i * X3_THREADS;                 // 0..2047: row = e/64, k = e%64
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < X3_NW; ++w) v += red[w * 2048 + e];
+      const int row = rb * HF_ROWS + (e >> 6);
+      if (row < B && (e & 63) < ((K + 3) & ~3)) a.dH_slab[((int64_t)cg * B + row) * HF_KP + (e & 63)] = v;
+    }
+#else
+    asm volatile("" :: "v"(dH[0][0]), "v"(dH[1][7]));
+    __syncthreads();
+#endif
+#ifndef X3_ABL_NOHC
+    h_commit();                                         // every wave passed a barrier after its last read of the H images
+#else
+    asm volatile("" :: "v"(hreg[0]), "v"(hreg[HPT - 1]));
+#endif
+  }
+
+  // ---- workgroup epilogue: dW / dbias slabs of this row group, loss partials ----
+  const int64_t ncols_pad = (int64_t)a.CG * X3_COLS;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a.dW_slab[((int64_t)rg * ncols_pad + c0 + cl + rho(r, h)) * HF_KP + kt * 32 + l31] = dW[kt][r];
+  {
+    const float s = db_acc + __shfl_xor(db_acc, 32, 64);
+    if (h == 0) a.db_slab[(int64_t)rg * ncols_pad + c0 + cl + l31] = s;
+  }
+  __syncthreads();
+  double* lsum = reinterpret_cast<double*>(red);
+  const double rs = wave_sum_d(rec_d), vs = wave_sum_d(vel_d);
+  if (lane == 0) { lsum[wave] = rs; lsum[X3_NW + wave] = vs; }
+  __syncthreads();
+  if (t == 0) {
+    double r = 0.0, v = 0.0;
+    for (int w = 0; w < X3_NW; ++w) { r += lsum[w]; v += lsum[X3_NW + w]; }
+    a.loss_part[2 * blockIdx.x] = r;
+    a.loss_part[2 * blockIdx.x + 1] = v;
+  }
+}
+
 // ONE launch folds everything the main kernel left behind, in fixed order (deterministic):
 //   workgroups [0, nH)        dH[r][k]  = sum over CG column-group slabs   (290 MB at B = 19 200: the only part that matters)
 //   workgroups [nH, nH+nW)    dW[c][k]  = sum over RG row-group slabs
@@ -558,21 +888,38 @@ static int head_launch(const HeadArgs& a, const HeadPlan& p, hipStream_t s) {
   return A2F_OK;
 }
 
+template <int K>
+static int head_x3_launch(const HeadArgs& a, const HeadPlan& p, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_x3_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS_BYTES);
+    if (e != hipSuccess) return set_err(A2F_ELAUNCH, "head_fused: hipFuncSetAttribute(%zu B LDS): %s", X3_LDS_BYTES, hipGetErrorString(e));
+    attr_set = true;
+  }
+  const bool prof = g_prof_on && g_prof_n < 64;
+  if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], s);
+  hipLaunchKernelGGL((head_x3_kernel<K>), dim3((unsigned)(p.CG * p.RG)), dim3(X3_THREADS), X3_LDS_BYTES, s, a);
+  if (prof) { (void)hipEventRecord(g_prof_ev[g_prof_n][1], s); ++g_prof_n; }
+  return A2F_OK;
+}
+
 }  // namespace a2f
 
 namespace a2f {
 // kernel configuration: 0 = 512 columns x 8 waves, 1 = 512 x 4 waves, 2 = 256 x 4 (two workgroups per CU),
-// 3 = 384 x 4 (no spills at one wave per SIMD), 4 = 256 x 8 (two waves per SIMD, 183 VGPRs, no spills; K = 50 only)
+// 3 = 384 x 4 (no spills at one wave per SIMD), 4 = 256 x 8 (two waves per SIMD, 183 VGPRs, no spills; K = 50 only):
+// all exact-fp32 MFMA; 5 = 256 x 8 with bf16x3 split-precision products (default).  A2F_HEAD_CFG overrides.
 static int head_cfg(int64_t K) {
   static const int env = [] { const char* e = getenv("A2F_HEAD_CFG"); return e ? atoi(e) : -1; }();
+  if (env == 5 || env < 0 || env > 5) return 5;
   if (K == 64) return (env >= 1 && env <= 3) ? env : 3;
-  // measured on MI355X (B = 19200, K = 50, kernel + slab folds): cfg4 1.55 ms, cfg3 1.61, cfg1 1.71-1.79, cfg0 2.0+, cfg2 2.4
-  return env >= 0 && env <= 4 ? env : 4;
+  // fp32 variants measured on MI355X (B = 19200, K = 50, kernel + slab folds): cfg4 1.55 ms, cfg3 1.61, cfg1 1.71-1.79, cfg0 2.0+, cfg2 2.4
+  return env;
 }
 static HeadPlan head_plan_for(int64_t B, int64_t n, int64_t K) {
   const int cfg = head_cfg(K);
   return cfg == 2 ? head_plan(B, n, 256, (K == 64) ? 256 : 512) : cfg == 3 ? head_plan(B, n, 384, 256)
-       : cfg == 4 ? head_plan(B, n, 256, 256) : head_plan(B, n, 512, 256);
+       : (cfg == 4 || cfg == 5) ? head_plan(B, n, 256, 256) : head_plan(B, n, 512, 256);
 }
 }  // namespace a2f
 
@@ -637,12 +984,13 @@ extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias,
   a.cv = (float)(2.0 * k_vel / ((double)(Bloss / 2) * V));
   const int cfg = head_cfg(K);
   int rc;
-  if (K == 50) rc = cfg == 0 ? head_launch<50, 8, 512, 2>(a, p, s) : cfg == 1 ? head_launch<50, 4, 512, 1>(a, p, s)
+  if (cfg == 5) rc = K == 50 ? head_x3_launch<50>(a, p, s) : head_x3_launch<64>(a, p, s);
+  else if (K == 50) rc = cfg == 0 ? head_launch<50, 8, 512, 2>(a, p, s) : cfg == 1 ? head_launch<50, 4, 512, 1>(a, p, s)
                   : cfg == 2 ? head_launch<50, 4, 256, 2>(a, p, s) : cfg == 4 ? head_launch<50, 8, 256, 2>(a, p, s)
                   : head_launch<50, 4, 384, 1>(a, p, s);
   else rc = cfg == 2 ? head_launch<64, 4, 256, 1>(a, p, s) : cfg == 3 ? head_launch<64, 4, 384, 1>(a, p, s) : head_launch<64, 4, 512, 1>(a, p, s);
   if (rc != A2F_OK) return rc;
-  const int64_t ncols_pad = (int64_t)p.CG * ((cfg == 2 || cfg == 4) ? 256 : cfg == 3 ? 384 : 512);
+  const int64_t ncols_pad = (int64_t)p.CG * ((cfg == 2 || cfg == 4 || cfg == 5) ? 256 : cfg == 3 ? 384 : 512);
   {
     HeadFoldArgs f;
     f.dH_slab = a.dH_slab; f.dW_slab = a.dW_slab; f.db_slab = a.db_slab; f.loss_part = a.loss_part;

@@ -1,10 +1,14 @@
 """GPU: every HIP entry point of liba2f_hip.so against the CPU emulator of its contract (include/a2f_hip.h).
 
 All calls go through the C ABI (ctypes) exactly as the product does.  fp32 tolerance: the f32 MFMA is an exact fp32
-fma chain, so only summation order differs from the float64 emulator -> 2e-5 relative L2 is ample; parity against the
-reference goldens is in test_gpu_models.py at the 1e-4 bar of BASELINE.json.
+fma chain, so only summation order differs from the float64 emulator -> 2e-5 relative L2 is ample; the head kernel's
+default configuration evaluates its products as bf16x3 split sums (hi*hi + hi*lo + lo*hi, fp32 accumulate: <= 2^-16 per
+product) and stays inside the same 2e-5.  Parity against the reference goldens is in test_gpu_models.py at the 1e-4 bar
+of BASELINE.json.
 """
 import math
+import os
+import sys
 
 import pytest
 import torch
@@ -222,6 +226,19 @@ def test_head_fused_vs_contract(B_, n, K, trows, Bloss):
     assert rel_l2(dH_h, dH_e) < 2e-5
     assert rel_l2(dW_h, dW_e) < 2e-5
     assert rel_l2(db_h, db_e) < 2e-5
+
+
+@pytest.mark.parametrize("cfg", ["4", "3"])
+def test_head_fused_exact_fp32_configs(cfg):
+    """The exact-fp32 MFMA shapes of the head kernel stay selectable (A2F_HEAD_CFG, read once per process): run the
+    contract test above in a child process for the two-waves-per-SIMD (4) and one-wave-per-SIMD (3) variants."""
+    import subprocess
+    if os.environ.get("A2F_TEST_NESTED"):
+        pytest.skip("nested run")
+    env = dict(os.environ, A2F_HEAD_CFG=cfg, A2F_TEST_NESTED="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_head_fused_vs_contract"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_head_fused_rejects_bad_arguments():

@@ -4,7 +4,7 @@ import csv, glob, sys
 f = sorted(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'head_fused_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'head_fused_kernel' in r['Kernel_Name'] or 'head_x3_kernel' in r['Kernel_Name']]
 j = idx[-2]
 while 'adam' not in rows[j]['Kernel_Name']:
     j -= 1

@@ -646,6 +646,10 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
         acc[r] = g0;
         acc[r + 1] = g1;
         gsum += g0 + g1;
+#ifdef X3_EARLY_PREFETCH  // measured SLOWER (1.02 vs 0.95 ms): refilling the two row-registers right here, next to the pred stores
+        issue_row(rb + 1, r);
+        issue_row(rb + 1, r + 1);
+#endif
       }
       db_acc += gsum;
     }
@@ -654,8 +658,10 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
 
 #ifdef X3_ABL_NODW
     asm volatile("" :: "v"(acc[0]), "v"(acc[5]), "v"(acc[10]), "v"(acc[15]));
+#ifndef X3_EARLY_PREFETCH
 #pragma unroll
     for (int q = 0; q < 16; ++q) issue_row(rb + 1, q);
+#endif
 #else
     // ---- G as bf16 fragments, column on the lane: k-step s of dW takes accumulator registers 8s .. 8s+7 ----
     u32x4_t gc_h[2], gc_l[2];
@@ -683,8 +689,10 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
         const u32x4_t bh = *reinterpret_cast<const u32x4_t*>(hcol_l + 32 * kt * X3_HCOL_PITCH + 32 * s);
         const u32x4_t bl = *reinterpret_cast<const u32x4_t*>(hcol_l + HF_KP * X3_HCOL_PITCH + 32 * kt * X3_HCOL_PITCH + 32 * s);
         dW[kt] = x3_mac(gc_h[s], gc_l[s], bh, bl, dW[kt]);
+#ifndef X3_EARLY_PREFETCH
 #pragma unroll
         for (int q = 0; q < 4; ++q) issue_row(rb + 1, (2 * s + kt) * 4 + q);
+#endif
       }
 #endif
 

@@ -133,7 +133,13 @@ __device__ __forceinline__ void wgrad_body(const WgradProb& pr, int blk, float (
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) {
+#ifdef WG_ABL_NOMFMA     // timing ablation only
+          if (u == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i] + av[(u + 1) % WG_U][i] + av[(u + 3) % WG_U][i] + av[(u + 5) % WG_U][i] + av[(u+2) % WG_U][i] + av[(u+4) % WG_U][i]+ av[(u+6) % WG_U][i]+ av[(u+7) % WG_U][i], bv[u][j]+bv[(u+1)%WG_U][j]+bv[(u+2)%WG_U][j]+bv[(u+3)%WG_U][j]+bv[(u+4)%WG_U][j]+bv[(u+5)%WG_U][j]+bv[(u+6)%WG_U][j]+bv[(u+7)%WG_U][j], acc[i][j], 0, 0, 0);
+#else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+#endif
+        }
   };
 
   float a0[WG_U][MT], b0[WG_U][NT], a1[WG_U][MT], b1[WG_U][NT];

@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..functional import A2M_CH, A2MTrunkFn, HeadFn
+from ..functional import A2M_CH, A2MTrunkFn, HeadFn, HeadLossFusedFn
 
 
 class Audio2Mesh(nn.Module):
@@ -65,3 +65,15 @@ class Audio2Mesh(nn.Module):
 
     def predict(self, x, one_hot, template, **kwargs):
         return self(x, one_hot, template, **kwargs)
+
+    def forward_with_loss(self, x, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0, unit_grad: bool = False):
+        """Training fast path (same contract as ``Voca.forward_with_loss``): ``output_net.4`` + template add + VocaLoss +
+        their backward in one pass over the (B, 15069) frame matrix instead of a GEMM, two loss passes and two more
+        GEMMs.  Returns (pred (B,V,3) detached, {"loss","rec_loss","vel_loss"}); only "loss" carries gradient."""
+        bs = x.size(0)
+        if bs % 2 != 0:
+            raise RuntimeError(f"VocaLoss pairs consecutive frames (loss.py:33-35): batch {bs} must be even")
+        h3 = self.trunk(x, one_hot)
+        pred, out3 = HeadLossFusedFn.apply(h3, self.output_net[4].weight, self.output_net[4].bias, template.reshape(bs, -1),
+                                           gt.reshape(bs, -1), bs, k_rec, k_vel, unit_grad)
+        return pred.view(bs, -1, 3), {"loss": out3[0], "rec_loss": out3[1].detach(), "vel_loss": out3[2].detach()}

@@ -62,6 +62,18 @@ class FlatAdam:
                                 self.eps, self.wd, 1.0 / self.world(), self.step_count)
 
 
+class StepOutput(dict):
+    """{"loss", "rec_loss", "vel_loss"} of a step; "err" (mse_error of lightning_model.py:119-125 == rec_loss / 3 for
+    3-vectors) is derived on first access instead of costing an extra launch in every step."""
+
+    def __missing__(self, key):
+        if key != "err":
+            raise KeyError(key)
+        v = self["rec_loss"].detach() / 3.0
+        self[key] = v
+        return v
+
+
 class TrainStep:
     """fwd -> loss -> bwd -> (all-reduce) -> Adam, mirroring Audio2FaceModel.training_step + configure_optimizers."""
 
@@ -120,7 +132,7 @@ class TrainStep:
             # autograd-free launch sequence that overwrites the flat gradient views (no zero fill, no accumulation kernels)
             lf = getattr(self.loss_fn, "loss", self.loss_fn)
             _pred, out3 = self.model.train_step_direct(x, one_hot, template, gt, lf.k_rec, lf.k_vel)
-            return {"loss": out3[0], "rec_loss": out3[1], "vel_loss": out3[2], "err": out3[1] / 3.0}
+            return StepOutput({"loss": out3[0], "rec_loss": out3[1], "vel_loss": out3[2]})
         self.opt.zero_grad()
         if self.fused:
             lf = getattr(self.loss_fn, "loss", self.loss_fn)          # FaceFormerLoss wraps a VocaLoss

@@ -159,6 +159,31 @@ def test_audio2mesh_golden_g2(mode):
                 assert packed_error(g, "train::buffer::" + k, b) < 1e-5, k
 
 
+def test_audio2mesh_fused_training_path_golden_g2():
+    """forward_with_loss (output_net.4 + template + VocaLoss + head backward in one pass) against the same G2 fixture:
+    prediction, loss terms and every gradient (train mode: BN batch statistics)."""
+    g = load("g2_audio2mesh")
+    m = a2f_amd.Audio2Mesh(n_verts=NV, n_onehot=12)
+    m.load_state_dict(W.formula_state_dict(W.audio2mesh_shapes(NV, 12), gains={"output_net.4": 4.0}))
+    m.to(DEV).train()
+    B = 4
+    x = W.formula_input("g2.x", (B, 52, 32)).to(DEV)
+    one_hot = torch.from_numpy(g["one_hot"]).to(DEV)
+    template = W.formula_input("g2.template", (B, 5023, 3), 5.0)
+    gt = (template + W.formula_input("g2.gt", (B, 5023, 3), 0.5)).to(DEV)
+    pred, loss = m.forward_with_loss(x, one_hot, template.to(DEV), gt)
+    assert packed_error(g, "train::pred", pred) < TOL
+    for k in ("loss", "rec_loss", "vel_loss"):
+        assert abs(float(loss[k].detach()) - float(g[f"train::loss::{k}"])) <= 2e-5 * abs(float(g[f"train::loss::{k}"]))
+    loss["loss"].backward()
+    for k, p in m.named_parameters():
+        if k in BN_CANCELLED:
+            wgrad = dict(m.named_parameters())[k.replace(".bias", ".weight")].grad
+            assert float(p.grad.norm()) < 1e-3 * float(wgrad.norm()), k
+            continue
+        assert packed_error(g, f"train::grad::{k}", p.grad) < 5e-4, k
+
+
 def test_audio2mesh_audio_sample_windows_g7():
     """Config 1 plumbing: windows cut from assets/audio_sample.npy, batch = 1 per frame, eval mode."""
     g = load("g7_audio_sample_audio2mesh")

@@ -89,6 +89,7 @@ class TrainStep:
         self._graph_inputs = None
         self._graph_out = None
         self._warm = 0
+        self._side = None
         # fused = head + loss + head-backward in one HIP pass when the model offers it and the loss is the stock VocaLoss
         self.fused = fused and hasattr(model, "forward_with_loss") and type(loss_fn).__name__ in ("VocaLoss", "FaceFormerLoss")
         self.opt = FlatAdam(model.parameters(), lr=lr, weight_decay=lr / 10, process_group=process_group)
@@ -110,14 +111,22 @@ class TrainStep:
     def _graph_step(self, x, one_hot, gt, template):
         ins = (x, one_hot, gt, template)
         if self._graph is None:
+            # Warm-up and capture run on ONE side stream: autograd's AccumulateGrad nodes remember the stream their
+            # gradient buffers were last used on, and a capture that has to synchronise with another stream is illegal.
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+                self._side.wait_stream(torch.cuda.current_stream())
             if self._warm < 2:                                  # eager warm-up: allocator pools, LDS attributes, autotune-free
                 self._warm += 1
-                loss = self._fwd_bwd(*ins)
+                with torch.cuda.stream(self._side):
+                    loss = self._fwd_bwd(*ins)
+                torch.cuda.current_stream().wait_stream(self._side)
                 self.opt.step()
+                self._side.wait_stream(torch.cuda.current_stream())
                 return loss
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=self._side):
                 out = self._fwd_bwd(*ins)
             self._graph, self._graph_inputs, self._graph_out = g, ins, out
         else:

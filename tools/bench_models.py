@@ -32,7 +32,7 @@ def timeit(fn, warm=3, iters=10):
 def audio2mesh(B):
     torch.manual_seed(0)
     m = a2f_amd.Audio2Mesh(NV, 12).to(dev).train()
-    step = TrainStep(m, a2f_amd.VocaLoss(), lr=1e-4)
+    step = TrainStep(m, a2f_amd.VocaLoss(), lr=1e-4, use_graph=os.environ.get("A2M_GRAPH", "1") == "1")
     x = torch.randn(B, 52, 32, device=dev)
     oh = torch.zeros(B, 12, device=dev); oh[torch.arange(B), torch.arange(B) % 12] = 1
     t = torch.randn(B, 5023, 3, device=dev) * 5

@@ -65,16 +65,25 @@ class Voca(nn.Module):
         return pred.view(bs, -1, 3), {"loss": out3[0], "rec_loss": out3[1].detach(), "vel_loss": out3[2].detach()}
 
     @torch.no_grad()
-    def train_step_direct(self, x, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0):
+    def train_step_direct(self, x, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0, phase: int = 0):
         """Autograd-free training pass for the trainer: forward + VocaLoss + backward as one fixed launch sequence that
         OVERWRITES every parameter's preallocated ``.grad`` (the flat-gradient views of ``FlatAdam``) - no autograd
         graph, no gradient-accumulation kernels, no zero fill, hipGraph-capturable.  Same arithmetic as
-        ``forward_with_loss(...)["loss"].backward()``.  Returns (pred (B,V,3), out3 = [loss, rec, vel])."""
+        ``forward_with_loss(...)["loss"].backward()``.  Returns (pred (B,V,3), out3 = [loss, rec, vel]).
+
+        ``phase`` splits the sequence for data parallel overlap: 1 = trunk forward + fused head (the gradients of
+        ``decoder.4`` - 92 % of all gradient bytes - are final afterwards and can be all-reduced while phase 2 runs),
+        2 = trunk backward from the state phase 1 left on the module; 0 = both."""
         be = ops.backend()
+        tp = self._trunk_params()
+        if phase == 2:
+            saved, dH, ret = self._direct_state
+            self._direct_state = None
+            voca_trunk_bwd(be, saved, dH, out=[p.grad for p in tp])
+            return ret
         bs = x.size(0)
         if bs % 2 != 0:
             raise RuntimeError(f"VocaLoss pairs consecutive frames (loss.py:33-35): batch {bs} must be even")
-        tp = self._trunk_params()
         head_w, head_b = self.decoder[4].weight, self.decoder[4].bias
         for p in tp + [head_w, head_b]:
             if p.grad is None or not p.grad.is_contiguous():
@@ -87,5 +96,13 @@ class Voca(nn.Module):
         dH = torch.empty(bs, K, device=dev, dtype=torch.float32)
         be.head_fused(h3, head_w.data, head_b.data, template.reshape(bs, n).contiguous(), bs, gt.reshape(bs, n).contiguous(), bs, bs, n, K,
                       float(k_rec), float(k_vel), pred, out3, dH, head_w.grad, head_b.grad)
+        ret = (pred.view(bs, -1, 3), out3)
+        if phase == 1:
+            self._direct_state = (saved, dH, ret)
+            return ret
         voca_trunk_bwd(be, saved, dH, out=[p.grad for p in tp])
-        return pred.view(bs, -1, 3), out3
+        return ret
+
+    def early_grad_params(self):
+        """Parameters whose gradients are final after phase 1 of ``train_step_direct``."""
+        return [self.decoder[4].weight, self.decoder[4].bias]

@@ -4,6 +4,7 @@ step (xGMI), then one fused Adam launch over the flat parameter buffer.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Iterable, Optional
 
 import torch
@@ -34,6 +35,7 @@ class FlatAdam:
             offs.append(total)
             total += (p.numel() + 3) // 4 * 4           # 16-byte aligned segments
         self.numel = total
+        self._offsets = {id(p): (o, (p.numel() + 3) // 4 * 4) for p, o in zip(self.params, offs)}
         self.flat_p = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
         self.m = torch.zeros(total, device=dev, dtype=torch.float32)
@@ -50,13 +52,29 @@ class FlatAdam:
     def world(self) -> int:
         return dist.get_world_size(self.pg) if dist.is_available() and dist.is_initialized() else 1
 
-    def allreduce_grads(self):
+    def allreduce_grads(self, lo: int = 0, hi: Optional[int] = None, async_op: bool = False):
+        """Sum the flat gradient range [lo, hi) over the ranks (the 1/world factor lives in the Adam kernel)."""
         if self.world() > 1:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
+            return dist.all_reduce(self.flat_g[lo:self.numel if hi is None else hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+        return None
 
-    def step(self):
-        """All-reduce (if distributed) + fused Adam.  The 1/world averaging is folded into the Adam kernel."""
-        self.allreduce_grads()
+    def tail_segment(self, params) -> Optional[int]:
+        """Offset at which ``params`` start if they occupy exactly the tail of the flat buffer, else None."""
+        spans = sorted(self._offsets[id(p)] for p in params if id(p) in self._offsets)
+        if len(spans) != len(list(params)) or not spans:
+            return None
+        pos = spans[0][0]
+        for o, n in spans:
+            if o != pos:
+                return None
+            pos += n
+        return spans[0][0] if pos == self.numel else None
+
+    def step(self, reduced: bool = False):
+        """All-reduce (if distributed and not already ``reduced`` by the caller) + fused Adam.  The 1/world averaging is
+        folded into the Adam kernel."""
+        if not reduced:
+            self.allreduce_grads()
         self.step_count += 1
         ops.backend().adam_step(self.flat_p, self.flat_g, self.m, self.v, self.numel, self.lr, self.betas[0], self.betas[1],
                                 self.eps, self.wd, 1.0 / self.world(), self.step_count)
@@ -78,7 +96,7 @@ class TrainStep:
     """fwd -> loss -> bwd -> (all-reduce) -> Adam, mirroring Audio2FaceModel.training_step + configure_optimizers."""
 
     def __init__(self, model: torch.nn.Module, loss_fn, lr: float, process_group=None, fused: bool = True,
-                 use_graph: bool = False):
+                 use_graph: bool = False, overlap: Optional[bool] = None):
         self.model = model
         self.loss_fn = loss_fn
         # use_graph: capture zero_grad + forward + loss + backward (~90 launches) into one hipGraph after a warm-up and
@@ -93,6 +111,31 @@ class TrainStep:
         # fused = head + loss + head-backward in one HIP pass when the model offers it and the loss is the stock VocaLoss
         self.fused = fused and hasattr(model, "forward_with_loss") and type(loss_fn).__name__ in ("VocaLoss", "FaceFormerLoss")
         self.opt = FlatAdam(model.parameters(), lr=lr, weight_decay=lr / 10, process_group=process_group)
+        # overlap: split the direct step after the fused head, start the all-reduce of the head's gradient segment (the
+        # tail of the flat buffer, 92 % of the bytes for VOCA) and run the trunk backward underneath it; the small trunk
+        # segment is reduced afterwards.  Default: on when distributed (A2F_DP_OVERLAP=0 disables), off otherwise.
+        self._head_off = None
+        if self.fused and hasattr(model, "train_step_direct") and hasattr(model, "early_grad_params"):
+            self._head_off = self.opt.tail_segment(model.early_grad_params())
+        if overlap is None:
+            overlap = self.opt.world() > 1 and os.environ.get("A2F_DP_OVERLAP", "1") != "0"
+        self.overlap = bool(overlap) and self._head_off is not None
+        self._graph2 = None
+
+    def _direct(self, ins, phase):
+        lf = getattr(self.loss_fn, "loss", self.loss_fn)
+        x, one_hot, gt, template = ins
+        _pred, out3 = self.model.train_step_direct(x, one_hot, template, gt, lf.k_rec, lf.k_vel, phase=phase)
+        return StepOutput({"loss": out3[0], "rec_loss": out3[1], "vel_loss": out3[2]})
+
+    def _finish_overlapped(self, second_phase):
+        """head segment all-reduce (async) || trunk backward, then the trunk segment, then Adam."""
+        work = self.opt.allreduce_grads(self._head_off, None, async_op=True)
+        second_phase()
+        self.opt.allreduce_grads(0, self._head_off)
+        if work is not None:
+            work.wait()
+        self.opt.step(reduced=True)
 
     @staticmethod
     def unpack_batch(batch: Dict[str, torch.Tensor], scale: float = 100.0):
@@ -104,6 +147,11 @@ class TrainStep:
     def __call__(self, x, one_hot, gt, template) -> Dict[str, torch.Tensor]:
         if self.use_graph and x.is_cuda:
             return self._graph_step(x, one_hot, gt, template)
+        if self.overlap:
+            ins = (x, one_hot, gt, template)
+            loss = self._direct(ins, 1)
+            self._finish_overlapped(lambda: self._direct(ins, 2))
+            return loss
         loss = self._fwd_bwd(x, one_hot, gt, template)
         self.opt.step()
         return loss
@@ -119,29 +167,43 @@ class TrainStep:
             if self._warm < 2:                                  # eager warm-up: allocator pools, LDS attributes, autotune-free
                 self._warm += 1
                 with torch.cuda.stream(self._side):
-                    loss = self._fwd_bwd(*ins)
+                    loss = self._direct(ins, 1) if self.overlap else self._fwd_bwd(*ins)
                 torch.cuda.current_stream().wait_stream(self._side)
-                self.opt.step()
+                if self.overlap:
+                    def second():
+                        self._side.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(self._side):
+                            self._direct(ins, 2)
+                        torch.cuda.current_stream().wait_stream(self._side)
+                    self._finish_overlapped(second)
+                else:
+                    self.opt.step()
                 self._side.wait_stream(torch.cuda.current_stream())
                 return loss
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=self._side):
-                out = self._fwd_bwd(*ins)
+                out = self._direct(ins, 1) if self.overlap else self._fwd_bwd(*ins)
+            if self.overlap:                                    # second graph: trunk backward, same memory pool
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, stream=self._side, pool=g.pool()):
+                    self._direct(ins, 2)
+                self._graph2 = g2
             self._graph, self._graph_inputs, self._graph_out = g, ins, out
         else:
             if any(a.data_ptr() != b.data_ptr() for a, b in zip(ins, self._graph_inputs)):
                 raise RuntimeError("TrainStep(use_graph=True) replays a captured graph: pass the same input tensors each step")
         self._graph.replay()
-        self.opt.step()
+        if self.overlap:
+            self._finish_overlapped(self._graph2.replay)
+        else:
+            self.opt.step()
         return self._graph_out
 
     def _fwd_bwd(self, x, one_hot, gt, template) -> Dict[str, torch.Tensor]:
         if self.fused and hasattr(self.model, "train_step_direct"):
             # autograd-free launch sequence that overwrites the flat gradient views (no zero fill, no accumulation kernels)
-            lf = getattr(self.loss_fn, "loss", self.loss_fn)
-            _pred, out3 = self.model.train_step_direct(x, one_hot, template, gt, lf.k_rec, lf.k_vel)
-            return StepOutput({"loss": out3[0], "rec_loss": out3[1], "vel_loss": out3[2]})
+            return self._direct((x, one_hot, gt, template), 0)
         self.opt.zero_grad()
         if self.fused:
             lf = getattr(self.loss_fn, "loss", self.loss_fn)          # FaceFormerLoss wraps a VocaLoss

@@ -34,7 +34,7 @@ def _make_batch(B):
     return x, oh, gt, t
 
 
-def _run(rank, world, port, out_path, fused):
+def _run(rank, world, port, out_path, fused, overlap=None):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -51,7 +51,8 @@ def _run(rank, world, port, out_path, fused):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(11)
     model = a2f_amd.Voca(n_verts=NV, n_onehot=12)
-    step = TrainStep(model, a2f_amd.VocaLoss(), lr=1e-3, fused=fused)
+    step = TrainStep(model, a2f_amd.VocaLoss(), lr=1e-3, fused=fused, overlap=overlap)
+    assert overlap is None or step.overlap == (overlap and fused)
     x, oh, gt, t = _make_batch(8)
     per = 8 // world
     sl = slice(rank * per, (rank + 1) * per)
@@ -64,15 +65,17 @@ def _run(rank, world, port, out_path, fused):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fused", [False, True])
-def test_dp2_gloo_matches_single_process(fused):
-    """fused=True exercises the trainer's autograd-free direct step (grads written straight into the flat buffer)."""
+@pytest.mark.parametrize("fused,overlap", [(False, None), (True, False), (True, True)])
+def test_dp2_gloo_matches_single_process(fused, overlap):
+    """fused=True exercises the trainer's autograd-free direct step (grads written straight into the flat buffer);
+    overlap=True its two-phase form: the head's gradient segment is all-reduced asynchronously while the trunk backward
+    runs, the trunk segment afterwards (the default when distributed)."""
     with tempfile.TemporaryDirectory() as d:
         p1, p2 = os.path.join(d, "w1.pt"), os.path.join(d, "w2.pt")
         _run(0, 1, 0, p1, False)                 # reference run: plain autograd graph, one process, full batch
         from a2f_amd import ops
         ops.set_backend(None)
-        mp.spawn(_run, args=(2, _free_port(), p2, fused), nprocs=2, join=True)
+        mp.spawn(_run, args=(2, _free_port(), p2, fused, overlap), nprocs=2, join=True)
         a, b = torch.load(p1), torch.load(p2)
         rel = float((a["flat"] - b["flat"]).norm() / a["flat"].norm())
         assert rel < 1e-5, rel

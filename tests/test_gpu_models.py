@@ -126,6 +126,30 @@ def test_voca_fused_equals_unfused_large():
         assert rel_l2(b.grad, a.grad) < 5e-5, k
 
 
+def test_voca_two_phase_graph_step_equals_single_graph():
+    """The data-parallel overlap form (two captured graphs split after the fused head, segment-wise all-reduce hooks)
+    must leave exactly the parameters of the single-graph step (world size 1: the collectives are no-ops)."""
+    from a2f_amd.trainer import TrainStep
+    flats = []
+    for overlap in (False, True):
+        torch.manual_seed(7)
+        m = a2f_amd.Voca(n_verts=NV, n_onehot=12).to(DEV)
+        step = TrainStep(m, a2f_amd.VocaLoss(), lr=1e-3, use_graph=True, overlap=overlap)
+        assert step.overlap == overlap
+        g = torch.Generator().manual_seed(3)
+        B = 64
+        x = torch.randn(B, 29, 16, generator=g).to(DEV)
+        oh = torch.zeros(B, 12); oh[torch.arange(B), torch.arange(B) % 8] = 1
+        t = torch.randn(B, 5023, 3, generator=g) * 5
+        gt = (t + 0.5 * torch.randn(B, 5023, 3, generator=g)).to(DEV)
+        oh, t = oh.to(DEV), t.to(DEV)
+        for _ in range(5):                                 # 2 eager warm-ups, capture, 2 replays
+            out = step(x, oh, gt, t)
+        torch.cuda.synchronize()
+        flats.append((step.opt.flat_p.clone(), float(out["loss"])))
+    assert torch.equal(flats[0][0], flats[1][0]) and flats[0][1] == flats[1][1]
+
+
 BN_CANCELLED = {f"analysis_net.{3 * l}.bias" for l in range(5)} | {f"articulation_net.{i}.bias" for i in (0, 3, 6)}
 
 

@@ -59,19 +59,24 @@ struct WgradProb {
   int mask_period, mask_phase, mask_lo, mask_hi;   // mask_period == 0: no window mask
   int rows_per_wave, blocks, shape;                // shape = MT * 8 + NT of the instantiated tile set
   int unpack_kh;                                   // > 0: column kh*Ci+ci is stored at ci*KH+kh (Conv2d weight layout)
+  int m_off, n_off, n_glob;                        // this sub-problem's corner in the caller's output, and its full width
   int blk_beg, fold_beg;                           // first workgroup of this problem in the GEMM / fold launch
 };
 
+// A caller's problem is cut into sub-problems of at most 2 x 4 accumulator tiles (64 rows x 128 columns of the output):
+// 128 accumulator registers, so the kernel fits 256 VGPRs and TWO workgroups share a CU - the loop is bound by the loads a
+// CU keeps in flight, and the extra operand re-reads (A once per column range, B once per row range) are small.
+constexpr int WG_MAX_SUBS = 16;
 struct WgradBatch {
   int count;
-  WgradProb p[A2F_WGRAD_BATCH_MAX];
+  WgradProb p[WG_MAX_SUBS];
 };
 
 // the problem a workgroup belongs to: wave-uniform select chain over the kernel arguments (no scratch copy)
 __device__ __forceinline__ WgradProb pick_problem(const WgradBatch& b, int blk, bool fold) {
   WgradProb pr = b.p[0];
 #pragma unroll
-  for (int i = 1; i < A2F_WGRAD_BATCH_MAX; ++i)
+  for (int i = 1; i < WG_MAX_SUBS; ++i)
     if (i < b.count && blk >= (fold ? b.p[i].fold_beg : b.p[i].blk_beg)) pr = b.p[i];
   return pr;
 }
@@ -189,19 +194,16 @@ __device__ __forceinline__ void wgrad_body(const WgradProb& pr, int blk, float (
 #endif
 }
 
-__global__ __launch_bounds__(WG_THREADS, 1) void wgrad_batch_kernel(const WgradBatch b) {
-  __shared__ float red[4][WG_NT_MAX * 1024];             // 112 KB: one row of accumulator tiles per wave
+__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_batch_kernel(const WgradBatch b) {
+  __shared__ float red[4][WG_NT_MAX * 1024];
   const WgradProb pr = pick_problem(b, blockIdx.x, false);
   const int blk = blockIdx.x - pr.blk_beg;
   switch (pr.shape) {
+    case 1 * 8 + 3: wgrad_body<1, 3>(pr, blk, red); break;
     case 1 * 8 + 4: wgrad_body<1, 4>(pr, blk, red); break;
-    case 1 * 8 + 7: wgrad_body<1, 7>(pr, blk, red); break;
-    case 2 * 8 + 4: wgrad_body<2, 4>(pr, blk, red); break;
-    case 2 * 8 + 5: wgrad_body<2, 5>(pr, blk, red); break;
-    case 2 * 8 + 7: wgrad_body<2, 7>(pr, blk, red); break;
-    case 3 * 8 + 3: wgrad_body<3, 3>(pr, blk, red); break;
-    case 3 * 8 + 4: wgrad_body<3, 4>(pr, blk, red); break;
-    default: wgrad_body<4, 3>(pr, blk, red); break;
+    case 2 * 8 + 1: wgrad_body<2, 1>(pr, blk, red); break;
+    case 2 * 8 + 3: wgrad_body<2, 3>(pr, blk, red); break;
+    default: wgrad_body<2, 4>(pr, blk, red); break;
   }
 }
 
@@ -234,32 +236,29 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const WgradBatch b) {
     for (int g = 0; g < 16; ++g) s += sh[g][t];
     const int row = (int)(i / pr.Neff), col = (int)(i - (int64_t)row * pr.Neff);
     if (col < pr.N) {
-      int c = col;
-      if (pr.unpack_kh > 0) { const int ci_n = pr.N / pr.unpack_kh, kh = col / ci_n; c = (col - kh * ci_n) * pr.unpack_kh + kh; }
-      pr.C[(int64_t)row * pr.ldc + c] = s;
+      int c = pr.n_off + col;
+      if (pr.unpack_kh > 0) { const int ci_n = pr.n_glob / pr.unpack_kh, kh = c / ci_n; c = (c - kh * ci_n) * pr.unpack_kh + kh; }
+      pr.C[(int64_t)(pr.m_off + row) * pr.ldc + c] = s;
     } else {
-      pr.ones_out[row] = s;
+      pr.ones_out[pr.m_off + row] = s;
     }
   }
 }
 
 struct WgradPlan { int rows_per_wave, blocks; };
 
-// smallest instantiated tile set that covers (mt, nt); 0 if none
+// smallest instantiated tile set that covers a sub-problem of (mt <= 2, nt <= 4) tiles
 static int wgrad_shape(int mt, int nt) {
-  if (mt == 1) return nt <= 4 ? 1 * 8 + 4 : nt <= 7 ? 1 * 8 + 7 : 0;
-  if (mt == 2) return nt <= 4 ? 2 * 8 + 4 : nt <= 5 ? 2 * 8 + 5 : nt <= 7 ? 2 * 8 + 7 : 0;
-  if (mt == 3) return nt <= 3 ? 3 * 8 + 3 : nt <= 4 ? 3 * 8 + 4 : 0;
-  if (mt == 4) return nt <= 3 ? 4 * 8 + 3 : 0;
-  return 0;
+  if (mt == 1) return nt <= 3 ? 1 * 8 + 3 : 1 * 8 + 4;
+  return nt == 1 ? 2 * 8 + 1 : nt <= 3 ? 2 * 8 + 3 : 2 * 8 + 4;
 }
 
 // The loop moves (MT+NT) x 256 B per k-step and wave, so a workgroup that owns ~800/(MT+NT) rows per wave moves ~0.4 MB:
-// the seven trunk problems of a 19 200-frame step then make ~600 equally heavy workgroups (one 512-register workgroup per
-// CU).  Short contractions are cut into at least ~64 workgroups; a wave's slice is a multiple of one register set pair.
+// the trunk problems of a 19 200-frame step then make several hundred equally heavy workgroups.  Short contractions are cut
+// into at least ~64 workgroups; a wave's slice is a multiple of one register set pair.  All sub-problems of a caller's
+// problem share its plan (same number of slabs), so the workspace bound blocks x M x (N+1) holds for their union.
 static WgradPlan wgrad_plan(int64_t M, int64_t N, int64_t K) {
-  const int shape = wgrad_shape((int)((M + 31) / 32), (int)((N + 1 + 31) / 32));
-  const int64_t tiles = shape ? (shape / 8 + shape % 8) : 8;
+  const int64_t tiles = std::min<int64_t>((M + 31) / 32, 2) + std::min<int64_t>((N + 1 + 31) / 32, 4);
   int64_t rpw = std::min<int64_t>(WG_TARGET / tiles, cdiv(K, 4 * 64));
   rpw = std::max<int64_t>(4 * WG_U, cdiv(rpw, 4 * WG_U) * (4 * WG_U));
   WgradPlan p;
@@ -277,16 +276,23 @@ extern "C" size_t a2f_wgrad_ws_floats(int64_t M, int64_t N, int64_t K) {
 
 extern "C" int a2f_wgrad_supported(int64_t M, int64_t N) {
   if (M <= 0 || N <= 0) return 0;
-  return a2f::wgrad_shape((int)((M + 31) / 32), (int)((N + 1 + 31) / 32)) ? 1 : 0;
+  return (M <= 128 && N + 1 <= 224) ? 1 : 0;
 }
 
 extern "C" int a2f_wgrad_batch_f32(const a2f_gemm_desc* descs, int32_t count, a2f_stream_t stream) {
   using namespace a2f;
   A2F_CHECK_ARG(descs != nullptr && count >= 1 && count <= A2F_WGRAD_BATCH_MAX, "wgrad: 1..%d descriptors per batch", A2F_WGRAD_BATCH_MAX);
+  hipStream_t s = (hipStream_t)stream;
   WgradBatch b;
   memset(&b, 0, sizeof(b));
-  b.count = count;
   int blk = 0, fold = 0;
+  auto flush = [&]() {
+    if (b.count == 0) return;
+    hipLaunchKernelGGL(wgrad_batch_kernel, dim3(blk), dim3(WG_THREADS), 0, s, b);
+    hipLaunchKernelGGL(wgrad_fold_kernel, dim3(fold), dim3(256), 0, s, b);
+    memset(&b, 0, sizeof(b));
+    blk = fold = 0;
+  };
   for (int i = 0; i < count; ++i) {
     const a2f_gemm_desc& d = descs[i];
     A2F_CHECK_ARG(d.A && d.B && d.C && d.splitk_ws, "wgrad[%d]: null pointer (A, B, C and splitk_ws are required)", i);
@@ -301,27 +307,37 @@ extern "C" int a2f_wgrad_batch_f32(const a2f_gemm_desc* descs, int32_t count, a2
     A2F_CHECK_ARG(d.ldc >= d.N, "wgrad[%d]: ldc < N", i);
     A2F_CHECK_ARG(d.c_unpack_kh >= 0 && (d.c_unpack_kh == 0 || d.N % d.c_unpack_kh == 0), "wgrad[%d]: c_unpack_kh must divide N", i);
     const WgradPlan pl = wgrad_plan(d.M, d.N, d.K);
-    WgradProb& p = b.p[i];
-    p.A = d.A + d.a_off;
-    p.B = d.B + d.b_off;
-    p.ws = d.splitk_ws;
-    p.C = d.C;
-    p.ones_out = d.ones_out;
-    p.a_cs = (int)d.a_cs; p.b_rs = (int)d.b_rs; p.ldc = (int)d.ldc;
-    p.M = (int)d.M; p.N = (int)d.N; p.K = (int)d.K; p.Neff = (int)d.N + (d.ones_out ? 1 : 0);
-    if (d.mask_operand == 2) { p.mask_period = d.mask_period; p.mask_phase = d.mask_phase; p.mask_lo = d.mask_lo; p.mask_hi = d.mask_hi; }
-    p.rows_per_wave = pl.rows_per_wave;
-    p.blocks = pl.blocks;
-    p.shape = wgrad_shape((int)((d.M + 31) / 32), (p.Neff + 31) / 32);
-    p.unpack_kh = d.c_unpack_kh;
-    p.blk_beg = blk;
-    p.fold_beg = fold;
-    blk += pl.blocks;
-    fold += (int)cdiv((int64_t)p.M * p.Neff, 16);
+    const int M = (int)d.M, N = (int)d.N, Neff = N + (d.ones_out ? 1 : 0);
+    float* ws = d.splitk_ws;
+    for (int m0 = 0; m0 < M; m0 += 64)
+      for (int n0 = 0; n0 < Neff; n0 += 128) {
+        if (b.count == WG_MAX_SUBS) flush();
+        const int m1 = std::min(M, m0 + 64), n1 = std::min(Neff, n0 + 128);
+        WgradProb& p = b.p[b.count++];
+        p.A = d.A + d.a_off + m0;
+        p.B = d.B + d.b_off + n0;
+        p.ws = ws;
+        p.C = d.C;
+        p.ones_out = d.ones_out;
+        p.a_cs = (int)d.a_cs; p.b_rs = (int)d.b_rs; p.ldc = (int)d.ldc;
+        p.M = m1 - m0;
+        p.Neff = n1 - n0;
+        p.N = std::min(N, n1) - n0;                       // real columns of this range (the ones column, if any, is the last of the last range)
+        p.K = (int)d.K;
+        if (d.mask_operand == 2) { p.mask_period = d.mask_period; p.mask_phase = d.mask_phase; p.mask_lo = d.mask_lo - n0; p.mask_hi = d.mask_hi - n0; }
+        p.rows_per_wave = pl.rows_per_wave;
+        p.blocks = pl.blocks;
+        p.shape = wgrad_shape((p.M + 31) / 32, (p.Neff + 31) / 32);
+        p.unpack_kh = d.c_unpack_kh;
+        p.m_off = m0; p.n_off = n0; p.n_glob = N;
+        p.blk_beg = blk;
+        p.fold_beg = fold;
+        blk += pl.blocks;
+        fold += (int)cdiv((int64_t)p.M * p.Neff, 16);
+        ws += (int64_t)pl.blocks * p.M * p.Neff;
+      }
   }
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(wgrad_batch_kernel, dim3(blk), dim3(WG_THREADS), 0, s, b);
-  hipLaunchKernelGGL(wgrad_fold_kernel, dim3(fold), dim3(256), 0, s, b);
+  flush();
   A2F_CHECK_LAUNCH("wgrad_batch_f32");
   return A2F_OK;
 }

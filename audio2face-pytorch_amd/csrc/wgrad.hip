@@ -32,12 +32,12 @@ constexpr int WG_NT_MAX = 7;
 constexpr int WG_NT_MAX = 1;
 #endif
 #ifndef WG_U_SET
-#define WG_U_SET 8
+#define WG_U_SET 4
 #endif
 #ifndef WG_TARGET
 #define WG_TARGET 800
 #endif
-constexpr int WG_U = WG_U_SET;               // k-steps (of 2 rows) per register set; two sets are in flight
+constexpr int WG_U = WG_U_SET;               // k-steps (of 2 rows) per register set; two sets are in flight (<= 63 loads: the vmcnt limit)
 
 using wrsrc_t = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ wrsrc_t wg_rsrc(const float* base, int bytes) {
@@ -194,7 +194,10 @@ __device__ __forceinline__ void wgrad_body(const WgradProb& pr, int blk, float (
 #endif
 }
 
-__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_batch_kernel(const WgradBatch b) {
+#ifndef WG_LB
+#define WG_LB 2
+#endif
+__global__ __launch_bounds__(WG_THREADS, WG_LB) void wgrad_batch_kernel(const WgradBatch b) {
   __shared__ float red[4][WG_NT_MAX * 1024];
   const WgradProb pr = pick_problem(b, blockIdx.x, false);
   const int blk = blockIdx.x - pr.blk_beg;

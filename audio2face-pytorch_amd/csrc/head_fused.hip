@@ -57,6 +57,19 @@ __device__ __forceinline__ float buf_load(rsrc_t r, int byte_off, int soff = 0) 
 __device__ __forceinline__ void buf_store(rsrc_t r, int byte_off, float v, int soff = 0) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, soff, 0);
 }
+// streaming forms for data touched exactly once per launch (cache-policy experiments: X3_STREAM_LD / X3_STREAM_ST = aux bits)
+#ifndef X3_STREAM_LD
+#define X3_STREAM_LD 0
+#endif
+#ifndef X3_STREAM_ST
+#define X3_STREAM_ST 0
+#endif
+__device__ __forceinline__ float buf_load_stream(rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, X3_STREAM_LD));
+}
+__device__ __forceinline__ void buf_store_stream(rsrc_t r, int byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, X3_STREAM_ST);
+}
 
 // NW waves per workgroup, each owning CPW = 16/NW chunks of 32 columns.  NW = 8 (two waves per SIMD, <= 256 registers
 // each: 64 dW accumulators) hides LDS / HBM latency behind the partner wave's MFMAs and is used when the LDS budget
@@ -558,8 +571,8 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
     asm volatile("" : "+v"(lo), "+v"(lot), "+v"(h4));
     const int rr = (r & 3) + 8 * (r >> 2);
     const int inval = ~(mcol & ((rr + h4 - rlim) >> 31));
-    tc[r] = buf_load(tb, (4 * (rr * (int)a.ldt + lot)) | inval);
-    gcur[r] = buf_load(gb, (4 * (rr * n + lo)) | inval);
+    tc[r] = buf_load_stream(tb, (4 * (rr * (int)a.ldt + lot)) | inval);
+    gcur[r] = buf_load_stream(gb, (4 * (rr * n + lo)) | inval);
   };
 #pragma unroll
   for (int r = 0; r < 16; ++r) issue_row(rb0, r);
@@ -633,8 +646,8 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
         const float p1 = acc[r + 1] + bias_r + tc[r + 1];
         const int so0 = (4 * (rr * n + lo)) | ~(mint | (mcolv & ((rr + h4 - rlim) >> 31)));
         const int so1 = (4 * ((rr + 1) * n + lo)) | ~(mint | (mcolv & ((rr + 1 + h4 - rlim) >> 31)));
-        buf_store(pbuf, so0, p0);
-        buf_store(pbuf, so1, p1);
+        buf_store_stream(pbuf, so0, p0);
+        buf_store_stream(pbuf, so1, p1);
         const bool in_loss = colok && (rb * HF_ROWS + rr + h4 + 1 < a.Bloss);
         const float d0 = in_loss ? p0 - gcur[r] : 0.f;
         const float d1 = in_loss ? p1 - gcur[r + 1] : 0.f;

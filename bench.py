@@ -107,8 +107,8 @@ def cpu_baseline_voca(seconds: float = 12.0, B: int = 2048):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="voca", choices=["voca"])
     ap.add_argument("--seqs", type=int, default=32)
     ap.add_argument("--frames", type=int, default=600)

@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("mask_operand", i32), ("mask_period", i32), ("mask_phase", i32), ("mask_lo", i32), ("mask_hi", i32),
         ("c_unpack_kh", i32),
         ("splitk_ws", c_f32p),
+        ("precision", i32), ("reserved", i32),
     ]
 
 

@@ -19,6 +19,58 @@ constexpr int G_BM = 128;
 constexpr int G_BK = 16;
 constexpr int G_THREADS = 256;
 
+// Epilogue shared by the fp32 and the split-precision kernel.  C/D layout of the 32x32 MFMA: col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int NT>
+__device__ __forceinline__ void gemm_epilogue(const a2f_gemm_desc& d, const f32x16 (&acc)[NT], int m0, int n0, int wave, int lane, int M, int N,
+                                              int Neff) {
+  const bool atomic = d.split_k > 1;
+  if (atomic && d.splitk_ws) {            // slab mode: this split's partial tile -> ws[z][row][col], pitch Neff
+    float* slab = d.splitk_ws + (int64_t)blockIdx.z * M * Neff;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + j * 32 + (lane & 31);
+      if (col >= Neff) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M) slab[(int64_t)row * Neff + col] = acc[j][r];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + j * 32 + (lane & 31);
+    if (col >= Neff) continue;
+    const float bias = (d.bias && col < N) ? d.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row >= M) continue;
+      float v = acc[j][r];
+      if (col == N) {                       // virtual ones column -> bias gradient
+        if (atomic) atomicAdd(d.ones_out + row, v);
+        else d.ones_out[row] = d.accumulate ? d.ones_out[row] + v : v;
+        continue;
+      }
+      float* cp = d.C + (int64_t)row * d.ldc + col;
+      if (atomic) { atomicAdd(cp, v); continue; }
+      v += bias;
+      if (d.accumulate) v += *cp;
+      if (d.act == 1) v = fmaxf(v, 0.f);
+      else if (d.act == 2) v = tanhf(v);
+      if (d.aux_mode) {
+        const float ax = d.aux[(int64_t)row * d.ldaux + col];
+        if (d.aux_mode == 1) v = ax > 0.f ? v : 0.f;
+        else if (d.aux_mode == 2) v *= (1.f - ax * ax);
+        else v += ax;
+      }
+      *cp = v;
+    }
+  }
+}
+
 template <int BN>
 __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const a2f_gemm_desc d) {
   constexpr int NT = BN / 32;
@@ -149,52 +201,172 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const a2f_gemm_desc
     __syncthreads();
   }
 
-  // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const bool atomic = d.split_k > 1;
-  if (atomic && d.splitk_ws) {            // slab mode: this split's partial tile -> ws[z][row][col], pitch Neff
-    float* slab = d.splitk_ws + (int64_t)blockIdx.z * M * Neff;
+  gemm_epilogue<NT>(d, acc, m0, n0, wave, lane, M, N, Neff);
+}
+
+// =====================================================================================================================
+// Split-precision variant (d.precision == 1): same tiling, same operand contract, same epilogue, but every product on
+// the bf16 matrix pipe as three bf16 MFMAs (x = hi + lo; lo*hi' + hi*lo' + hi*hi', fp32 accumulation; <= 2^-16 relative
+// error per product - see head_fused.hip).  Matrix time drops 5.3x against v_mfma_f32_32x32x2_f32; used for the
+// convolution GEMMs of Audio2Mesh, which are matrix-pipe bound in fp32.
+// Operands are split when they are stored to LDS: a thread owns PAIRS of consecutive k, so one v_cvt_pk_bf16_f32 pair
+// yields a packed dword per image; the images are [row][16 k] bf16 with a 48-byte pitch, which makes every fragment of
+// v_mfma_f32_32x32x16_bf16 (8 consecutive k of one row) ONE conflict-free ds_read_b128.
+using gx_bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using gx_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using gx_f32x2 = __attribute__((ext_vector_type(2))) float;
+using gx_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ void gx_split2(float a, float b, unsigned& hi, unsigned& lo) {
+  const gx_f32x2 v = {a, b};
+  const gx_bf16x2 hb = __builtin_convertvector(v, gx_bf16x2);
+  const gx_f32x2 r = v - __builtin_convertvector(hb, gx_f32x2);
+  hi = __builtin_bit_cast(unsigned, hb);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, gx_bf16x2));
+}
+__device__ __forceinline__ f32x16 gx_mfma(gx_u32x4 a, gx_u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gx_bf16x8, a), __builtin_bit_cast(gx_bf16x8, b), c, 0, 0, 0);
+}
+constexpr int GX_PITCH = 48;          // bytes per image row: 16 bf16 + 16 B pad
+
+template <int BN>
+__global__ __launch_bounds__(G_THREADS) void gemm_x3_kernel(const a2f_gemm_desc d) {
+  constexpr int NT = BN / 32;
+  constexpr int KP = G_BK / 2;                                   // k-pairs per tile
+  constexpr int A_PAIRS = G_BM * KP / G_THREADS;                 // 4
+  constexpr int B_PAIRS = (BN * KP + G_THREADS - 1) / G_THREADS;
+  constexpr int A_IMG = G_BM * GX_PITCH, B_IMG = BN * GX_PITCH;  // one bf16 image (hi or lo)
+  __shared__ __attribute__((aligned(16))) char smem[2 * (2 * A_IMG + 2 * B_IMG)];   // [buffer][A hi | A lo | B hi | B lo]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int M = (int)d.M, N = (int)d.N, K = (int)d.K;
+  const int Neff = N + (d.ones_out ? 1 : 0);
+  const int m0 = blockIdx.x * G_BM;
+  const int n0 = blockIdx.y * BN;
+
+  int kbeg = 0, kend = K;
+  if (d.split_k > 1) {
+    const int ktiles = (K + G_BK - 1) / G_BK;
+    const int per = (ktiles + d.split_k - 1) / d.split_k;
+    kbeg = (int)blockIdx.z * per * G_BK;
+    kend = min(K, kbeg + per * G_BK);
+    if (kbeg >= kend) return;
+  }
+  const int nkt = (kend - kbeg + G_BK - 1) / G_BK;
+
+  const bool a_kfast = (d.a_rs != 1);
+  const bool b_kfast = (d.b_cs != 1);
+  const float* __restrict__ Ap = d.A + d.a_off;
+  const float* __restrict__ Bp = d.B + d.b_off;
+
+  // per-thread pair coordinates inside a tile: (row, k-pair); fixed across k-tiles
+  int a_mm[A_PAIRS], a_kp[A_PAIRS];
+  unsigned a_rowmask = 0;
+#pragma unroll
+  for (int i = 0; i < A_PAIRS; ++i) {
+    const int e = t + i * G_THREADS;
+    if (a_kfast) { a_kp[i] = e % KP; a_mm[i] = e / KP; }
+    else         { a_mm[i] = e % G_BM; a_kp[i] = e / G_BM; }
+    if (d.mask_operand == 1 && (m0 + a_mm[i]) % d.mask_period == d.mask_phase) a_rowmask |= (1u << i);
+  }
+  int b_nn[B_PAIRS], b_kp[B_PAIRS];
+#pragma unroll
+  for (int i = 0; i < B_PAIRS; ++i) {
+    const int e = t + i * G_THREADS;
+    if (b_kfast) { b_kp[i] = e % KP; b_nn[i] = e / KP; }
+    else         { b_nn[i] = e % BN; b_kp[i] = e / BN; }
+  }
+
+  float ra[A_PAIRS][2], rb[B_PAIRS][2];
+  auto load_tile = [&](int kt) {
+    const int k0 = kbeg + kt * G_BK;
+#pragma unroll
+    for (int i = 0; i < A_PAIRS; ++i) {
+      const int m = m0 + a_mm[i];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int k = k0 + 2 * a_kp[i] + q;
+        bool ok = (m < M) && (k < kend);
+        if ((a_rowmask >> i) & 1u) ok = ok && !(k >= d.mask_lo && k < d.mask_hi);
+        ra[i][q] = ok ? Ap[(int64_t)m * d.a_rs + (int64_t)k * d.a_cs] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PAIRS; ++i) {
+      const int e = t + i * G_THREADS;
+      const int n = n0 + b_nn[i];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int k = k0 + 2 * b_kp[i] + q;
+        float v = 0.f;
+        if (e < BN * KP && k < kend) {
+          if (n < N) {
+            bool ok = true;
+            if (d.mask_operand == 2) ok = !((k % d.mask_period == d.mask_phase) && n >= d.mask_lo && n < d.mask_hi);
+            if (ok) v = Bp[(int64_t)k * d.b_rs + (int64_t)n * d.b_cs];
+          } else if (n == N && d.ones_out) {
+            v = 1.f;
+          }
+        }
+        rb[i][q] = v;
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* base = smem + buf * (2 * A_IMG + 2 * B_IMG);
+#pragma unroll
+    for (int i = 0; i < A_PAIRS; ++i) {
+      unsigned hi, lo;
+      gx_split2(ra[i][0], ra[i][1], hi, lo);
+      const int off = a_mm[i] * GX_PITCH + a_kp[i] * 4;
+      *reinterpret_cast<unsigned*>(base + off) = hi;
+      *reinterpret_cast<unsigned*>(base + A_IMG + off) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PAIRS; ++i) {
+      const int e = t + i * G_THREADS;
+      if (e < BN * KP) {
+        unsigned hi, lo;
+        gx_split2(rb[i][0], rb[i][1], hi, lo);
+        const int off = 2 * A_IMG + b_nn[i] * GX_PITCH + b_kp[i] * 4;
+        *reinterpret_cast<unsigned*>(base + off) = hi;
+        *reinterpret_cast<unsigned*>(base + B_IMG + off) = lo;
+      }
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  // fragment of a 16-k tile: lane (row = lane&31, h = lane>>5) takes k = 8h .. 8h+7 of its row
+  const int frag_a = (wave * 32 + (lane & 31)) * GX_PITCH + (lane >> 5) * 16;
+  const int frag_b = 2 * A_IMG + (lane & 31) * GX_PITCH + (lane >> 5) * 16;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    const char* base = smem + buf * (2 * A_IMG + 2 * B_IMG);
+    const gx_u32x4 ah = *reinterpret_cast<const gx_u32x4*>(base + frag_a);
+    const gx_u32x4 al = *reinterpret_cast<const gx_u32x4*>(base + A_IMG + frag_a);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int col = n0 + j * 32 + (lane & 31);
-      if (col >= Neff) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < M) slab[(int64_t)row * Neff + col] = acc[j][r];
-      }
+      const gx_u32x4 bh = *reinterpret_cast<const gx_u32x4*>(base + frag_b + j * 32 * GX_PITCH);
+      const gx_u32x4 bl = *reinterpret_cast<const gx_u32x4*>(base + B_IMG + frag_b + j * 32 * GX_PITCH);
+      acc[j] = gx_mfma(al, bh, acc[j]);
+      acc[j] = gx_mfma(ah, bl, acc[j]);
+      acc[j] = gx_mfma(ah, bh, acc[j]);
     }
-    return;
+    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    __syncthreads();
   }
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = n0 + j * 32 + (lane & 31);
-    if (col >= Neff) continue;
-    const float bias = (d.bias && col < N) ? d.bias[col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row >= M) continue;
-      float v = acc[j][r];
-      if (col == N) {                       // virtual ones column -> bias gradient
-        if (atomic) atomicAdd(d.ones_out + row, v);
-        else d.ones_out[row] = d.accumulate ? d.ones_out[row] + v : v;
-        continue;
-      }
-      float* cp = d.C + (int64_t)row * d.ldc + col;
-      if (atomic) { atomicAdd(cp, v); continue; }
-      v += bias;
-      if (d.accumulate) v += *cp;
-      if (d.act == 1) v = fmaxf(v, 0.f);
-      else if (d.act == 2) v = tanhf(v);
-      if (d.aux_mode) {
-        const float ax = d.aux[(int64_t)row * d.ldaux + col];
-        if (d.aux_mode == 1) v = ax > 0.f ? v : 0.f;
-        else if (d.aux_mode == 2) v *= (1.f - ax * ax);
-        else v += ax;
-      }
-      *cp = v;
-    }
-  }
+  gemm_epilogue<NT>(d, acc, m0, n0, wave, lane, M, N, Neff);
 }
 
 // fold split-K slabs in fixed order: C[row][col] = sum_z slab[z][row][col]; virtual ones column -> ones_out
@@ -234,11 +406,21 @@ extern "C" int a2f_gemm_f32(const a2f_gemm_desc* dp, a2f_stream_t stream) {
   dim3 grid((unsigned)cdiv(d.M, G_BM), (unsigned)cdiv(neff, bn), (unsigned)split);
   A2F_CHECK_ARG(grid.y <= 65535, "gemm: N too large for grid.y");
   hipStream_t s = (hipStream_t)stream;
-  switch (bn) {
-    case 32: hipLaunchKernelGGL(gemm_f32_kernel<32>, grid, dim3(G_THREADS), 0, s, d); break;
-    case 64: hipLaunchKernelGGL(gemm_f32_kernel<64>, grid, dim3(G_THREADS), 0, s, d); break;
-    case 96: hipLaunchKernelGGL(gemm_f32_kernel<96>, grid, dim3(G_THREADS), 0, s, d); break;
-    default: hipLaunchKernelGGL(gemm_f32_kernel<128>, grid, dim3(G_THREADS), 0, s, d); break;
+  A2F_CHECK_ARG(d.precision == 0 || d.precision == 1, "gemm: precision must be 0 (exact fp32 MFMA) or 1 (bf16x3 split products)");
+  if (d.precision == 1) {
+    switch (bn) {
+      case 32: hipLaunchKernelGGL(gemm_x3_kernel<32>, grid, dim3(G_THREADS), 0, s, d); break;
+      case 64: hipLaunchKernelGGL(gemm_x3_kernel<64>, grid, dim3(G_THREADS), 0, s, d); break;
+      case 96: hipLaunchKernelGGL(gemm_x3_kernel<96>, grid, dim3(G_THREADS), 0, s, d); break;
+      default: hipLaunchKernelGGL(gemm_x3_kernel<128>, grid, dim3(G_THREADS), 0, s, d); break;
+    }
+  } else {
+    switch (bn) {
+      case 32: hipLaunchKernelGGL(gemm_f32_kernel<32>, grid, dim3(G_THREADS), 0, s, d); break;
+      case 64: hipLaunchKernelGGL(gemm_f32_kernel<64>, grid, dim3(G_THREADS), 0, s, d); break;
+      case 96: hipLaunchKernelGGL(gemm_f32_kernel<96>, grid, dim3(G_THREADS), 0, s, d); break;
+      default: hipLaunchKernelGGL(gemm_f32_kernel<128>, grid, dim3(G_THREADS), 0, s, d); break;
+    }
   }
   if (split > 1 && d.splitk_ws) {
     // a split whose K range is empty stores nothing: clamp the fold to the splits that exist

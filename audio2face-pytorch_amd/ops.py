@@ -44,6 +44,7 @@ class HipBackend:
     def __init__(self):
         self.lib = _lib.load()
         self.prof = None          # when a dict: tag -> list of (start_event, end_event) recorded on the launch stream
+        self.gemm_precision = 0   # a2f_gemm_desc.precision of subsequent gemm() calls: 0 exact fp32 MFMA, 1 bf16x3 split products
 
     @staticmethod
     def _stream(t: torch.Tensor):
@@ -76,6 +77,7 @@ class HipBackend:
         d.aux, d.ldaux = _ptr(aux, aux_off), ldaux
         d.ones_out = _ptr(ones_out)
         d.act, d.aux_mode, d.accumulate, d.split_k = act, aux_mode, int(accumulate), split_k
+        d.precision = self.gemm_precision
         if mask is not None:
             d.mask_operand, d.mask_period, d.mask_phase, d.mask_lo, d.mask_hi = mask
         if splitk_ws is not None:

@@ -31,6 +31,7 @@ class EmuBackend:
     name = "emu"
 
     def __init__(self, strict_bounds: bool = True):
+        self.gemm_precision = 0          # accepted and ignored: the emulator is the float64 contract
         self.strict = strict_bounds
         self.calls = []
 

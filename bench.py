@@ -176,7 +176,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         be = ops.backend()
         be.profile_head(True)                                  # HIP events on the launch stream around head_fused_kernel alone
-        nprof = max(3, min(args.steps, 10))
+        nprof = max(3, min(args.steps, 60))                    # the in-library ring holds 64 event pairs
         eager = TrainStep.__new__(TrainStep)                   # same model/optimizer, eager launches (events are not graph nodes)
         eager.__dict__.update(step.__dict__)
         eager.use_graph = False

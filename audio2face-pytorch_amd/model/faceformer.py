@@ -78,8 +78,17 @@ class Faceformer(nn.Module):
                  L.norm1.weight, L.norm1.bias, L.norm2.weight, L.norm2.bias, L.norm3.weight, L.norm3.bias, A, c]
         return torch.cat([p.reshape(-1) for p in parts])
 
+    # Mixed precision of the reference's trainer (`percision: "16-mixed"`, config.yaml:6 -> Lightning autocast) applies to
+    # the torch-op wav2vec2 encoder only: set to torch.bfloat16 / torch.float16 (registry.build_from_config does it from
+    # the config key); the HIP decoder / head / loss always compute in fp32 on the fp32 view of the encoder states.
+    encoder_autocast = None
+
     def encode(self, audio, frame_num):
         wave = normalize_waveform(audio)                                     # audio_preprocessor, faceformer.py:142-144
+        if self.encoder_autocast is not None and wave.is_cuda:
+            with torch.autocast("cuda", dtype=self.encoder_autocast):
+                h = self.audio_encoder(wave, self.dataset, frame_num=frame_num).last_hidden_state
+            return h.float()
         return self.audio_encoder(wave, self.dataset, frame_num=frame_num).last_hidden_state
 
     def decode_hidden(self, enc, one_hot):

@@ -65,4 +65,20 @@ def get_loss_fn(modelname: str):
 def build_from_config(config: ExpConfig):
     """(model, loss_fn) exactly as Audio2FaceModel.__init__ builds them (lightning_model.py:96-99)."""
     model = get_model(config.modelname)(n_verts=config.vertex_count, n_onehot=config.one_hot_size)
+    # `percision` (the reference's spelling) is Lightning's precision flag: "16-mixed" / "bf16-mixed" autocast the torch-op
+    # encoder of FaceFormer; everything that runs in the HIP library is fp32 storage with fp32 accumulation regardless.
+    amp = mixed_precision_dtype(config.percision)
+    if amp is not None and hasattr(model, "encoder_autocast"):
+        model.encoder_autocast = amp
     return model, get_loss_fn(config.modelname)
+
+
+def mixed_precision_dtype(percision: str):
+    """Lightning precision string -> autocast dtype (None for the 32-bit settings)."""
+    import torch
+    p = str(percision).lower()
+    if p.startswith("bf16"):
+        return torch.bfloat16
+    if p.startswith("16"):
+        return torch.float16
+    return None

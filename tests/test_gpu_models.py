@@ -326,3 +326,21 @@ def test_voca_fused_trunk_backward_equals_layerwise(B):
     g_l = voca_trunk_bwd_layerwise(be, saved, dh3)
     for i, (a, b) in enumerate(zip(g_f, g_l)):
         assert rel_l2(a, b) < 2e-5, i
+
+
+def test_faceformer_encoder_autocast_close_to_fp32():
+    """`percision: 16-mixed`: the wav2vec2 encoder under bf16 autocast, decoder / head / loss in fp32 - same function to
+    mixed-precision accuracy (the 1e-4 parity bar is defined on the fp32 setting)."""
+    torch.manual_seed(0)
+    m = a2f_amd.Faceformer(n_verts=NV, n_onehot=12).to(DEV)
+    with torch.no_grad():
+        m.vertice_map_r.weight.normal_(0, 0.1); m.vertice_map.weight.normal_(0, 0.001)
+    T = 30
+    audio = torch.randn(1, T * 16000 // 60 + 8, device=DEV) * 0.1
+    oh = torch.zeros(1, 12, device=DEV); oh[0, 3] = 1
+    t = torch.randn(1, 5023, 3, device=DEV)
+    with torch.no_grad():
+        ref = m(audio, oh, t)
+        m.encoder_autocast = torch.bfloat16
+        amp = m(audio, oh, t)
+    assert amp.dtype == torch.float32 and rel_l2((amp - t.view(1, 1, -1, 3)).cpu(), (ref - t.view(1, 1, -1, 3)).cpu()) < 5e-2

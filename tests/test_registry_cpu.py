@@ -35,6 +35,16 @@ def test_expconfig_parses_reference_yaml_keys():
     assert isinstance(loss, a2f_amd.VocaLoss)
 
 
+def test_percision_key_maps_to_encoder_autocast():
+    """`percision` is Lightning's precision flag (lightning_model.py / config.yaml:6): the mixed settings autocast the
+    torch-op wav2vec2 encoder of FaceFormer, the 32-bit settings leave it alone; the HIP-side models have no such switch."""
+    import torch
+    from a2f_amd.registry import mixed_precision_dtype
+    assert mixed_precision_dtype("16-mixed") is torch.float16 and mixed_precision_dtype("bf16-mixed") is torch.bfloat16
+    assert mixed_precision_dtype("32-true") is None and mixed_precision_dtype("32") is None
+    assert a2f_amd.Faceformer.encoder_autocast is None and not hasattr(a2f_amd.Voca, "encoder_autocast")
+
+
 def test_registries():
     assert get_model("voca") is a2f_amd.Voca and get_model("faceformer") is a2f_amd.Faceformer
     assert isinstance(get_loss_fn("faceformer"), a2f_amd.FaceFormerLoss) and isinstance(get_loss_fn("voca"), a2f_amd.VocaLoss)

@@ -45,6 +45,9 @@ def audio2mesh(B):
 def faceformer(S, T, encoder=True):
     torch.manual_seed(0)
     m = a2f_amd.Faceformer(NV, 12, audio_encoder=None if encoder else torch.nn.Identity()).to(dev)
+    amp = os.environ.get("FF_AUTOCAST")                      # "bf16" / "fp16": the reference's `percision: 16-mixed` on the encoder
+    if amp:
+        m.encoder_autocast = torch.bfloat16 if amp == "bf16" else torch.float16
     with torch.no_grad():                      # non-zero head so the recurrence is exercised
         m.vertice_map_r.weight.normal_(0, 0.1); m.vertice_map.weight.normal_(0, 0.001)
     params = [p for p in m.parameters() if p.requires_grad]
@@ -70,7 +73,7 @@ def faceformer(S, T, encoder=True):
         loss["loss"].backward()
         opt.step()
     dt = timeit(step, warm=2, iters=5)
-    print(json.dumps({"model": "faceformer" + ("" if encoder else "-decoder+head-only"), "sequences": S, "T": T, "ms_per_step": round(dt * 1e3, 2),
+    print(json.dumps({"model": "faceformer" + ("" if encoder else "-decoder+head-only") + (f" (encoder autocast {amp})" if amp else ""), "sequences": S, "T": T, "ms_per_step": round(dt * 1e3, 2),
                       "frames_per_s": round(S * T / dt, 1)}), flush=True)
 
 

@@ -120,24 +120,41 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_fwd_kernel(const flo
       const float4 qv = *reinterpret_cast<const float4*>(qs + wave * FHD + dq * 4);
       const float* kbase = svbase + SV_K + wave * FHD + dq * 4;
       const float* vbase = svbase + SV_V + wave * FHD + dq * 4;
-      float mloc = -INFINITY;
-      for (int j = js; j <= i; j += 16) {
-        float p = dot4(qv, *reinterpret_cast<const float4*>(kbase + (int64_t)j * SV_STRIDE));
-        p += __shfl_xor(p, 1, 64);
-        p += __shfl_xor(p, 2, 64);
-        mloc = fmaxf(mloc, p - slope * (float)((i - j) / period));
-      }
-      const float m = wave_max(mloc);
-      float lsum = 0.f;
+      // ONE pass over the keys with a running maximum (online softmax), four key slots per trip: the K/V rows come from
+      // L2 and the loop is bound by that latency, so the eight loads of a trip are issued before any of them is used.
+      // A slot past i re-reads row i (always valid memory) and is masked out.
+      float mrun = -INFINITY, lsum = 0.f;
       float4 cacc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int j = js; j <= i; j += 16) {
-        float p = dot4(qv, *reinterpret_cast<const float4*>(kbase + (int64_t)j * SV_STRIDE));
-        p += __shfl_xor(p, 1, 64);
-        p += __shfl_xor(p, 2, 64);
-        const float e = expf(p - slope * (float)((i - j) / period) - m);
-        const float4 vv = *reinterpret_cast<const float4*>(vbase + (int64_t)j * SV_STRIDE);
-        lsum += e;
-        cacc.x += e * vv.x; cacc.y += e * vv.y; cacc.z += e * vv.z; cacc.w += e * vv.w;
+      for (int j0 = js; j0 <= i; j0 += 64) {
+        float4 kk[4], vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t off = (int64_t)min(j0 + 16 * u, i) * SV_STRIDE;
+          kk[u] = *reinterpret_cast<const float4*>(kbase + off);
+          vv[u] = *reinterpret_cast<const float4*>(vbase + off);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = j0 + 16 * u;
+          float p = dot4(qv, kk[u]);
+          p += __shfl_xor(p, 1, 64);
+          p += __shfl_xor(p, 2, 64);
+          const bool valid = j <= i;
+          p = valid ? p - slope * (float)((i - j) / period) : -INFINITY;
+          const float mnew = fmaxf(mrun, p);
+          const float sc = mnew == -INFINITY ? 1.f : expf(mrun - mnew);
+          const float e = valid ? expf(p - mnew) : 0.f;
+          lsum = lsum * sc + e;
+          cacc.x = cacc.x * sc + e * vv[u].x; cacc.y = cacc.y * sc + e * vv[u].y;
+          cacc.z = cacc.z * sc + e * vv[u].z; cacc.w = cacc.w * sc + e * vv[u].w;
+          mrun = mnew;
+        }
+      }
+      const float m = wave_max(mrun);
+      {
+        const float sc = mrun == -INFINITY ? 0.f : expf(mrun - m);       // slots that saw no key contribute nothing
+        lsum *= sc;
+        cacc.x *= sc; cacc.y *= sc; cacc.z *= sc; cacc.w *= sc;
       }
       // fold the 16 key slots (lanes with equal dq): xor 4, 8, 16, 32
 #pragma unroll
@@ -374,38 +391,42 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
       float* vbase = svbase + SV_V + wave * FHD + dq * 4;
       float* dkbase = svbase + SV_DK + wave * FHD + dq * 4;
       float* dvbase = svbase + SV_DV + wave * FHD + dq * 4;
-      float rs = 0.f;
-      for (int j = js; j <= i; j += 16) {              // pass 1: a, da, sum a*da, dV
-        const int64_t off = (int64_t)j * SV_STRIDE;
-        float p = dot4(qv, *reinterpret_cast<const float4*>(kbase + off));
-        p += __shfl_xor(p, 1, 64);
-        p += __shfl_xor(p, 2, 64);
-        const float a = expf(p - slope * (float)((i - j) / period) - m) * invl;
-        float da = dot4(dcv, *reinterpret_cast<const float4*>(vbase + off));
-        da += __shfl_xor(da, 1, 64);
-        da += __shfl_xor(da, 2, 64);
-        if (dq == 0) rs += a * da;
-        float4 dv = *reinterpret_cast<float4*>(dvbase + off);
-        dv.x += a * dcv.x; dv.y += a * dcv.y; dv.z += a * dcv.z; dv.w += a * dcv.w;
-        *reinterpret_cast<float4*>(dvbase + off) = dv;
-      }
-      const float rowsum = wave_sum(rs);
+      // sum_j a_j da_j = dctx . ctx (ctx = sum_j a_j v_j is saved), so ONE pass over the keys does everything: a, da, ds,
+      // dq, dK += ds q, dV += a dctx.  Four key slots per trip, all sixteen loads issued before use (L2 latency bound);
+      // a slot past i re-reads row i and neither accumulates nor stores.
+      float rowsum = dot4(dcv, *reinterpret_cast<const float4*>(cs + wave * FHD + dq * 4));
+      rowsum += __shfl_xor(rowsum, 1, 64);
+      rowsum += __shfl_xor(rowsum, 2, 64);
       float4 dqa = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int j = js; j <= i; j += 16) {              // pass 2: ds, dq, dK
-        const int64_t off = (int64_t)j * SV_STRIDE;
-        const float4 kv = *reinterpret_cast<const float4*>(kbase + off);
-        float p = dot4(qv, kv);
-        p += __shfl_xor(p, 1, 64);
-        p += __shfl_xor(p, 2, 64);
-        const float a = expf(p - slope * (float)((i - j) / period) - m) * invl;
-        float da = dot4(dcv, *reinterpret_cast<const float4*>(vbase + off));
-        da += __shfl_xor(da, 1, 64);
-        da += __shfl_xor(da, 2, 64);
-        const float ds = a * (da - rowsum);
-        dqa.x += ds * kv.x; dqa.y += ds * kv.y; dqa.z += ds * kv.z; dqa.w += ds * kv.w;
-        float4 dk = *reinterpret_cast<float4*>(dkbase + off);
-        dk.x += ds * qv.x; dk.y += ds * qv.y; dk.z += ds * qv.z; dk.w += ds * qv.w;
-        *reinterpret_cast<float4*>(dkbase + off) = dk;
+      for (int j0 = js; j0 <= i; j0 += 64) {
+        float4 kk[4], vv[4], dk[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t off = (int64_t)min(j0 + 16 * u, i) * SV_STRIDE;
+          kk[u] = *reinterpret_cast<const float4*>(kbase + off);
+          vv[u] = *reinterpret_cast<const float4*>(vbase + off);
+          dk[u] = *reinterpret_cast<const float4*>(dkbase + off);
+          dv[u] = *reinterpret_cast<const float4*>(dvbase + off);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = j0 + 16 * u;
+          const bool valid = j <= i;
+          float p = dot4(qv, kk[u]);
+          p += __shfl_xor(p, 1, 64);
+          p += __shfl_xor(p, 2, 64);
+          float da = dot4(dcv, vv[u]);
+          da += __shfl_xor(da, 1, 64);
+          da += __shfl_xor(da, 2, 64);
+          const float a = valid ? expf(p - slope * (float)((i - min(j, i)) / period) - m) * invl : 0.f;
+          const float ds = a * (da - rowsum);
+          dqa.x += ds * kk[u].x; dqa.y += ds * kk[u].y; dqa.z += ds * kk[u].z; dqa.w += ds * kk[u].w;
+          if (valid) {
+            const int64_t off = (int64_t)j * SV_STRIDE;
+            *reinterpret_cast<float4*>(dkbase + off) = make_float4(dk[u].x + ds * qv.x, dk[u].y + ds * qv.y, dk[u].z + ds * qv.z, dk[u].w + ds * qv.w);
+            *reinterpret_cast<float4*>(dvbase + off) = make_float4(dv[u].x + a * dcv.x, dv[u].y + a * dcv.y, dv[u].z + a * dcv.z, dv[u].w + a * dcv.w);
+          }
+        }
       }
 #pragma unroll
       for (int off = 4; off < 64; off <<= 1) {

@@ -27,6 +27,13 @@ constexpr int FH = 4;                  // heads
 constexpr int FHD = 16;                // head dim
 constexpr int FFF = 128;               // feed-forward width
 constexpr int FF_THREADS = 256;
+#ifndef FA_U_SET
+#define FA_U_SET 4
+#endif
+#ifndef FB_U_SET
+#define FB_U_SET 8
+#endif
+constexpr int FA_U = FA_U_SET, FB_U = FB_U_SET;   // key slots (of 16 keys) per attention trip, forward / backward
 // per-step save row (floats); K/V/dK/dV sub-rows are 256-byte aligned
 constexpr int SV_X = 0, SV_Q = 64, SV_CTX = 128, SV_XH1 = 192, SV_XH2 = 256, SV_H = 320, SV_XH3 = 448, SV_ST = 512;
 constexpr int SV_K = 576, SV_V = 640, SV_DK = 704, SV_DV = 768, SV_STRIDE = 896;
@@ -120,21 +127,21 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_fwd_kernel(const flo
       const float4 qv = *reinterpret_cast<const float4*>(qs + wave * FHD + dq * 4);
       const float* kbase = svbase + SV_K + wave * FHD + dq * 4;
       const float* vbase = svbase + SV_V + wave * FHD + dq * 4;
-      // ONE pass over the keys with a running maximum (online softmax), four key slots per trip: the K/V rows come from
+      // ONE pass over the keys with a running maximum (online softmax), FA_U key slots per trip: the K/V rows come from
       // L2 and the loop is bound by that latency, so the eight loads of a trip are issued before any of them is used.
       // A slot past i re-reads row i (always valid memory) and is masked out.
       float mrun = -INFINITY, lsum = 0.f;
       float4 cacc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int j0 = js; j0 <= i; j0 += 64) {
-        float4 kk[4], vv[4];
+      for (int j0 = js; j0 <= i; j0 += 16 * FA_U) {
+        float4 kk[FA_U], vv[FA_U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < FA_U; ++u) {
           const int64_t off = (int64_t)min(j0 + 16 * u, i) * SV_STRIDE;
           kk[u] = *reinterpret_cast<const float4*>(kbase + off);
           vv[u] = *reinterpret_cast<const float4*>(vbase + off);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < FA_U; ++u) {
           const int j = j0 + 16 * u;
           float p = dot4(qv, kk[u]);
           p += __shfl_xor(p, 1, 64);
@@ -392,16 +399,16 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
       float* dkbase = svbase + SV_DK + wave * FHD + dq * 4;
       float* dvbase = svbase + SV_DV + wave * FHD + dq * 4;
       // sum_j a_j da_j = dctx . ctx (ctx = sum_j a_j v_j is saved), so ONE pass over the keys does everything: a, da, ds,
-      // dq, dK += ds q, dV += a dctx.  Four key slots per trip, all sixteen loads issued before use (L2 latency bound);
+      // dq, dK += ds q, dV += a dctx.  FB_U key slots per trip, all loads issued before use (L2 latency bound);
       // a slot past i re-reads row i and neither accumulates nor stores.
       float rowsum = dot4(dcv, *reinterpret_cast<const float4*>(cs + wave * FHD + dq * 4));
       rowsum += __shfl_xor(rowsum, 1, 64);
       rowsum += __shfl_xor(rowsum, 2, 64);
       float4 dqa = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int j0 = js; j0 <= i; j0 += 64) {
-        float4 kk[4], vv[4], dk[4], dv[4];
+      for (int j0 = js; j0 <= i; j0 += 16 * FB_U) {
+        float4 kk[FB_U], vv[FB_U], dk[FB_U], dv[FB_U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < FB_U; ++u) {
           const int64_t off = (int64_t)min(j0 + 16 * u, i) * SV_STRIDE;
           kk[u] = *reinterpret_cast<const float4*>(kbase + off);
           vv[u] = *reinterpret_cast<const float4*>(vbase + off);
@@ -409,7 +416,7 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
           dv[u] = *reinterpret_cast<const float4*>(dvbase + off);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < FB_U; ++u) {
           const int j = j0 + 16 * u;
           const bool valid = j <= i;
           float p = dot4(qv, kk[u]);

@@ -51,10 +51,8 @@ def make_voca_batch(n_seq: int, n_frames: int, rank: int, device):
     per sequence, per-subject template ~ N(0,5), gt = template + N(0,0.5) (already x100-scaled units)."""
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     feats = torch.randn(n_seq, n_frames, 29, generator=g)
-    pad = torch.zeros(n_seq, 8, 29)
-    fp = torch.cat([pad, feats, pad], 1)                                    # (S, T+16, 29)
-    win = fp.unfold(1, 16, 1)[:, :n_frames]                                 # (S, T, 29, 16) window t = frames t-8..t+7
-    x = win.reshape(n_seq * n_frames, 29, 16).contiguous()
+    from a2f_amd.data import feature_windows
+    x = feature_windows(feats)                                              # (S*T, 29, 16): window t = frames t-8..t+7, zero-padded ends
     subj = torch.randint(0, 8, (n_seq,), generator=g)
     one_hot = torch.zeros(n_seq, 12)
     one_hot[torch.arange(n_seq), subj] = 1.0

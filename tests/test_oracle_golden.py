@@ -3,6 +3,8 @@
 The fixtures were produced by importing /root/reference in the build container
 (tests/golden/gen_golden.py); this test needs neither the reference nor a GPU.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -169,3 +171,36 @@ def test_g8_faceformer_end_to_end():
         enc = o_w2v.wav2vec2_forward(sd_enc, o_w2v.normalize_waveform(audio), T)
         pred = o_ff.decode_incremental(sd_dec, enc, one_hot, template)
     assert packed_error(g, "pred", pred) < 1e-5
+
+
+def test_vocaset_helpers_golden_g9():
+    """Data-side helpers against vectors produced by the reference's own functions
+    (vocaset.py:50-54, :64-69, :408-430; tests/golden/gen_golden_data.py)."""
+    from a2f_amd import data
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g9_vocaset_helpers.npz"))
+    for ci, idx, shift, sr, length_ms, is_none in g["cases"]:
+        frag = data.get_audio_fragment(g[f"c{ci}::audio"], int(idx), fps=60, sample_rate=int(sr), length=length_ms / 1000.0, shift=int(shift))
+        if is_none:
+            assert frag is None
+        else:
+            ref = g[f"c{ci}::frag::{idx}::{shift}"]
+            assert frag.dtype == ref.dtype and np.array_equal(frag, ref)
+    assert len(g["cases"]) >= 40 and int(g["cases"][:, 5].sum()) >= 4
+    assert np.array_equal(data.normalize_audio(g["norm::in"]), g["norm::out"])
+    with pytest.raises(TypeError):
+        data.normalize_audio(g["norm::out"])
+    assert np.array_equal(np.stack([data.human_id_one_hot(h) for h in data.ALL_SUBJECTS]), g["one_hot"])
+
+
+def test_feature_windows_layout():
+    """VOCA input windows: window t = frames t-8 .. t+7 of its own sequence, zeros beyond the ends, (B, 29, 16) layout."""
+    from a2f_amd.data import feature_windows
+    S, T, C = 3, 21, 29
+    f = torch.arange(S * T * C, dtype=torch.float32).reshape(S, T, C) + 1
+    w = feature_windows(f)
+    assert w.shape == (S * T, C, 16)
+    for s, t in ((0, 0), (1, 7), (2, 20), (1, 12)):
+        for k in range(16):
+            src = t - 8 + k
+            exp = f[s, src] if 0 <= src < T else torch.zeros(C)
+            assert torch.equal(w[s * T + t, :, k], exp)

@@ -21,9 +21,21 @@ def test_library_builds_and_exports_declared_symbols():
 
 
 def test_gemm_desc_layout_matches_header():
+    """The ctypes mirror of a2f_gemm_desc must have the C compiler's layout: compile the header with gcc and compare the
+    size and the offset of every field."""
     import ctypes
-    # 3 pointers+3*3 int64 ... : the struct is all 8-byte fields followed by ten int32
-    assert ctypes.sizeof(_lib.GemmDesc) == 17 * 8 + 10 * 4 + 8
+    import subprocess
+    import tempfile
+    fields = [f for f, _ in _lib.GemmDesc._fields_]
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "a2f_hip.h"\nint main(void) {\n  printf("%zu\\n", sizeof(a2f_gemm_desc));\n'
+    prog += "".join(f'  printf("%zu\\n", offsetof(a2f_gemm_desc, {f}));\n' for f in fields) + "  return 0;\n}\n"
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "layout.c"), os.path.join(d, "layout")
+        open(src, "w").write(prog)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        out = [int(x) for x in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(_lib.GemmDesc)
+    assert out[1:] == [getattr(_lib.GemmDesc, f).offset for f in fields]
 
 
 def test_product_does_not_import_oracle():

@@ -14,9 +14,10 @@
 //   * registers: the FFN weight slices (forward) / FFN weight columns + every weight-gradient accumulator (backward);
 //   * K/V cache rows (256 B each) in global memory, L2-resident, read as float4 by 4 lanes per (key, head);
 //   * wave64 butterfly reductions for softmax statistics and LayerNorm moments; one wave per attention head.
-// Attention scores are never stored: pass 1 finds the row maximum, pass 2 recomputes the scores and accumulates
-// exp / context (and, in the backward, pass 1 accumulates sum(a*da) and dV, pass 2 forms ds, dq, dK), so LDS use
-// does not grow with T (T = 3000 runs in the same kernel).
+// Attention scores are never stored and every K/V row is read ONCE per step: the forward keeps a running maximum
+// (online softmax) and merges the 16 key slots of a head at the end; the backward needs no separate pass for
+// sum_j a_j da_j because that sum equals dctx . ctx (ctx is saved), so one sweep forms a, da, ds, dq, dK and dV.  LDS use
+// does not grow with T (T = 3000 runs in the same kernel); several key slots per trip keep the L2 latency covered.
 // ALiBi-style bias in closed form: -2^{-2(h+1)} * floor((i-j)/period) (faceformer.py:22-54).
 #include "a2f_common.h"
 

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
         }
       }
     }
+    VT_STAMP(0, 9);
     // ---- conv1: rows (f,p<8) = 256 = 8 tiles, 2 per wave; window = R0[f*629 + 2p*37 ..+111) ----
 #pragma unroll
     for (int it = 0; it < 2; ++it) {

@@ -31,7 +31,7 @@ for _ in range(N):
     F.voca_trunk_bwd(be, saved, dh3)
 torch.cuda.synchronize()
 be.lib.a2f_debug_trunk_stamps(buf)
-fw = ["wait top barrier", "stage x -> LDS (+prefetch issue)", "a0 store + conv1", "conv2 (+zeroing, one-hot)", "conv3", "conv4", "fc0", "fc1+tanh", "fc3"]
+fw = ["wait top barrier", "stage x -> LDS (+prefetch issue)", "conv1 (after the a0 copy)", "conv2 (+zeroing, one-hot)", "conv3", "conv4", "fc0", "fc1+tanh", "fc3", "a0 copy LDS -> HBM"]
 bw = ["wait top barrier", "dh -> LDS + mask loads issue", "fc3' (+tanh')", "fc1'", "fc0'", "conv4'", "conv3'", "conv2'"]
 for k, names in ((0, fw), (1, bw)):
     tot = sum(buf[k * 16 + i] for i in range(len(names)))

@@ -369,17 +369,34 @@ __global__ __launch_bounds__(G_THREADS) void gemm_x3_kernel(const a2f_gemm_desc 
   gemm_epilogue<NT>(d, acc, m0, n0, wave, lane, M, N, Neff);
 }
 
-// fold split-K slabs in fixed order: C[row][col] = sum_z slab[z][row][col]; virtual ones column -> ones_out
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, int Neff, float* __restrict__ C,
-                                                             int64_t ldc, float* __restrict__ ones_out) {
+// fold split-K slabs in fixed order and apply the descriptor's epilogue: C[row][col] = epi(sum_z slab[z][row][col]);
+// virtual ones column -> ones_out.  With the slabs, split-K is deterministic AND compatible with every epilogue, so the
+// host layer also uses it to spread short-M GEMMs (a handful of 128-row tiles with K = 768..1024) over the chip.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const a2f_gemm_desc d, int splits, int Neff) {
+  const int M = (int)d.M, N = (int)d.N;
   const int64_t total = (int64_t)M * Neff;
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= total) return;
+  const float* __restrict__ ws = d.splitk_ws;
   float v = 0.f;
   for (int z = 0; z < splits; ++z) v += ws[(int64_t)z * total + i];
   const int row = (int)(i / Neff), col = (int)(i - (int64_t)row * Neff);
-  if (col < N) C[(int64_t)row * ldc + col] = v;
-  else ones_out[row] = v;
+  if (col == N) {
+    d.ones_out[row] = d.accumulate ? d.ones_out[row] + v : v;
+    return;
+  }
+  float* cp = d.C + (int64_t)row * d.ldc + col;
+  if (d.bias) v += d.bias[col];
+  if (d.accumulate) v += *cp;
+  if (d.act == 1) v = fmaxf(v, 0.f);
+  else if (d.act == 2) v = tanhf(v);
+  if (d.aux_mode) {
+    const float ax = d.aux[(int64_t)row * d.ldaux + col];
+    if (d.aux_mode == 1) v = ax > 0.f ? v : 0.f;
+    else if (d.aux_mode == 2) v *= (1.f - ax * ax);
+    else v += ax;
+  }
+  *cp = v;
 }
 
 }  // namespace a2f
@@ -397,9 +414,9 @@ extern "C" int a2f_gemm_f32(const a2f_gemm_desc* dp, a2f_stream_t stream) {
   A2F_CHECK_ARG(d.mask_operand >= 0 && d.mask_operand <= 2, "gemm: bad mask_operand");
   A2F_CHECK_ARG(d.mask_operand == 0 || d.mask_period > 0, "gemm: mask_period must be > 0");
   const int split = d.split_k > 1 ? d.split_k : 1;
-  if (split > 1)
+  if (split > 1 && !d.splitk_ws)
     A2F_CHECK_ARG(d.act == 0 && d.aux_mode == 0 && d.bias == nullptr && !d.accumulate,
-                  "gemm: split_k only with a linear epilogue into a zeroed C");
+                  "gemm: atomic split_k (no splitk_ws) only with a linear epilogue into a zeroed C");
   A2F_CHECK_ARG(split <= 65535, "gemm: split_k too large");
   const int64_t neff = d.N + (d.ones_out ? 1 : 0);
   const int bn = neff <= 32 ? 32 : neff <= 64 ? 64 : neff <= 96 ? 96 : 128;
@@ -428,8 +445,7 @@ extern "C" int a2f_gemm_f32(const a2f_gemm_desc* dp, a2f_stream_t stream) {
     const int per = (ktiles + split - 1) / split;
     const int live = (ktiles + per - 1) / per;
     const int64_t total = d.M * neff;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, (const float*)d.splitk_ws, live, (int)d.M,
-                       (int)d.N, (int)neff, d.C, d.ldc, d.ones_out);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, d, live, (int)neff);
   }
   A2F_CHECK_LAUNCH("gemm_f32");
   return A2F_OK;

@@ -44,6 +44,7 @@ class HipBackend:
     def __init__(self):
         self.lib = _lib.load()
         self.prof = None          # when a dict: tag -> list of (start_event, end_event) recorded on the launch stream
+        self.auto_split_k = True  # gemm(): slab split-K for under-filled grids (see gemm)
         self.gemm_precision = 0   # a2f_gemm_desc.precision of subsequent gemm() calls: 0 exact fp32 MFMA, 1 bf16x3 split products
 
     @staticmethod
@@ -68,6 +69,15 @@ class HipBackend:
              act=ACT_NONE, aux=None, aux_off=0, ldaux=0, aux_mode=AUX_NONE, accumulate=False, split_k=1, ones_out=None,
              mask: Optional[Tuple[int, int, int, int, int]] = None, tag: Optional[str] = None, splitk_ws=None):
         _chk(A, B, Cout, bias, aux, ones_out, splitk_ws)
+        if split_k == 1 and self.auto_split_k and K >= 256:
+            # few output tiles and a long contraction (e.g. the Audio2Mesh articulation convolutions: 1..64 tiles, K = 768):
+            # deterministic slab split-K spreads the k-loop over the chip; the fold applies the epilogue
+            neff = N + (1 if ones_out is not None else 0)
+            tiles = ((M + 127) // 128) * ((neff + 127) // 128)
+            if tiles < 96:
+                split_k = max(1, min(256 // tiles, K // 128, 16))
+                if split_k > 1:
+                    splitk_ws = torch.empty(split_k * M * (N + 1), device=Cout.device, dtype=torch.float32)
         d = GemmDesc()
         d.A, d.a_off, d.a_rs, d.a_cs = _ptr(A), a[0], a[1], a[2]
         d.B, d.b_off, d.b_rs, d.b_cs = _ptr(B), b[0], b[1], b[2]

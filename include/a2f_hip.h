@@ -53,11 +53,13 @@ const char* a2f_last_error(void);
  *      aux_mode 3: v += aux                       (template add, voca.py:49)
  * ones_out != NULL appends a virtual all-ones column n == N to B and routes it to ones_out[m]
  * (bias gradients as part of the weight-gradient GEMM).
- * split_k > 1 partitions K over grid.z; only valid with act = aux_mode = 0, bias = NULL, accumulate = 0.
- *   splitk_ws == NULL: partial tiles are added with fp32 atomics into a C (and ones_out) the caller has zeroed;
+ * split_k > 1 partitions K over grid.z.
+ *   splitk_ws == NULL: partial tiles are added with fp32 atomics into a C (and ones_out) the caller has zeroed; only
+ *   valid with act = aux_mode = 0, bias = NULL, accumulate = 0;
  *   splitk_ws != NULL: (>= split_k*M*(N+1) floats) every split stores its partial tile there and a second
- *   kernel folds the splits in fixed order into C / ones_out (overwrite): deterministic, and free of the atomic
- *   contention that dominates when the output is tiny (weight gradients).
+ *   kernel folds the splits in fixed order and applies the full epilogue into C / ones_out: deterministic, free of the
+ *   atomic contention that dominates when the output is tiny (weight gradients), and valid with every epilogue - also
+ *   the way to spread a GEMM with few 128-row tiles and a long K over the whole chip.
  * Replaces torch.nn.Linear / Conv2d forward+backward as dispatched by the reference models.
  */
 typedef struct a2f_gemm_desc {

@@ -150,6 +150,31 @@ def test_conv_implicit_gemm_fwd_wgrad_dgrad(B_, P_out, Cin, Co):
     assert rel_l2(d_in2.cpu(), x.grad.permute(0, 2, 1) * (act > 0)) < 5e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 256, 768), (500, 243, 486), (37, 50, 300)])
+def test_gemm_slab_splitk_with_every_epilogue(M, N, K):
+    """Deterministic slab split-K is valid with the full epilogue (bias, activation, aux modes, accumulate): the fold kernel
+    applies it.  Explicit split_k and the host layer's automatic choice for under-filled grids."""
+    A, B = rnd(M, K, seed=70), rnd(N, K, seed=71)
+    bias, aux, C0 = rnd(N, seed=72), rnd(M, N, seed=73), rnd(M, N + 3, seed=74)
+    for kw in (dict(bias=bias, act=1), dict(bias=bias, act=2), dict(aux=aux, ldaux=N, aux_mode=1), dict(aux=aux, ldaux=N, aux_mode=2, accumulate=True),
+               dict(bias=bias, aux=aux, ldaux=N, aux_mode=3)):
+        for split in (1, 5):                                     # 1: automatic (K >= 256, few tiles), 5: explicit
+            kk = dict(kw)
+            if split > 1:
+                kk.update(split_k=split, splitk_ws=torch.empty(split * M * (N + 1), device=DEV))
+            hip, emu = ops.HipBackend(), EmuBackend()
+            outs = []
+            for be, dev in ((hip, DEV), (emu, "cpu")):
+                k2 = {k: (v.clone().to(dev) if torch.is_tensor(v) and k != "splitk_ws" else v) for k, v in kk.items()}
+                if dev == "cpu":
+                    k2.pop("splitk_ws", None); k2.pop("split_k", None)
+                Cc = C0.clone().to(dev)
+                be.gemm(A.to(dev), B.to(dev), Cc, M, N, K, (0, K, 1), (0, 1, K), N + 3, **k2)
+                outs.append(Cc.cpu())
+            assert rel_l2(outs[0][:, :N], outs[1][:, :N]) < 2e-5, (kw.keys(), split)
+            assert torch.equal(outs[0][:, N:], C0[:, N:])
+
+
 def test_gemm_splitk_ones_column():
     M, N, K = 50, 128, 5000
     dy, x = rnd(K, M, seed=16), rnd(K, N, seed=17)

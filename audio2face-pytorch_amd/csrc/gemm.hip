@@ -205,10 +205,12 @@ __global__ __launch_bounds__(G_THREADS) void gemm_f32_kernel(const a2f_gemm_desc
 }
 
 // =====================================================================================================================
-// Split-precision variant (d.precision == 1): same tiling, same operand contract, same epilogue, but every product on
-// the bf16 matrix pipe as three bf16 MFMAs (x = hi + lo; lo*hi' + hi*lo' + hi*hi', fp32 accumulation; <= 2^-16 relative
-// error per product - see head_fused.hip).  Matrix time drops 5.3x against v_mfma_f32_32x32x2_f32; used for the
-// convolution GEMMs of Audio2Mesh, which are matrix-pipe bound in fp32.
+// Split-precision variants (d.precision == 1 / 2): same tiling, same operand contract, same epilogue, but every product on
+// the bf16 matrix pipe.  precision 1: x = hi + lo, three bf16 MFMAs per product (lo*hi' + hi*lo' + hi*hi'), <= 2^-16
+// relative error per product, 5.3x less matrix time than v_mfma_f32_32x32x2_f32 (see head_fused.hip).  precision 2:
+// x = hi + mid + lo (24 significant bits), the six products whose pieces multiply to >= 2^-16 of the full product
+// (hh', hm', mh', hl', lh', mm'), fp32 accumulation: error <= ~2^-23 per product, i.e. fp32-class results at 2.7x less
+// matrix time.  Used for the convolution GEMMs of Audio2Mesh, which are matrix-pipe bound in fp32.
 // Operands are split when they are stored to LDS: a thread owns PAIRS of consecutive k, so one v_cvt_pk_bf16_f32 pair
 // yields a packed dword per image; the images are [row][16 k] bf16 with a 48-byte pitch, which makes every fragment of
 // v_mfma_f32_32x32x16_bf16 (8 consecutive k of one row) ONE conflict-free ds_read_b128.
@@ -216,26 +218,31 @@ using gx_bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using gx_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using gx_f32x2 = __attribute__((ext_vector_type(2))) float;
 using gx_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-__device__ __forceinline__ void gx_split2(float a, float b, unsigned& hi, unsigned& lo) {
-  const gx_f32x2 v = {a, b};
-  const gx_bf16x2 hb = __builtin_convertvector(v, gx_bf16x2);
-  const gx_f32x2 r = v - __builtin_convertvector(hb, gx_f32x2);
-  hi = __builtin_bit_cast(unsigned, hb);
-  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, gx_bf16x2));
+// (a, b) -> NS packed bf16 pair images: piece q = bf16(x - sum of the earlier pieces); 2 pieces carry 16 bits, 3 carry 24
+template <int NS>
+__device__ __forceinline__ void gx_split(float a, float b, unsigned (&img)[NS]) {
+  gx_f32x2 r = {a, b};
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const gx_bf16x2 p = __builtin_convertvector(r, gx_bf16x2);
+    img[q] = __builtin_bit_cast(unsigned, p);
+    if (q + 1 < NS) r = r - __builtin_convertvector(p, gx_f32x2);
+  }
 }
 __device__ __forceinline__ f32x16 gx_mfma(gx_u32x4 a, gx_u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gx_bf16x8, a), __builtin_bit_cast(gx_bf16x8, b), c, 0, 0, 0);
 }
 constexpr int GX_PITCH = 48;          // bytes per image row: 16 bf16 + 16 B pad
 
-template <int BN>
-__global__ __launch_bounds__(G_THREADS) void gemm_x3_kernel(const a2f_gemm_desc d) {
+template <int BN, int NS>
+__global__ __launch_bounds__(G_THREADS) void gemm_split_kernel(const a2f_gemm_desc d) {
   constexpr int NT = BN / 32;
   constexpr int KP = G_BK / 2;                                   // k-pairs per tile
   constexpr int A_PAIRS = G_BM * KP / G_THREADS;                 // 4
   constexpr int B_PAIRS = (BN * KP + G_THREADS - 1) / G_THREADS;
   constexpr int A_IMG = G_BM * GX_PITCH, B_IMG = BN * GX_PITCH;  // one bf16 image (hi or lo)
-  __shared__ __attribute__((aligned(16))) char smem[2 * (2 * A_IMG + 2 * B_IMG)];   // [buffer][A hi | A lo | B hi | B lo]
+  constexpr int BUF_BYTES = NS * (A_IMG + B_IMG);                 // [A images hi, (mid,) lo | B images hi, (mid,) lo]
+  extern __shared__ __attribute__((aligned(16))) char smem[];    // two buffers
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -314,24 +321,24 @@ __global__ __launch_bounds__(G_THREADS) void gemm_x3_kernel(const a2f_gemm_desc 
     }
   };
   auto store_tile = [&](int buf) {
-    char* base = smem + buf * (2 * A_IMG + 2 * B_IMG);
+    char* base = smem + buf * BUF_BYTES;
 #pragma unroll
     for (int i = 0; i < A_PAIRS; ++i) {
-      unsigned hi, lo;
-      gx_split2(ra[i][0], ra[i][1], hi, lo);
+      unsigned img[NS];
+      gx_split<NS>(ra[i][0], ra[i][1], img);
       const int off = a_mm[i] * GX_PITCH + a_kp[i] * 4;
-      *reinterpret_cast<unsigned*>(base + off) = hi;
-      *reinterpret_cast<unsigned*>(base + A_IMG + off) = lo;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) *reinterpret_cast<unsigned*>(base + q * A_IMG + off) = img[q];
     }
 #pragma unroll
     for (int i = 0; i < B_PAIRS; ++i) {
       const int e = t + i * G_THREADS;
       if (e < BN * KP) {
-        unsigned hi, lo;
-        gx_split2(rb[i][0], rb[i][1], hi, lo);
-        const int off = 2 * A_IMG + b_nn[i] * GX_PITCH + b_kp[i] * 4;
-        *reinterpret_cast<unsigned*>(base + off) = hi;
-        *reinterpret_cast<unsigned*>(base + B_IMG + off) = lo;
+        unsigned img[NS];
+        gx_split<NS>(rb[i][0], rb[i][1], img);
+        const int off = NS * A_IMG + b_nn[i] * GX_PITCH + b_kp[i] * 4;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) *reinterpret_cast<unsigned*>(base + q * B_IMG + off) = img[q];
       }
     }
   };
@@ -348,20 +355,24 @@ __global__ __launch_bounds__(G_THREADS) void gemm_x3_kernel(const a2f_gemm_desc 
 
   // fragment of a 16-k tile: lane (row = lane&31, h = lane>>5) takes k = 8h .. 8h+7 of its row
   const int frag_a = (wave * 32 + (lane & 31)) * GX_PITCH + (lane >> 5) * 16;
-  const int frag_b = 2 * A_IMG + (lane & 31) * GX_PITCH + (lane >> 5) * 16;
+  const int frag_b = NS * A_IMG + (lane & 31) * GX_PITCH + (lane >> 5) * 16;
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nkt) load_tile(kt + 1);
-    const char* base = smem + buf * (2 * A_IMG + 2 * B_IMG);
-    const gx_u32x4 ah = *reinterpret_cast<const gx_u32x4*>(base + frag_a);
-    const gx_u32x4 al = *reinterpret_cast<const gx_u32x4*>(base + A_IMG + frag_a);
+    const char* base = smem + buf * BUF_BYTES;
+    gx_u32x4 af[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) af[q] = *reinterpret_cast<const gx_u32x4*>(base + q * A_IMG + frag_a);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const gx_u32x4 bh = *reinterpret_cast<const gx_u32x4*>(base + frag_b + j * 32 * GX_PITCH);
-      const gx_u32x4 bl = *reinterpret_cast<const gx_u32x4*>(base + B_IMG + frag_b + j * 32 * GX_PITCH);
-      acc[j] = gx_mfma(al, bh, acc[j]);
-      acc[j] = gx_mfma(ah, bl, acc[j]);
-      acc[j] = gx_mfma(ah, bh, acc[j]);
+      gx_u32x4 bf[NS];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) bf[q] = *reinterpret_cast<const gx_u32x4*>(base + q * B_IMG + frag_b + j * 32 * GX_PITCH);
+      // every product of pieces whose magnitudes multiply to >= 2^-8(NS-1) of the full product, smallest terms first
+#pragma unroll
+      for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+        for (int qa = 0; qa <= sum; ++qa) acc[j] = gx_mfma(af[qa], bf[sum - qa], acc[j]);
     }
     if (kt + 1 < nkt) store_tile(buf ^ 1);
     __syncthreads();
@@ -399,6 +410,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const a2f_gemm_desc 
   *cp = v;
 }
 
+template <int BN, int NS>
+static int split_launch(const a2f_gemm_desc& d, dim3 grid, hipStream_t s) {
+  const size_t lds = 2 * (size_t)NS * (G_BM + BN) * GX_PITCH;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<BN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return set_err(A2F_ELAUNCH, "gemm: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_split_kernel<BN, NS>), grid, dim3(G_THREADS), lds, s, d);
+  return A2F_OK;
+}
+
 }  // namespace a2f
 
 extern "C" int a2f_gemm_f32(const a2f_gemm_desc* dp, a2f_stream_t stream) {
@@ -423,14 +447,11 @@ extern "C" int a2f_gemm_f32(const a2f_gemm_desc* dp, a2f_stream_t stream) {
   dim3 grid((unsigned)cdiv(d.M, G_BM), (unsigned)cdiv(neff, bn), (unsigned)split);
   A2F_CHECK_ARG(grid.y <= 65535, "gemm: N too large for grid.y");
   hipStream_t s = (hipStream_t)stream;
-  A2F_CHECK_ARG(d.precision == 0 || d.precision == 1, "gemm: precision must be 0 (exact fp32 MFMA) or 1 (bf16x3 split products)");
-  if (d.precision == 1) {
-    switch (bn) {
-      case 32: hipLaunchKernelGGL(gemm_x3_kernel<32>, grid, dim3(G_THREADS), 0, s, d); break;
-      case 64: hipLaunchKernelGGL(gemm_x3_kernel<64>, grid, dim3(G_THREADS), 0, s, d); break;
-      case 96: hipLaunchKernelGGL(gemm_x3_kernel<96>, grid, dim3(G_THREADS), 0, s, d); break;
-      default: hipLaunchKernelGGL(gemm_x3_kernel<128>, grid, dim3(G_THREADS), 0, s, d); break;
-    }
+  A2F_CHECK_ARG(d.precision >= 0 && d.precision <= 2, "gemm: precision must be 0 (exact fp32 MFMA), 1 (bf16x3) or 2 (bf16x6 split products)");
+  if (d.precision == 1 || d.precision == 2) {
+    const int rc = d.precision == 1 ? (bn == 32 ? split_launch<32, 2>(d, grid, s) : bn == 64 ? split_launch<64, 2>(d, grid, s) : bn == 96 ? split_launch<96, 2>(d, grid, s) : split_launch<128, 2>(d, grid, s))
+                                    : (bn == 32 ? split_launch<32, 3>(d, grid, s) : bn == 64 ? split_launch<64, 3>(d, grid, s) : bn == 96 ? split_launch<96, 3>(d, grid, s) : split_launch<128, 3>(d, grid, s));
+    if (rc != A2F_OK) return rc;
   } else {
     switch (bn) {
       case 32: hipLaunchKernelGGL(gemm_f32_kernel<32>, grid, dim3(G_THREADS), 0, s, d); break;

@@ -236,12 +236,13 @@ class VocaTrunkFn(torch.autograd.Function):
 # =================================================================================================
 A2M_CH = (1, 72, 108, 162, 243, 256)           # analysis channels; width 32 -> 16 -> 8 -> 4 -> 2 -> 1   (audio2face.py:13-29)
 A2M_BN_MOMENTUM, A2M_BN_EPS = 0.1, 1e-5
-# a2f_gemm_desc.precision of the Audio2Mesh GEMMs.  0 (default) = exact fp32 MFMA.  1 = bf16x3 split products: the
-# fp32-MFMA convolutions are matrix-pipe bound and the step gets 1.3x faster (B = 1024: 13.5 -> 10.3 ms), the prediction
-# stays at 9e-6 of the reference, but the batch-statistics BatchNorm backward amplifies the 2^-16 product error: on the
-# G2 fixture (B = 4) weight gradients of the analysis stack move from ~1e-4 to 1e-3 .. 5e-3 of the reference
-# (tools/a2m_grad_errors.py).  Opt in with A2F_A2M_PRECISION=1 when that is acceptable.
-A2M_GEMM_PRECISION = int(os.environ.get("A2F_A2M_PRECISION", "0"))
+# a2f_gemm_desc.precision of the Audio2Mesh GEMMs (the fp32-MFMA convolutions are matrix-pipe bound):
+#   2 (default) = bf16x6 split products: fp32-class results (G2 fixture: worst weight-gradient error 1.7e-5 of the
+#       reference vs 1.1e-5 with exact fp32 MFMA) at 2.7x less matrix time - B = 1024 step 13.0 -> 11.4 ms;
+#   1 = bf16x3: 9.8 ms, prediction still at 9e-6, but the batch-statistics BatchNorm backward amplifies the 2^-16 product
+#       error: weight gradients of the analysis stack move to 1e-3 .. 5e-3 of the reference (tools/a2m_grad_errors.py);
+#   0 = exact fp32 MFMA.
+A2M_GEMM_PRECISION = int(os.environ.get("A2F_A2M_PRECISION", "2"))
 
 
 @contextlib.contextmanager

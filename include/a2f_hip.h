@@ -74,7 +74,7 @@ typedef struct a2f_gemm_desc {
   int32_t mask_operand, mask_period, mask_phase, mask_lo, mask_hi;
   int32_t c_unpack_kh;   /* a2f_wgrad_* only: > 0 stores column kh*Ci+ci (Ci = N/c_unpack_kh) at ci*KH+kh, i.e. C in nn.Conv2d's (Co,Ci,KH,1) layout */
   float* splitk_ws;
-  int32_t precision;     /* a2f_gemm_f32 only: 0 = exact fp32 MFMA (default), 1 = bf16x3 split products (x = hi + lo in bf16; lo*hi' + hi*lo' + hi*hi', fp32 accumulate; <= 2^-16 per product) */
+  int32_t precision;     /* a2f_gemm_f32 only: 0 = exact fp32 MFMA (default); 1 = bf16x3 split products (x = hi + lo in bf16; three bf16 MFMAs, fp32 accumulate; <= 2^-16 per product); 2 = bf16x6 (x = hi + mid + lo; six bf16 MFMAs; <= ~2^-23 per product, fp32-class) */
   int32_t reserved;
 } a2f_gemm_desc;
 

@@ -44,9 +44,10 @@ def run_gemm_both(A, B, Cinit, M, N, K, a, b, ldc, precision=0, **kw):
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 50, 50), (300, 72, 111), (513, 129, 67), (200, 96, 192), (1000, 243, 486), (64, 15, 3)])
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
-def test_gemm_bf16x3_precision_layouts_and_epilogues(M, N, K, layout):
-    """a2f_gemm_desc.precision = 1 (three bf16 MFMAs per product, fp32 accumulate) against the float64 contract: same
-    operand layouts, masks, epilogues and split-K slabs as the exact kernel; error budget 2^-16 per product."""
+@pytest.mark.parametrize("precision,tol", [(1, 3e-5), (2, 2e-6)])
+def test_gemm_split_precision_layouts_and_epilogues(M, N, K, layout, precision, tol):
+    """a2f_gemm_desc.precision = 1 (bf16x3: three bf16 MFMAs per product, 2^-16) and 2 (bf16x6: six MFMAs, fp32-class)
+    against the float64 contract: same operand layouts, masks, epilogues and split-K slabs as the exact kernel."""
     if layout == "nt":
         A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
         a, b = (0, K, 1), (0, 1, K)
@@ -59,18 +60,18 @@ def test_gemm_bf16x3_precision_layouts_and_epilogues(M, N, K, layout):
     bias, aux, C0 = rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N + 3, seed=5)
     for kw in (dict(), dict(bias=bias, act=1), dict(aux=aux, ldaux=N, aux_mode=2, accumulate=True), dict(bias=bias, aux=aux, ldaux=N, aux_mode=3),
                dict(mask=(1, 4, 1, 0, min(3, K))), dict(mask=(2, 5, 0, 0, min(7, N)))):
-        (c_hip, _), (c_emu, _) = run_gemm_both(A, B, C0, M, N, K, a, b, N + 3, precision=1, **kw)
-        assert rel_l2(c_hip[:, :N], c_emu[:, :N]) < 3e-5, kw.keys()
+        (c_hip, _), (c_emu, _) = run_gemm_both(A, B, C0, M, N, K, a, b, N + 3, precision=precision, **kw)
+        assert rel_l2(c_hip[:, :N], c_emu[:, :N]) < tol, kw.keys()
         assert torch.equal(c_hip[:, N:], C0[:, N:])
     if K >= 50:                                                  # deterministic split-K slabs + ones column
         ws = torch.empty(3 * M * (N + 1), device=DEV)
-        hip = ops.HipBackend(); hip.gemm_precision = 1
+        hip = ops.HipBackend(); hip.gemm_precision = precision
         Cc, ones = torch.zeros(M, N, device=DEV), torch.zeros(M, device=DEV)
         hip.gemm(A.to(DEV), B.to(DEV), Cc, M, N, K, a, b, N, split_k=3, ones_out=ones, splitk_ws=ws)
         ref = (A.double() if layout != "tn" else A.double().t()) @ (B.double().t() if layout == "nt" else B.double())
-        assert rel_l2(Cc.cpu(), ref) < 3e-5
+        assert rel_l2(Cc.cpu(), ref) < tol
         asum = (A.double() if layout != "tn" else A.double().t()).sum(1)
-        assert rel_l2(ones.cpu(), asum) < 3e-5
+        assert rel_l2(ones.cpu(), asum) < tol
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 50, 50), (128, 32, 16), (300, 72, 111), (513, 129, 67), (200, 96, 192), (64, 15, 3)])

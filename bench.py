@@ -119,11 +119,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    # A2F_BENCH_BACKEND=gloo A2F_BENCH_SHARE_GPU=1: rehearsal of the multi-rank flow on a one-GPU box (every rank on cuda:0,
+    # collectives through gloo); the real runs use one GPU per rank and RCCL
+    backend = os.environ.get("A2F_BENCH_BACKEND", "nccl")
+    if os.environ.get("A2F_BENCH_SHARE_GPU") == "1":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import a2f_amd
@@ -179,7 +187,8 @@ def main():
         eager.__dict__.update(step.__dict__)
         eager.use_graph = False
         for _ in range(nprof):
-            eager(x, one_hot, gt, templ)
+            eager._fwd_bwd(x, one_hot, gt, templ)              # forward + loss + backward only: rank 0 runs this leg alone, so no collective
+
         torch.cuda.synchronize()
         head_ms, nl = be.profile_head_ms()
         be.profile_head(False)

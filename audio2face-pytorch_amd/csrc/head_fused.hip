@@ -36,6 +36,7 @@ struct HeadArgs {
   float* pred; float* dH_slab; float* dW_slab; float* db_slab; double* loss_part;
   unsigned long long* dbg;             // diagnostic build only (HF_STAMPS): per-wave phase cycle totals
   int64_t ldt;                         // template row stride: n, or 0 for one broadcast row
+  int ldh;                             // dH slab row pitch in floats: HF_KP, or K rounded up to 4 (rows back to back: only whole lines are written)
   int B, Bloss, n, CG, RG, NRB;
   float cr, cv;                        // 2 k_rec / (Bloss V), 2 k_vel / ((Bloss/2) V)
 };
@@ -63,6 +64,11 @@ __device__ __forceinline__ void buf_store(rsrc_t r, int byte_off, float v, int s
 #endif
 #ifndef X3_STREAM_ST
 #define X3_STREAM_ST 0
+#endif
+// when the next row block's tile rows are requested: 0 = between the dW products, 1 = right after the staging barrier
+// (the request registers are free from there on), 2 = after the epilogue
+#ifndef X3_ISSUE_AT
+#define X3_ISSUE_AT 0
 #endif
 __device__ __forceinline__ float buf_load_stream(rsrc_t r, int byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, X3_STREAM_LD));
@@ -478,6 +484,11 @@ __device__ __forceinline__ void x3_split2(float a, float b, unsigned& hi, unsign
 __device__ __forceinline__ f32x16 x3_mfma(u32x4_t a, u32x4_t b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
+using u32x2_t = __attribute__((ext_vector_type(2))) unsigned;
+using i16x4_t = __attribute__((ext_vector_type(4))) short;
+__device__ __forceinline__ u32x2_t x3_tr_read(const char* lds_addr) {
+  return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4_t*)(lds_addr)));
+}
 // c += (ah + al) * (bh + bl) without the lo*lo term; small terms first
 __device__ __forceinline__ f32x16 x3_mac(u32x4_t ah, u32x4_t al, u32x4_t bh, u32x4_t bl, f32x16 c) {
   c = x3_mfma(al, bh, c);
@@ -490,6 +501,7 @@ constexpr int X3_HROW_PITCH = 72 * 2;                 // bytes per row of the ro
 constexpr int X3_HCOL_PITCH = 40 * 2;                 // bytes per k of the k-major H image        [split][k][p(row)] (rows padded to 40)
 constexpr int X3_HROW_BYTES = 2 * HF_ROWS * X3_HROW_PITCH;      // 9216
 constexpr int X3_HCOL_BYTES = 2 * HF_KP * X3_HCOL_PITCH;        // 10240
+constexpr int X3_GIMG_PITCH = 72, X3_GIMG_BYTES = 32 * X3_GIMG_PITCH;     // per-wave G images (bf16 hi, lo)
 constexpr int X3_RED_FLOATS = X3_NW * HF_ROWS * HF_KP;          // [wave][32][64] fp32 dH partials; a wave's slice doubles as its G transpose tile
 constexpr int X3_WB_BYTES = X3_NW * 8 * 64 * 16;               // per wave: dH B fragments [kt][s][split][lane] x 16 B (lane-linear)
 constexpr size_t X3_LDS_BYTES = X3_HROW_BYTES + X3_HCOL_BYTES + (size_t)X3_RED_FLOATS * 4 + X3_WB_BYTES;
@@ -503,10 +515,22 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
 
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int cg = blockIdx.x % a.CG, rg = blockIdx.x / a.CG;
+  // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8): remap so that every XCD owns ONE contiguous run of
+  // (row group, column group) pairs - neighbouring column groups share their boundary cache lines in the same L2
+  // (tools/membench2.hip: 0.72 -> 0.62 ms for the row-contiguous tile I/O below).
+  int vb;
+  {
+    const int nb = (int)gridDim.x, x = blockIdx.x & 7, q = nb >> 3, rem = nb & 7;
+    vb = x * q + (x < rem ? x : rem) + ((int)blockIdx.x >> 3);
+  }
+  const int cg = vb % a.CG, rg = vb / a.CG;
   const int c0 = cg * X3_COLS, cl = wave * 32;
   const int n = a.n, B = a.B;
-  float* Gt = red + wave * (HF_ROWS * HF_KP);           // [32 cols][33] fp32 inside this wave's fold slice
+  // G as bf16 hi / lo images [32 cols][32 rows] (72-byte pitch) inside this wave's fold slice: written from the
+  // accumulator layout (column on the lane), read back with the row on the lane by transposing LDS reads
+  char* gimg_w = reinterpret_cast<char*>(red + wave * (HF_ROWS * HF_KP)) + l31 * X3_GIMG_PITCH + 8 * h;             // + 16 g  (+ X3_GIMG_BYTES: lo)
+  const char* gimg_r = reinterpret_cast<const char*>(red + wave * (HF_ROWS * HF_KP)) + (8 * h + ((lane & 15) >> 2)) * X3_GIMG_PITCH
+                       + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;                                             // + (16 s + 4 u) * pitch
   u32x4_t* wbl = reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(red + X3_RED_FLOATS) + wave * (8 * 64 * 16)) + lane;   // + 64 * ((kt*2 + s)*2 + split)
 
   // both H images start as zeros: k >= K and rows >= B never get written
@@ -557,52 +581,73 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
   const int rb0 = (int)(((int64_t)rg * a.NRB) / a.RG);
   const int rb1 = (int)(((int64_t)(rg + 1) * a.NRB) / a.RG);
   const int lane_off = 4 * h * n + l31;
-  const int lane_off_t = 4 * h * (int)a.ldt + l31;
 
-  // template / gt tile of the row block whose epilogue runs next, refilled row-register by row-register between the
-  // backward MFMAs of the current one (same scheme and the same branch-free predication as the fp32 kernel)
-  float tc[16], gcur[16];
-  auto issue_row = [&](int rb, int r) {
-    const rsrc_t gb = tile_rsrc(a.gt + ((int64_t)rb * HF_ROWS * n + (c0 + cl)));
-    const rsrc_t tb = tile_rsrc(a.templ + ((int64_t)rb * HF_ROWS * a.ldt + (c0 + cl)));
-    const int rlim = B - rb * HF_ROWS;
-    const int mcol = ((colg - n) >> 31) & ((rb - rb1) >> 31);
-    int lo = lane_off, lot = lane_off_t, h4 = 4 * h;
-    asm volatile("" : "+v"(lo), "+v"(lot), "+v"(h4));
-    const int rr = (r & 3) + 8 * (r >> 2);
-    const int inval = ~(mcol & ((rr + h4 - rlim) >> 31));
-    tc[r] = buf_load_stream(tb, (4 * (rr * (int)a.ldt + lot)) | inval);
-    gcur[r] = buf_load_stream(gb, (4 * (rr * n + lo)) | inval);
+  // template / gt tile I/O.  A workgroup's tile row is 256 columns = ONE 1-KB run of the frame matrix: wave w fetches rows
+  // 4w .. 4w+3 of the next row block with one dwordx4 per lane (lane l: columns c0 + 4l .. 4l+3; rows are only 4-byte
+  // aligned, which dword-multiple buffer loads allow) - 8 wave-wide 1-KB requests per wave and block instead of 32 requests
+  // of two misaligned 128-B segments (tools/membench2.hip: this pattern streams 1.5x faster).  At the top of the block
+  // the rows are parked in LDS, already cut into the per-wave 32-column chunks [chunk][templ | gt][32 rows][32], and every
+  // wave reads its chunk back in the MFMA accumulator layout.  A wave's chunk pair (8 KB) IS its slice of the dH fold
+  // buffer: dead while the tile values are needed, and only the owning wave overwrites it (G transpose, dH partials)
+  // before the fold barrier.  Odd chunks keep row r at position r ^ 1 so a 16-lane write group covers all 64 banks.
+  u32x4_t tq[4], gq[4];
+  const int stage_p = (lane >> 3) & 1;
+  float* stage_w = red + (lane >> 3) * 2048 + (lane & 7) * 4 + 4 * wave * 32;        // + 32 * (m ^ stage_p)  (+ 1024: gt)
+  const float* stage_r = red + wave * 2048 + l31;                                     // + 32 * (row ^ (wave & 1))
+  const int qcol_ok = ((c0 + 4 * lane) - n) >> 31;                                    // -1: this lane's first column exists
+  auto issue_q = [&](int rb, int m) {
+    const int row0 = rb * HF_ROWS;
+    const int64_t gfirst = (int64_t)row0 * n + c0, tfirst = (int64_t)row0 * a.ldt + c0;
+    int64_t grec = ((int64_t)B * n - gfirst) * 4, trec = (a.ldt ? ((int64_t)B * a.ldt - tfirst) : (int64_t)(n - c0)) * 4;
+    grec = grec < 0 ? 0 : grec > 0x7FFFFFF0 ? 0x7FFFFFF0 : grec;                      // loads past the tensors' last element return 0
+    trec = trec < 0 ? 0 : trec > 0x7FFFFFF0 ? 0x7FFFFFF0 : trec;
+    const rsrc_t gb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gt + gfirst), 0, (int)grec, 0x00020000);
+    const rsrc_t tb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.templ + tfirst), 0, (int)trec, 0x00020000);
+    const int row = 4 * wave + m;
+    int l4 = 4 * lane;
+    asm volatile("" : "+v"(l4));
+    const int ok = qcol_ok & ((rb - rb1) >> 31) & ((row0 + row - B) >> 31);
+    tq[m] = __builtin_amdgcn_raw_buffer_load_b128(tb, (4 * (row * (int)a.ldt + l4)) | ~ok, 0, X3_STREAM_LD);
+    gq[m] = __builtin_amdgcn_raw_buffer_load_b128(gb, (4 * (row * n + l4)) | ~ok, 0, X3_STREAM_LD);
   };
 #pragma unroll
-  for (int r = 0; r < 16; ++r) issue_row(rb0, r);
+  for (int m = 0; m < 4; ++m) issue_q(rb0, m);
 
   // H tile of the NEXT row block travels in registers (requested at the top of a row block, split and written to the two
-  // bf16 images at the bottom)
-  constexpr int HPT = (HF_ROWS * K + X3_THREADS - 1) / X3_THREADS;
+  // bf16 images at the bottom).  A thread owns one 2 x 2 block (rows 2rp, 2rp+1; k = 2kp, 2kp+1) and fetches it twice -
+  // with k running fastest over the lanes for the row-major image and with the row pair running fastest for the k-major
+  // image - so both images are written as packed bf16 PAIRS with 32-bit stores whose lanes walk consecutive dwords (the
+  // 16-bit stores of single elements were 4-way bank-conflicted: 0.05 ms of the kernel).
+  constexpr int KPAIRS = K / 2, HBLK = (HF_ROWS / 2) * KPAIRS;            // 400 (K = 50) / 512 (K = 64) blocks
+  static_assert(HBLK <= X3_THREADS && K % 2 == 0, "one 2x2 block of the H tile per thread");
   const rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.H), 0, B * K * 4, 0x00020000);
-  float hreg[HPT];
+  const int h_rpa = t / KPAIRS, h_kpa = t - h_rpa * KPAIRS, h_kpb = t >> 4, h_rpb = t & 15;
+  f32x2_t hra[2], hrb[2];
   auto h_request = [&](int rb) {
+    const int ok = (t < HBLK && rb < rb1) ? 0 : -1;                       // rows >= B are out of range -> 0
 #pragma unroll
-    for (int i = 0; i < HPT; ++i) {
-      const int e = t + i * X3_THREADS;
-      hreg[i] = buf_load(hres, (e < HF_ROWS * K && rb < rb1) ? (rb * HF_ROWS * K + e) * 4 : -1);     // rows >= B are out of range -> 0
+    for (int j = 0; j < 2; ++j) {
+      hra[j] = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(hres, (((rb * HF_ROWS + 2 * h_rpa + j) * K + 2 * h_kpa) * 4) | ok, 0, 0));
+      hrb[j] = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(hres, (((rb * HF_ROWS + 2 * h_rpb + j) * K + 2 * h_kpb) * 4) | ok, 0, 0));
     }
   };
   auto h_commit = [&]() {
+    if (t < HBLK) {
+      unsigned hi, lo;
 #pragma unroll
-    for (int i = 0; i < HPT; ++i) {
-      const int e = t + i * X3_THREADS;
-      if (e < HF_ROWS * K) {
-        const int row = e / K, k = e - row * K;
-        // accumulator-order position of a tile row: row = 16s + 4h' + (j&3) + 8(j>>2)  ->  p = 16s + 8h' + j
-        const int p = (row & 16) + 8 * ((row >> 2) & 1) + (row & 3) + 4 * ((row >> 3) & 1);
-        unsigned hi, lo;
-        x3_split2(hreg[i], 0.f, hi, lo);
-        *reinterpret_cast<unsigned short*>(Hrow + row * X3_HROW_PITCH + k * 2) = (unsigned short)hi;
-        *reinterpret_cast<unsigned short*>(Hrow + HF_ROWS * X3_HROW_PITCH + row * X3_HROW_PITCH + k * 2) = (unsigned short)lo;
-        *reinterpret_cast<unsigned short*>(Hcol + k * X3_HCOL_PITCH + p * 2) = (unsigned short)hi;
-        *reinterpret_cast<unsigned short*>(Hcol + HF_KP * X3_HCOL_PITCH + k * X3_HCOL_PITCH + p * 2) = (unsigned short)lo;
+      for (int j = 0; j < 2; ++j) {                     // row-major image: (k, k+1) pairs of rows 2rp + j
+        x3_split2(hra[j][0], hra[j][1], hi, lo);
+        *reinterpret_cast<unsigned*>(Hrow + (2 * h_rpa + j) * X3_HROW_PITCH + h_kpa * 4) = hi;
+        *reinterpret_cast<unsigned*>(Hrow + HF_ROWS * X3_HROW_PITCH + (2 * h_rpa + j) * X3_HROW_PITCH + h_kpa * 4) = lo;
+      }
+      // accumulator-order position of a tile row: row = 16s + 4h' + (j&3) + 8(j>>2)  ->  p = 16s + 8h' + j; p(row + 1) = p(row) + 1 for even rows
+      const int row = 2 * h_rpb;
+      const int p = (row & 16) + 8 * ((row >> 2) & 1) + (row & 3) + 4 * ((row >> 3) & 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {                     // k-major image: (row, row+1) pairs of k = 2kp + j
+        x3_split2(hrb[0][j], hrb[1][j], hi, lo);
+        *reinterpret_cast<unsigned*>(Hcol + (2 * h_kpb + j) * X3_HCOL_PITCH + p * 2) = hi;
+        *reinterpret_cast<unsigned*>(Hcol + HF_KP * X3_HCOL_PITCH + (2 * h_kpb + j) * X3_HCOL_PITCH + p * 2) = lo;
       }
     }
   };
@@ -613,8 +658,16 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
   const char* hrow_l = Hrow + l31 * X3_HROW_PITCH + 16 * h;           // forward A fragment s: + 32 s   (+ split image)
   const char* hcol_l = Hcol + l31 * X3_HCOL_PITCH + 16 * h;           // dW B fragment (s, kt): + 32 kt * pitch + 32 s
 
+#ifdef HF_STAMPS
+  unsigned long long stp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sa, sb;
+  HF_STAMP(sa);
+#define X3_PHASE(i) do { HF_STAMP(sb); stp[i] += sb - sa; sa = sb; } while (0)
+#else
+#define X3_PHASE(i) do { } while (0)
+#endif
   for (int rb = rb0; rb < rb1; ++rb) {
     __syncthreads();                                    // H images of this row block complete; fold buffer free
+    X3_PHASE(0);                                        // 0: waiting at the top barrier
     h_request(rb + 1);
 
     // ---- forward tile: acc[row][col] = sum_k H[row][k] W[col][k] ----
@@ -626,6 +679,30 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
       const u32x4_t ah = *reinterpret_cast<const u32x4_t*>(hrow_l + 32 * s);
       const u32x4_t al = *reinterpret_cast<const u32x4_t*>(hrow_l + HF_ROWS * X3_HROW_PITCH + 32 * s);
       acc = x3_mac(ah, al, wf_h[s], wf_l[s], acc);
+    }
+    X3_PHASE(1);                                        // 1: H request + forward products
+    // ---- this block's template / gt rows: registers -> LDS chunks -> accumulator layout ----
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      *reinterpret_cast<u32x4_t*>(stage_w + 32 * (m ^ stage_p)) = tq[m];
+      *reinterpret_cast<u32x4_t*>(stage_w + 1024 + 32 * (m ^ stage_p)) = gq[m];
+    }
+#ifdef HF_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    X3_PHASE(2);                                        // 2: tile rows arrive + staging stores
+#endif
+    __syncthreads();
+    X3_PHASE(3);                                        // 3: staging barrier
+#if X3_ISSUE_AT == 1
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_q(rb + 1, q);
+#endif
+    float tc[16], gcur[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pos = ((r & 3) + 8 * (r >> 2) + 4 * h) ^ (wave & 1);
+      tc[r] = stage_r[32 * pos];
+      gcur[r] = stage_r[1024 + 32 * pos];
     }
     // ---- epilogue: pred, loss partials, G (in place of acc), all fp32 ----
     float rec = 0.f, vel = 0.f;
@@ -659,23 +736,24 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
         acc[r] = g0;
         acc[r + 1] = g1;
         gsum += g0 + g1;
-#ifdef X3_EARLY_PREFETCH  // measured SLOWER (1.02 vs 0.95 ms): refilling the two row-registers right here, next to the pred stores
-        issue_row(rb + 1, r);
-        issue_row(rb + 1, r + 1);
-#endif
       }
       db_acc += gsum;
     }
     rec_d += (double)rec;
     vel_d += (double)vel;
+    X3_PHASE(4);                                        // 4: chunk read-back + epilogue (pred stores, loss, G)
 
+#if X3_ISSUE_AT == 2
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_q(rb + 1, q);
+#endif
 #ifdef X3_ABL_NODW
     asm volatile("" :: "v"(acc[0]), "v"(acc[5]), "v"(acc[10]), "v"(acc[15]));
-#ifndef X3_EARLY_PREFETCH
+#if X3_ISSUE_AT == 0
 #pragma unroll
-    for (int q = 0; q < 16; ++q) issue_row(rb + 1, q);
+    for (int q = 0; q < 4; ++q) issue_q(rb + 1, q);
 #endif
-#else
+#endif
     // ---- G as bf16 fragments, column on the lane: k-step s of dW takes accumulator registers 8s .. 8s+7 ----
     u32x4_t gc_h[2], gc_l[2];
 #pragma unroll
@@ -686,11 +764,14 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
         x3_split2(acc[8 * s + j], acc[8 * s + j + 1], hi, lo);
         gc_h[s][j >> 1] = hi; gc_l[s][j >> 1] = lo;
       }
-#endif
 #ifndef X3_ABL_NODH
-    // the G transpose tile (for dH) is written now so its reads can overlap the dW products
+    // the same packed pairs are the G images dH reads back transposed: registers 4g .. 4g+3 = rows 8g + 4h .. + 3 of this
+    // lane's column = 8 contiguous bytes (written now so the reads can overlap the dW products)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Gt[l31 * HF_HP + 4 * h + (r & 3) + 8 * (r >> 2)] = acc[r];
+    for (int g = 0; g < 4; ++g) {
+      *reinterpret_cast<u32x2_t*>(gimg_w + 16 * g) = u32x2_t{gc_h[g >> 1][2 * (g & 1)], gc_h[g >> 1][2 * (g & 1) + 1]};
+      *reinterpret_cast<u32x2_t*>(gimg_w + X3_GIMG_BYTES + 16 * g) = u32x2_t{gc_l[g >> 1][2 * (g & 1)], gc_l[g >> 1][2 * (g & 1) + 1]};
+    }
 #endif
 #ifndef X3_ABL_NODW
 
@@ -702,13 +783,13 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
         const u32x4_t bh = *reinterpret_cast<const u32x4_t*>(hcol_l + 32 * kt * X3_HCOL_PITCH + 32 * s);
         const u32x4_t bl = *reinterpret_cast<const u32x4_t*>(hcol_l + HF_KP * X3_HCOL_PITCH + 32 * kt * X3_HCOL_PITCH + 32 * s);
         dW[kt] = x3_mac(gc_h[s], gc_l[s], bh, bl, dW[kt]);
-#ifndef X3_EARLY_PREFETCH
-#pragma unroll
-        for (int q = 0; q < 4; ++q) issue_row(rb + 1, (2 * s + kt) * 4 + q);
+#if X3_ISSUE_AT == 0
+        issue_q(rb + 1, 2 * s + kt);
 #endif
       }
 #endif
 
+    X3_PHASE(5);                                        // 5: G split / transpose store + dW products (+ next tile requests)
     // ---- dH[row][k] += sum_col G[row][col] W[col][k]: G with the row on the lane, through the wave's LDS tile ----
     f32x16 dH[2];
 #pragma unroll
@@ -718,13 +799,15 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
 #ifndef X3_ABL_NODH
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
+      // A fragment of k-step s: G[row = lane & 31][cols 16s + 8h .. + 7]: two transposing reads of 4 columns x 16 rows per
+      // 16-lane group (ds_read_b64_tr_b16: lane 4q + p supplies the address of column q, rows 4p .. 4p+3)
       u32x4_t gh, gl;
 #pragma unroll
-      for (int j = 0; j < 8; j += 2) {
-        const float v0 = Gt[(16 * s + 8 * h + j) * HF_HP + l31], v1 = Gt[(16 * s + 8 * h + j + 1) * HF_HP + l31];
-        unsigned hi, lo;
-        x3_split2(v0, v1, hi, lo);
-        gh[j >> 1] = hi; gl[j >> 1] = lo;
+      for (int u = 0; u < 2; ++u) {
+        const u32x2_t xh = x3_tr_read(gimg_r + (16 * s + 4 * u) * X3_GIMG_PITCH);
+        const u32x2_t xl = x3_tr_read(gimg_r + X3_GIMG_BYTES + (16 * s + 4 * u) * X3_GIMG_PITCH);
+        gh[2 * u] = xh[0]; gh[2 * u + 1] = xh[1];
+        gl[2 * u] = xl[0]; gl[2 * u + 1] = xl[1];
       }
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) dH[kt] = x3_mac(gh, gl, wbl[64 * ((kt * 2 + s) * 2 + 0)], wbl[64 * ((kt * 2 + s) * 2 + 1)], dH[kt]);
@@ -738,27 +821,43 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) red[(wave * 2048 + 4 * h * 64 + kt * 32 + l31) + ((r & 3) + 8 * (r >> 2)) * 64] = dH[kt][r];
+    X3_PHASE(6);                                        // 6: dH products + partial stores
     __syncthreads();
+    {
+      // one 16-byte piece per thread; slab rows are K4 = K rounded up to 4 floats, back to back, so the 32 rows of a block are
+      // ONE contiguous run and every cache line of the slab is written whole (256-B-pitch rows left a 16-byte tail in a
+      // 32-byte sector of every row)
+      constexpr int K4 = (K + 3) / 4;
+      const int frow = t / K4, fk = 4 * (t - frow * K4);
+      if (t < HF_ROWS * K4) {
+        const int e = frow * HF_KP + fk;
+        f32x4 v = *reinterpret_cast<const f32x4*>(red + e);
 #pragma unroll
-    for (int i = 0; i < 2048 / X3_THREADS; ++i) {
-      const int e = t + i * X3_THREADS;                 // 0..2047: row = e/64, k = e%64
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < X3_NW; ++w) v += red[w * 2048 + e];
-      const int row = rb * HF_ROWS + (e >> 6);
-      if (row < B && (e & 63) < ((K + 3) & ~3)) a.dH_slab[((int64_t)cg * B + row) * HF_KP + (e & 63)] = v;
+        for (int w = 1; w < X3_NW; ++w) v += *reinterpret_cast<const f32x4*>(red + w * 2048 + e);
+        const int row = rb * HF_ROWS + frow;
+#ifndef X3_ABL_NOSLAB
+        if (row < B) *reinterpret_cast<f32x4*>(a.dH_slab + ((int64_t)cg * B + row) * (4 * K4) + fk) = v;
+#else
+        asm volatile("" :: "v"(v));
+#endif
+      }
     }
 #else
     asm volatile("" :: "v"(dH[0][0]), "v"(dH[1][7]));
     __syncthreads();
 #endif
+    X3_PHASE(7);                                        // 7: fold barrier + fold
 #ifndef X3_ABL_NOHC
     h_commit();                                         // every wave passed a barrier after its last read of the H images
 #else
-    asm volatile("" :: "v"(hreg[0]), "v"(hreg[HPT - 1]));
+    asm volatile("" :: "v"(hra[0][0]), "v"(hra[1][1]), "v"(hrb[0][0]), "v"(hrb[1][1]));
 #endif
   }
 
+#ifdef HF_STAMPS
+  if (lane == 0 && a.dbg)
+    for (int i = 0; i < 8; ++i) a.dbg[((int64_t)blockIdx.x * X3_NW + wave) * 8 + i] = stp[i];
+#endif
   // ---- workgroup epilogue: dW / dbias slabs of this row group, loss partials ----
   const int64_t ncols_pad = (int64_t)a.CG * X3_COLS;
 #pragma unroll
@@ -794,17 +893,17 @@ struct HeadFoldArgs {
   float* dH; float* dW; float* db; float* out3;
   int64_t sH, sW, sb;                 // slab strides (floats)
   int64_t rowsH, rowsW, lenb;
-  int nslabH, nslabW, nparts, K;
+  int nslabH, nslabW, nparts, K, p4H;
   int nH, nW, nb;                     // workgroup counts of the three ranges
   double inv_rec, inv_vel;
   float k_rec, k_vel;
 };
 
 __device__ __forceinline__ void fold_rows(const float* __restrict__ slab, int nslabs, int64_t sstride, int64_t rows, int K,
-                                          float* __restrict__ out, int64_t blk) {
-  const int64_t q = blk * 256 + threadIdx.x;               // float4 index: row = q / 16, k = 4 * (q % 16)
-  const int64_t row = q >> 4;
-  const int k = (int)(q & 15) * 4;
+                                          float* __restrict__ out, int64_t blk, int p4) {
+  const int64_t q = blk * 256 + threadIdx.x;               // float4 index: row = q / p4, k = 4 * (q % p4); p4 = slab row pitch / 4
+  const int64_t row = q / p4;
+  const int k = (int)(q - row * p4) * 4;
   if (row >= rows || k >= K) return;
   const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(slab) + q;
   const int64_t st4 = sstride >> 2;
@@ -843,9 +942,9 @@ __device__ __forceinline__ void fold_rows(const float* __restrict__ slab, int ns
 __global__ __launch_bounds__(256) void head_fold_kernel(const HeadFoldArgs f) {
   const int b = blockIdx.x;
   if (b < f.nH) {
-    fold_rows(f.dH_slab, f.nslabH, f.sH, f.rowsH, f.K, f.dH, b);
+    fold_rows(f.dH_slab, f.nslabH, f.sH, f.rowsH, f.K, f.dH, b, f.p4H);
   } else if (b < f.nH + f.nW) {
-    fold_rows(f.dW_slab, f.nslabW, f.sW, f.rowsW, f.K, f.dW, b - f.nH);
+    fold_rows(f.dW_slab, f.nslabW, f.sW, f.rowsW, f.K, f.dW, b - f.nH, HF_KP / 4);
   } else if (b < f.nH + f.nW + f.nb) {
     const int64_t i = (int64_t)(b - f.nH - f.nW) * 256 + threadIdx.x;
     if (i < f.lenb) {
@@ -949,6 +1048,7 @@ static int head_cfg(int64_t K) {
   // fp32 variants measured on MI355X (B = 19200, K = 50, kernel + slab folds): cfg4 1.55 ms, cfg3 1.61, cfg1 1.71-1.79, cfg0 2.0+, cfg2 2.4
   return env;
 }
+static bool cfg_is_x3(int64_t K) { return head_cfg(K) == 5; }
 static HeadPlan head_plan_for(int64_t B, int64_t n, int64_t K) {
   const int cfg = head_cfg(K);
   return cfg == 2 ? head_plan(B, n, 256, (K == 64) ? 256 : 512) : cfg == 3 ? head_plan(B, n, 384, 256)
@@ -1011,6 +1111,7 @@ extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias,
   a.loss_part = (double*)(w8 + p.off_loss);
   a.dbg = (unsigned long long*)(w8 + p.off_dbg);
   a.ldt = template_rows == 1 ? 0 : n;
+  a.ldh = cfg_is_x3(K) ? (int)((K + 3) & ~(int64_t)3) : HF_KP;
   a.B = (int)B; a.Bloss = (int)Bloss; a.n = (int)n; a.CG = p.CG; a.RG = p.RG; a.NRB = p.NRB;
   const double V = (double)(n / 3);
   a.cr = (float)(2.0 * k_rec / ((double)Bloss * V));
@@ -1028,10 +1129,10 @@ extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias,
     HeadFoldArgs f;
     f.dH_slab = a.dH_slab; f.dW_slab = a.dW_slab; f.db_slab = a.db_slab; f.loss_part = a.loss_part;
     f.dH = dH; f.dW = dW; f.db = dbias; f.out3 = out3;
-    f.sH = (int64_t)B * HF_KP; f.sW = ncols_pad * HF_KP; f.sb = ncols_pad;
+    f.sH = (int64_t)B * a.ldh; f.sW = ncols_pad * HF_KP; f.sb = ncols_pad; f.p4H = a.ldh / 4;
     f.rowsH = B; f.rowsW = n; f.lenb = n;
     f.nslabH = p.CG; f.nslabW = p.RG; f.nparts = p.CG * p.RG; f.K = (int)K;
-    f.nH = (int)cdiv(B * 16, 256); f.nW = (int)cdiv(n * 16, 256); f.nb = (int)cdiv(n, 256);
+    f.nH = (int)cdiv(B * f.p4H, 256); f.nW = (int)cdiv(n * 16, 256); f.nb = (int)cdiv(n, 256);
     f.inv_rec = 1.0 / ((double)Bloss * V); f.inv_vel = 1.0 / ((double)(Bloss / 2) * V);
     f.k_rec = k_rec; f.k_vel = k_vel;
     hipLaunchKernelGGL(head_fold_kernel, dim3((unsigned)(f.nH + f.nW + f.nb + 1)), dim3(256), 0, s, f);

@@ -280,6 +280,8 @@ def test_head_fused_vs_contract(B_, n, K, trows, Bloss):
         outs.append([t.cpu() for t in (pred, out3, dH, dW, db)])
     (p_h, o_h, dH_h, dW_h, db_h), (p_e, o_e, dH_e, dW_e, db_e) = outs
     assert rel_l2(p_h, p_e) < 2e-6
+    # the tile rows are fetched as 16-byte pieces that may straddle the row end: the very last elements must still be exact-class
+    assert torch.allclose(p_h[-1, -8:], p_e[-1, -8:], rtol=1e-4, atol=1e-4) and torch.allclose(p_h[:, -1], p_e[:, -1], rtol=1e-4, atol=1e-4)
     assert torch.allclose(o_h, o_e, rtol=2e-5, atol=0)
     assert rel_l2(dH_h, dH_e) < 2e-5
     assert rel_l2(dW_h, dW_e) < 2e-5

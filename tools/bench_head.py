@@ -27,4 +27,11 @@ torch.cuda.synchronize()
 ms = [a.elapsed_time(b) for a, b in be.prof["head_fused"]]
 ms.sort()
 byts = B * (3 * n * 4 + 2 * K * 4)
+be.profile_head(True)
+for _ in range(iters):
+    be.head_fused(H, W, bias, t, B, gt, B, B, n, K, 1.0, 10.0, pred, out3, dH, dW, db)
+torch.cuda.synchronize()
+kms, nl = be.profile_head_ms()
+be.profile_head(False)
+print(f"head kernel alone (in-library HIP events, {nl} launches): {kms:.4f} ms = {B * (3 * n * 4 + 2 * K * 4) / kms / 1e6:.0f} GB/s algorithmic")
 print(f"head_fused B={B} K={K}: median {ms[len(ms)//2]:.4f} ms  min {ms[0]:.4f} ms  -> {byts / ms[len(ms)//2] / 1e6:.1f} GB/s algorithmic (incl. reduce kernels)")

@@ -181,12 +181,14 @@ class TrainStep:
                 self._side.wait_stream(torch.cuda.current_stream())
                 return loss
             torch.cuda.synchronize()
+            # thread_local: the capture must not be invalidated by HIP calls of other threads of this process (RCCL's
+            # watchdog polls events while the ranks are between collectives)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self._side):
+            with torch.cuda.graph(g, stream=self._side, capture_error_mode="thread_local"):
                 out = self._direct(ins, 1) if self.overlap else self._fwd_bwd(*ins)
             if self.overlap:                                    # second graph: trunk backward, same memory pool
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, stream=self._side, pool=g.pool()):
+                with torch.cuda.graph(g2, stream=self._side, pool=g.pool(), capture_error_mode="thread_local"):
                     self._direct(ins, 2)
                 self._graph2 = g2
             self._graph, self._graph_inputs, self._graph_out = g, ins, out

@@ -10,7 +10,7 @@ import torch
 import a2f_amd  # noqa: F401
 from a2f_amd import ops
 
-B = int(os.environ.get("HB", 19200)); n = 15069; K = int(os.environ.get("HK", 50)); iters = int(os.environ.get("HI", 20))
+B = int(os.environ.get("HB", 19200)); n = int(os.environ.get("HN", 15069)); K = int(os.environ.get("HK", 50)); iters = int(os.environ.get("HI", 20))
 dev = "cuda"
 be = ops.backend()
 H = torch.randn(B, K, device=dev); W = torch.randn(n, K, device=dev) * 0.1; bias = torch.randn(n, device=dev)

@@ -22,7 +22,7 @@ ws = torch.zeros(nb // 4, dtype=torch.float32, device=dev)
 for _ in range(3):
     be.head_fused(H, W, bias, t, B, gt, B, B, n, K, 1.0, 10.0, pred, out3, dH, dW, db, ws=ws)
 torch.cuda.synchronize()
-nwg = 236
+nwg = 256
 raw = ws.view(torch.int64)[-(nwg * 8 * 8):].view(nwg, 8, 8).cpu().double()
 tot = raw.sum(-1)
 names = ["0 wait at the top barrier", "1 H request + forward products", "2 tile rows arrive + staging stores", "3 staging barrier",

@@ -74,6 +74,7 @@ struct TrunkArgs {
   const float* fw[3]; const float* fb[3];                  // decoder.{0,1,3}
   float* a0; float* a1; float* a2; float* a3; float* cat; float* z1; float* z2; float* h3;
   int B, no, NB;
+  int T;                                                   // 0: x holds (B,29,16) windows; > 0: x holds (B/T, T, 29) per-frame features
 };
 
 // B-operand fragments of one 32-column weight tile, kept in REGISTERS for the whole (persistent) kernel:
@@ -136,14 +137,32 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
   static_assert(XR * VT_THREADS == VT_F * 464, "x tile must divide evenly");
   float px[XR];
   float poh;                                               // one_hot[f0 + t/8][t%8] of the same block
-  const vt_rsrc_t rx = vt_rsrc(a.x, B, 464), roh = vt_rsrc(a.one_hot, B, a.no);
+  // sequence mode (a.T > 0): the input is the per-frame feature tensor (S, T, 29) and the 16-frame window
+  // of frame F = s T + t is the CONTIGUOUS run of 464 floats starting at row F - 8, rows outside [0, T) of the frame's own
+  // sequence reading as zeros (= feature_windows() / the zero-padded slices of vocaset.py) - 116 B per frame from HBM
+  // instead of 1 856 B, and no window tensor to build on the host
+  const vt_rsrc_t rx = vt_rsrc(a.x, B, a.T ? 29 : 464), roh = vt_rsrc(a.one_hot, B, a.no);
   const vt_rsrc_t ra0 = vt_rsrc(a.a0, B, 592), ra1 = vt_rsrc(a.a1, B, 256), ra2 = vt_rsrc(a.a2, B, 128), ra3 = vt_rsrc(a.a3, B, 128);
   const vt_rsrc_t rcat = vt_rsrc(a.cat, B, 72), rz1 = vt_rsrc(a.z1, B, 72), rz2 = vt_rsrc(a.z2, B, 128), rh3 = vt_rsrc(a.h3, B, 50);
   auto fetch_x = [&](int blk) {
-    int voff = blk * VT_F * 464 + t;
-    asm volatile("" : "+v"(voff));                         // keep ONE address register, the rest are immediates / adds
+    if (a.T == 0) {
+      int voff = blk * VT_F * 464 + t;
+      asm volatile("" : "+v"(voff));                       // keep ONE address register, the rest are immediates / adds
 #pragma unroll
-    for (int u = 0; u < XR; ++u) px[u] = vt_ld(rx, voff + u * VT_THREADS);
+      for (int u = 0; u < XR; ++u) px[u] = vt_ld(rx, voff + u * VT_THREADS);
+    } else {
+      const int T = a.T, tf = (blk * VT_F) % T;            // frame index of the block's first frame inside its sequence
+      int to = t;
+      asm volatile("" : "+v"(to));
+#pragma unroll
+      for (int u = 0; u < XR; ++u) {
+        const int e = to + u * VT_THREADS, f = e / 464, r = e - f * 464, w = r / 29;
+        int tt = tf + f;                                   // T >= 32 = VT_F: a block crosses at most one sequence boundary
+        tt = tt >= T ? tt - T : tt;
+        const bool ok = (unsigned)(tt - 8 + w) < (unsigned)T;
+        px[u] = vt_ld(rx, ok ? (blk * VT_F + f - 8) * 29 + r : -1);
+      }
+    }
     poh = vt_ld(roh, (blk * VT_F + (t >> 3)) * a.no + (t & 7));
   };
   if ((int)blockIdx.x < a.NB) fetch_x(blockIdx.x);
@@ -157,10 +176,18 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
     {
       int to = t;
       asm volatile("" : "+v"(to));                         // recompute the 58 scatter addresses per block instead of keeping them live
+      if (a.T == 0) {
 #pragma unroll
-      for (int u = 0; u < XR; ++u) {
-        const int e = to + u * VT_THREADS, f = e / 464, r = e - f * 464, c = r >> 4, hh = r & 15;
-        R0[f * VT_S0 + (1 + hh) * 37 + c] = px[u];
+        for (int u = 0; u < XR; ++u) {
+          const int e = to + u * VT_THREADS, f = e / 464, r = e - f * 464, c = r >> 4, hh = r & 15;
+          R0[f * VT_S0 + (1 + hh) * 37 + c] = px[u];
+        }
+      } else {                                             // feature rows are already channels-last: r = 29 w + c
+#pragma unroll
+        for (int u = 0; u < XR; ++u) {
+          const int e = to + u * VT_THREADS, f = e / 464, r = e - f * 464, w = r / 29, c = r - 29 * w;
+          R0[f * VT_S0 + (1 + w) * 37 + c] = px[u];
+        }
       }
     }
     // one-hot channels (voca.py:40-45 repeat/view quirk): window row h carries one_hot[f][h % 8] in its 8 trailing
@@ -533,9 +560,9 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
 
 }  // namespace a2f
 
-extern "C" int a2f_voca_trunk_fwd(const float* x, const float* one_hot, int64_t B, int64_t n_onehot, const float* const* conv_w,
-                                  const float* const* conv_b, const float* const* fc_w, const float* const* fc_b, float* a0, float* a1,
-                                  float* a2, float* a3, float* cat72, float* z1, float* z2, float* h3, a2f_stream_t stream) {
+static int voca_trunk_fwd_impl(const float* x, int64_t seq_len, const float* one_hot, int64_t B, int64_t n_onehot, const float* const* conv_w,
+                               const float* const* conv_b, const float* const* fc_w, const float* const* fc_b, float* a0, float* a1,
+                               float* a2, float* a3, float* cat72, float* z1, float* z2, float* h3, a2f_stream_t stream) {
   using namespace a2f;
   A2F_CHECK_ARG(x && one_hot && conv_w && conv_b && fc_w && fc_b && a0 && a1 && a2 && a3 && cat72 && z1 && z2 && h3, "voca_trunk_fwd: null pointer");
   A2F_CHECK_ARG(B > 0 && B <= VT_MAX_FRAMES && n_onehot >= 8 && n_onehot <= 512, "voca_trunk_fwd: B=%lld (1..%d frames per call) n_onehot=%lld", (long long)B, VT_MAX_FRAMES, (long long)n_onehot);
@@ -544,7 +571,7 @@ extern "C" int a2f_voca_trunk_fwd(const float* x, const float* one_hot, int64_t 
   for (int i = 0; i < 4; ++i) { A2F_CHECK_ARG(conv_w[i] && conv_b[i], "voca_trunk_fwd: null conv parameter"); a.cw[i] = conv_w[i]; a.cb[i] = conv_b[i]; }
   for (int i = 0; i < 3; ++i) { A2F_CHECK_ARG(fc_w[i] && fc_b[i], "voca_trunk_fwd: null decoder parameter"); a.fw[i] = fc_w[i]; a.fb[i] = fc_b[i]; }
   a.a0 = a0; a.a1 = a1; a.a2 = a2; a.a3 = a3; a.cat = cat72; a.z1 = z1; a.z2 = z2; a.h3 = h3;
-  a.B = (int)B; a.no = (int)n_onehot; a.NB = (int)cdiv(B, VT_F);
+  a.B = (int)B; a.no = (int)n_onehot; a.NB = (int)cdiv(B, VT_F); a.T = (int)seq_len;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&voca_trunk_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VT_LDS_BYTES);
@@ -555,6 +582,21 @@ extern "C" int a2f_voca_trunk_fwd(const float* x, const float* one_hot, int64_t 
   hipLaunchKernelGGL(voca_trunk_fwd_kernel, dim3(grid), dim3(VT_THREADS), VT_LDS_BYTES, (hipStream_t)stream, a);
   A2F_CHECK_LAUNCH("voca_trunk_fwd");
   return A2F_OK;
+}
+
+extern "C" int a2f_voca_trunk_fwd(const float* x, const float* one_hot, int64_t B, int64_t n_onehot, const float* const* conv_w,
+                                  const float* const* conv_b, const float* const* fc_w, const float* const* fc_b, float* a0, float* a1,
+                                  float* a2, float* a3, float* cat72, float* z1, float* z2, float* h3, a2f_stream_t stream) {
+  return voca_trunk_fwd_impl(x, 0, one_hot, B, n_onehot, conv_w, conv_b, fc_w, fc_b, a0, a1, a2, a3, cat72, z1, z2, h3, stream);
+}
+
+extern "C" int a2f_voca_trunk_fwd_seq(const float* feats, int64_t n_seq, int64_t seq_len, const float* one_hot, int64_t n_onehot,
+                                      const float* const* conv_w, const float* const* conv_b, const float* const* fc_w,
+                                      const float* const* fc_b, float* a0, float* a1, float* a2, float* a3, float* cat72, float* z1,
+                                      float* z2, float* h3, a2f_stream_t stream) {
+  A2F_CHECK_ARG(n_seq > 0 && seq_len >= 32 && n_seq * seq_len <= a2f::VT_MAX_FRAMES,
+                "voca_trunk_fwd_seq: n_seq=%lld seq_len=%lld (sequences of >= 32 frames, <= %d frames per call)", (long long)n_seq, (long long)seq_len, a2f::VT_MAX_FRAMES);
+  return voca_trunk_fwd_impl(feats, seq_len, one_hot, n_seq * seq_len, n_onehot, conv_w, conv_b, fc_w, fc_b, a0, a1, a2, a3, cat72, z1, z2, h3, stream);
 }
 
 extern "C" int a2f_voca_trunk_bwd_data(const float* dh3, const float* z2, const float* cat72, const float* a3, const float* a2,

@@ -88,23 +88,44 @@ class HeadFn(torch.autograd.Function):
 VOCA_CONVS = ((37, 32, 8), (32, 32, 4), (32, 64, 2), (64, 64, 1))      # (Cin, Cout, positions out); input has 16 positions
 
 
+def voca_is_features(x) -> bool:
+    """True when ``x`` is the per-frame feature tensor (S, T, 29) rather than windows (B, 29, 16): the trunk then builds
+    the 16-frame windows itself."""
+    return x.dim() == 3 and x.shape[-1] == 29          # windows are (B, 29, 16): last dimension 16
+
+
+def voca_frames(x) -> int:
+    return x.shape[0] * x.shape[1] if voca_is_features(x) else x.shape[0]
+
+
 def voca_trunk_fwd(be, x, one_hot, params):
-    """x (B,29,16), one_hot (B,>=8), params = 8 conv tensors + 6 decoder tensors -> (h3 (B,50), saved tuple).
+    """x (B,29,16) windows - or (S,T,29) per-frame features, B = S*T, windows built on chip - one_hot (B,>=8),
+    params = 8 conv tensors + 6 decoder tensors -> (h3 (B,50), saved tuple).
 
     One fused launch (csrc/voca_trunk.hip): the activations of a 32-frame block stay in LDS through all seven layers.
     ``layerwise=True`` in ``voca_trunk_fwd_layerwise`` keeps the per-layer implicit-GEMM sequence (used by tests to
     cross-check the fused kernel)."""
+    feats = voca_is_features(x)
     if not hasattr(be, "voca_trunk_fwd"):
+        if feats:
+            from .data import feature_windows
+            x = feature_windows(x)
         return voca_trunk_fwd_layerwise(be, x, one_hot, params)
     cw = [_f32c(p) for p in params[0:8]]
     fw0, fb0, fw1, fb1, fw3, fb3 = (_f32c(p) for p in params[8:14])
-    B = x.shape[0]
+    B = voca_frames(x)
+    if one_hot.shape[0] != B:
+        raise ValueError(f"one_hot has {one_hot.shape[0]} rows for {B} frames")
     dev = x.device
     new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
     xc, oh = _f32c(x), _f32c(one_hot)
     a0, a1, a2, a3 = new(B, 16, 37), new(B, 8, 32), new(B, 4, 32), new(B, 2, 64)
     cat, z1, z2, h3 = new(B, 72), new(B, 72), new(B, 128), new(B, 50)
-    be.voca_trunk_fwd(xc, oh, B, oh.shape[1], cw[0::2], cw[1::2], [fw0, fw1, fw3], [fb0, fb1, fb3], a0, a1, a2, a3, cat, z1, z2, h3)
+    if feats:
+        be.voca_trunk_fwd_seq(xc, x.shape[0], x.shape[1], oh, oh.shape[1], cw[0::2], cw[1::2], [fw0, fw1, fw3], [fb0, fb1, fb3],
+                              a0, a1, a2, a3, cat, z1, z2, h3)
+    else:
+        be.voca_trunk_fwd(xc, oh, B, oh.shape[1], cw[0::2], cw[1::2], [fw0, fw1, fw3], [fb0, fb1, fb3], a0, a1, a2, a3, cat, z1, z2, h3)
     return h3, (a0, a1, a2, a3, cat, z1, z2, fw0, fw1, fw3, cw[0], cw[2], cw[4], cw[6])
 
 

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..functional import HeadFn, HeadLossFusedFn, VocaTrunkFn, VOCA_CONVS, voca_trunk_bwd, voca_trunk_fwd
+from ..functional import HeadFn, HeadLossFusedFn, VocaTrunkFn, VOCA_CONVS, voca_frames, voca_trunk_bwd, voca_trunk_fwd
 
 _FC = ((72, 72), (72, 128), None, (128, 50))        # decoder slots 0,1,(2 = Tanh),3; slot 4 is the vertex head
 
@@ -38,11 +38,13 @@ class Voca(nn.Module):
         return ps
 
     def trunk(self, x, one_hot):
-        """(B,29,16),(B,n_onehot) -> 50-wide bottleneck (B,50)."""
+        """(B,29,16),(B,n_onehot) -> 50-wide bottleneck (B,50).  Extension: ``x`` may be the per-frame
+        feature tensor (S,T,29) of S sequences; the 16-frame windows (vocaset.py zero-padded slices) are then built inside
+        the trunk kernel and B = S*T."""
         return VocaTrunkFn.apply(x, one_hot, *self._trunk_params())
 
     def forward(self, x, one_hot, template, **kwargs):
-        bs = x.size(0)
+        bs = voca_frames(x)
         h3 = self.trunk(x, one_hot)
         pred = HeadFn.apply(h3, self.decoder[4].weight, self.decoder[4].bias, template.reshape(bs, -1))
         return pred.view(bs, -1, 3)
@@ -56,7 +58,7 @@ class Voca(nn.Module):
         Returns (pred (B,V,3) detached, {"loss","rec_loss","vel_loss"}); only "loss" carries gradient.  Numerically the
         same function as ``VocaLoss(k_rec,k_vel)(self(x, one_hot, template), gt)``.
         """
-        bs = x.size(0)
+        bs = voca_frames(x)
         if bs % 2 != 0:
             raise RuntimeError(f"VocaLoss pairs consecutive frames (loss.py:33-35): batch {bs} must be even")
         h3 = self.trunk(x, one_hot)
@@ -81,7 +83,7 @@ class Voca(nn.Module):
             self._direct_state = None
             voca_trunk_bwd(be, saved, dH, out=[p.grad for p in tp])
             return ret
-        bs = x.size(0)
+        bs = voca_frames(x)
         if bs % 2 != 0:
             raise RuntimeError(f"VocaLoss pairs consecutive frames (loss.py:33-35): batch {bs} must be even")
         head_w, head_b = self.decoder[4].weight, self.decoder[4].bias

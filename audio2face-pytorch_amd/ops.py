@@ -181,6 +181,13 @@ class HipBackend:
                                                _ptr(a0), _ptr(a1), _ptr(a2), _ptr(a3), _ptr(cat72), _ptr(z1), _ptr(z2), _ptr(h3),
                                                self._stream(x)), "a2f_voca_trunk_fwd")
 
+    def voca_trunk_fwd_seq(self, feats, n_seq, seq_len, one_hot, n_onehot, conv_w, conv_b, fc_w, fc_b, a0, a1, a2, a3, cat72, z1, z2, h3):
+        _chk(feats, one_hot, *conv_w, *conv_b, *fc_w, *fc_b, a0, a1, a2, a3, cat72, z1, z2, h3)
+        arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        _lib.check(self.lib.a2f_voca_trunk_fwd_seq(_ptr(feats), n_seq, seq_len, _ptr(one_hot), n_onehot, arr(conv_w), arr(conv_b), arr(fc_w),
+                                                   arr(fc_b), _ptr(a0), _ptr(a1), _ptr(a2), _ptr(a3), _ptr(cat72), _ptr(z1), _ptr(z2),
+                                                   _ptr(h3), self._stream(feats)), "a2f_voca_trunk_fwd_seq")
+
     def voca_trunk_bwd_data(self, dh3, z2, cat, a3, a2, a1, fw3, fw1, fw0, cw4, cw3, cw2, B, g_z2, g_z1, g_c4, g_c3, g_c2, g_c1):
         ts = (dh3, z2, cat, a3, a2, a1, fw3, fw1, fw0, cw4, cw3, cw2)
         outs = (g_z2, g_z1, g_c4, g_c3, g_c2, g_c1)

@@ -46,7 +46,7 @@ ALGO_BYTES_PER_FRAME = {
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
-def make_voca_batch(n_seq: int, n_frames: int, rank: int, device):
+def make_voca_batch(n_seq: int, n_frames: int, rank: int, device, features: bool = False):
     """C2 of SURVEY §8(d): features (n_seq, n_frames, 29) ~ N(0,1) -> 16-frame windows (zero-padded ends), one subject
     per sequence, per-subject template ~ N(0,5), gt = template + N(0,0.5) (already x100-scaled units)."""
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -63,7 +63,7 @@ def make_voca_batch(n_seq: int, n_frames: int, rank: int, device):
     templ = templates.to(device)[subj.to(device)].repeat_interleave(n_frames, 0).contiguous()     # (B,5023,3)
     gg = torch.Generator(device=device).manual_seed(4321 + rank)
     gt = templ + torch.randn(B, 5023, 3, generator=gg, device=device) * 0.5
-    return x, one_hot, gt, templ
+    return (feats.to(device) if features else x), one_hot, gt, templ
 
 
 def cpu_baseline_voca(seconds: float = 12.0, B: int = 2048):
@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--workload", default="voca", choices=["voca"])
     ap.add_argument("--seqs", type=int, default=32)
     ap.add_argument("--frames", type=int, default=600)
+    ap.add_argument("--input", default="windows", choices=["windows", "features"],
+                    help="windows: x = (B,29,16) as the reference's Voca.forward takes it (default, the headline); features: x = (S,T,29), "
+                         "the 16-frame windows are built inside the trunk kernel (SURVEY §8(f) N4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the ~90 kernels of a step eagerly instead of replaying a hipGraph")
@@ -141,8 +144,8 @@ def main():
     torch.manual_seed(1234)                                  # identical initial weights on every rank
     model = a2f_amd.Voca(n_verts=NV3, n_onehot=12).to(device)
     step = TrainStep(model, a2f_amd.VocaLoss(), lr=1e-4, use_graph=not args.no_graph)
-    x, one_hot, gt, templ = make_voca_batch(args.seqs, args.frames, rank, device)
-    B = x.shape[0]
+    x, one_hot, gt, templ = make_voca_batch(args.seqs, args.frames, rank, device, features=args.input == "features")
+    B = one_hot.shape[0]
 
     def barrier():
         if world > 1:
@@ -173,7 +176,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (head matrix products: bf16x3 split operands, f32 accumulate)", "data": "synthetic",
         "config": {"workload": f"VOCA train step (fwd+VocaLoss+bwd+Adam), {args.seqs} seq x {args.frames} frames = {B} windows "
-                               f"(29,16) per GPU per step, 5023-vertex meshes, BASELINE configs[1]",
+                               f"(29,16) per GPU per step{' built on chip from (S,T,29) features' if args.input == 'features' else ''}, 5023-vertex meshes, BASELINE configs[1]",
                    "frames_per_gpu_step": B, "parallelism": f"dp{world}", "final_loss": round(loss_val, 6),
                    "launch": ("eager" if args.no_graph else "hipGraph replay (fwd+loss+bwd) + eager all-reduce/Adam")
                              + ("; head-gradient all-reduce overlapped with the trunk backward" if step.overlap else "")},

@@ -154,6 +154,17 @@ int a2f_voca_trunk_fwd(const float* x, const float* one_hot, int64_t B, int64_t 
                        const float* const* conv_b, const float* const* fc_w, const float* const* fc_b, float* a0, float* a1,
                        float* a2, float* a3, float* cat72, float* z1, float* z2, float* h3, a2f_stream_t stream);
 
+/* The same trunk fed from the per-frame feature tensor instead of materialised windows (the window
+ * semantics are those of the reference's data side, /root/reference/src/dataset/vocaset.py:408-430 zero-padded slices,
+ * restated in a2f_amd.data.feature_windows): feats (n_seq, seq_len, 29); frame t of a sequence sees feature rows
+ * t-8 .. t+7 of ITS sequence, rows outside [0, seq_len) read as zeros.  B = n_seq * seq_len frames, one_hot (B, n_onehot)
+ * and every output as in a2f_voca_trunk_fwd (a0 holds the windows, so the backward entry points are unchanged).
+ * seq_len >= 32.  HBM reads of the input drop from 1 856 to 116 bytes per frame. */
+int a2f_voca_trunk_fwd_seq(const float* feats, int64_t n_seq, int64_t seq_len, const float* one_hot, int64_t n_onehot,
+                           const float* const* conv_w, const float* const* conv_b, const float* const* fc_w,
+                           const float* const* fc_b, float* a0, float* a1, float* a2, float* a3, float* cat72, float* z1,
+                           float* z2, float* h3, a2f_stream_t stream);
+
 /* Fused data-gradient chain of the same trunk: d(h3) (B,50) -> pre-activation gradients of every layer, one launch:
  *   g_z2 (B,128) = d(decoder.1 pre-tanh), g_z1 (B,72) = d(decoder.0 output), g_c4 (B,64), g_c3 (B,2,64), g_c2 (B,4,32),
  *   g_c1 (B,8,32) = d(conv pre-ReLU outputs).  Reads the forward's saved activations for the tanh' / ReLU masks and the

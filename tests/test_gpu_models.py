@@ -367,3 +367,46 @@ def test_bench_two_rank_flow_rehearsal_on_one_gpu():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["value"] > 0
     assert "overlapped" in out["config"]["launch"] and out["roofline"]["kernel"] == "head_x3_kernel"
+
+
+@pytest.mark.parametrize("S,T", [(3, 40), (2, 601), (5, 32)])
+def test_voca_trunk_on_the_fly_windows_equal_materialised_windows(S, T):
+    """SURVEY §8(f) N4: the trunk fed with per-frame features (S,T,29) builds the 16-frame zero-padded windows on chip;
+    every output must be bit-identical to the same kernel fed with feature_windows(feats) (sequence boundaries fall inside
+    32-frame blocks for these shapes)."""
+    from a2f_amd import ops
+    from a2f_amd.data import feature_windows
+    from a2f_amd.functional import voca_trunk_fwd
+    be = ops.backend()
+    m = a2f_amd.Voca(n_verts=15069, n_onehot=12).to(DEV)
+    params = [p.data for p in m._trunk_params()]
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(S, T, 29, generator=g)
+    oh = torch.zeros(S * T, 12); oh[torch.arange(S * T), torch.arange(S * T) % 8] = 1
+    h_w, s_w = voca_trunk_fwd(be, feature_windows(feats).to(DEV), oh.to(DEV), params)
+    h_f, s_f = voca_trunk_fwd(be, feats.to(DEV), oh.to(DEV), params)
+    assert torch.equal(h_w, h_f)
+    for a, b in zip(s_w[:7], s_f[:7]):
+        assert torch.equal(a, b)
+
+
+def test_voca_train_step_from_features_matches_windows():
+    from a2f_amd.data import feature_windows
+    from a2f_amd.trainer import TrainStep
+    S, T = 2, 48
+    g = torch.Generator().manual_seed(6)
+    feats = torch.randn(S, T, 29, generator=g)
+    B = S * T
+    oh = torch.zeros(B, 12); oh[:, 2] = 1
+    templ = torch.randn(B, 5023, 3, generator=g) * 5
+    gt = templ + torch.randn(B, 5023, 3, generator=g) * 0.5
+    outs = []
+    for x in (feature_windows(feats), feats):
+        torch.manual_seed(11)
+        m = a2f_amd.Voca(n_verts=15069, n_onehot=12).to(DEV)
+        step = TrainStep(m, a2f_amd.VocaLoss(), lr=1e-4)
+        out = step(x.to(DEV), oh.to(DEV), gt.to(DEV), templ.to(DEV))
+        outs.append((float(out["loss"]), [p.detach().clone() for p in m.parameters()]))
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)

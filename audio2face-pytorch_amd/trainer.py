@@ -29,6 +29,8 @@ class FlatAdam:
         dev = self.params[0].device
         self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
         self.pg = process_group
+        # rehearsal hook: run the collectives even in a one-rank group (exercises RCCL + hipGraph interplay on one GPU)
+        self.force_collectives = os.environ.get("A2F_DP_FORCE_COLLECTIVES") == "1"
         self.step_count = 0
         offs, total = [], 0
         for p in self.params:
@@ -54,7 +56,7 @@ class FlatAdam:
 
     def allreduce_grads(self, lo: int = 0, hi: Optional[int] = None, async_op: bool = False):
         """Sum the flat gradient range [lo, hi) over the ranks (the 1/world factor lives in the Adam kernel)."""
-        if self.world() > 1:
+        if self.world() > 1 or (self.force_collectives and dist.is_available() and dist.is_initialized()):
             return dist.all_reduce(self.flat_g[lo:self.numel if hi is None else hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
         return None
 
@@ -118,7 +120,7 @@ class TrainStep:
         if self.fused and hasattr(model, "train_step_direct") and hasattr(model, "early_grad_params"):
             self._head_off = self.opt.tail_segment(model.early_grad_params())
         if overlap is None:
-            overlap = self.opt.world() > 1 and os.environ.get("A2F_DP_OVERLAP", "1") != "0"
+            overlap = (self.opt.world() > 1 or self.opt.force_collectives) and os.environ.get("A2F_DP_OVERLAP", "1") != "0"
         self.overlap = bool(overlap) and self._head_off is not None
         self._graph2 = None
 

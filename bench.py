@@ -129,7 +129,8 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("A2F_BENCH_FORCE_DIST") == "1"      # rehearsal: a one-rank RCCL group (tests/test_gpu_models.py)
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -148,7 +149,7 @@ def main():
     B = one_hot.shape[0]
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -214,7 +215,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline_voca()
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -369,6 +369,25 @@ def test_bench_two_rank_flow_rehearsal_on_one_gpu():
     assert "overlapped" in out["config"]["launch"] and out["roofline"]["kernel"] == "head_x3_kernel"
 
 
+def test_bench_rccl_one_rank_rehearsal():
+    """The RCCL side of the multi-GPU flow on the one GPU the test box has: a one-rank nccl (= RCCL) process group, the
+    two-phase hipGraphs captured while RCCL's watchdog thread is alive, the asynchronous head-segment all-reduce issued
+    between the two graph replays, the trunk-segment all-reduce, barriers, destroy_process_group."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, A2F_BENCH_FORCE_DIST="1", A2F_DP_FORCE_COLLECTIVES="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "3",
+                        "--seqs", "4", "--frames", "64", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and "overlapped" in out["config"]["launch"]
+
+
 @pytest.mark.parametrize("S,T", [(3, 40), (2, 601), (5, 32)])
 def test_voca_trunk_on_the_fly_windows_equal_materialised_windows(S, T):
     """SURVEY §8(f) N4: the trunk fed with per-frame features (S,T,29) builds the 16-frame zero-padded windows on chip;

@@ -9,7 +9,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "liba2f_hip.so")
-SOURCES = ["capi.hip", "gemm.hip", "wgrad.hip", "voca_trunk.hip", "loss.hip", "pack.hip", "adam.hip", "bn.hip", "head_fused.hip", "ff_decoder.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "wgrad.hip", "voca_trunk.hip", "loss.hip", "pack.hip", "adam.hip", "bn.hip", "head_fused.hip", "ff_decoder.hip", "interp.hip"]
 
 
 def _hipcc() -> str:

@@ -57,6 +57,8 @@ SIGNATURES = {
                                      C.POINTER(C.c_void_p), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "a2f_voca_trunk_fwd_seq": (C.c_int, [c_f32p, i64, i64, c_f32p, i64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_void_p), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "a2f_interp_linear_fwd": (C.c_int, [c_f32p, i64, i64, i64, i64, c_f32p, C.c_void_p]),
+    "a2f_interp_linear_bwd": (C.c_int, [c_f32p, i64, i64, i64, i64, c_f32p, C.c_void_p]),
     "a2f_voca_trunk_bwd_data": (C.c_int, [c_f32p] * 12 + [i64] + [c_f32p] * 6 + [C.c_void_p]),
     "a2f_a2m_pack": (C.c_int, [c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, i64, i64, C.c_void_p]),
     "a2f_conv_weight_pack": (C.c_int, [c_f32p, c_f32p, i64, i64, i64, i32, C.c_void_p]),

@@ -563,3 +563,28 @@ class FFDecoderFn(torch.autograd.Function):
         dstyle = torch.empty(S, 64, device=dy.device, dtype=torch.float32)
         be.ff_decoder_bwd(pc, dy, S, T, period, save, dparams, dcross, dstyle)
         return dparams, None, dcross, dstyle, None
+
+
+# =================================================================================================
+# Linear interpolation along time   (reference: src/model/wav2vec.py:76-84 linear_interpolation)
+# =================================================================================================
+class LinearInterpFn(torch.autograd.Function):
+    """features (N, L_in, C) -> (N, L_out, C), align_corners=True linear interpolation along L (csrc/interp.hip):
+    the same function as ``F.interpolate(x.transpose(1, 2), size=L_out, align_corners=True, mode="linear").transpose(1, 2)``."""
+
+    @staticmethod
+    def forward(ctx, x, l_out: int):
+        x = _f32c(x)
+        N, L, C_ = x.shape
+        y = torch.empty(N, l_out, C_, device=x.device, dtype=torch.float32)
+        ops.backend().interp_linear(x, N, L, C_, l_out, y)
+        ctx.dims = (N, L, C_, l_out)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, L, C_, l_out = ctx.dims
+        dy = _f32c(dy)
+        dx = torch.empty(N, L, C_, device=dy.device, dtype=torch.float32)
+        ops.backend().interp_linear(dy, N, L, C_, l_out, dx, backward=True)
+        return dx, None

@@ -188,6 +188,12 @@ class HipBackend:
                                                    arr(fc_b), _ptr(a0), _ptr(a1), _ptr(a2), _ptr(a3), _ptr(cat72), _ptr(z1), _ptr(z2),
                                                    _ptr(h3), self._stream(feats)), "a2f_voca_trunk_fwd_seq")
 
+    def interp_linear(self, x, N, L_in, C_, L_out, y, backward=False):
+        """forward: x (N,L_in,C) -> y (N,L_out,C); backward=True: x = dy (N,L_out,C) -> y = dx (N,L_in,C)."""
+        _chk(x, y)
+        fn = self.lib.a2f_interp_linear_bwd if backward else self.lib.a2f_interp_linear_fwd
+        _lib.check(fn(_ptr(x), N, L_in, C_, L_out, _ptr(y), self._stream(x)), "a2f_interp_linear")
+
     def voca_trunk_bwd_data(self, dh3, z2, cat, a3, a2, a1, fw3, fw1, fw0, cw4, cw3, cw2, B, g_z2, g_z1, g_c4, g_c3, g_c2, g_c1):
         ts = (dh3, z2, cat, a3, a2, a1, fw3, fw1, fw0, cw4, cw3, cw2)
         outs = (g_z2, g_z1, g_c4, g_c3, g_c2, g_c1)

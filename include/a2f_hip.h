@@ -231,6 +231,15 @@ int a2f_ff_decoder_bwd(const float* params, const float* dy, int64_t S, int64_t 
                        size_t save_bytes, float* dparams, float* dcross, float* dstyle, a2f_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Linear interpolation along time (align_corners = True) of channels-last feature rows: x (N, L_in, C) -> y (N, L_out, C),
+ * C a multiple of 4, 16-byte aligned buffers.  Replaces F.interpolate(features.transpose(1, 2), size=L_out,
+ * align_corners=True, mode="linear").transpose(1, 2) of /root/reference/src/model/wav2vec.py:76-84 (the 49 Hz -> frame
+ * rate resampling of the wav2vec2 conv features; same index arithmetic as torch: scale = (L_in-1)/(L_out-1) in fp32).
+ * _bwd: dy (N, L_out, C) -> dx (N, L_in, C), gather form, deterministic. */
+int a2f_interp_linear_fwd(const float* x, int64_t N, int64_t L_in, int64_t C, int64_t L_out, float* y, a2f_stream_t stream);
+int a2f_interp_linear_bwd(const float* dy, int64_t N, int64_t L_in, int64_t C, int64_t L_out, float* dx, a2f_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused Adam step on flat fp32 buffers (torch.optim.Adam semantics as configured at
  * lightning_model.py:209-213: L2-style weight decay added to the gradient, bias correction, eps outside sqrt):
  *   g = grad*grad_scale + wd*p ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;

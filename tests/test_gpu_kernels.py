@@ -457,3 +457,23 @@ def test_conv_window_masks_large():
     d_in = torch.full((B_, P_in, Cin), float("nan"), device=DEV)
     ops.conv_k3s2_bwd_input(be, d_pre, wg, d_in, R, P_out, Cin, Co)
     assert rel_l2(d_in.cpu(), x.grad.permute(0, 2, 1)) < 5e-5
+
+
+@pytest.mark.parametrize("N,Lin,Lout,C_", [(2, 499, 600, 512), (1, 2499, 3000, 512), (3, 600, 499, 64), (2, 1, 7, 8), (2, 9, 1, 8), (1, 50, 50, 4)])
+def test_interp_linear_matches_torch_interpolate(N, Lin, Lout, C_):
+    """csrc/interp.hip against the torch fp32 CPU op it replaces (wav2vec.py:76-84: F.interpolate on the transposed view,
+    align_corners=True), forward and backward; tolerance 1e-6 relative L2 (fp32, fused multiply-add differences only)."""
+    import torch.nn.functional as F
+    from a2f_amd.functional import LinearInterpFn
+    x = rnd(N, Lin, C_, seed=70).to(DEV).requires_grad_(True)
+    gy = rnd(N, Lout, C_, seed=71).to(DEV)
+    y = LinearInterpFn.apply(x, Lout)
+    y.backward(gy)
+    # the reference path is the CPU op (torch's HIP kernel fuses the index arithmetic and lands an ulp of the source
+    # position away: 1e-5 relative at L = 600)
+    x2 = x.detach().cpu().clone().requires_grad_(True)
+    y2 = F.interpolate(x2.transpose(1, 2), size=Lout, align_corners=True, mode="linear").transpose(1, 2)
+    y2.backward(gy.cpu())
+    assert y.shape == y2.shape
+    assert rel_l2(y.detach().cpu(), y2.detach().cpu()) < 1e-6
+    assert rel_l2(x.grad.cpu(), x2.grad.cpu()) < 1e-6

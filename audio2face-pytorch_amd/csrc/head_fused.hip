@@ -71,6 +71,14 @@ __device__ __forceinline__ void buf_store(rsrc_t r, int byte_off, float v, int s
 #ifndef X3_ISSUE_AT
 #define X3_ISSUE_AT 0
 #endif
+// dH = G W: 0 (default) = every wave contracts its own 32 columns for the whole 32 x 64 tile and the eight partial tiles are
+// folded through LDS; 1 = every wave contracts over ALL 256 columns of the workgroup for its own 16-row x 16-k output tile
+// (16x16x32 MFMAs fed from the eight per-wave G images after one barrier; no fp32 partials, no LDS fold) - parity-green
+// but measured SLOWER (0.787 vs 0.755 ms): the 24 MFMAs + 48 LDS reads + 64-byte slab pieces sit behind the barrier on the
+// block's critical path, where the fold has 8 reads and one 16-byte store
+#ifndef X3_DH_FULL
+#define X3_DH_FULL 0
+#endif
 __device__ __forceinline__ float buf_load_stream(rsrc_t r, int byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, X3_STREAM_LD));
 }
@@ -482,6 +490,9 @@ __device__ __forceinline__ void x3_split2(float a, float b, unsigned& hi, unsign
   hi = __builtin_bit_cast(unsigned, hb);
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
 }
+__device__ __forceinline__ f32x4 x3_mfma16(u32x4_t a, u32x4_t b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
 __device__ __forceinline__ f32x16 x3_mfma(u32x4_t a, u32x4_t b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
@@ -533,9 +544,23 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
   // G as bf16 hi / lo images [32 cols][32 rows] (72-byte pitch) inside this wave's fold slice: written from the
   // accumulator layout (column on the lane), read back with the row on the lane by transposing LDS reads
   char* gimg_w = reinterpret_cast<char*>(red + wave * (HF_ROWS * HF_KP)) + l31 * X3_GIMG_PITCH + 8 * h;             // + 16 g  (+ X3_GIMG_BYTES: lo)
+#if X3_DH_FULL
+  // full-contraction dH: wave w owns the output tile rows 16 (w & 1) .. + 15, k = 16 (w >> 1) .. + 15 and reads EVERY wave's G
+  // image: A fragment of column chunk c (16x16x32: lane l holds row l & 15, columns 8 (l >> 4) .. + 7 of the chunk) = two
+  // transposing reads, lane 4q + p of a 16-lane group supplying column 8 (l >> 4) + 4u + q, rows 16 (w & 1) + 4p .. + 3
+  const char* gimg_r = reinterpret_cast<const char*>(red) + (8 * (lane >> 4) + ((lane & 15) >> 2)) * X3_GIMG_PITCH
+                       + (16 * (wave & 1) + 4 * (lane & 3)) * 2;                           // + c * 8192 + 4 u * pitch (+ X3_GIMG_BYTES: lo)
+#else
   const char* gimg_r = reinterpret_cast<const char*>(red + wave * (HF_ROWS * HF_KP)) + (8 * h + ((lane & 15) >> 2)) * X3_GIMG_PITCH
                        + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;                                             // + (16 s + 4 u) * pitch
+#endif
+#if X3_DH_FULL
+  // dH B fragments [k quarter][column chunk][split][lane] x 16 B: W[c0 + 32 c + 8 (l >> 4) + j][16 kq + (l & 15)]
+  u32x4_t* wb_all = reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(red + X3_RED_FLOATS)) + lane;       // + 64 * ((kq * 8 + c) * 2 + split)
+  const u32x4_t* wbq = wb_all + 64 * ((wave >> 1) * 16);                                                   // this wave's k quarter: + 64 * (2 c + split)
+#else
   u32x4_t* wbl = reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(red + X3_RED_FLOATS) + wave * (8 * 64 * 16)) + lane;   // + 64 * ((kt*2 + s)*2 + split)
+#endif
 
   // both H images start as zeros: k >= K and rows >= B never get written
   for (int e = t; e < (X3_HROW_BYTES + X3_HCOL_BYTES) / 4; e += X3_THREADS) reinterpret_cast<unsigned*>(Hrow)[e] = 0u;
@@ -556,6 +581,24 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
     }
   // dH B operand [kt][s]: W[c0 + cl + 16s + 8h + j][32kt + l31]; parked in this wave's private LDS region (lane-linear
   // 16-byte fragments: one conflict-free ds_read_b128 each) - 32 fewer live registers than keeping them next to wf
+#if X3_DH_FULL
+  // wave w fills k quarter w >> 1, column chunks 4 (w & 1) .. + 3 (the two waves of a quarter share what they read later)
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+    const int c = 4 * (wave & 1) + cc, kq = wave >> 1;
+    u32x4_t fh, fl;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const int k = 16 * kq + (lane & 15), col = c0 + 32 * c + 8 * (lane >> 4) + j;
+      const float v0 = buf_load(wres, k < K ? (col * K + k) * 4 : -1), v1 = buf_load(wres, k < K ? ((col + 1) * K + k) * 4 : -1);
+      unsigned hi, lo;
+      x3_split2(v0, v1, hi, lo);
+      fh[j >> 1] = hi; fl[j >> 1] = lo;
+    }
+    wb_all[64 * ((kq * 8 + c) * 2 + 0)] = fh;
+    wb_all[64 * ((kq * 8 + c) * 2 + 1)] = fl;
+  }
+#else
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -572,6 +615,7 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
       wbl[64 * ((kt * 2 + s) * 2 + 0)] = fh;
       wbl[64 * ((kt * 2 + s) * 2 + 1)] = fl;
     }
+#endif
   const int cend = (c0 + a.CW < n) ? c0 + a.CW : n;      // first column this group does not own
   const float bias_r = colg < cend ? a.bias[colg] : 0.f;
 
@@ -795,6 +839,44 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
 #endif
 
     X3_PHASE(5);                                        // 5: G split / transpose store + dW products (+ next tile requests)
+#if X3_DH_FULL
+    // ---- dH[row][k] = sum over the workgroup's 256 columns of G[row][col] W[col][k]: this wave's 16 x 16 output tile ----
+    X3_PHASE(6);
+    __syncthreads();                                    // every wave's G images are complete
+    {
+      f32x4 dh = {0.f, 0.f, 0.f, 0.f};
+#ifndef X3_ABL_NODH
+#pragma unroll
+      for (int c = 0; c < X3_NW; ++c) {
+        u32x4_t gh, gl;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const u32x2_t xh = x3_tr_read(gimg_r + c * 8192 + 4 * u * X3_GIMG_PITCH);
+          const u32x2_t xl = x3_tr_read(gimg_r + c * 8192 + X3_GIMG_BYTES + 4 * u * X3_GIMG_PITCH);
+          gh[2 * u] = xh[0]; gh[2 * u + 1] = xh[1];
+          gl[2 * u] = xl[0]; gl[2 * u + 1] = xl[1];
+        }
+        const u32x4_t bh = wbq[64 * (2 * c)], bl = wbq[64 * (2 * c + 1)];
+        dh = x3_mfma16(gl, bh, dh);
+        dh = x3_mfma16(gh, bl, dh);
+        dh = x3_mfma16(gh, bh, dh);
+      }
+#endif
+      // C layout of the 16x16 tile: lane l holds k = 16 kq + (l & 15), rows 16 (w & 1) + 4 (l >> 4) + r; slab rows are K4 * 4
+      // floats back to back (every line of the slab is written whole by the eight waves of the block)
+      constexpr int KS = (K + 3) & ~3;
+      const int kk = 16 * (wave >> 1) + (lane & 15);
+#ifndef X3_ABL_NOSLAB
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rb * HF_ROWS + 16 * (wave & 1) + 4 * (lane >> 4) + r;
+        if (kk < KS && row < B) a.dH_slab[((int64_t)cg * B + row) * KS + kk] = dh[r];
+      }
+#else
+      asm volatile("" :: "v"(dh));
+#endif
+    }
+#else
     // ---- dH[row][k] += sum_col G[row][col] W[col][k]: G with the row on the lane, through the wave's LDS tile ----
     f32x16 dH[2];
 #pragma unroll
@@ -850,6 +932,7 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
 #else
     asm volatile("" :: "v"(dH[0][0]), "v"(dH[1][7]));
     __syncthreads();
+#endif
 #endif
     X3_PHASE(7);                                        // 7: fold barrier + fold
 #ifndef X3_ABL_NOHC

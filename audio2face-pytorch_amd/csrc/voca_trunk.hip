@@ -106,6 +106,9 @@ __device__ __forceinline__ f32x16 vt_tile(const float* ap, const float (&bw)[KS]
   return acc;
 }
 
+// SEQ: the input is the per-frame feature tensor (a.T = sequence length); a separate instantiation so the window-mode
+// kernel keeps its register allocation
+template <bool SEQ>
 __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const TrunkArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* R0 = lds;
@@ -141,11 +144,11 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
   // of frame F = s T + t is the CONTIGUOUS run of 464 floats starting at row F - 8, rows outside [0, T) of the frame's own
   // sequence reading as zeros (= feature_windows() / the zero-padded slices of vocaset.py) - 116 B per frame from HBM
   // instead of 1 856 B, and no window tensor to build on the host
-  const vt_rsrc_t rx = vt_rsrc(a.x, B, a.T ? 29 : 464), roh = vt_rsrc(a.one_hot, B, a.no);
+  const vt_rsrc_t rx = vt_rsrc(a.x, B, SEQ ? 29 : 464), roh = vt_rsrc(a.one_hot, B, a.no);
   const vt_rsrc_t ra0 = vt_rsrc(a.a0, B, 592), ra1 = vt_rsrc(a.a1, B, 256), ra2 = vt_rsrc(a.a2, B, 128), ra3 = vt_rsrc(a.a3, B, 128);
   const vt_rsrc_t rcat = vt_rsrc(a.cat, B, 72), rz1 = vt_rsrc(a.z1, B, 72), rz2 = vt_rsrc(a.z2, B, 128), rh3 = vt_rsrc(a.h3, B, 50);
   auto fetch_x = [&](int blk) {
-    if (a.T == 0) {
+    if constexpr (!SEQ) {
       int voff = blk * VT_F * 464 + t;
       asm volatile("" : "+v"(voff));                       // keep ONE address register, the rest are immediates / adds
 #pragma unroll
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
     {
       int to = t;
       asm volatile("" : "+v"(to));                         // recompute the 58 scatter addresses per block instead of keeping them live
-      if (a.T == 0) {
+      if constexpr (!SEQ) {
 #pragma unroll
         for (int u = 0; u < XR; ++u) {
           const int e = to + u * VT_THREADS, f = e / 464, r = e - f * 464, c = r >> 4, hh = r & 15;
@@ -574,12 +577,14 @@ static int voca_trunk_fwd_impl(const float* x, int64_t seq_len, const float* one
   a.B = (int)B; a.no = (int)n_onehot; a.NB = (int)cdiv(B, VT_F); a.T = (int)seq_len;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&voca_trunk_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VT_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&voca_trunk_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VT_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&voca_trunk_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VT_LDS_BYTES);
     if (e != hipSuccess) return set_err(A2F_ELAUNCH, "voca_trunk_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
   const int grid = a.NB < 256 ? a.NB : 256;
-  hipLaunchKernelGGL(voca_trunk_fwd_kernel, dim3(grid), dim3(VT_THREADS), VT_LDS_BYTES, (hipStream_t)stream, a);
+  if (a.T > 0) hipLaunchKernelGGL(voca_trunk_fwd_kernel<true>, dim3(grid), dim3(VT_THREADS), VT_LDS_BYTES, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(voca_trunk_fwd_kernel<false>, dim3(grid), dim3(VT_THREADS), VT_LDS_BYTES, (hipStream_t)stream, a);
   A2F_CHECK_LAUNCH("voca_trunk_fwd");
   return A2F_OK;
 }

@@ -10,7 +10,7 @@ import torch
 import a2f_amd
 from a2f_amd import ops
 from emu_backend import EmuBackend
-from golden_util import load, packed_error
+from golden_util import load, packed_error, rel_l2
 from oracle import weights as W
 
 NV = 15069
@@ -215,3 +215,33 @@ def test_faceformer_end_to_end_golden_g8(emu):
     with torch.no_grad():
         pred = m(audio, one_hot, template)
     assert packed_error(g, "pred", pred) < 1e-5
+
+
+def test_voca_accepts_per_frame_features(emu):
+    """SURVEY §8(f) N4 host logic: Voca fed with (S,T,29) per-frame features must equal Voca fed with the materialised
+    16-frame zero-padded windows (a2f_amd.data.feature_windows) - prediction, loss and every gradient - and the oracle."""
+    from a2f_amd.data import feature_windows
+    from oracle import voca as o_voca
+    S, T = 2, 6
+    feats = W.formula_input("n4.feats", (S, T, 29))
+    B = S * T
+    one_hot = torch.zeros(B, 12); one_hot[torch.arange(B), torch.arange(B) % 8] = 1.0
+    template = W.formula_input("n4.template", (B, 5023, 3), 5.0)
+    gt = template + W.formula_input("n4.gt", (B, 5023, 3), 0.5)
+    sd = W.formula_state_dict(W.voca_shapes(NV), gains={"decoder.4": 4.0})
+    outs = []
+    for x in (feature_windows(feats), feats):
+        m = a2f_amd.Voca(n_verts=NV, n_onehot=12)
+        m.load_state_dict(sd)
+        pred = m(x, one_hot, template)
+        loss = a2f_amd.VocaLoss()(pred, gt)
+        loss["loss"].backward()
+        outs.append((pred.detach(), float(loss["loss"]), [p.grad.clone() for p in m.parameters()]))
+    assert outs[0][0].shape == (B, 5023, 3) and torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)
+    ref = o_voca.voca_forward({k: v for k, v in sd.items()}, feature_windows(feats), one_hot, template)
+    assert rel_l2(outs[1][0] - template, ref - template) < 1e-5
+    # window semantics: frame t of a sequence sees rows t-8 .. t+7 of ITS sequence, zeros outside
+    w = feature_windows(feats)
+    assert torch.equal(w[0, :, 8], feats[0, 0]) and torch.all(w[0, :, :8] == 0) and torch.equal(w[T, :, 8], feats[1, 0]) and torch.all(w[T, :, :8] == 0)

@@ -264,7 +264,8 @@ def test_adam_matches_torch_optim():
 
 
 @pytest.mark.parametrize("B_,n,K,trows,Bloss", [(4, 15069, 50, 4, 4), (70, 1536, 50, 70, 70), (64, 999, 64, 1, 64), (33, 600, 64, 1, 32),
-                                                 (2, 3, 50, 2, 2), (130, 15069, 64, 1, 130), (256, 15069, 50, 256, 256)])
+                                                 (2, 3, 50, 2, 2), (130, 15069, 64, 1, 130), (256, 15069, 50, 256, 256),
+                                                 (601, 15069, 64, 1, 600), (1031, 4002, 50, 1031, 1030)])
 def test_head_fused_vs_contract(B_, n, K, trows, Bloss):
     hip, emu = ops.HipBackend(), EmuBackend()
     H, Wt, bias = rnd(B_, K, seed=50), rnd(n, K, seed=51, scale=0.3), rnd(n, seed=52)

@@ -50,3 +50,23 @@ def test_registries():
     assert isinstance(get_loss_fn("faceformer"), a2f_amd.FaceFormerLoss) and isinstance(get_loss_fn("voca"), a2f_amd.VocaLoss)
     with pytest.raises(KeyError):
         get_model("song2face")
+
+
+def test_resampler_properties():
+    """N3: 22 kHz -> 16 kHz sinc/Hann resampler restated from torchaudio's published algorithm (parity unpinned: torchaudio
+    is absent) - length, DC gain and an in-band tone are checked instead."""
+    import math
+    import torch
+    from a2f_amd.data import resample_sinc_hann
+    L = 22000
+    x = torch.ones(2, L)
+    y = resample_sinc_hann(x, 22000, 16000)
+    assert y.shape == (2, math.ceil(16000 * L / 22000))
+    assert torch.allclose(y[:, 200:-200], torch.ones_like(y[:, 200:-200]), atol=2e-3)          # unit DC gain away from the zero-padded ends
+    t = torch.arange(L) / 22000.0
+    tone = torch.sin(2 * math.pi * 440.0 * t)
+    r = resample_sinc_hann(tone, 22000, 16000)
+    t2 = torch.arange(r.shape[-1]) / 16000.0
+    ref = torch.sin(2 * math.pi * 440.0 * t2)
+    assert (r[200:-200] - ref[200:-200]).abs().max() < 5e-3
+    assert resample_sinc_hann(tone, 16000, 16000) is tone

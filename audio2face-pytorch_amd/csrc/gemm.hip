@@ -296,7 +296,11 @@ __global__ __launch_bounds__(G_THREADS) void gemm_split_kernel(const a2f_gemm_de
         const int k = k0 + 2 * a_kp[i] + q;
         bool ok = (m < M) && (k < kend);
         if ((a_rowmask >> i) & 1u) ok = ok && !(k >= d.mask_lo && k < d.mask_hi);
+#ifdef GX_ABL_NOLOAD      // timing ablation only (wrong results)
+        ra[i][q] = ok ? 1.f : 0.f;
+#else
         ra[i][q] = ok ? Ap[(int64_t)m * d.a_rs + (int64_t)k * d.a_cs] : 0.f;
+#endif
       }
     }
 #pragma unroll
@@ -311,7 +315,11 @@ __global__ __launch_bounds__(G_THREADS) void gemm_split_kernel(const a2f_gemm_de
           if (n < N) {
             bool ok = true;
             if (d.mask_operand == 2) ok = !((k % d.mask_period == d.mask_phase) && n >= d.mask_lo && n < d.mask_hi);
+#ifdef GX_ABL_NOLOAD
+            if (ok) v = 1.f;
+#else
             if (ok) v = Bp[(int64_t)k * d.b_rs + (int64_t)n * d.b_cs];
+#endif
           } else if (n == N && d.ones_out) {
             v = 1.f;
           }
@@ -372,7 +380,12 @@ __global__ __launch_bounds__(G_THREADS) void gemm_split_kernel(const a2f_gemm_de
 #pragma unroll
       for (int sum = NS - 1; sum >= 0; --sum)
 #pragma unroll
-        for (int qa = 0; qa <= sum; ++qa) acc[j] = gx_mfma(af[qa], bf[sum - qa], acc[j]);
+        for (int qa = 0; qa <= sum; ++qa) {
+#ifdef GX_ABL_NOMFMA     // timing ablation only (wrong results): one product instead of NS (NS + 1) / 2
+          if (sum == 0)
+#endif
+          acc[j] = gx_mfma(af[qa], bf[sum - qa], acc[j]);
+        }
     }
     if (kt + 1 < nkt) store_tile(buf ^ 1);
     __syncthreads();

@@ -1,0 +1,95 @@
+"""Audio front end in front of the Audio2Mesh path: ``MFCCExtractor``.
+
+Reference: /root/reference/src/model/extractor.py:10-59 - a thin wrapper around ``torchaudio.transforms.MFCC`` followed by
+a bilinear resize to ``out_dim`` frames; constructed at lightning_model.py:86-93 as
+``MFCCExtractor(sample_rate=22000, n_feature=32, out_dim=52, win_length=440, hop_length=None, n_fft=1024)`` and applied
+to the 0.52 s audio window of a frame (``feature = extractor(x).detach()``, lightning_model.py:115: no gradient flows
+into it, so it is a pure pre-processing step upstream of the hot path).
+
+torchaudio is NOT in this image and the reference pins no version, so the arithmetic below is a restatement of torchaudio's
+published defaults with plain torch ops (they run on the HIP device through rocFFT / rocBLAS) - **PARITY UNPINNED**: there
+is no torchaudio build, reference test or fixture here to check it against; tests pin structural properties only.
+    MelSpectrogram: torch.stft(center=True, pad_mode="reflect", hann window of win_length, onesided) -> |.|^2 ->
+                    HTK mel filter bank (n_mels=128, f_min=0, f_max=sr/2, norm=None)
+    AmplitudeToDB("power", top_db=80): 10 log10(max(x, 1e-10)), floored at (max over the clip) - 80
+    DCT-II, norm="ortho", first n_mfcc coefficients
+``Wav2VecExtractor`` (extractor.py:62-96) is the wav2vec2 encoder of ``model/wav2vec.py`` behind torchaudio's resampler
+(``data.resample_sinc_hann``); it needs the pretrained weights, which are not available offline, and is not restated.
+"""
+from __future__ import annotations
+
+import logging
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def melscale_fbanks_htk(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int) -> torch.Tensor:
+    """(n_freqs, n_mels) triangular filters on the HTK mel scale, no area normalisation (torchaudio F.melscale_fbanks)."""
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    hz2mel = lambda f: 2595.0 * math.log10(1.0 + f / 700.0)
+    m_pts = torch.linspace(hz2mel(f_min), hz2mel(f_max), n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.clamp(torch.minimum(down, up), min=0.0)
+
+
+def create_dct_ortho(n_mfcc: int, n_mels: int) -> torch.Tensor:
+    """(n_mels, n_mfcc) DCT-II matrix with orthonormal scaling (torchaudio F.create_dct(norm="ortho"))."""
+    n = torch.arange(float(n_mels))
+    k = torch.arange(float(n_mfcc)).unsqueeze(1)
+    dct = torch.cos(math.pi / float(n_mels) * (n + 0.5) * k)
+    dct[0] *= 1.0 / math.sqrt(2.0)
+    dct *= math.sqrt(2.0 / float(n_mels))
+    return dct.t().contiguous()
+
+
+class MFCCExtractor(nn.Module):
+    """Input (batch, time) -> output (batch, out_dim, n_mfcc); same constructor as extractor.py:16-35."""
+
+    def __init__(self, sample_rate: int, n_feature: int, out_dim: int, win_length: int, hop_length: int = None, n_fft: int = None,
+                 n_mels: int = 128, top_db: float = 80.0):
+        super().__init__()
+        self.sample_rate = sample_rate
+        self.n_mfcc = n_feature
+        self.out_dim = out_dim
+        self.win_length = win_length
+        self.hop_length = hop_length if hop_length else win_length // 2          # extractor.py:29-31
+        self.n_fft = n_fft if n_fft else win_length                               # extractor.py:32
+        self.top_db = top_db
+        if self.n_mfcc > n_mels:
+            raise ValueError("Cannot select more MFCC coefficients than # mel bins")
+        self.register_buffer("window", torch.hann_window(self.win_length), persistent=False)
+        self.register_buffer("fb", melscale_fbanks_htk(self.n_fft // 2 + 1, 0.0, float(sample_rate // 2), n_mels, sample_rate), persistent=False)
+        self.register_buffer("dct_mat", create_dct_ortho(self.n_mfcc, n_mels), persistent=False)
+        self._first = True
+
+    def mel_spectrogram(self, x: torch.Tensor) -> torch.Tensor:
+        spec = torch.stft(x, self.n_fft, hop_length=self.hop_length, win_length=self.win_length, window=self.window, center=True,
+                          pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+        power = spec.real * spec.real + spec.imag * spec.imag                     # (batch, n_freqs, frames)
+        return torch.matmul(power.transpose(-1, -2), self.fb).transpose(-1, -2)   # (batch, n_mels, frames)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        mel = self.mel_spectrogram(x)
+        db = 10.0 * torch.log10(torch.clamp(mel, min=1e-10))
+        db = torch.maximum(db, db.amax(dim=(-2, -1), keepdim=True) - self.top_db)
+        mfcc = torch.matmul(db.transpose(-1, -2), self.dct_mat)                    # (batch, frames, n_mfcc) = T(x).transpose(1, 2)
+        if self.out_dim != mfcc.shape[1]:                                          # extractor.py:49-58
+            if self._first:
+                logging.warning(f"MFCCExtractor: Got tensor shape {mfcc.shape}, resizing to {self.out_dim} using bilinear interpolation")
+                self._first = False
+            mfcc = F.interpolate(mfcc.unsqueeze(1), size=(self.out_dim, self.n_mfcc), mode="bilinear").squeeze(1)
+        return mfcc
+
+
+def get_extractor(extractor: str):
+    """lightning_model.py:61-67."""
+    if extractor == "mfcc":
+        return MFCCExtractor
+    raise KeyError(f"feature extractor '{extractor}' is not restated here (wav2vec needs the pretrained facebook/wav2vec2-base-960h weights)")

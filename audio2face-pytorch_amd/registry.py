@@ -62,6 +62,23 @@ def get_loss_fn(modelname: str):
     return FaceFormerLoss() if modelname == "faceformer" else VocaLoss()
 
 
+def get_extractor(name: Optional[str]):
+    """lightning_model.py:61-67; None -> no extractor (features are fed directly, lightning_model.py:112-113)."""
+    if name is None:
+        return None
+    from .extractor import get_extractor as _get
+    return _get(name)
+
+
+def build_extractor(config: ExpConfig):
+    """The feature extractor exactly as Audio2FaceModel.__init__ constructs it (lightning_model.py:84-93), or None."""
+    fe = get_extractor(config.feature_extractor)
+    if fe is None:
+        return None
+    return fe(sample_rate=config.sample_rate, n_feature=config.n_feature, out_dim=config.out_dim, win_length=config.win_length,
+              hop_length=config.hop_length, n_fft=1024)
+
+
 def build_from_config(config: ExpConfig):
     """(model, loss_fn) exactly as Audio2FaceModel.__init__ builds them (lightning_model.py:96-99)."""
     model = get_model(config.modelname)(n_verts=config.vertex_count, n_onehot=config.one_hot_size)

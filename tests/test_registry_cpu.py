@@ -70,3 +70,36 @@ def test_resampler_properties():
     ref = torch.sin(2 * math.pi * 440.0 * t2)
     assert (r[200:-200] - ref[200:-200]).abs().max() < 5e-3
     assert resample_sinc_hann(tone, 16000, 16000) is tone
+
+
+def test_mfcc_extractor_structure():
+    """N2 (parity unpinned: torchaudio absent): the MFCC front end restated with torch ops - output shape of the
+    config.yaml setting (0.52 s @ 22 kHz -> (B, 52, 32)), orthonormal DCT, triangular mel filters, top_db floor."""
+    import torch
+    from a2f_amd.extractor import MFCCExtractor, create_dct_ortho, get_extractor, melscale_fbanks_htk
+    ex = get_extractor("mfcc")(sample_rate=22000, n_feature=32, out_dim=52, win_length=440, hop_length=None, n_fft=1024)
+    x = torch.randn(3, 11440) * 0.1
+    y = ex(x)
+    assert y.shape == (3, 52, 32) and torch.isfinite(y).all()
+    assert ex.hop_length == 220 and ex.n_fft == 1024
+    d = create_dct_ortho(128, 128)
+    assert torch.allclose(d.t() @ d, torch.eye(128), atol=1e-5)                  # full DCT-II with ortho scaling is orthonormal
+    fb = melscale_fbanks_htk(513, 0.0, 11000.0, 128, 22000)
+    assert fb.shape == (513, 128) and (fb >= 0).all() and (fb.max(0).values <= 1.0 + 1e-6).all()
+    peaks = fb.argmax(0)
+    assert (peaks[1:] >= peaks[:-1]).all()                                        # centre frequencies increase
+    mel = ex.mel_spectrogram(x)
+    assert mel.shape[1] == 128 and mel.shape[2] == 11440 // 220 + 1               # centred frames: 53 -> resized to 52
+    # a louder clip shifts every coefficient-0 by the same dB amount (log-power linearity), others unchanged
+    y2 = ex(x * 10.0)
+    assert torch.allclose(y2[..., 1:], y[..., 1:], atol=2e-2)
+
+
+def test_build_extractor_from_config_yaml():
+    import os
+    import torch
+    from a2f_amd.registry import ExpConfig, build_extractor
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = ExpConfig.from_yaml(os.path.join(root, "config.yaml"))
+    ex = build_extractor(cfg)
+    assert ex is not None and ex(torch.zeros(2, 11440)).shape == (2, cfg.out_dim, cfg.n_feature)

@@ -95,11 +95,15 @@ def test_mfcc_extractor_structure():
     assert torch.allclose(y2[..., 1:], y[..., 1:], atol=2e-2)
 
 
-def test_build_extractor_from_config_yaml():
+def test_build_extractor_from_config():
+    """The reference's own config.yaml (audio2mesh + mfcc) builds the MFCC extractor; this repo's VOCA config (features fed
+    directly, feature_extractor: null) builds none."""
     import os
     import torch
     from a2f_amd.registry import ExpConfig, build_extractor
+    ref_cfg = ExpConfig(batch_size=128, modelname="audio2mesh", vertex_count=15069, one_hot_size=12, split_frame=True, percision="16-mixed",
+                        lr=1e-4, feature_extractor="mfcc", sample_rate=22000, n_feature=32, out_dim=52, win_length=440)
+    ex = build_extractor(ref_cfg)
+    assert ex is not None and ex(torch.zeros(2, 11440)).shape == (2, ref_cfg.out_dim, ref_cfg.n_feature)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cfg = ExpConfig.from_yaml(os.path.join(root, "config.yaml"))
-    ex = build_extractor(cfg)
-    assert ex is not None and ex(torch.zeros(2, 11440)).shape == (2, cfg.out_dim, cfg.n_feature)
+    assert build_extractor(ExpConfig.from_yaml(os.path.join(root, "config.yaml"))) is None

@@ -61,6 +61,7 @@ struct WgradProb {
   int unpack_kh;                                   // > 0: column kh*Ci+ci is stored at ci*KH+kh (Conv2d weight layout)
   int m_off, n_off, n_glob;                        // this sub-problem's corner in the caller's output, and its full width
   int blk_beg, fold_beg;                           // first workgroup of this problem in the GEMM / fold launch
+  int x3;                                          // a2f_gemm_desc.precision == 1: bf16x3 split products on the bf16 matrix pipe
 };
 
 // A caller's problem is cut into sub-problems of at most 2 x 4 accumulator tiles (64 rows x 128 columns of the output):
@@ -79,6 +80,47 @@ __device__ __forceinline__ WgradProb pick_problem(const WgradBatch& b, int blk, 
   for (int i = 1; i < WG_MAX_SUBS; ++i)
     if (i < b.count && blk >= (fold ? b.p[i].fold_beg : b.p[i].blk_beg)) pr = b.p[i];
   return pr;
+}
+
+// fold the four waves of the workgroup through LDS and leave ONE partial slab per workgroup: [m][n], pitch Neff.
+template <int MT, int NT>
+__device__ __forceinline__ void wgrad_store_slab(const WgradProb& pr, int blk, f32x16 (&acc)[MT][NT], float (*red)[WG_NT_MAX * 1024], int t,
+                                                 int wave, int l31, int h, int M, int Neff) {
+  // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* slab = pr.ws + (int64_t)blk * M * Neff;
+#ifdef WG_FOLD_ROW
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave][j * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4 * NT; ++q) {
+      const int e = t + q * WG_THREADS;                    // tile j = e / 1024, row = (e % 1024) / 32, col = e % 32
+      const int m = i * 32 + ((e & 1023) >> 5), n = (e >> 10) * 32 + (e & 31);
+      if (m < M && n < Neff) slab[(int64_t)m * Neff + n] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    }
+  }
+#else
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[i][j][r];
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = t + q * WG_THREADS;                  // 0..1023: row = e / 32, col = e % 32
+        const int m = i * 32 + (e >> 5), n = j * 32 + (e & 31);
+        if (m < M && n < Neff) slab[(int64_t)m * Neff + n] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+      }
+    }
+#endif
 }
 
 template <int MT, int NT>
@@ -156,42 +198,100 @@ __device__ __forceinline__ void wgrad_body(const WgradProb& pr, int blk, float (
     mfma_set(a1, b1);
   }
 
-  // fold the four waves of the workgroup through LDS and leave ONE partial slab per workgroup: [m][n], pitch Neff.
-  // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  float* slab = pr.ws + (int64_t)blk * M * Neff;
-#ifdef WG_FOLD_ROW
+  wgrad_store_slab<MT, NT>(pr, blk, acc, red, t, wave, l31, h, M, Neff);
+}
+
+// ---- split-precision variant (a2f_gemm_desc.precision == 1) ---------------------------------------------------------
+// The fp32 MFMA (32x32x2, 64 cycles per 2 rows) is what the loop above spends its issue time on; here every operand value is
+// split x = hi + lo (bf16 each, round to nearest) and a product is lo*hi' + hi*lo' + hi*hi' on v_mfma_f32_32x32x16_bf16
+// (16 rows per 3 x 32 cycles: 5.3x less matrix time, <= 2^-16 relative error per product, fp32 accumulation).  A register
+// set is 16 rows: lane (l31, h) reads rows k0 + 8h + u (u = 0..7) - the k order of the bf16 operand fragments - converts
+// them to packed hi / lo fragments, requests the next set into the same registers and multiplies.
+using wbf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+using wbf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
+using wf32x2_t = __attribute__((ext_vector_type(2))) float;
+using wu32x4_t = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ void wx_split2(float a, float b, unsigned& hi, unsigned& lo) {
+  const wf32x2_t v = {a, b};
+  const wbf16x2_t hb = __builtin_convertvector(v, wbf16x2_t);
+  const wf32x2_t r = v - __builtin_convertvector(hb, wf32x2_t);
+  hi = __builtin_bit_cast(unsigned, hb);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, wbf16x2_t));
+}
+__device__ __forceinline__ f32x16 wx_mfma(wu32x4_t a, wu32x4_t b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wbf16x8_t, a), __builtin_bit_cast(wbf16x8_t, b), c, 0, 0, 0);
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void wgrad_body_x3(const WgradProb& pr, int blk, float (*red)[WG_NT_MAX * 1024]) {
+  const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int M = pr.M, N = pr.N, Neff = pr.Neff;
+  const int kbeg = (blk * 4 + wave) * pr.rows_per_wave;
+  const int kend = kbeg + pr.rows_per_wave;              // a multiple of 16; rows >= K read as 0
+  const wrsrc_t ra = wg_rsrc(pr.A, ((pr.K - 1) * pr.a_cs + M) * 4), rb = wg_rsrc(pr.B, ((pr.K - 1) * pr.b_rs + N) * 4);
+  const bool ones = Neff > N;
+  const int lane_a = (8 * h * pr.a_cs + l31) * 4, lane_b = (8 * h * pr.b_rs + l31) * 4;     // + (k0 + u) * stride: row k0 + 8h + u
+  const bool masked = pr.mask_period > 0;
+  const int period = masked ? pr.mask_period : 1, adv8 = 8 % period;
+  int pos = (kbeg + 8 * h) % period;                       // (row of the next load) mod period, in load order
+  bool bmask[NT], bone[NT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[wave][j * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[i][j][r];
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4 * NT; ++q) {
-      const int e = t + q * WG_THREADS;                    // tile j = e / 1024, row = (e % 1024) / 32, col = e % 32
-      const int m = i * 32 + ((e & 1023) >> 5), n = (e >> 10) * 32 + (e & 31);
-      if (m < M && n < Neff) slab[(int64_t)m * Neff + n] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-    }
+  for (int j = 0; j < NT; ++j) {
+    const int n = j * 32 + l31;
+    bmask[j] = masked && n >= pr.mask_lo && n < pr.mask_hi;
+    bone[j] = ones && n == N;
   }
-#else
+  f32x16 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      __syncthreads();
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[i][j][r];
-      __syncthreads();
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float av[8][MT], bv[8][NT];
+  auto load_set = [&](int k0) {
+    const int va0 = lane_a + k0 * pr.a_cs * 4, vb0 = lane_b + k0 * pr.b_rs * 4;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int e = t + q * WG_THREADS;                  // 0..1023: row = e / 32, col = e % 32
-        const int m = i * 32 + (e >> 5), n = j * 32 + (e & 31);
-        if (m < M && n < Neff) slab[(int64_t)m * Neff + n] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    for (int u = 0; u < 8; ++u) {
+      const int va = va0 + u * pr.a_cs * 4, vb = vb0 + u * pr.b_rs * 4;
+      const bool padrow = masked && pos == pr.mask_phase;
+      const bool inside = k0 + 8 * h + u < pr.K;
+      pos = pos + 1 == period ? 0 : pos + 1;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) av[u][i] = wg_load(ra, va + i * 128);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float v = wg_load(rb, (padrow && bmask[j]) ? -1 : vb + j * 128);
+        bv[u][j] = (bone[j] && inside) ? 1.f : v;
       }
     }
-#endif
+    pos += adv8;                                           // this lane's next set starts 16 rows on: 8 counted above
+    if (pos >= period) pos -= period;
+  };
+  load_set(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    wu32x4_t ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) { unsigned hi, lo; wx_split2(av[u][i], av[u + 1][i], hi, lo); ah[i][u >> 1] = hi; al[i][u >> 1] = lo; }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) { unsigned hi, lo; wx_split2(bv[u][j], bv[u + 1][j], hi, lo); bh[j][u >> 1] = hi; bl[j][u >> 1] = lo; }
+    if (k0 + 16 < kend) load_set(k0 + 16);                 // in flight under the products below
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        acc[i][j] = wx_mfma(al[i], bh[j], acc[i][j]);
+        acc[i][j] = wx_mfma(ah[i], bl[j], acc[i][j]);
+        acc[i][j] = wx_mfma(ah[i], bh[j], acc[i][j]);
+      }
+  }
+  wgrad_store_slab<MT, NT>(pr, blk, acc, red, t, wave, l31, h, M, Neff);
 }
 
 #ifndef WG_LB
@@ -207,6 +307,18 @@ __global__ __launch_bounds__(WG_THREADS, WG_LB) void wgrad_batch_kernel(const Wg
     case 2 * 8 + 1: wgrad_body<2, 1>(pr, blk, red); break;
     case 2 * 8 + 3: wgrad_body<2, 3>(pr, blk, red); break;
     default: wgrad_body<2, 4>(pr, blk, red); break;
+  }
+}
+
+// the split-precision launch: sub-problems are cut at 96 columns (2 x 3 tiles: 96 accumulators + two 40-register operand sets)
+__global__ __launch_bounds__(WG_THREADS, WG_LB) void wgrad_batch_x3_kernel(const WgradBatch b) {
+  __shared__ float red[4][WG_NT_MAX * 1024];
+  const WgradProb pr = pick_problem(b, blockIdx.x, false);
+  const int blk = blockIdx.x - pr.blk_beg;
+  switch (pr.shape) {
+    case 1 * 8 + 3: wgrad_body_x3<1, 3>(pr, blk, red); break;
+    case 2 * 8 + 1: wgrad_body_x3<2, 1>(pr, blk, red); break;
+    default: wgrad_body_x3<2, 3>(pr, blk, red); break;
   }
 }
 
@@ -289,9 +401,11 @@ extern "C" int a2f_wgrad_batch_f32(const a2f_gemm_desc* descs, int32_t count, a2
   WgradBatch b;
   memset(&b, 0, sizeof(b));
   int blk = 0, fold = 0;
+  bool cur_x3 = false;
   auto flush = [&]() {
     if (b.count == 0) return;
-    hipLaunchKernelGGL(wgrad_batch_kernel, dim3(blk), dim3(WG_THREADS), 0, s, b);
+    if (cur_x3) hipLaunchKernelGGL(wgrad_batch_x3_kernel, dim3(blk), dim3(WG_THREADS), 0, s, b);
+    else hipLaunchKernelGGL(wgrad_batch_kernel, dim3(blk), dim3(WG_THREADS), 0, s, b);
     hipLaunchKernelGGL(wgrad_fold_kernel, dim3(fold), dim3(256), 0, s, b);
     memset(&b, 0, sizeof(b));
     blk = fold = 0;
@@ -312,10 +426,14 @@ extern "C" int a2f_wgrad_batch_f32(const a2f_gemm_desc* descs, int32_t count, a2
     const WgradPlan pl = wgrad_plan(d.M, d.N, d.K);
     const int M = (int)d.M, N = (int)d.N, Neff = N + (d.ones_out ? 1 : 0);
     float* ws = d.splitk_ws;
+    const bool x3 = d.precision == 1;
+    if (b.count > 0 && x3 != cur_x3) flush();              // one precision per launch
+    cur_x3 = x3;
+    const int ncut = x3 ? 96 : 128;
     for (int m0 = 0; m0 < M; m0 += 64)
-      for (int n0 = 0; n0 < Neff; n0 += 128) {
+      for (int n0 = 0; n0 < Neff; n0 += ncut) {
         if (b.count == WG_MAX_SUBS) flush();
-        const int m1 = std::min(M, m0 + 64), n1 = std::min(Neff, n0 + 128);
+        const int m1 = std::min(M, m0 + 64), n1 = std::min(Neff, n0 + ncut);
         WgradProb& p = b.p[b.count++];
         p.A = d.A + d.a_off + m0;
         p.B = d.B + d.b_off + n0;
@@ -332,6 +450,7 @@ extern "C" int a2f_wgrad_batch_f32(const a2f_gemm_desc* descs, int32_t count, a2
         p.blocks = pl.blocks;
         p.shape = wgrad_shape((p.M + 31) / 32, (p.Neff + 31) / 32);
         p.unpack_kh = d.c_unpack_kh;
+        p.x3 = x3 ? 1 : 0;
         p.m_off = m0; p.n_off = n0; p.n_glob = N;
         p.blk_beg = blk;
         p.fold_beg = fold;

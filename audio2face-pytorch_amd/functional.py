@@ -155,6 +155,11 @@ def voca_trunk_fwd_layerwise(be, x, one_hot, params):
     return h3, (a0, acts[1], acts[2], acts[3], cat, z1, z2, fw0, fw1, fw3, _f32c(cw[0]), _f32c(cw[2]), _f32c(cw[4]), _f32c(cw[6]))
 
 
+# a2f_gemm_desc.precision of the VOCA trunk's batched weight gradients: 1 (default) = bf16x3 split products (the contraction
+# runs over 1e4 .. 1e5 rows of smooth products: 1e-5-class error, 5.3x less matrix time), 0 = exact fp32 MFMA
+VOCA_WGRAD_PRECISION = int(os.environ.get("A2F_VOCA_WGRAD_PRECISION", "1"))
+
+
 def voca_trunk_bwd(be, saved, dh3, out=None):
     """Gradients of the 14 trunk parameters (same order as ``params``).  ``out``: optional list of 14 preallocated
     tensors (e.g. the trainer's flat-gradient views) that are OVERWRITTEN in place; otherwise new tensors are returned.
@@ -175,6 +180,8 @@ def voca_trunk_bwd(be, saved, dh3, out=None):
     # problems first so the light ones fill the tail
     grads = [None] * 14
     items = []
+    old_prec = getattr(be, "wgrad_precision", 0)
+    be.wgrad_precision = VOCA_WGRAD_PRECISION
     for li, (act_in, g) in enumerate(((a0, g_c1), (a1, g_c2), (a2, g_c3), (a3, g_c4))):
         ci, co, pout = VOCA_CONVS[li]
         dw, dbias = tgt(2 * li, co, ci, 3, 1), tgt(2 * li + 1, co)
@@ -184,6 +191,7 @@ def voca_trunk_bwd(be, saved, dh3, out=None):
     items.append(ops.linear_wgrad_item(be, g_z1, cat, dW0, db0, B, 72, 72))
     items.append(ops.linear_wgrad_item(be, g_z2, z1, dW1, db1, B, 128, 72))
     items.append(ops.linear_wgrad_item(be, dh3, z2, dW3, db3, B, 50, 128))
+    be.wgrad_precision = old_prec
     be.wgrad_batch(items)
     grads[8:14] = [dW0, db0, dW1, db1, dW3, db3]
     return grads

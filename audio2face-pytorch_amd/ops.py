@@ -46,6 +46,7 @@ class HipBackend:
         self.prof = None          # when a dict: tag -> list of (start_event, end_event) recorded on the launch stream
         self.auto_split_k = True  # gemm(): slab split-K for under-filled grids (see gemm)
         self.gemm_precision = 0   # a2f_gemm_desc.precision of subsequent gemm() calls: 0 exact fp32 MFMA, 1 bf16x3 split products
+        self.wgrad_precision = 0  # a2f_gemm_desc.precision of subsequent wgrad_item() calls: 0 exact fp32 MFMA, 1 bf16x3
 
     @staticmethod
     def _stream(t: torch.Tensor):
@@ -114,6 +115,7 @@ class HipBackend:
         d.M, d.N, d.K = M, N, K
         d.ones_out = _ptr(ones_out)
         d.split_k = 1
+        d.precision = self.wgrad_precision
         d.c_unpack_kh = unpack_kh
         if mask is not None:
             d.mask_operand, d.mask_period, d.mask_phase, d.mask_lo, d.mask_hi = mask

@@ -86,7 +86,9 @@ int a2f_gemm_f32(const a2f_gemm_desc* d, a2f_stream_t stream);
  * ones_out) OVERWRITTEN.  One register tile set per wave, operands read from global memory in MFMA layout, per-wave
  * partial slabs in d->splitk_ws (>= a2f_wgrad_ws_floats(M,N,K) floats) folded in fixed order (deterministic).
  * a2f_wgrad_batch_f32 runs up to A2F_WGRAD_BATCH_MAX independent problems (e.g. all seven trunk layers of a VOCA step)
- * in one launch pair; each descriptor carries its own workspace.  Operands must span less than 2 GB each. */
+ * in one launch pair; each descriptor carries its own workspace.  Operands must span less than 2 GB each.
+ * d->precision: 0 = exact fp32 MFMA; 1 = bf16x3 split products (x = hi + lo, lo*hi' + hi*lo' + hi*hi' on the bf16 matrix pipe,
+ * fp32 accumulation, <= 2^-16 relative error per product; 16-row register sets, 96-column sub-problems); other values = 0. */
 #define A2F_WGRAD_BATCH_MAX 8
 int a2f_wgrad_supported(int64_t M, int64_t N);
 size_t a2f_wgrad_ws_floats(int64_t M, int64_t N, int64_t K);

@@ -363,12 +363,15 @@ def test_ff_decoder_kernels_vs_spec(S, T, period):
         o += sz_
 
 
+@pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("M,N,K", [(32, 111, 5000), (32, 96, 777), (64, 96, 3001), (64, 192, 1200), (72, 72, 640), (128, 72, 19), (50, 128, 2048), (1, 1, 3)])
-def test_wgrad_kernel_vs_contract(M, N, K):
-    """dW = dY^T X with the ones column and a conv padding mask, against the float64 emulation of the contract."""
+def test_wgrad_kernel_vs_contract(M, N, K, prec):
+    """dW = dY^T X with the ones column and a conv padding mask, against the float64 emulation of the contract; prec 0 = exact
+    fp32 MFMA, 1 = bf16x3 split products (16-row register sets, 96-column sub-problems): both inside 2e-5."""
     dy, x = rnd(K, M, seed=80), rnd(K + 2, N, seed=81)
     period = 4
     hip, emu = ops.HipBackend(), EmuBackend()
+    hip.wgrad_precision = prec
     assert hip.wgrad_supported(M, N)
     outs = []
     for be, dev in ((hip, DEV), (emu, "cpu")):

@@ -34,6 +34,9 @@ def synthetic_batch(cfg: ExpConfig, batch: int, device, seed: int):
 
 
 def main(argv=None):
+    # Lightning's Trainer(benchmark=None) turns cudnn.benchmark on when training is not deterministic (train.py:46-60): MIOpen then
+    # autotunes every convolution shape once - the wav2vec2 feature encoder gains 8 % per FaceFormer step, backward included
+    torch.backends.cudnn.benchmark = True
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=str, default="config.yaml")
     ap.add_argument("--steps", type=int, default=20)

@@ -15,6 +15,7 @@ import a2f_amd
 from a2f_amd.trainer import FlatAdam, TrainStep
 
 dev = torch.device("cuda")
+torch.backends.cudnn.benchmark = True          # as the reference harness (Lightning, non-deterministic training) sets it
 NV = 15069
 
 

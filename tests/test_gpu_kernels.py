@@ -481,3 +481,16 @@ def test_interp_linear_matches_torch_interpolate(N, Lin, Lout, C_):
     assert y.shape == y2.shape
     assert rel_l2(y.detach().cpu(), y2.detach().cpu()) < 1e-6
     assert rel_l2(x.grad.cpu(), x2.grad.cpu()) < 1e-6
+
+
+def test_cabi_from_a_plain_host_program():
+    """The boundary is a C ABI, not a torch extension: tools/cabi_smoke.cpp (no Python, no torch; device buffers from the HIP
+    runtime) calls a2f_head_fused and a2f_vocaloss_fwd and checks them against a double-precision host evaluation of the
+    reference formulas (voca.py:48-49, loss.py:24-55)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+    exe = ge.build_cabi_smoke()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "CABI_SMOKE_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

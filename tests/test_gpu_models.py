@@ -429,3 +429,27 @@ def test_voca_train_step_from_features_matches_windows():
     assert outs[0][0] == outs[1][0]
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
+
+
+def test_faceformer_config5_long_context_prefix_property():
+    """BASELINE configs[4] shape (T = 3000 frames, beyond the reference's 600-frame tables): the decoder is causal, so the
+    first 600 frames of a 3000-frame sequence must equal the 600-frame run on the same encoder-state prefix (a size
+    -independent parity property), and the fused loss / backward of the long sequence must be finite."""
+    m = _faceformer()
+    T, Tp = 3000, 600
+    g = torch.Generator().manual_seed(12)
+    enc = torch.randn(1, T, 768, generator=g).to(DEV)
+    oh = torch.zeros(1, 12, device=DEV); oh[0, 5] = 1
+    templ = (torch.randn(1, 5023, 3, generator=g) * 5).to(DEV)
+    with torch.no_grad():
+        long = m(torch.zeros(1, T * 16000 // 60 + 8, device=DEV), oh, templ, encoder_states=enc)
+        short = m(torch.zeros(1, Tp * 16000 // 60 + 8, device=DEV), oh, templ, encoder_states=enc[:, :Tp].contiguous())
+    assert long.shape == (1, T, 5023, 3) and bool(torch.isfinite(long).all())
+    t4 = templ.view(1, 1, 5023, 3)
+    assert rel_l2((long[:, :Tp] - t4).cpu(), (short - t4).cpu()) < 1e-5
+    gt = long.detach() + 0.5 * torch.randn(long.shape, generator=g).to(DEV)
+    enc_g = enc.clone().requires_grad_(True)
+    pred = m(torch.zeros(1, T * 16000 // 60 + 8, device=DEV), oh, templ, encoder_states=enc_g)
+    loss = a2f_amd.FaceFormerLoss()(pred, gt)
+    loss["loss"].backward()
+    assert bool(torch.isfinite(loss["loss"])) and bool(torch.isfinite(enc_g.grad).all()) and float(enc_g.grad.abs().sum()) > 0

@@ -494,3 +494,36 @@ def test_cabi_from_a_plain_host_program():
     exe = ge.build_cabi_smoke()
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "CABI_SMOKE_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_head_fused_at_bench_size_properties():
+    """BASELINE configs[1] size (19 200 frames x 15 069 columns, K = 50), where the CPU contract would take minutes: size
+    -independent properties instead.  (a) pred of sampled rows against a float64 evaluation; (b) the batch split into two even
+    halves gives the same pred rows bit for bit, the mean of the two losses, half-scaled dH rows and the mean of the dW / db;
+    (c) the standalone VocaLoss kernel agrees with the fused loss."""
+    B, n, K = 19200, 15069, 50
+    hip = ops.HipBackend()
+    g = torch.Generator(device=DEV).manual_seed(77)
+    H = torch.randn(B, K, device=DEV, generator=g); Wt = torch.randn(n, K, device=DEV, generator=g) * 0.3
+    bias = torch.randn(n, device=DEV, generator=g)
+    templ = torch.randn(B, n, device=DEV, generator=g) * 5; gt = templ + torch.randn(B, n, device=DEV, generator=g) * 0.5
+
+    def run(lo, hi):
+        b = hi - lo
+        pred = torch.empty(b, n, device=DEV); out3 = torch.empty(3, device=DEV)
+        dH, dW, db = torch.empty(b, K, device=DEV), torch.empty(n, K, device=DEV), torch.empty(n, device=DEV)
+        hip.head_fused(H[lo:hi].contiguous(), Wt, bias, templ[lo:hi].contiguous(), b, gt[lo:hi].contiguous(), b, b, n, K, 1.0, 10.0, pred, out3, dH, dW, db)
+        return pred, out3, dH, dW, db
+    p_f, o_f, dH_f, dW_f, db_f = run(0, B)
+    rows = torch.randint(0, B, (48,), generator=torch.Generator().manual_seed(3)).to(DEV)
+    ref = H[rows].double() @ Wt.double().t() + bias.double() + templ[rows].double()
+    assert rel_l2((p_f[rows].double() - templ[rows].double()).cpu(), (ref - templ[rows].double()).cpu()) < 2e-5
+    p_a, o_a, dH_a, dW_a, db_a = run(0, B // 2)
+    p_b, o_b, dH_b, dW_b, db_b = run(B // 2, B)
+    assert torch.equal(p_f[:B // 2], p_a) and torch.equal(p_f[B // 2:], p_b)
+    assert torch.allclose(o_f, (o_a + o_b) / 2, rtol=1e-5, atol=0)
+    assert rel_l2(dH_f.cpu(), torch.cat([dH_a, dH_b]).cpu() / 2) < 1e-5
+    assert rel_l2(dW_f.cpu(), ((dW_a + dW_b) / 2).cpu()) < 1e-5 and rel_l2(db_f.cpu(), ((db_a + db_b) / 2).cpu()) < 1e-5
+    l3 = torch.empty(3, device=DEV)
+    hip.vocaloss_fwd(p_f, gt, B, n, 1.0, 10.0, l3)
+    assert torch.allclose(l3, o_f, rtol=1e-5, atol=0)

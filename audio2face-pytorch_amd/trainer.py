@@ -185,14 +185,24 @@ class TrainStep:
             torch.cuda.synchronize()
             # thread_local: the capture must not be invalidated by HIP calls of other threads of this process (RCCL's
             # watchdog polls events while the ranks are between collectives)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self._side, capture_error_mode="thread_local"):
-                out = self._direct(ins, 1) if self.overlap else self._fwd_bwd(*ins)
-            if self.overlap:                                    # second graph: trunk backward, same memory pool
-                g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, stream=self._side, pool=g.pool(), capture_error_mode="thread_local"):
-                    self._direct(ins, 2)
-                self._graph2 = g2
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self._side, capture_error_mode="thread_local"):
+                    out = self._direct(ins, 1) if self.overlap else self._fwd_bwd(*ins)
+                if self.overlap:                                # second graph: trunk backward, same memory pool
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2, stream=self._side, pool=g.pool(), capture_error_mode="thread_local"):
+                        self._direct(ins, 2)
+                    self._graph2 = g2
+            except RuntimeError as e:
+                # a failed capture executes nothing: keep training with eager launches of the same HIP kernels (slower
+                # launches, same arithmetic) instead of aborting the job
+                import warnings
+                warnings.warn(f"hipGraph capture of the train step failed ({e}); continuing with eager launches")
+                torch.cuda.synchronize()
+                self.use_graph = False
+                self._graph = self._graph2 = None
+                return self.__call__(*ins)
             self._graph, self._graph_inputs, self._graph_out = g, ins, out
         else:
             if any(a.data_ptr() != b.data_ptr() for a, b in zip(ins, self._graph_inputs)):

@@ -179,7 +179,7 @@ def main():
         "config": {"workload": f"VOCA train step (fwd+VocaLoss+bwd+Adam), {args.seqs} seq x {args.frames} frames = {B} windows "
                                f"(29,16) per GPU per step{' built on chip from (S,T,29) features' if args.input == 'features' else ''}, 5023-vertex meshes, BASELINE configs[1]",
                    "frames_per_gpu_step": B, "parallelism": f"dp{world}", "final_loss": round(loss_val, 6),
-                   "launch": ("eager" if args.no_graph else "hipGraph replay (fwd+loss+bwd) + eager all-reduce/Adam")
+                   "launch": ("eager" if not step.use_graph else "hipGraph replay (fwd+loss+bwd) + eager all-reduce/Adam")
                              + ("; head-gradient all-reduce overlapped with the trunk backward" if step.overlap else "")},
     }
 

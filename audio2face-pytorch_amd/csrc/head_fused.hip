@@ -473,10 +473,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs
 // relative error of a product <= 2^-16 (the dropped lo*lo' term and the bf16 rounding of lo), i.e. ~1e-5 relative on
 // pred / dH / dW / db - inside the 1e-4 parity bar, with the loss and every elementwise step still in fp32.
 //
-// Layout differences from the fp32 kernel: the W slice lives in REGISTERS (each wave owns one 32-column chunk for the
-// whole kernel: forward B fragments and dH B fragments, hi and lo, 64 VGPRs), H tiles are kept in LDS as bf16 hi/lo in
-// two images (row-major for the forward A operand, k-major with the accumulator row permutation for the dW B operand) so
-// every fragment is ONE ds_read_b128, and the only fp32 LDS traffic left is the G transpose and the dH fold.
+// Layout differences from the fp32 kernel: a wave owns one 32-column chunk of W for the whole kernel - the forward B
+// fragments (hi, lo: 32 VGPRs) stay in registers, the dH B fragments are parked in a private lane-linear LDS region - and
+// H tiles are kept in LDS as bf16 hi/lo in two images (row-major for the forward A operand, k-major with the accumulator
+// row permutation for the dW B operand) so every fragment is ONE ds_read_b128.  Tile I/O (v13): template / gt rows are
+// fetched as 1-KB runs (dwordx4 per lane), staged through LDS chunks that alias the dH fold slices and read back in the
+// accumulator layout; G reaches dH through per-wave bf16 images read with transposing LDS reads; the only fp32 LDS traffic
+// left is the tile staging and the dH fold.  Workgroups are remapped so each XCD owns a contiguous run of column groups.
 using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
 using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
 using f32x2_t = __attribute__((ext_vector_type(2))) float;
@@ -514,7 +517,7 @@ constexpr int X3_HCOL_PITCH = 40 * 2;                 // bytes per k of the k-ma
 constexpr int X3_HROW_BYTES = 2 * HF_ROWS * X3_HROW_PITCH;      // 9216
 constexpr int X3_HCOL_BYTES = 2 * HF_KP * X3_HCOL_PITCH;        // 10240
 constexpr int X3_GIMG_PITCH = 72, X3_GIMG_BYTES = 32 * X3_GIMG_PITCH;     // per-wave G images (bf16 hi, lo)
-constexpr int X3_RED_FLOATS = X3_NW * HF_ROWS * HF_KP;          // [wave][32][64] fp32 dH partials; a wave's slice doubles as its G transpose tile
+constexpr int X3_RED_FLOATS = X3_NW * HF_ROWS * HF_KP;          // [wave][32][64] fp32 dH partials; a wave's 8-KB slice doubles as its tile staging chunks (template | gt) and its G images
 constexpr int X3_WB_BYTES = X3_NW * 8 * 64 * 16;               // per wave: dH B fragments [kt][s][split][lane] x 16 B (lane-linear)
 constexpr size_t X3_LDS_BYTES = X3_HROW_BYTES + X3_HCOL_BYTES + (size_t)X3_RED_FLOATS * 4 + X3_WB_BYTES;
 

@@ -1,15 +1,24 @@
-"""Build liba2f_hip.so (gfx950) in-tree with hipcc.  No torch headers, no pybind: plain C ABI."""
+"""Build liba2f_hip.so (gfx950) in-tree with hipcc.  No torch headers, no pybind: plain C ABI.
+
+Every ``csrc/*.hip`` is compiled to its own object under ``build/obj`` (git-ignored), up to A2F_BUILD_JOBS files at a
+time, and only when the source (or a shared header) is newer than the object; the objects are then linked into the
+shared library.  ``force=True`` rebuilds everything.
+"""
 from __future__ import annotations
 
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "liba2f_hip.so")
-SOURCES = ["capi.hip", "gemm.hip", "wgrad.hip", "voca_trunk.hip", "loss.hip", "pack.hip", "adam.hip", "bn.hip", "head_fused.hip", "ff_decoder.hip", "interp.hip"]
+OBJ_DIR = os.path.join(PKG_DIR, "..", "build", "obj")
+SOURCES = ["capi.hip", "gemm.hip", "wgrad.hip", "voca_trunk.hip", "loss.hip", "pack.hip", "adam.hip", "bn.hip", "head_fused.hip",
+           "ff_decoder.hip", "interp.hip", "util.hip", "gemm_mfma.hip", "rowops.hip", "attention.hip", "featenc.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc() -> str:
@@ -19,25 +28,58 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm's hipcc to build liba2f_hip.so)")
 
 
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(PKG_DIR, "..", "include", "a2f_hip.h"))
+    return [h for h in hs if os.path.exists(h)]
+
+
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG_DIR, "..", "include", "a2f_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    deps = [os.path.join(CSRC, s) for s in _sources()] + _headers()
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile_one(src: str, obj: str, verbose: bool):
+    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {os.path.basename(src)}:\n" + r.stdout + r.stderr)
+    os.replace(obj + ".tmp", obj)
+    return r.stderr
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-           "-o", LIB_PATH + ".tmp"] + srcs
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr_t = max(os.path.getmtime(h) for h in _headers())
+    jobs, objs = [], []
+    for s in _sources():
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append((src, obj))
+    nj = max(1, int(os.environ.get("A2F_BUILD_JOBS", str(min(8, os.cpu_count() or 1)))))
+    with ThreadPoolExecutor(max_workers=nj) as ex:
+        for warn in ex.map(lambda so: _compile_one(so[0], so[1], verbose), jobs):
+            if verbose and warn:
+                print(warn, file=sys.stderr)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 

@@ -71,6 +71,8 @@ SIGNATURES = {
     "a2f_ff_decoder_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, i32, c_f32p, C.c_void_p, sz, C.c_void_p]),
     "a2f_ff_decoder_bwd": (C.c_int, [c_f32p, c_f32p, i64, i64, i32, C.c_void_p, sz, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "a2f_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, f32, f32, f32, f32, f32, f32, i32, C.c_void_p]),
+    "a2f_stream_copy": (C.c_int, [c_f32p, c_f32p, i64, C.c_void_p]),
+    "a2f_stream_triad": (C.c_int, [c_f32p, c_f32p, c_f32p, i64, C.c_void_p]),
 }
 
 _LIB = None

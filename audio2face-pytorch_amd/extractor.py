@@ -11,7 +11,8 @@ published defaults with plain torch ops (they run on the HIP device through rocF
 is no torchaudio build, reference test or fixture here to check it against; tests pin structural properties only.
     MelSpectrogram: torch.stft(center=True, pad_mode="reflect", hann window of win_length, onesided) -> |.|^2 ->
                     HTK mel filter bank (n_mels=128, f_min=0, f_max=sr/2, norm=None)
-    AmplitudeToDB("power", top_db=80): 10 log10(max(x, 1e-10)), floored at (max over the clip) - 80
+    AmplitudeToDB("power", top_db=80): 10 log10(max(x, 1e-10)), floored at (max over the whole (batch, mel, time) input) - 80
+                    (torchaudio treats a 3-D input as one packed item; per item only for 4-D input)
     DCT-II, norm="ortho", first n_mfcc coefficients
 ``Wav2VecExtractor`` (extractor.py:62-96) is the wav2vec2 encoder of ``model/wav2vec.py`` behind torchaudio's resampler
 (``data.resample_sinc_hann``); it needs the pretrained weights, which are not available offline, and is not restated.
@@ -78,7 +79,11 @@ class MFCCExtractor(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         mel = self.mel_spectrogram(x)
         db = 10.0 * torch.log10(torch.clamp(mel, min=1e-10))
-        db = torch.maximum(db, db.amax(dim=(-2, -1), keepdim=True) - self.top_db)
+        # torchaudio.functional.amplitude_to_DB packs a (batch, mel, time) input as ONE (1, batch, mel, time) item: the top_db
+        # floor is the maximum over the whole batch minus top_db (per item only for 4-D input).  extractor.py:47 feeds (batch, time)
+        # audio, so the spectrogram is 3-D here.
+        red = (-3, -2, -1) if db.dim() == 3 else (-2, -1)
+        db = torch.maximum(db, db.amax(dim=red, keepdim=True) - self.top_db)
         mfcc = torch.matmul(db.transpose(-1, -2), self.dct_mat)                    # (batch, frames, n_mfcc) = T(x).transpose(1, 2)
         if self.out_dim != mfcc.shape[1]:                                          # extractor.py:49-58
             if self._first:

@@ -250,6 +250,16 @@ class HipBackend:
                                           self._stream(p)), "a2f_adam_step")
 
 
+    # ---- measurement helpers -----------------------------------------------------------------
+    def stream_copy(self, dst, src):
+        _chk(dst, src)
+        _lib.check(self.lib.a2f_stream_copy(_ptr(dst), _ptr(src), dst.numel(), self._stream(dst)), "a2f_stream_copy")
+
+    def stream_triad(self, dst, a, b):
+        _chk(dst, a, b)
+        _lib.check(self.lib.a2f_stream_triad(_ptr(dst), _ptr(a), _ptr(b), dst.numel(), self._stream(dst)), "a2f_stream_triad")
+
+
 _BACKEND = None
 
 

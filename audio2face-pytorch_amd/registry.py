@@ -97,5 +97,10 @@ def mixed_precision_dtype(percision: str):
     if p.startswith("bf16"):
         return torch.bfloat16
     if p.startswith("16"):
-        return torch.float16
+        # Lightning's "16-mixed" = fp16 autocast + GradScaler (dynamic loss scale, unscale, skip-on-inf).  TrainStep / FlatAdam
+        # carry no loss scaling, so fp16 gradients could underflow or push an inf into Adam: the 16-bit setting runs as bf16
+        # (fp32 exponent range, no scaler needed) and says so.
+        import warnings
+        warnings.warn('percision "16-mixed": no GradScaler in this trainer - the encoder runs in bf16 mixed precision instead of fp16')
+        return torch.bfloat16
     return None

@@ -84,14 +84,13 @@ class FlatAdam:
 
 class StepOutput(dict):
     """{"loss", "rec_loss", "vel_loss"} of a step; "err" (mse_error of lightning_model.py:119-125 == rec_loss / 3 for
-    3-vectors) is derived on first access instead of costing an extra launch in every step."""
+    3-vectors) is derived on every access instead of costing an extra launch in every step.  It is NOT cached: under
+    hipGraph replay the same StepOutput object wraps static loss buffers that every replay rewrites."""
 
     def __missing__(self, key):
         if key != "err":
             raise KeyError(key)
-        v = self["rec_loss"].detach() / 3.0
-        self[key] = v
-        return v
+        return self["rec_loss"].detach() / 3.0
 
 
 class TrainStep:
@@ -221,7 +220,11 @@ class TrainStep:
         self.opt.zero_grad()
         if self.fused:
             lf = getattr(self.loss_fn, "loss", self.loss_fn)          # FaceFormerLoss wraps a VocaLoss
-            _pred, loss = self.model.forward_with_loss(x, one_hot, template, gt, lf.k_rec, lf.k_vel, unit_grad=True)
+            if hasattr(self.model, "forward_with_loss_batch") and x.dim() == 2 and x.shape[0] > 1:
+                # S independent batch-1 FaceFormer problems per step (train.py:33 fixes batch = 1)
+                _pred, loss = self.model.forward_with_loss_batch(x, one_hot, template, gt, lf.k_rec, lf.k_vel)
+            else:
+                _pred, loss = self.model.forward_with_loss(x, one_hot, template, gt, lf.k_rec, lf.k_vel, unit_grad=True)
         else:
             pred = self.model(x, one_hot, template)
             loss = self.loss_fn(pred, gt)

@@ -250,6 +250,14 @@ int a2f_interp_linear_bwd(const float* dy, int64_t N, int64_t L_in, int64_t C, i
 int a2f_adam_step(float* p, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float grad_scale, int32_t step, a2f_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Measurement helpers (no model arithmetic): float4 streaming copy (1 read + 1 write) and triad dst = a + b (2 reads +
+ * 1 write, the access mix of the fused head kernel) over n fp32 elements (n % 4 == 0, 16-byte aligned buffers).
+ * bench.py times them with HIP events to report the HBM rate the box gives plain streaming kernels next to the
+ * nominal 8 TB/s. */
+int a2f_stream_copy(float* dst, const float* src, int64_t n, a2f_stream_t stream);
+int a2f_stream_triad(float* dst, const float* a, const float* b, int64_t n, a2f_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

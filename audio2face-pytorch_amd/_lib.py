@@ -35,6 +35,29 @@ class GemmDesc(C.Structure):
     ]
 
 
+class MMOperand(C.Structure):
+    """Mirror of ``a2f_mm_operand`` (include/a2f_hip.h)."""
+    _fields_ = [("p", c_f32p), ("bytes", i64), ("ld", i64), ("trans", i32), ("reserved", i32),
+                ("lines_per_seq", i64), ("seq_stride", i64), ("off", i64), ("seq_elems", i64)]
+
+
+class MMDesc(C.Structure):
+    """Mirror of ``a2f_mm_desc`` (include/a2f_hip.h)."""
+    _fields_ = [
+        ("A", MMOperand), ("B", MMOperand),
+        ("C", c_f32p), ("ldc", i64), ("c_rows_per_seq", i64), ("c_seq_stride", i64),
+        ("C2", c_f32p),
+        ("M", i64), ("N", i64), ("K", i64),
+        ("bias", c_f32p),
+        ("aux", c_f32p), ("ldaux", i64),
+        ("act", i32), ("aux_mode", i32), ("precision", i32), ("split_k", i32),
+        ("ws", c_f32p),
+        ("batch", i32), ("accumulate", i32),
+        ("a_bstride", i64), ("b_bstride", i64), ("c_bstride", i64), ("bias_bstride", i64),
+        ("alpha", f32), ("reserved", i32),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol include/a2f_hip.h declares
 SIGNATURES = {
     "a2f_version": (C.c_int, []),
@@ -71,6 +94,7 @@ SIGNATURES = {
     "a2f_ff_decoder_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, i32, c_f32p, C.c_void_p, sz, C.c_void_p]),
     "a2f_ff_decoder_bwd": (C.c_int, [c_f32p, c_f32p, i64, i64, i32, C.c_void_p, sz, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "a2f_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, f32, f32, f32, f32, f32, f32, i32, C.c_void_p]),
+    "a2f_mm": (C.c_int, [C.POINTER(MMDesc), C.c_void_p]),
     "a2f_stream_copy": (C.c_int, [c_f32p, c_f32p, i64, C.c_void_p]),
     "a2f_stream_triad": (C.c_int, [c_f32p, c_f32p, c_f32p, i64, C.c_void_p]),
 }

@@ -1,0 +1,474 @@
+// bf16-MFMA GEMM family for gfx950 (C ABI: a2f_mm, contract in include/a2f_hip.h).
+//
+// What it replaces: every dense contraction of the wav2vec2 encoder behind FaceFormer (HF Wav2Vec2Model as wrapped by
+// /root/reference/src/model/wav2vec.py:91-189: conv feature encoder as implicit GEMMs, feature projection, grouped
+// positional convolution, q/k/v/out projections, feed-forward layers; forward, data and weight gradients) and the
+// Audio2Mesh convolutions (audio2face.py:13-47), which the reference dispatches to rocBLAS / MIOpen through torch.
+//
+// Shape of the kernel (one workgroup = 4 waves = one 128 x 128 (or 128 x 64) tile of C, 32-deep k-tiles):
+//   * storage is fp32; a k-tile of A and B is fetched with 16-byte raw buffer loads (range-checked: out-of-range and masked
+//     elements read as zero, no branches), converted to bf16 IN REGISTERS and written to LDS as bf16 images - one image for
+//     precision 0, a hi and a lo image for bf16x3 (x = hi + lo, hi = RNE(x), lo = RNE(x - hi));
+//   * k-contiguous operands ("R" images, [line][32 k], 64-byte rows, 16-byte chunks XOR-swizzled with (line >> 2) & 3) give
+//     each v_mfma_f32_32x32x16_bf16 fragment as ONE conflict-free ds_read_b128; operands whose contiguous axis is m / n
+//     ("T" images, [k][lines], pitch 2*lines + 64 bytes) are stored as they arrive (coalesced 8-byte writes) and read with
+//     the transposing ds_read_b64_tr_b16 (two per fragment, conflict-free with that pitch);
+//   * the loads of k-tile t+1 are in flight while tile t is multiplied (register staging, LDS double buffer, one barrier
+//     per k-tile); a wave owns a 64 x 64 (32 x 64) block of C = 2 x 2 (1 x 2) accumulator tiles, so a 16-deep k-step is
+//     8 (6) fragment reads for 12 (6) MFMAs in bf16x3;
+//   * split-K slabs + fixed-order fold for weight gradients (K = rows of the batch), batch index for grouped convolutions.
+#include "a2f_common.h"
+
+namespace a2f {
+namespace mm {
+
+using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
+using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
+using u32x2_t = __attribute__((ext_vector_type(2))) unsigned;
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
+using i16x4_t = __attribute__((ext_vector_type(4))) short;
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+constexpr int BK = 32;
+constexpr int THREADS = 256;
+
+struct Op {
+  const float* p;
+  unsigned bytes;
+  int ld, lps, off, seq_elems;
+  long long seq_stride;
+  long long bstride;
+};
+
+struct Args {
+  Op A, B;
+  float* C;
+  float* C2;
+  const float* bias;
+  const float* aux;
+  float* ws;
+  long long ldc, c_seq_stride, c_bstride, bias_bstride, ldaux;
+  int c_rps;
+  int M, N, K;
+  int act, aux_mode, accumulate, split_k, batch;
+  float alpha;
+};
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// one output element through the epilogue (shared by the GEMM kernel and the split-K fold)
+__device__ __forceinline__ void epilogue_store(const Args& a, int bz, int m, int n, long long crow, float v) {
+  v *= a.alpha;
+  if (a.bias) v += a.bias[bz * a.bias_bstride + n];
+  const long long ci = bz * a.c_bstride + crow + n;
+  if (a.C2) a.C2[ci] = v;
+  if (a.act == 1) v = fmaxf(v, 0.f);
+  else if (a.act == 3) v = gelu_f(v);
+  if (a.aux_mode) {
+    const float x = a.aux[(long long)bz * a.M * a.ldaux + (long long)m * a.ldaux + n];
+    if (a.aux_mode == 1) v += x;
+    else if (a.aux_mode == 2) v *= gelu_grad_f(x);
+    else v *= (x > 0.f ? 1.f : 0.f);
+  }
+  if (a.accumulate) v += a.C[ci];
+  a.C[ci] = v;
+}
+
+__device__ __forceinline__ long long c_row_offset(const Args& a, int m) {
+  if (a.c_rps <= 0) return (long long)m * a.ldc;
+  return (long long)(m / a.c_rps) * a.c_seq_stride + (long long)(m % a.c_rps) * a.ldc;
+}
+
+__device__ __forceinline__ void split4(const u32x4_t raw, u32x2_t& hi, u32x2_t& lo) {
+  const f32x2_t v0 = {__builtin_bit_cast(float, raw.x), __builtin_bit_cast(float, raw.y)};
+  const f32x2_t v1 = {__builtin_bit_cast(float, raw.z), __builtin_bit_cast(float, raw.w)};
+  const bf16x2_t h0 = __builtin_convertvector(v0, bf16x2_t);
+  const bf16x2_t h1 = __builtin_convertvector(v1, bf16x2_t);
+  const f32x2_t r0 = v0 - __builtin_convertvector(h0, f32x2_t);
+  const f32x2_t r1 = v1 - __builtin_convertvector(h1, f32x2_t);
+  hi.x = __builtin_bit_cast(unsigned, h0);
+  hi.y = __builtin_bit_cast(unsigned, h1);
+  lo.x = __builtin_bit_cast(unsigned, __builtin_convertvector(r0, bf16x2_t));
+  lo.y = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
+}
+__device__ __forceinline__ u32x2_t cvt4(const u32x4_t raw) {
+  const f32x2_t v0 = {__builtin_bit_cast(float, raw.x), __builtin_bit_cast(float, raw.y)};
+  const f32x2_t v1 = {__builtin_bit_cast(float, raw.z), __builtin_bit_cast(float, raw.w)};
+  u32x2_t r;
+  r.x = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, bf16x2_t));
+  r.y = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, bf16x2_t));
+  return r;
+}
+__device__ __forceinline__ u32x2_t tr_read(const char* lds_addr) {
+  return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4_t*)(lds_addr)));
+}
+__device__ __forceinline__ f32x16 mfma(u32x4_t a, u32x4_t b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One operand's staging: X = number of lines (R) or contiguous extent (T) a tile spans (BM for A, BN for B).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool T, int X>
+struct Stage {
+  static constexpr int NL = T ? (BK * X / 4) / THREADS : (X * 8) / THREADS;      // float4 units per thread
+  static constexpr int PITCH = T ? (2 * X + 64) : 64;                            // bytes
+  static constexpr int IMG = T ? BK * PITCH : X * 64;                            // bytes of one bf16 image
+  // R: fixed lines; T: fixed contiguous offset, lines advance with k
+  unsigned boff[NL];
+  int e0[NL];
+  unsigned valid;          // R: bit i = line i exists; T: bit 0 = the contiguous float4 is inside the operand's extent
+  int lds_w[NL];           // byte offset of this thread's 8-byte slot in an image
+  // T only: running (sequence, position) of the tile's first k-line
+  int q0;
+  long long s0base;        // s0 * seq_stride (elements)
+  int jx;                  // contiguous element index of this thread's float4
+
+  __device__ __forceinline__ void init(const Op& op, int x0, int xcount, int kbeg, int t) {
+    valid = 0;
+    if constexpr (!T) {
+      const int kq = t & 7;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int ll = (t >> 3) + 32 * i;
+        const int line = x0 + ll;
+        long long s = 0;
+        int q = line;
+        if (op.lps > 0) { s = line / op.lps; q = line - (int)s * op.lps; }
+        const long long e = (long long)q * op.ld + op.off + kq * 4;
+        e0[i] = (int)e;
+        boff[i] = (unsigned)((s * op.seq_stride + e) * 4);
+        if (line < xcount) valid |= (1u << i);
+        lds_w[i] = ll * 64 + ((((kq >> 1) ^ ((ll >> 2) & 3))) << 4) + ((kq & 1) << 3);
+      }
+    } else {
+      constexpr int PER_ROW = X / 4;
+      const int nq = t % PER_ROW;
+      jx = x0 + nq * 4;
+      if (jx < xcount) valid = 1;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int kl = t / PER_ROW + (THREADS / PER_ROW) * i;
+        e0[i] = kl;                                  // local k-line of this unit
+        lds_w[i] = kl * PITCH + nq * 8;
+      }
+      q0 = kbeg;
+      s0base = 0;
+      if (op.lps > 0) {
+        const int s = kbeg / op.lps;
+        q0 = kbeg - s * op.lps;
+        s0base = (long long)s * op.seq_stride;
+      }
+    }
+  }
+
+  // issue the loads of the k-tile starting at k0 (kend = end of this split's k-range)
+  __device__ __forceinline__ void load(const Op& op, rsrc_t rs, int k0, int kend, u32x4_t (&reg)[NL]) {
+    if constexpr (!T) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int e = e0[i] + k0;
+        const bool ok = ((valid >> i) & 1u) && (k0 + (int)(threadIdx.x & 7) * 4 < kend) && e >= 0 && e < op.seq_elems;
+        reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? boff[i] + (unsigned)k0 * 4u : 0xFFFFFFFFu, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int kl = e0[i];
+        int q = q0 + kl;
+        long long sb = s0base;
+        if (op.lps > 0) {
+          while (q >= op.lps) { q -= op.lps; sb += op.seq_stride; }
+        }
+        const long long e = (long long)q * op.ld + op.off + jx;
+        const bool ok = valid && (k0 + kl < kend) && e >= 0 && e < op.seq_elems;
+        reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)((sb + e) * 4) : 0xFFFFFFFFu, 0, 0);
+      }
+    }
+  }
+
+  __device__ __forceinline__ void advance(const Op& op) {
+    if constexpr (T) {
+      q0 += BK;
+      if (op.lps > 0) {
+        while (q0 >= op.lps) { q0 -= op.lps; s0base += op.seq_stride; }
+      }
+    }
+  }
+
+  template <int PREC>
+  __device__ __forceinline__ void commit(char* img, const u32x4_t (&reg)[NL]) const {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      if constexpr (PREC == 1) {
+        u32x2_t hi, lo;
+        split4(reg[i], hi, lo);
+        *reinterpret_cast<u32x2_t*>(img + lds_w[i]) = hi;
+        *reinterpret_cast<u32x2_t*>(img + IMG + lds_w[i]) = lo;
+      } else {
+        *reinterpret_cast<u32x2_t*>(img + lds_w[i]) = cvt4(reg[i]);
+      }
+    }
+  }
+
+  // fragment of the 32-line tile starting at local line `rb`, k16 step ks
+  __device__ __forceinline__ static u32x4_t frag(const char* img, int rb, int ks, int lane) {
+    if constexpr (!T) {
+      const int line = rb + (lane & 31);
+      const int chunk = ks * 2 + (lane >> 5);
+      return *reinterpret_cast<const u32x4_t*>(img + line * 64 + ((chunk ^ ((line >> 2) & 3)) << 4));
+    } else {
+      const int g = lane >> 4, i = lane & 15;
+      const int krow = ks * 16 + 8 * (g >> 1) + (i >> 2);
+      const char* p = img + krow * PITCH + (rb + 16 * (g & 1) + 4 * (i & 3)) * 2;
+      const u32x2_t r0 = tr_read(p);
+      const u32x2_t r1 = tr_read(p + 4 * PITCH);
+      return u32x4_t{r0.x, r0.y, r1.x, r1.y};
+    }
+  }
+};
+
+// CFG 0: 128 x 128 tile, waves 2 x 2, 2 x 2 accumulator tiles per wave.  CFG 1: 128 x 64 tile, waves 4 x 1, 1 x 2 tiles.
+template <bool AT, bool BT, int PREC, int CFG>
+__global__ __launch_bounds__(THREADS, 2) void gemm_mfma_kernel(const Args a) {
+  constexpr int BM = 128, BN = CFG == 0 ? 128 : 64;
+  constexpr int WGN = CFG == 0 ? 2 : 1;
+  constexpr int TM = CFG == 0 ? 2 : 1, TN = 2;
+  constexpr int NIMG = PREC == 1 ? 2 : 1;
+  using SA = Stage<AT, BM>;
+  using SB = Stage<BT, BN>;
+  constexpr int A_BYTES = NIMG * SA::IMG, B_BYTES = NIMG * SB::IMG;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // two stages
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int bz = blockIdx.z / a.split_k, sk = blockIdx.z % a.split_k;
+
+  int kbeg = 0, kend = a.K;
+  if (a.split_k > 1) {
+    const int ktiles = (a.K + BK - 1) / BK;
+    const int per = (ktiles + a.split_k - 1) / a.split_k;
+    kbeg = sk * per * BK;
+    kend = min(a.K, kbeg + per * BK);
+  }
+  const int nkt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+
+  Op opA = a.A, opB = a.B;
+  opA.p += bz * opA.bstride;
+  opB.p += bz * opB.bstride;
+  const rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(opA.p), 0, opA.bytes, 0x00020000);
+  const rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(opB.p), 0, opB.bytes, 0x00020000);
+
+  SA sa;
+  SB sb;
+  sa.init(opA, m0, a.M, kbeg, t);
+  sb.init(opB, n0, a.N, kbeg, t);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4_t ra[SA::NL], rb[SB::NL];
+  if (nkt > 0) {
+    sa.load(opA, rsA, kbeg, kend, ra);
+    sb.load(opB, rsB, kbeg, kend, rb);
+    sa.advance(opA);
+    sb.advance(opB);
+    sa.template commit<PREC>(smem, ra);
+    sb.template commit<PREC>(smem + A_BYTES, rb);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const char* cur = smem + (kt & 1) * STAGE;
+    char* nxt = smem + ((kt + 1) & 1) * STAGE;
+    const bool more = kt + 1 < nkt;
+    if (more) {
+      const int k0 = kbeg + (kt + 1) * BK;
+      sa.load(opA, rsA, k0, kend, ra);
+      sb.load(opB, rsB, k0, kend, rb);
+      sa.advance(opA);
+      sb.advance(opB);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4_t fa[NIMG][TM], fb[NIMG][TN];
+#pragma unroll
+      for (int q = 0; q < NIMG; ++q) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[q][i] = SA::frag(cur + q * SA::IMG, (wm * TM + i) * 32, ks, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[q][j] = SB::frag(cur + A_BYTES + q * SB::IMG, (wn * TN + j) * 32, ks, lane);
+      }
+      if constexpr (PREC == 1) {           // small terms first; consecutive MFMAs hit different accumulators
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma(fa[1][i], fb[0][j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma(fa[0][i], fb[1][j], acc[i][j]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma(fa[0][i], fb[0][j], acc[i][j]);
+    }
+    if (more) {
+      sa.template commit<PREC>(nxt, ra);
+      sb.template commit<PREC>(nxt + A_BYTES, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  const int h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int mb = m0 + (wm * TM + i) * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m >= a.M) continue;
+      long long crow = 0;
+      if (a.split_k <= 1) crow = c_row_offset(a, m);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+        if (n >= a.N) continue;
+        if (a.split_k > 1) {
+          a.ws[((long long)blockIdx.z * a.M + m) * a.N + n] = acc[i][j][r];
+        } else {
+          epilogue_store(a, bz, m, n, crow, acc[i][j][r]);
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_mfma_fold_kernel(const Args a) {
+  const long long total = (long long)a.batch * a.M * a.N;
+  const long long mn = (long long)a.M * a.N;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int bz = (int)(idx / mn);
+    const long long r = idx - bz * mn;
+    const int m = (int)(r / a.N), n = (int)(r - (long long)m * a.N);
+    float v = 0.f;
+    for (int s = 0; s < a.split_k; ++s) v += a.ws[((long long)(bz * a.split_k + s)) * mn + r];
+    epilogue_store(a, bz, m, n, c_row_offset(a, m), v);
+  }
+}
+
+template <bool AT, bool BT, int PREC, int CFG>
+static int launch(const Args& a, hipStream_t st) {
+  constexpr int BM = 128, BN = CFG == 0 ? 128 : 64;
+  constexpr int NIMG = PREC == 1 ? 2 : 1;
+  constexpr int smem = 2 * NIMG * (Stage<AT, BM>::IMG + Stage<BT, BN>::IMG);
+  auto kern = gemm_mfma_kernel<AT, BT, PREC, CFG>;
+  static bool attr_done = false;                        // set-once per instantiation (idempotent; safe to repeat)
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return set_err(A2F_ELAUNCH, "a2f_mm: cannot reserve %d bytes of LDS", smem);
+    attr_done = true;
+  }
+  dim3 grid((unsigned)cdiv(a.N, BN), (unsigned)cdiv(a.M, BM), (unsigned)(a.batch * a.split_k));
+  hipLaunchKernelGGL(kern, grid, dim3(THREADS), smem, st, a);
+  return A2F_OK;
+}
+
+template <int PREC, int CFG>
+static int dispatch_layout(const Args& a, bool at, bool bt, hipStream_t st) {
+  if (!at && !bt) return launch<false, false, PREC, CFG>(a, st);
+  if (!at && bt) return launch<false, true, PREC, CFG>(a, st);
+  if (at && bt) return launch<true, true, PREC, CFG>(a, st);
+  return launch<true, false, PREC, CFG>(a, st);
+}
+
+static int fill_op(const a2f_mm_operand& o, int64_t bstride, int64_t contiguous_extent, Op& k, const char* name) {
+  A2F_CHECK_ARG(o.p != nullptr, "a2f_mm: operand %s is null", name);
+  A2F_CHECK_ARG(((uintptr_t)o.p & 15) == 0, "a2f_mm: operand %s must be 16-byte aligned", name);
+  A2F_CHECK_ARG(o.bytes > 0 && o.bytes < (int64_t)0xFFFFFFF0ll, "a2f_mm: operand %s spans %lld bytes (must be < 4 GiB)", name, (long long)o.bytes);
+  A2F_CHECK_ARG(o.ld % 4 == 0 && o.off % 4 == 0 && o.seq_stride % 4 == 0 && bstride % 4 == 0 && contiguous_extent % 4 == 0,
+                "a2f_mm: operand %s: ld, off, seq_stride, batch stride and the contiguous extent must be multiples of 4 elements", name);
+  A2F_CHECK_ARG(o.lines_per_seq >= 0 && o.lines_per_seq < (1ll << 31) && o.ld < (1ll << 31) && llabs(o.off) < (1ll << 31),
+                "a2f_mm: operand %s: window parameters out of range", name);
+  k.p = o.p;
+  k.bytes = (unsigned)o.bytes;
+  k.ld = (int)o.ld;
+  k.lps = (int)o.lines_per_seq;
+  k.off = o.lines_per_seq > 0 ? (int)o.off : 0;
+  k.seq_elems = o.lines_per_seq > 0 ? (int)(o.seq_elems < 0x7FFFFFF0ll ? o.seq_elems : 0x7FFFFFF0ll) : 0x7FFFFFF0;
+  k.seq_stride = o.lines_per_seq > 0 ? o.seq_stride : 0;
+  k.bstride = bstride;
+  return A2F_OK;
+}
+
+}  // namespace mm
+}  // namespace a2f
+
+extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
+  using namespace a2f;
+  using namespace a2f::mm;
+  A2F_CHECK_ARG(d != nullptr, "a2f_mm: null descriptor");
+  A2F_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0 && d->M < (1ll << 31) && d->N < (1ll << 31) && d->K < (1ll << 31),
+                "a2f_mm: M=%lld N=%lld K=%lld", (long long)d->M, (long long)d->N, (long long)d->K);
+  A2F_CHECK_ARG(d->C != nullptr, "a2f_mm: C is null");
+  A2F_CHECK_ARG(d->precision == 0 || d->precision == 1, "a2f_mm: precision %d (0 = bf16, 1 = bf16x3)", d->precision);
+  A2F_CHECK_ARG(d->act == 0 || d->act == 1 || d->act == 3, "a2f_mm: act %d", d->act);
+  A2F_CHECK_ARG(d->aux_mode >= 0 && d->aux_mode <= 3 && (d->aux_mode == 0 || d->aux != nullptr), "a2f_mm: aux_mode %d / aux", d->aux_mode);
+  const int batch = d->batch > 0 ? d->batch : 1;
+  const int split = d->split_k > 1 ? d->split_k : 1;
+  A2F_CHECK_ARG(split == 1 || d->ws != nullptr, "a2f_mm: split_k needs a workspace");
+  A2F_CHECK_ARG((int64_t)batch * split <= 65535, "a2f_mm: batch * split_k = %lld exceeds the grid limit", (long long)batch * split);
+  Args a;
+  int rc = fill_op(d->A, d->a_bstride, d->A.trans ? d->M : d->K, a.A, "A");
+  if (rc) return rc;
+  rc = fill_op(d->B, d->b_bstride, d->B.trans ? d->N : d->K, a.B, "B");
+  if (rc) return rc;
+  a.C = d->C;
+  a.C2 = d->C2;
+  a.bias = d->bias;
+  a.aux = d->aux;
+  a.ws = d->ws;
+  a.ldc = d->ldc;
+  a.c_seq_stride = d->c_seq_stride;
+  a.c_bstride = d->c_bstride;
+  a.bias_bstride = d->bias_bstride;
+  a.ldaux = d->ldaux;
+  a.c_rps = (int)d->c_rows_per_seq;
+  a.M = (int)d->M;
+  a.N = (int)d->N;
+  a.K = (int)d->K;
+  a.act = d->act;
+  a.aux_mode = d->aux_mode;
+  a.accumulate = d->accumulate;
+  a.split_k = split;
+  a.batch = batch;
+  a.alpha = d->alpha == 0.f ? 1.f : d->alpha;
+  const bool at = d->A.trans != 0, bt = d->B.trans != 0;
+  const int cfg = d->N <= 64 ? 1 : 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->precision == 1) rc = cfg == 0 ? dispatch_layout<1, 0>(a, at, bt, st) : dispatch_layout<1, 1>(a, at, bt, st);
+  else rc = cfg == 0 ? dispatch_layout<0, 0>(a, at, bt, st) : dispatch_layout<0, 1>(a, at, bt, st);
+  if (rc) return rc;
+  A2F_CHECK_LAUNCH("a2f_mm");
+  if (split > 1) {
+    const long long total = (long long)batch * a.M * a.N;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gemm_mfma_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    A2F_CHECK_LAUNCH("a2f_mm fold");
+  }
+  return A2F_OK;
+}

@@ -14,10 +14,29 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import A2FError, GemmDesc
+from ._lib import A2FError, GemmDesc, MMDesc, MMOperand
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 AUX_NONE, AUX_RELU_BWD, AUX_TANH_BWD, AUX_ADD = 0, 1, 2, 3
+# a2f_mm (bf16-MFMA GEMM family) epilogue codes
+MM_ACT_NONE, MM_ACT_RELU, MM_ACT_GELU = 0, 1, 3
+MM_AUX_NONE, MM_AUX_ADD, MM_AUX_GELU_BWD, MM_AUX_RELU_BWD = 0, 1, 2, 3
+
+
+class MMOp:
+    """One operand of ``HipBackend.mm`` (a2f_mm_operand): tensor + line stride; ``trans`` = the contiguous axis is m / n
+    instead of k; ``lines_per_seq`` > 0 switches on the window structure (sequence stride, in-sequence offset, bounds)."""
+
+    def __init__(self, t: torch.Tensor, ld: int, *, trans: bool = False, lines_per_seq: int = 0, seq_stride: int = 0, off: int = 0,
+                 seq_elems: int = 0, ptr_off: int = 0):
+        self.t, self.ld, self.trans = t, int(ld), bool(trans)
+        self.lines_per_seq, self.seq_stride, self.off, self.seq_elems, self.ptr_off = int(lines_per_seq), int(seq_stride), int(off), int(seq_elems), int(ptr_off)
+
+    def fill(self, o: MMOperand):
+        o.p = self.t.data_ptr() + 4 * self.ptr_off
+        o.bytes = 4 * (self.t.numel() - self.ptr_off)
+        o.ld, o.trans = self.ld, int(self.trans)
+        o.lines_per_seq, o.seq_stride, o.off, o.seq_elems = self.lines_per_seq, self.seq_stride, self.off, self.seq_elems
 
 
 def _ptr(t: Optional[torch.Tensor], off: int = 0) -> Optional[int]:
@@ -98,6 +117,43 @@ class HipBackend:
         ev = self._prof_begin(tag)
         _lib.check(self.lib.a2f_gemm_f32(C.byref(d), self._stream(Cout)), "a2f_gemm_f32")
         self._prof_end(tag, ev)
+
+    # ---- a2f_mm (bf16-MFMA GEMM family) ---------------------------------------------------------
+    mm_precision = 1          # 1 = bf16x3 split products (fp32-class, the parity setting); 0 = plain bf16 operands (16-mixed)
+
+    def mm(self, A: "MMOp", B: "MMOp", Cout, M, N, K, ldc, *, c_off=0, c_rows_per_seq=0, c_seq_stride=0, C2=None, bias=None, aux=None,
+           ldaux=0, act=MM_ACT_NONE, aux_mode=MM_AUX_NONE, precision=None, split_k=1, batch=1, a_bstride=0, b_bstride=0, c_bstride=0,
+           bias_bstride=0, accumulate=False, alpha=1.0, tag="gemm_mfma"):
+        """C[m,n] = epi(alpha * sum_k A(m,k) B(k,n)) on the bf16 matrix pipe (contract: include/a2f_hip.h, a2f_mm)."""
+        _chk(A.t, B.t, Cout, C2, bias, aux)
+        d = MMDesc()
+        A.fill(d.A)
+        B.fill(d.B)
+        d.C, d.ldc, d.c_rows_per_seq, d.c_seq_stride = _ptr(Cout, c_off), ldc, c_rows_per_seq, c_seq_stride
+        d.C2 = _ptr(C2, c_off)
+        d.M, d.N, d.K = M, N, K
+        d.bias = _ptr(bias)
+        d.aux, d.ldaux = _ptr(aux), ldaux
+        d.act, d.aux_mode = act, aux_mode
+        d.precision = self.mm_precision if precision is None else precision
+        if split_k == 0:                                        # auto: enough workgroups for the chip, slabs stay small
+            tiles = ((M + 127) // 128) * ((N + (127 if N > 64 else 63)) // (128 if N > 64 else 64)) * batch
+            split_k = max(1, min(512 // max(tiles, 1), K // 256, 64)) if tiles < 192 else 1
+        d.split_k = split_k
+        ws = None
+        if split_k > 1:
+            ws = torch.empty(batch * split_k * M * N, device=Cout.device, dtype=torch.float32)
+            d.ws = _ptr(ws)
+        d.batch, d.accumulate = batch, int(accumulate)
+        d.a_bstride, d.b_bstride, d.c_bstride, d.bias_bstride = a_bstride, b_bstride, c_bstride, bias_bstride
+        d.alpha = alpha
+        ev = self._prof_begin(tag)
+        _lib.check(self.lib.a2f_mm(C.byref(d), self._stream(Cout)), "a2f_mm")
+        self._prof_end(tag, ev)
+        if self.prof is not None and tag is not None:
+            pf = getattr(self, "prof_flops", None)
+            if pf is not None:
+                pf[tag] = pf.get(tag, 0.0) + 2.0 * M * N * K * batch
 
     # ---- a2f_wgrad_f32 ------------------------------------------------------------------------
     def wgrad_supported(self, M, N):

@@ -258,6 +258,57 @@ int a2f_adam_step(float* p, const float* grad, float* m, float* v, int64_t n, fl
 int a2f_stream_copy(float* dst, const float* src, int64_t n, a2f_stream_t stream);
 int a2f_stream_triad(float* dst, const float* a, const float* b, int64_t n, a2f_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * bf16-MFMA GEMM family (csrc/gemm_mfma.hip): the matrix products of the wav2vec2 encoder that FaceFormer trains through
+ * (HF Wav2Vec2Model as wrapped by /root/reference/src/model/wav2vec.py:91-189: the 7-layer convolutional feature encoder
+ * as implicit GEMMs, feature projection, grouped positional convolution, the q/k/v/out projections and the feed-forward
+ * layers of the 12 Transformer layers - forward, data gradients and weight gradients) and of the Audio2Mesh convolutions
+ * (audio2face.py:13-47).
+ *     C[m,n] = epi( alpha * sum_k A(m,k) * B(k,n) )
+ * Storage is fp32; operands are converted to bf16 while they are staged into LDS and multiplied with
+ * v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  precision 1 (bf16x3): x = hi + lo, lo*hi' + hi*lo' + hi*hi', <= 2^-16
+ * relative error per product - the setting the 1e-4 parity bar is met with; precision 0: plain bf16 operands (the
+ * reference's `percision: 16-mixed`).
+ * Operands (a2f_mm_operand): `trans` = 0: a line is a row of A (column of B) and k is the contiguous axis; `trans` = 1: a
+ * line is one k and the m (n) index is contiguous.  Line i of an operand with lines_per_seq > 0 belongs to sequence
+ * s = i / lines_per_seq, position q = i % lines_per_seq; element j of the line sits at element offset
+ * e = q*ld + j + off inside the sequence and reads as ZERO unless 0 <= e < seq_elems; its address is
+ * p + s*seq_stride + e.  lines_per_seq = 0: plain matrix (address p + i*ld + j).  This is how strided convolutions over
+ * channels-last (sequence, position, channel) activations run as implicit GEMMs with no im2col buffer: overlapping windows
+ * are lines with ld < K, zero padding and sequence ends are the bounds test.  `bytes` = addressable span from p (< 4 GiB):
+ * anything beyond reads as zero.  All of p, ld, off, seq_stride and the contiguous extent must be multiples of 4 elements
+ * (16-byte vector loads).
+ * Epilogue, per element: v = alpha*acc; if bias: v += bias[n]; C2 (optional) = v;  act: 0 none, 1 ReLU, 3 GELU (erf form);
+ * aux_mode 1: v += aux[m*ldaux+n]; 2: v *= gelu'(aux); 3: v *= (aux > 0); accumulate: v += C_old.  Row m of C (and C2) is
+ * stored at C + (m / c_rows_per_seq)*c_seq_stride + (m % c_rows_per_seq)*ldc + n  (c_rows_per_seq = 0: C + m*ldc + n).
+ * split_k > 1: the contraction is cut into split_k slabs stored in `ws` (>= batch*split_k*M*N floats) and folded in fixed
+ * order by a second kernel that applies the epilogue (deterministic; how weight gradients with K = 10^4 rows fill the chip).
+ * batch > 1: independent problems at p + b*{a,b,c,bias}_bstride (the 16 groups of the positional convolution).
+ */
+typedef struct a2f_mm_operand {
+  const float* p;
+  int64_t bytes;
+  int64_t ld;
+  int32_t trans, reserved;
+  int64_t lines_per_seq, seq_stride, off, seq_elems;
+} a2f_mm_operand;
+
+typedef struct a2f_mm_desc {
+  a2f_mm_operand A, B;
+  float* C; int64_t ldc, c_rows_per_seq, c_seq_stride;
+  float* C2;
+  int64_t M, N, K;
+  const float* bias;
+  const float* aux; int64_t ldaux;
+  int32_t act, aux_mode, precision, split_k;
+  float* ws;
+  int32_t batch, accumulate;
+  int64_t a_bstride, b_bstride, c_bstride, bias_bstride;
+  float alpha; int32_t reserved;
+} a2f_mm_desc;
+
+int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

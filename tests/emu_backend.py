@@ -94,6 +94,63 @@ class EmuBackend:
             s = Am.sum(dim=1).float()
             ones_out[:M] = ones_out[:M] + s if accumulate else s
 
+    # ------------------------------------------------------------------ a2f_mm (bf16-MFMA GEMM family), float64 contract
+    mm_precision = 1
+
+    @staticmethod
+    def _mm_matrix(op, nlines, ncontig):
+        """(nlines, ncontig) float64 matrix of an a2f_mm_operand by the header's contract (zeros outside the windows)."""
+        flat = op.t.reshape(-1)[op.ptr_off:].double()
+        i = torch.arange(nlines).view(-1, 1)
+        j = torch.arange(ncontig).view(1, -1)
+        if op.lines_per_seq > 0:
+            s, q = i // op.lines_per_seq, i % op.lines_per_seq
+            e = q * op.ld + j + op.off
+            ok = (e >= 0) & (e < op.seq_elems)
+            idx = s * op.seq_stride + e
+        else:
+            idx = i * op.ld + j
+            ok = torch.ones_like(idx, dtype=torch.bool)
+        ok = ok & (idx >= 0) & (idx < flat.numel())
+        return torch.where(ok, flat[idx.clamp(0, flat.numel() - 1)], torch.zeros((), dtype=torch.double))
+
+    def mm(self, A, B, Cout, M, N, K, ldc, *, c_off=0, c_rows_per_seq=0, c_seq_stride=0, C2=None, bias=None, aux=None, ldaux=0, act=0,
+           aux_mode=0, precision=None, split_k=1, batch=1, a_bstride=0, b_bstride=0, c_bstride=0, bias_bstride=0, accumulate=False,
+           alpha=1.0, tag=None):
+        import copy
+        self.calls.append(("mm", M, N, K, batch))
+        cflat = Cout.reshape(-1)
+        c2flat = C2.reshape(-1) if C2 is not None else None
+        m = torch.arange(M).view(-1, 1)
+        crow = m * ldc if c_rows_per_seq <= 0 else (m // c_rows_per_seq) * c_seq_stride + (m % c_rows_per_seq) * ldc
+        for bz in range(batch):
+            Ab, Bb = copy.copy(A), copy.copy(B)
+            Ab.ptr_off, Bb.ptr_off = A.ptr_off + bz * a_bstride, B.ptr_off + bz * b_bstride
+            Am = self._mm_matrix(Ab, K, M).t() if A.trans else self._mm_matrix(Ab, M, K)
+            Bm = self._mm_matrix(Bb, K, N) if B.trans else self._mm_matrix(Bb, N, K).t()
+            v = alpha * (Am @ Bm)
+            if bias is not None:
+                v = v + bias.reshape(-1)[bz * bias_bstride: bz * bias_bstride + N].double().view(1, -1)
+            cidx = c_off + bz * c_bstride + crow + torch.arange(N).view(1, -1)
+            assert int(cidx.max()) < cflat.numel(), "mm emu: C write outside its buffer"
+            if c2flat is not None:
+                c2flat[cidx] = v.float()
+            if act == 1:
+                v = v.clamp_min(0)
+            elif act == 3:
+                v = 0.5 * v * (1 + torch.erf(v / math.sqrt(2.0)))
+            if aux_mode:
+                ax = aux.reshape(-1)[bz * M * ldaux + m * ldaux + torch.arange(N).view(1, -1)].double()
+                if aux_mode == 1:
+                    v = v + ax
+                elif aux_mode == 2:
+                    v = v * (0.5 * (1 + torch.erf(ax / math.sqrt(2.0))) + ax * torch.exp(-0.5 * ax * ax) / math.sqrt(2 * math.pi))
+                else:
+                    v = torch.where(ax > 0, v, torch.zeros_like(v))
+            if accumulate:
+                v = v + cflat[cidx].double()
+            cflat[cidx] = v.float()
+
     def wgrad_supported(self, M, N):
         mt, nt = (M + 31) // 32, (N + 1 + 31) // 32
         return (nt <= 7) if mt in (1, 2) else (nt <= 4) if mt == 3 else (nt <= 3) if mt == 4 else False

@@ -38,6 +38,29 @@ def test_gemm_desc_layout_matches_header():
     assert out[1:] == [getattr(_lib.GemmDesc, f).offset for f in fields]
 
 
+def test_mm_desc_layout_matches_header():
+    """Same check for a2f_mm_desc / a2f_mm_operand (the bf16-MFMA GEMM family)."""
+    import ctypes
+    import subprocess
+    import tempfile
+    op_fields = [f for f, _ in _lib.MMOperand._fields_]
+    fields = [f for f, _ in _lib.MMDesc._fields_]
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "a2f_hip.h"\nint main(void) {\n  printf("%zu\\n", sizeof(a2f_mm_operand));\n'
+    prog += "".join(f'  printf("%zu\\n", offsetof(a2f_mm_operand, {f}));\n' for f in op_fields)
+    prog += '  printf("%zu\\n", sizeof(a2f_mm_desc));\n'
+    prog += "".join(f'  printf("%zu\\n", offsetof(a2f_mm_desc, {f}));\n' for f in fields) + "  return 0;\n}\n"
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "layout.c"), os.path.join(d, "layout")
+        open(src, "w").write(prog)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        out = [int(x) for x in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    n = len(op_fields)
+    assert out[0] == ctypes.sizeof(_lib.MMOperand)
+    assert out[1:1 + n] == [getattr(_lib.MMOperand, f).offset for f in op_fields]
+    assert out[1 + n] == ctypes.sizeof(_lib.MMDesc)
+    assert out[2 + n:] == [getattr(_lib.MMDesc, f).offset for f in fields]
+
+
 def test_product_does_not_import_oracle():
     pkg = os.path.join(ROOT, "audio2face-pytorch_amd")
     for dp, _, fs in os.walk(pkg):

@@ -437,3 +437,62 @@ def conv_nonoverlap_bwd_input(be, dout, wg, d_in, R, Cin, Co, KH, *, relu_of=Non
     """Data gradient when stride == kernel and pad == 0 (audio2face.py:45): d_in[r, kh*Cin+ci] = dout[r,:] wg[:, kh*Cin+ci]."""
     am = AUX_RELU_BWD if relu_of is not None else AUX_NONE
     be.gemm(dout, wg, d_in, R, KH * Cin, Co, (0, Co, 1), (0, KH * Cin, 1), KH * Cin, aux=relu_of, ldaux=KH * Cin, aux_mode=am)
+
+
+# =================================================================================================
+# Layer composers over backend.mm (bf16-MFMA GEMM family): Linear and channels-last Conv1d, forward / data / weight
+# gradients.  Activations are (sequence, position, channel) rows; a strided convolution is an implicit GEMM whose A
+# lines are overlapping windows of the activation buffer (no im2col), see include/a2f_hip.h (a2f_mm).
+# =================================================================================================
+_BIG = (1 << 31) - 16
+
+
+def mm_linear_fwd(be, x, W, bias, out, M, N, K, *, act=MM_ACT_NONE, pre=None, aux=None, aux_mode=MM_AUX_NONE, tag="gemm_mfma"):
+    """out[M,N] = act(x[M,K] W[N,K]^T + bias) (+ aux);  pre (optional) receives the pre-activation values."""
+    be.mm(MMOp(x, K), MMOp(W, K), out, M, N, K, N, bias=bias, act=act, C2=pre, aux=aux, ldaux=N, aux_mode=aux_mode, tag=tag)
+
+
+def mm_linear_dgrad(be, dy, W, dx, M, N, K, *, aux=None, aux_mode=MM_AUX_NONE, tag="gemm_mfma"):
+    """dx[M,K] = dy[M,N] W[N,K], optionally times an activation derivative evaluated on aux[M,K]."""
+    be.mm(MMOp(dy, N), MMOp(W, K, trans=True), dx, M, K, N, K, aux=aux, ldaux=K, aux_mode=aux_mode, tag=tag)
+
+
+def mm_linear_wgrad(be, dy, x, dW, M, N, K, *, tag="gemm_mfma"):
+    """dW[N,K] = dy[M,N]^T x[M,K]: the contraction runs over the M rows of the batch (split-K slabs, fixed-order fold)."""
+    be.mm(MMOp(dy, N, trans=True), MMOp(x, K, trans=True), dW, N, K, M, K, split_k=0, tag=tag)
+
+
+def mm_conv_fwd(be, x, Wg, y, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, bias=None, act=MM_ACT_NONE, pre=None, tag="gemm_mfma"):
+    """Conv1d over channels-last rows: x (S,Lin,Ci) -> y (S,Lout,Co), Wg (Co, KH*Ci) with k = kh*Ci + ci; `pad` zero
+    positions on the left of every sequence."""
+    A = MMOp(x, stride * Ci, lines_per_seq=Lout, seq_stride=Lin * Ci, off=-pad * Ci, seq_elems=Lin * Ci)
+    be.mm(A, MMOp(Wg, KH * Ci), y, S * Lout, Co, KH * Ci, Co, bias=bias, act=act, C2=pre, tag=tag)
+
+
+def mm_conv_wgrad(be, x, dy, dWg, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, tag="gemm_mfma"):
+    """dWg[Co, KH*Ci] = sum over (sequence, position) of dy[row, co] * window(x)[row, :]."""
+    A = MMOp(dy, Co, trans=True)
+    B = MMOp(x, stride * Ci, trans=True, lines_per_seq=Lout, seq_stride=Lin * Ci, off=-pad * Ci, seq_elems=Lin * Ci)
+    be.mm(A, B, dWg, Co, KH * Ci, S * Lout, KH * Ci, split_k=0, tag=tag)
+
+
+def mm_conv_dgrad(be, dy, Wg, dx, S, Lin, Lout, Ci, Co, KH, stride, *, aux=None, aux_mode=MM_AUX_NONE, tag="gemm_mfma"):
+    """dx (S,Lin,Ci) from dy (S,Lout,Co), gather form (no atomics, no col2im buffer); positions no window touches must be
+    zero in dx on entry.  Supported: KH == stride (non-overlapping windows) and KH = 3, stride = 2 (no padding).
+    aux / aux_mode: activation derivative evaluated on aux (S,Lin,Ci), fused into the store."""
+    if aux_mode != MM_AUX_NONE:
+        raise A2FError("mm_conv_dgrad: fused activation derivative is not supported on strided outputs")   # rows of C are remapped, aux rows are dense
+    if KH == stride:
+        be.mm(MMOp(dy, Co), MMOp(Wg, KH * Ci, trans=True), dx, S * Lout, KH * Ci, Co, KH * Ci, c_rows_per_seq=Lout, c_seq_stride=Lin * Ci, tag=tag)
+        return
+    if KH == 3 and stride == 2:
+        assert Lin >= 2 * Lout + 1
+        # even positions 2q, q = 0..Lout: window [dy[q-1], dy[q]] against [W_kh=2 ; W_kh=0]
+        A = MMOp(dy, Co, lines_per_seq=Lout + 1, seq_stride=Lout * Co, off=-Co, seq_elems=Lout * Co)
+        B = MMOp(Wg, 3 * Ci, trans=True, lines_per_seq=Co, seq_stride=-2 * Ci, off=2 * Ci, seq_elems=_BIG)
+        be.mm(A, B, dx, S * (Lout + 1), Ci, 2 * Co, 2 * Ci, c_rows_per_seq=Lout + 1, c_seq_stride=Lin * Ci, tag=tag)
+        # odd positions 2q+1, q = 0..Lout-1: dy[q] against W_kh=1
+        be.mm(MMOp(dy, Co), MMOp(Wg, 3 * Ci, trans=True, ptr_off=Ci), dx, S * Lout, Ci, Co, 2 * Ci, c_off=Ci, c_rows_per_seq=Lout,
+              c_seq_stride=Lin * Ci, tag=tag)
+        return
+    raise A2FError(f"mm_conv_dgrad: unsupported kernel/stride {KH}/{stride}")

@@ -1,0 +1,118 @@
+"""GPU: a2f_mm (bf16-MFMA GEMM family, csrc/gemm_mfma.hip) against the float64 emulator of its contract (include/a2f_hip.h).
+
+precision 1 (bf16x3 split products, the parity setting): <= 2^-16 relative error per product -> 3e-5 relative L2 on the
+result; precision 0 (plain bf16 operands, `percision: 16-mixed`): 2^-9 per operand -> 1e-2.  All calls go through the C ABI.
+"""
+import pytest
+import torch
+
+import a2f_amd
+from a2f_amd import ops
+from a2f_amd.ops import MMOp
+from emu_backend import EmuBackend
+from golden_util import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = {1: 3e-5, 0: 1e-2}
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def both(fn):
+    """fn(be, dev) -> list of output tensors; runs on the HIP backend and on the emulator."""
+    hip = ops.HipBackend()
+    emu = EmuBackend()
+    a = [t.cpu() for t in fn(hip, DEV)]
+    torch.cuda.synchronize()
+    b = fn(emu, "cpu")
+    return a, b
+
+
+@pytest.mark.parametrize("M,N,K", [(600, 768, 768), (130, 64, 768), (257, 48, 100), (1, 4, 4), (1200, 3072, 768), (96, 132, 36), (333, 200, 4)])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
+@pytest.mark.parametrize("precision", [1, 0])
+def test_mm_layouts_epilogues(M, N, K, layout, precision):
+    at, bt = layout[0] == "t", layout[1] == "n"
+    if at and M % 4:
+        M += 4 - M % 4                                     # the contiguous axis must be a multiple of 4 elements
+    if bt and N % 4:
+        N += 4 - N % 4
+    A = rnd(K, M, seed=1) if at else rnd(M, K, seed=1)
+    B = rnd(K, N, seed=2) if bt else rnd(N, K, seed=2)
+    bias, aux, C0 = rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N + 8, seed=5)
+
+    def run(be, dev):
+        outs = []
+        for kw in (dict(), dict(bias=bias.to(dev)), dict(bias=bias.to(dev), act=ops.MM_ACT_GELU, with_pre=True),
+                   dict(act=ops.MM_ACT_RELU, aux=aux.to(dev), aux_mode=ops.MM_AUX_ADD), dict(aux=aux.to(dev), aux_mode=ops.MM_AUX_GELU_BWD),
+                   dict(aux=aux.to(dev), aux_mode=ops.MM_AUX_RELU_BWD, accumulate=True, alpha=0.5), dict(split_k=3, bias=bias.to(dev))):
+            kw = dict(kw)
+            C = C0.clone().to(dev)
+            pre = torch.zeros(M, N + 8, device=dev) if kw.pop("with_pre", False) else None
+            be.mm(MMOp(A.to(dev), M if at else K, trans=at), MMOp(B.to(dev), N if bt else K, trans=bt), C, M, N, K, N + 8, C2=pre, ldaux=N,
+                  precision=precision, **kw)
+            outs.append(C)
+            if pre is not None:
+                outs.append(pre)
+        return outs
+    got, ref = both(run)
+    for g, r in zip(got, ref):
+        assert torch.equal(g[:, N:], r[:, N:])                                  # nothing written beyond the N columns
+        assert rel_l2(g[:, :N], r[:, :N]) < TOL[precision]
+
+
+@pytest.mark.parametrize("KH,stride,Lin", [(3, 2, 41), (3, 2, 42), (2, 2, 40), (2, 2, 41), (3, 2, 399)])
+@pytest.mark.parametrize("S", [1, 3])
+def test_mm_conv1d_composers_vs_torch(KH, stride, Lin, S):
+    """Conv1d forward / data gradient / weight gradient composed from a2f_mm windows against torch's conv1d in float64."""
+    Ci, Co = 64, 96
+    Lout = (Lin - KH) // stride + 1
+    x, W, dy = rnd(S, Lin, Ci, seed=1), rnd(Co, Ci, KH, seed=2, scale=0.1), rnd(S, Lout, Co, seed=3)
+    Wg = W.permute(0, 2, 1).reshape(Co, KH * Ci).contiguous()
+    xd, Wd = x.double().requires_grad_(True), W.double().requires_grad_(True)
+    ref = torch.nn.functional.conv1d(xd.transpose(1, 2), Wd, stride=stride).transpose(1, 2)
+    ref.backward(dy.double())
+    be = ops.HipBackend()
+    y = torch.empty(S, Lout, Co, device=DEV)
+    ops.mm_conv_fwd(be, x.to(DEV), Wg.to(DEV), y, S, Lin, Lout, Ci, Co, KH, stride)
+    assert rel_l2(y, ref) < 3e-5
+    dx = torch.zeros(S, Lin, Ci, device=DEV)
+    ops.mm_conv_dgrad(be, dy.to(DEV), Wg.to(DEV), dx, S, Lin, Lout, Ci, Co, KH, stride)
+    assert rel_l2(dx, xd.grad) < 3e-5
+    dWg = torch.empty(Co, KH * Ci, device=DEV)
+    ops.mm_conv_wgrad(be, x.to(DEV), dy.to(DEV), dWg, S, Lin, Lout, Ci, Co, KH, stride)
+    assert rel_l2(dWg, Wd.grad.permute(0, 2, 1).reshape(Co, KH * Ci)) < 3e-5
+
+
+def test_mm_batched_groups_and_split_k():
+    """The grouped positional convolution's shape: 16 independent problems (batch strides), N = 48, K = 6144, windows with
+    left/right zero padding; and a weight-gradient-shaped contraction over 9600 rows with automatic split-K."""
+    G, T, Cg, KH = 16, 100, 48, 128
+    pad = KH // 2
+    xg = rnd(G, T, Cg, seed=1)                       # group-major activations (G, T, Cg)
+    wg = rnd(G, Cg, KH * Cg, seed=2, scale=0.02)     # (G, Co_g, KH*Cg)
+    bias = rnd(G * Cg, seed=3)
+
+    def run(be, dev):
+        y = torch.zeros(T, G * Cg, device=dev)
+        A = MMOp(xg.to(dev), Cg, lines_per_seq=T, seq_stride=T * Cg, off=-pad * Cg, seq_elems=T * Cg)
+        be.mm(A, MMOp(wg.to(dev), KH * Cg), y, T, Cg, KH * Cg, G * Cg, bias=bias.to(dev), act=ops.MM_ACT_GELU, batch=G, a_bstride=T * Cg,
+              b_bstride=Cg * KH * Cg, c_bstride=Cg, bias_bstride=Cg)
+        dy, x = rnd(9600, 256, seed=4).to(dev), rnd(9600, 768, seed=5).to(dev)
+        dW = torch.empty(256, 768, device=dev)
+        ops.mm_linear_wgrad(be, dy, x, dW, 9600, 256, 768)
+        return [y, dW]
+    got, ref = both(run)
+    for g, r in zip(got, ref):
+        assert rel_l2(g, r) < 3e-5
+
+
+def test_mm_rejects_bad_arguments():
+    be = ops.HipBackend()
+    x = torch.zeros(8, 6, device=DEV)
+    with pytest.raises(a2f_amd.A2FError):
+        be.mm(MMOp(x, 6), MMOp(x, 6), torch.zeros(8, 8, device=DEV), 8, 8, 6, 8)       # K = 6 is not a multiple of 4

@@ -83,9 +83,12 @@ __device__ __forceinline__ long long c_row_offset(const Args& a, int m) {
   return (long long)(m / a.c_rps) * a.c_seq_stride + (long long)(m % a.c_rps) * a.ldc;
 }
 
+// NB: bit-cast the WHOLE vector first.  __builtin_bit_cast(float, raw.y) on a vector-element lvalue reads element 0 with
+// hipcc 7.2 (all four values came out as raw.x).
 __device__ __forceinline__ void split4(const u32x4_t raw, u32x2_t& hi, u32x2_t& lo) {
-  const f32x2_t v0 = {__builtin_bit_cast(float, raw.x), __builtin_bit_cast(float, raw.y)};
-  const f32x2_t v1 = {__builtin_bit_cast(float, raw.z), __builtin_bit_cast(float, raw.w)};
+  const f32x4 f = __builtin_bit_cast(f32x4, raw);
+  const f32x2_t v0 = {f.x, f.y};
+  const f32x2_t v1 = {f.z, f.w};
   const bf16x2_t h0 = __builtin_convertvector(v0, bf16x2_t);
   const bf16x2_t h1 = __builtin_convertvector(v1, bf16x2_t);
   const f32x2_t r0 = v0 - __builtin_convertvector(h0, f32x2_t);
@@ -96,8 +99,9 @@ __device__ __forceinline__ void split4(const u32x4_t raw, u32x2_t& hi, u32x2_t& 
   lo.y = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
 }
 __device__ __forceinline__ u32x2_t cvt4(const u32x4_t raw) {
-  const f32x2_t v0 = {__builtin_bit_cast(float, raw.x), __builtin_bit_cast(float, raw.y)};
-  const f32x2_t v1 = {__builtin_bit_cast(float, raw.z), __builtin_bit_cast(float, raw.w)};
+  const f32x4 f = __builtin_bit_cast(f32x4, raw);
+  const f32x2_t v0 = {f.x, f.y};
+  const f32x2_t v1 = {f.z, f.w};
   u32x2_t r;
   r.x = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, bf16x2_t));
   r.y = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, bf16x2_t));
@@ -118,75 +122,89 @@ struct Stage {
   static constexpr int NL = T ? (BK * X / 4) / THREADS : (X * 8) / THREADS;      // float4 units per thread
   static constexpr int PITCH = T ? (2 * X + 64) : 64;                            // bytes
   static constexpr int IMG = T ? BK * PITCH : X * 64;                            // bytes of one bf16 image
-  // R: fixed lines; T: fixed contiguous offset, lines advance with k
-  unsigned boff[NL];
-  int e0[NL];
-  unsigned valid;          // R: bit i = line i exists; T: bit 0 = the contiguous float4 is inside the operand's extent
+  // R: fixed lines, the loads walk along k.  T: fixed contiguous offset, the lines (= k) advance with the k-tiles.
+  // All address arithmetic is 32-bit and branch-free (selects): byte offsets are taken modulo 2^32 from the operand base
+  // (the span is < 4 GiB), an element offset inside a sequence is < 2^31.
+  unsigned boff[NL];       // R: byte offset of (line i, k = 0);  T: unused
+  int e0[NL];              // R: element offset inside the sequence of (line i, k = 0);  T: local k-line of unit i
+  unsigned okmask;         // R: bit i = line i exists;  T: bit 0 = this thread's float4 lies inside the contiguous extent
   int lds_w[NL];           // byte offset of this thread's 8-byte slot in an image
-  // T only: running (sequence, position) of the tile's first k-line
-  int q0;
-  long long s0base;        // s0 * seq_stride (elements)
-  int jx;                  // contiguous element index of this thread's float4
+  int kq4;                 // R: k offset of this thread's float4 inside a k-tile
+  int q0;                  // T: position (inside its sequence) of the current k-tile's first line
+  unsigned s0bytes;        // T: byte offset of that sequence (mod 2^32)
+  int jx;                  // T: contiguous element index of this thread's float4 (+ the window offset)
 
   __device__ __forceinline__ void init(const Op& op, int x0, int xcount, int kbeg, int t) {
-    valid = 0;
+    okmask = 0;
     if constexpr (!T) {
       const int kq = t & 7;
+      kq4 = kq * 4;
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const int ll = (t >> 3) + 32 * i;
         const int line = x0 + ll;
-        long long s = 0;
-        int q = line;
-        if (op.lps > 0) { s = line / op.lps; q = line - (int)s * op.lps; }
-        const long long e = (long long)q * op.ld + op.off + kq * 4;
-        e0[i] = (int)e;
-        boff[i] = (unsigned)((s * op.seq_stride + e) * 4);
-        if (line < xcount) valid |= (1u << i);
+        int s = 0, q = line;
+        if (op.lps > 0) { s = line / op.lps; q = line - s * op.lps; }
+        const int e = q * op.ld + op.off + kq4;
+        e0[i] = e;
+        boff[i] = (unsigned)s * (unsigned)(op.seq_stride * 4) + (unsigned)e * 4u;
+        if (line < xcount) okmask |= (1u << i);
         lds_w[i] = ll * 64 + ((((kq >> 1) ^ ((ll >> 2) & 3))) << 4) + ((kq & 1) << 3);
       }
     } else {
       constexpr int PER_ROW = X / 4;
       const int nq = t % PER_ROW;
       jx = x0 + nq * 4;
-      if (jx < xcount) valid = 1;
+      if (jx < xcount) okmask = 1;
+      jx += op.off;
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const int kl = t / PER_ROW + (THREADS / PER_ROW) * i;
-        e0[i] = kl;                                  // local k-line of this unit
+        e0[i] = kl;
         lds_w[i] = kl * PITCH + nq * 8;
       }
       q0 = kbeg;
-      s0base = 0;
+      s0bytes = 0;
       if (op.lps > 0) {
         const int s = kbeg / op.lps;
         q0 = kbeg - s * op.lps;
-        s0base = (long long)s * op.seq_stride;
+        s0bytes = (unsigned)s * (unsigned)(op.seq_stride * 4);
       }
     }
   }
 
-  // issue the loads of the k-tile starting at k0 (kend = end of this split's k-range)
+  // issue the loads of the k-tile starting at k0 (kend = end of this split's k-range); T operands: call advance() after it
   __device__ __forceinline__ void load(const Op& op, rsrc_t rs, int k0, int kend, u32x4_t (&reg)[NL]) {
     if constexpr (!T) {
+      const bool kin = (k0 + kq4) < kend;
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
-        const int e = e0[i] + k0;
-        const bool ok = ((valid >> i) & 1u) && (k0 + (int)(threadIdx.x & 7) * 4 < kend) && e >= 0 && e < op.seq_elems;
-        reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? boff[i] + (unsigned)k0 * 4u : 0xFFFFFFFFu, 0, 0);
+        const unsigned e = (unsigned)(e0[i] + k0);                       // negative offsets wrap to huge values: out of range
+        const bool ok = kin & (((okmask >> i) & 1u) != 0) & (e < (unsigned)op.seq_elems);
+        const unsigned off = boff[i] + (unsigned)k0 * 4u;
+        reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : 0xFFFFFFFFu, 0, 0);
       }
     } else {
+      const unsigned sstep = (unsigned)(op.seq_stride * 4);
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const int kl = e0[i];
         int q = q0 + kl;
-        long long sb = s0base;
+        unsigned sb = s0bytes;
         if (op.lps > 0) {
-          while (q >= op.lps) { q -= op.lps; sb += op.seq_stride; }
+          if (op.lps >= BK) {                                             // at most one sequence boundary inside a k-tile
+            const bool wrap = q >= op.lps;
+            q = wrap ? q - op.lps : q;
+            sb = wrap ? sb + sstep : sb;
+          } else {                                                        // very short sequences (tests): general form
+            const int w = q / op.lps;
+            q -= w * op.lps;
+            sb += (unsigned)w * sstep;
+          }
         }
-        const long long e = (long long)q * op.ld + op.off + jx;
-        const bool ok = valid && (k0 + kl < kend) && e >= 0 && e < op.seq_elems;
-        reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)((sb + e) * 4) : 0xFFFFFFFFu, 0, 0);
+        const unsigned e = (unsigned)(q * op.ld + jx);
+        const bool ok = (okmask != 0) & ((k0 + kl) < kend) & (e < (unsigned)op.seq_elems);
+        reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? sb + e * 4u : 0xFFFFFFFFu, 0, 0);
       }
     }
   }
@@ -195,7 +213,15 @@ struct Stage {
     if constexpr (T) {
       q0 += BK;
       if (op.lps > 0) {
-        while (q0 >= op.lps) { q0 -= op.lps; s0base += op.seq_stride; }
+        if (op.lps >= BK) {
+          const bool wrap = q0 >= op.lps;
+          q0 = wrap ? q0 - op.lps : q0;
+          s0bytes = wrap ? s0bytes + (unsigned)(op.seq_stride * 4) : s0bytes;
+        } else {
+          const int w = q0 / op.lps;
+          q0 -= w * op.lps;
+          s0bytes += (unsigned)w * (unsigned)(op.seq_stride * 4);
+        }
       }
     }
   }
@@ -248,7 +274,10 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_mfma_kernel(const Args a) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int bz = blockIdx.z / a.split_k, sk = blockIdx.z % a.split_k;
+  // readfirstlane: the batch / split indices come out of an integer division (vector ALU); telling the compiler they are
+  // wave-uniform keeps the buffer resources in SGPRs (otherwise every buffer load is wrapped in a waterfall loop)
+  const int bz = __builtin_amdgcn_readfirstlane((int)(blockIdx.z / a.split_k));
+  const int sk = __builtin_amdgcn_readfirstlane((int)(blockIdx.z % a.split_k));
 
   int kbeg = 0, kend = a.K;
   if (a.split_k > 1) {
@@ -260,8 +289,14 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_mfma_kernel(const Args a) {
   const int nkt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
 
   Op opA = a.A, opB = a.B;
-  opA.p += bz * opA.bstride;
-  opB.p += bz * opB.bstride;
+  // the operand bases as provably wave-uniform values: the buffer resources then live in SGPRs (no waterfall loops)
+  auto uniform_ptr = [](const float* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const float*)(((unsigned long long)hi << 32) | lo);
+  };
+  opA.p = uniform_ptr(opA.p + bz * opA.bstride);
+  opB.p = uniform_ptr(opB.p + bz * opB.bstride);
   const rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(opA.p), 0, opA.bytes, 0x00020000);
   const rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(opB.p), 0, opB.bytes, 0x00020000);
 
@@ -279,27 +314,16 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_mfma_kernel(const Args a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   u32x4_t ra[SA::NL], rb[SB::NL];
-  if (nkt > 0) {
-    sa.load(opA, rsA, kbeg, kend, ra);
-    sb.load(opB, rsB, kbeg, kend, rb);
-    sa.advance(opA);
-    sb.advance(opB);
-    sa.template commit<PREC>(smem, ra);
-    sb.template commit<PREC>(smem + A_BYTES, rb);
-  }
+  // prologue: k-tile 0 -> stage 0 (with nkt == 0 every load is out of range and the images are zeros)
+  sa.load(opA, rsA, kbeg, kend, ra);
+  sb.load(opB, rsB, kbeg, kend, rb);
+  sa.advance(opA);
+  sb.advance(opB);
+  sa.template commit<PREC>(smem, ra);
+  sb.template commit<PREC>(smem + A_BYTES, rb);
   __syncthreads();
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    const char* cur = smem + (kt & 1) * STAGE;
-    char* nxt = smem + ((kt + 1) & 1) * STAGE;
-    const bool more = kt + 1 < nkt;
-    if (more) {
-      const int k0 = kbeg + (kt + 1) * BK;
-      sa.load(opA, rsA, k0, kend, ra);
-      sb.load(opB, rsB, k0, kend, rb);
-      sa.advance(opA);
-      sb.advance(opB);
-    }
+  auto compute = [&](const char* cur) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       u32x4_t fa[NIMG][TM], fb[NIMG][TN];
@@ -325,35 +349,76 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_mfma_kernel(const Args a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma(fa[0][i], fb[0][j], acc[i][j]);
     }
-    if (more) {
-      sa.template commit<PREC>(nxt, ra);
-      sb.template commit<PREC>(nxt + A_BYTES, rb);
-    }
+  };
+
+  // steady state: the loads of tile kt+1 fly while tile kt is multiplied; the last tile is peeled (no loads, no commit)
+  for (int kt = 0; kt + 1 < nkt; ++kt) {
+    const int k0 = kbeg + (kt + 1) * BK;
+    sa.load(opA, rsA, k0, kend, ra);
+    sb.load(opB, rsB, k0, kend, rb);
+    sa.advance(opA);
+    sb.advance(opB);
+    // keep the load issue HERE: without the fence the machine scheduler sinks the buffer loads below the MFMA block, next
+    // to their first use, and the tile fetch no longer overlaps the multiplication
+    __builtin_amdgcn_sched_barrier(0);
+    compute(smem + (kt & 1) * STAGE);
+    __builtin_amdgcn_sched_barrier(0);
+    char* nxt = smem + ((kt + 1) & 1) * STAGE;
+    sa.template commit<PREC>(nxt, ra);
+    sb.template commit<PREC>(nxt + A_BYTES, rb);
     __syncthreads();
   }
+  if (nkt > 0) compute(smem + ((nkt - 1) & 1) * STAGE);
 
   // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   const int h = lane >> 5;
+  int ncol[TN];
+  float bv[TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int mb = m0 + (wm * TM + i) * 32;
+  for (int j = 0; j < TN; ++j) {
+    ncol[j] = n0 + (wn * TN + j) * 32 + (lane & 31);
+    bv[j] = (a.bias && a.split_k <= 1 && ncol[j] < a.N) ? a.bias[bz * a.bias_bstride + ncol[j]] : 0.f;
+  }
+  const bool generic = a.C2 || a.act || a.aux_mode || a.accumulate;     // wave-uniform
+  if (a.split_k > 1) {
+    float* wsz = a.ws + (long long)blockIdx.z * a.M * a.N;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (m >= a.M) continue;
-      long long crow = 0;
-      if (a.split_k <= 1) crow = c_row_offset(a, m);
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-        if (n >= a.N) continue;
-        if (a.split_k > 1) {
-          a.ws[((long long)blockIdx.z * a.M + m) * a.N + n] = acc[i][j][r];
-        } else {
-          epilogue_store(a, bz, m, n, crow, acc[i][j][r]);
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          if (m < a.M && ncol[j] < a.N) wsz[(long long)m * a.N + ncol[j]] = acc[i][j][r];
+      }
+  } else {
+    float* Cz = a.C + bz * a.c_bstride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= a.M) continue;
+        const long long crow = c_row_offset(a, m);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (ncol[j] >= a.N) continue;
+          float v = acc[i][j][r] * a.alpha + bv[j];
+          if (generic) {
+            if (a.C2) a.C2[bz * a.c_bstride + crow + ncol[j]] = v;
+            if (a.act == 1) v = fmaxf(v, 0.f);
+            else if (a.act == 3) v = gelu_f(v);
+            if (a.aux_mode) {
+              const float x = a.aux[(long long)bz * a.M * a.ldaux + (long long)m * a.ldaux + ncol[j]];
+              if (a.aux_mode == 1) v += x;
+              else if (a.aux_mode == 2) v *= gelu_grad_f(x);
+              else v *= (x > 0.f ? 1.f : 0.f);
+            }
+            if (a.accumulate) v += Cz[crow + ncol[j]];
+          }
+          Cz[crow + ncol[j]] = v;
         }
       }
-    }
   }
 }
 

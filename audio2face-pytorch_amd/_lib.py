@@ -95,6 +95,14 @@ SIGNATURES = {
     "a2f_ff_decoder_bwd": (C.c_int, [c_f32p, c_f32p, i64, i64, i32, C.c_void_p, sz, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "a2f_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, f32, f32, f32, f32, f32, f32, i32, C.c_void_p]),
     "a2f_mm": (C.c_int, [C.POINTER(MMDesc), C.c_void_p]),
+    "a2f_layernorm_fwd": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, f32, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "a2f_layernorm_bwd_ws_bytes": (sz, [i64, i64]),
+    "a2f_layernorm_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
+    "a2f_colsum_ws_bytes": (sz, [i64, i64]),
+    "a2f_colsum": (C.c_int, [c_f32p, i64, i64, i64, c_f32p, C.c_void_p, sz, C.c_void_p]),
+    "a2f_gelu_bwd": (C.c_int, [c_f32p, c_f32p, i64, c_f32p, C.c_void_p]),
+    "a2f_attn_fwd": (C.c_int, [c_f32p, i64, i64, i64, i64, f32, i32, c_f32p, i64, c_f32p, C.c_void_p]),
+    "a2f_attn_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, i64, i64, i64, f32, i32, c_f32p, c_f32p, C.c_void_p]),
     "a2f_stream_copy": (C.c_int, [c_f32p, c_f32p, i64, C.c_void_p]),
     "a2f_stream_triad": (C.c_int, [c_f32p, c_f32p, c_f32p, i64, C.c_void_p]),
 }

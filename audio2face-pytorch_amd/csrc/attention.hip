@@ -1,0 +1,614 @@
+// MFMA flash attention for the wav2vec2 encoder behind FaceFormer: 12 heads x 64, full (unmasked) self-attention over the
+// T frames of one sequence (T = 600 at BASELINE configs[2], 3000 at configs[4]), forward and backward.
+// Replaces softmax(q k^T) v of HF Wav2Vec2Attention (the encoder layers called at /root/reference/src/model/wav2vec.py:174-180;
+// q is pre-scaled by head_dim^-0.5 as HF does) and its autograd backward.
+//
+// Storage is fp32 in the fused (rows, 3*768) q|k|v projection buffer; operands are converted to bf16 on chip and multiplied
+// with v_mfma_f32_32x32x16_bf16 (fp32 accumulate, fp32 softmax).  PREC 1 = bf16x3 split products (x = hi + lo; lo*hi' +
+// hi*lo' + hi*hi'; fp32-class: the 1e-4 parity setting), PREC 0 = plain bf16 operands.
+//
+// Structure (all three kernels): a workgroup = 4 waves; the streamed operand tiles (64 rows x 64) are fetched with 16-byte
+// raw buffer loads (a resource per sequence: rows beyond T read as zero), converted in registers and kept in LDS as bf16
+// images with 128-byte rows whose 16-byte chunks are XOR-swizzled so that BOTH the row reads (ds_read_b128, MFMA operands
+// along d) and the transposing reads (ds_read_b64_tr_b16, operands along the row index) are bank-conflict free; double
+// buffered, loads of tile t+1 in flight under the MFMAs of tile t, one barrier per tile.
+//   forward : wave = 32 queries; S^T = K Q^T with the query on the lane -> online softmax per lane (one cross-half exchange
+//             per tile); P feeds O^T += V^T P straight from the accumulator registers (permuted-k operand order);
+//   dK / dV : wave = 32 keys (K, V fragments in registers), streams Q / dO tiles; P and dS feed dV^T, dK^T from registers;
+//   dQ      : wave = 32 queries (Q, dO fragments in registers), streams K / V tiles; dS^T feeds dQ^T from registers.
+// No atomics anywhere: every output element has exactly one owner (deterministic).
+#include "a2f_common.h"
+
+namespace a2f {
+namespace attn {
+
+using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
+using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
+using u32x2_t = __attribute__((ext_vector_type(2))) unsigned;
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
+using i16x4_t = __attribute__((ext_vector_type(4))) short;
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+constexpr int D = 64;            // head dimension
+constexpr int TILE = 64;         // rows of a streamed tile
+constexpr int IMG = TILE * 128;  // bytes of one bf16 image of a 64 x 64 tile
+constexpr int THREADS = 256;
+
+struct Args {
+  const float* qkv;      // (S*T, ld): q at column 0, k at koff, v at voff; head h at + 64 h
+  const float* ctx;      // forward output / backward input (S*T, ldo)
+  const float* dctx;     // (S*T, ldo)
+  const float* lse;      // (S, H, T) log-sum-exp of the scaled scores
+  const float* delta;    // (S, H, T) rowsum(dctx * ctx) per head
+  float* out_ctx;
+  float* out_lse;
+  float* out_delta;
+  float* dqkv;           // (S*T, ld)
+  int ld, ldo, koff, voff;
+  int S, T, H;
+  float scale;
+};
+
+__device__ __forceinline__ int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ int swz(int row) {           // chunk XOR of the dual-use image
+  const int x = (row >> 1) & 7;
+  return ((x & 1) << 2) | (x >> 1);
+}
+__device__ __forceinline__ int img_off(int row, int c16) { return row * 128 + ((c16 ^ swz(row)) << 4); }
+
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  const f32x2_t v = {a, b};
+  const bf16x2_t hb = __builtin_convertvector(v, bf16x2_t);
+  const f32x2_t r = v - __builtin_convertvector(hb, f32x2_t);
+  hi = __builtin_bit_cast(unsigned, hb);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+}
+__device__ __forceinline__ unsigned cvt2(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ u32x2_t tr_read(const char* lds_addr) {
+  return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4_t*)(lds_addr)));
+}
+__device__ __forceinline__ f32x16 mfma(u32x4_t a, u32x4_t b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// c += (ah + al)(bh + bl) without lo*lo; small terms first
+template <int PREC>
+__device__ __forceinline__ f32x16 mac(const u32x4_t (&a)[2], const u32x4_t (&b)[2], f32x16 c) {
+  if constexpr (PREC == 1) {
+    c = mfma(a[1], b[0], c);
+    c = mfma(a[0], b[1], c);
+  }
+  return mfma(a[0], b[0], c);
+}
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ rsrc_t seq_rsrc(const float* base, long long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(base)), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ld4(rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
+// ---- a streamed 64 x 64 fp32 tile: 4 float4 per thread (row = (t >> 4) + 16 i, columns 4 (t & 15) ..), bf16 image(s) in LDS
+template <int PREC>
+struct Tile {
+  f32x4 reg[4];
+  __device__ __forceinline__ void load(rsrc_t rs, int row0, int ld, int col0, int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = row0 + (t >> 4) + 16 * i;
+      reg[i] = ld4(rs, (unsigned)(row * ld + col0 + 4 * (t & 15)) * 4u);       // rows beyond the sequence are out of range: zeros
+    }
+  }
+  __device__ __forceinline__ void commit(char* img, int t, float mul = 1.f) const {
+    const int c4 = t & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (t >> 4) + 16 * i;
+      char* p = img + img_off(row, c4 >> 1) + ((c4 & 1) << 3);
+      u32x2_t hi, lo;
+      if constexpr (PREC == 1) {
+        unsigned h0, l0, h1, l1;
+        split2(reg[i].x * mul, reg[i].y * mul, h0, l0);
+        split2(reg[i].z * mul, reg[i].w * mul, h1, l1);
+        hi = u32x2_t{h0, h1};
+        lo = u32x2_t{l0, l1};
+        *reinterpret_cast<u32x2_t*>(p) = hi;
+        *reinterpret_cast<u32x2_t*>(p + IMG) = lo;
+      } else {
+        hi.x = cvt2(reg[i].x * mul, reg[i].y * mul);
+        hi.y = cvt2(reg[i].z * mul, reg[i].w * mul);
+        *reinterpret_cast<u32x2_t*>(p) = hi;
+      }
+    }
+  }
+};
+
+// MFMA operand along d (k = d): lane (r, h) <- row (rb + r), d = 16 ks + 8 h .. + 7
+template <int PREC>
+__device__ __forceinline__ void frag_rows(const char* img, int rb, int ks, int lane, u32x4_t (&f)[2]) {
+  const int row = rb + (lane & 31);
+  const int off = img_off(row, 2 * ks + (lane >> 5));
+  f[0] = *reinterpret_cast<const u32x4_t*>(img + off);
+  if constexpr (PREC == 1) f[1] = *reinterpret_cast<const u32x4_t*>(img + IMG + off);
+}
+// MFMA A operand along the tile's row index (k = row), rows taken in the PERMUTED order of an accumulator tile used as the
+// other operand: element j of lane half h <-> row rb + 16 s + 8 (j >> 2) + 4 h + (j & 3); lane r <-> column cb + r
+template <int PREC>
+__device__ __forceinline__ void frag_cols(const char* img, int rb, int s, int cb, int lane, u32x4_t (&f)[2]) {
+  const int g = lane >> 4, i = lane & 15;
+  const int row = rb + 16 * s + 4 * (g >> 1) + (i >> 2);
+  const int col = cb + 16 * (g & 1) + 4 * (i & 3);
+  const int o0 = img_off(row, col >> 3) + ((col & 7) << 1);
+  const int o1 = img_off(row + 8, col >> 3) + ((col & 7) << 1);
+  const u32x2_t a0 = tr_read(img + o0), a1 = tr_read(img + o1);
+  f[0] = u32x4_t{a0.x, a0.y, a1.x, a1.y};
+  if constexpr (PREC == 1) {
+    const u32x2_t b0 = tr_read(img + IMG + o0), b1 = tr_read(img + IMG + o1);
+    f[1] = u32x4_t{b0.x, b0.y, b1.x, b1.y};
+  }
+}
+// registers 8 s .. 8 s + 7 of an accumulator tile as the bf16 operand of k-step s (permuted-k order, see frag_cols)
+template <int PREC>
+__device__ __forceinline__ void acc_operand(const f32x16& x, int s, u32x4_t (&f)[2]) {
+  unsigned hi[4], lo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if constexpr (PREC == 1) split2(x[8 * s + 2 * j], x[8 * s + 2 * j + 1], hi[j], lo[j]);
+    else hi[j] = cvt2(x[8 * s + 2 * j], x[8 * s + 2 * j + 1]);
+  }
+  f[0] = u32x4_t{hi[0], hi[1], hi[2], hi[3]};
+  if constexpr (PREC == 1) f[1] = u32x4_t{lo[0], lo[1], lo[2], lo[3]};
+}
+// per-lane fragments of a (row = lane & 31) x 64 operand held in registers for the whole kernel: k-step ks <- d = 16 ks + 8 h ..
+template <int PREC>
+__device__ __forceinline__ void reg_operand(rsrc_t rs, int row, int ld, int col0, int lane, float mul, u32x4_t (&f)[4][2]) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const unsigned off = (unsigned)(row * ld + col0 + 16 * ks + 8 * h) * 4u;
+    const f32x4 a = ld4(rs, off), b = ld4(rs, off + 16u);
+    unsigned hi[4], lo[4];
+    if constexpr (PREC == 1) {
+      split2(a.x * mul, a.y * mul, hi[0], lo[0]);
+      split2(a.z * mul, a.w * mul, hi[1], lo[1]);
+      split2(b.x * mul, b.y * mul, hi[2], lo[2]);
+      split2(b.z * mul, b.w * mul, hi[3], lo[3]);
+      f[ks][1] = u32x4_t{lo[0], lo[1], lo[2], lo[3]};
+    } else {
+      hi[0] = cvt2(a.x * mul, a.y * mul);
+      hi[1] = cvt2(a.z * mul, a.w * mul);
+      hi[2] = cvt2(b.x * mul, b.y * mul);
+      hi[3] = cvt2(b.z * mul, b.w * mul);
+    }
+    f[ks][0] = u32x4_t{hi[0], hi[1], hi[2], hi[3]};
+  }
+}
+
+// =====================================================================================================================
+// forward
+// =====================================================================================================================
+template <int PREC>
+__global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
+  constexpr int NIMG = PREC == 1 ? 2 : 1;
+  constexpr int STAGE = 2 * NIMG * IMG;                       // K images, V images
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5;
+  const int head = blockIdx.y, seq = blockIdx.z;
+  const int T = a.T;
+  const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const rsrc_t rs = seq_rsrc(a.qkv + (long long)seq * T * a.ld, (long long)T * a.ld * 4);
+  const int hc = head * D;
+
+  u32x4_t qf[4][2];
+  reg_operand<PREC>(rs, q, a.ld, hc, lane, a.scale, qf);
+
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[0][r] = o[1][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  const int nt = (T + TILE - 1) / TILE;
+  Tile<PREC> kt_, vt_;
+  kt_.load(rs, 0, a.ld, a.koff + hc, t);
+  vt_.load(rs, 0, a.ld, a.voff + hc, t);
+  kt_.commit(smem, t);
+  vt_.commit(smem + NIMG * IMG, t);
+  __syncthreads();
+
+  for (int it = 0; it < nt; ++it) {
+    const char* kimg = smem + (it & 1) * STAGE;
+    const char* vimg = kimg + NIMG * IMG;
+    if (it + 1 < nt) {
+      kt_.load(rs, (it + 1) * TILE, a.ld, a.koff + hc, t);
+      vt_.load(rs, (it + 1) * TILE, a.ld, a.voff + hc, t);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S^T = K Q^T: keys on the registers, this lane's query on the lane
+    f32x16 st[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        u32x4_t kf[2];
+        frag_rows<PREC>(kimg, 32 * kb, ks, lane, kf);
+        st[kb] = mac<PREC>(kf, qf[ks], st[kb]);
+      }
+    }
+    if ((it + 1) * TILE > T) {                                  // ragged last tile: keys beyond T do not exist
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (it * TILE + 32 * kb + rho(r, h) >= T) st[kb][r] = -INFINITY;
+    }
+    // ---- online softmax (per lane = per query; the two lane halves hold disjoint keys of the same query)
+    float mx = st[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __expf(m - mn);
+    m = mn;
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[kb][r] = __expf(st[kb][r] - mn);
+        ps += st[kb][r];
+      }
+    l = l * alpha + ps;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o[0][r] *= alpha;
+      o[1][r] *= alpha;
+    }
+    // ---- O^T += V^T P: P straight from the accumulator registers
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        u32x4_t pf[2];
+        acc_operand<PREC>(st[kb], s, pf);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          u32x4_t vf[2];
+          frag_cols<PREC>(vimg, 32 * kb, s, 32 * dt, lane, vf);
+          o[dt] = mac<PREC>(vf, pf, o[dt]);
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + 1 < nt) {
+      char* nk = smem + ((it + 1) & 1) * STAGE;
+      kt_.commit(nk, t);
+      vt_.commit(nk + NIMG * IMG, t);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: O = O^T / l, rows = this lane's query, 4 consecutive d per register quad
+  const float lt = l + __shfl_xor(l, 32, 64);
+  const float inv = 1.f / lt;
+  if (q < T) {
+    float* orow = a.out_ctx + ((long long)seq * T + q) * a.ldo + hc;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const f32x4 v = {o[dt][4 * gq] * inv, o[dt][4 * gq + 1] * inv, o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv};
+        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * gq + 4 * h) = v;
+      }
+    if (h == 0) a.out_lse[((long long)seq * a.H + head) * T + q] = m + __logf(lt);
+  }
+}
+
+// delta[s,h,q] = sum_d dctx[q, 64 h + d] * ctx[q, 64 h + d]: one wave per row of (S*T), lane l <-> columns 4 l .. (ldo <= 1024)
+__global__ __launch_bounds__(THREADS) void attn_delta_kernel(const Args a) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
+  if (row >= (long long)a.S * a.T) return;
+  const int seq = (int)(row / a.T), q = (int)(row - (long long)seq * a.T);
+  const int ncol = a.H * D;
+  for (int c = 4 * lane; c < ncol; c += 256) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(a.ctx + row * a.ldo + c);
+    const f32x4 y = *reinterpret_cast<const f32x4*>(a.dctx + row * a.ldo + c);
+    float s = (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    // 16 lanes share a head (64 columns = 16 float4)
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    if ((lane & 15) == 0) a.out_delta[((long long)seq * a.H + c / D) * a.T + q] = s;
+  }
+}
+
+// =====================================================================================================================
+// backward, dK and dV: wave = 32 keys (registers), streams Q / dO tiles of 64 queries
+//   S[q][key] = Qs K^T (query on the registers, key on the lane);  P = exp(S - lse[q]);  dP = dO V^T;  dS = P (dP - delta[q])
+//   dV^T[d][key] += dO^T P;   dK^T[d][key] += Qs^T dS           (Qs = scale * Q, so dK needs no further factor)
+// =====================================================================================================================
+template <int PREC>
+__global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) {
+  constexpr int NIMG = PREC == 1 ? 2 : 1;
+  constexpr int STAGE = 2 * NIMG * IMG;                       // Q images, dO images
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5;
+  const int head = blockIdx.y, seq = blockIdx.z;
+  const int T = a.T;
+  const int key = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const rsrc_t rs = seq_rsrc(a.qkv + (long long)seq * T * a.ld, (long long)T * a.ld * 4);
+  const rsrc_t rd = seq_rsrc(a.dctx + (long long)seq * T * a.ldo, (long long)T * a.ldo * 4);
+  const int hc = head * D;
+  const float* lse = a.lse + ((long long)seq * a.H + head) * T;
+  const float* dlt = a.delta + ((long long)seq * a.H + head) * T;
+
+  u32x4_t kf[4][2], vf[4][2];
+  reg_operand<PREC>(rs, key, a.ld, a.koff + hc, lane, 1.f, kf);
+  reg_operand<PREC>(rs, key, a.ld, a.voff + hc, lane, 1.f, vf);
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dk[0][r] = dk[1][r] = dv[0][r] = dv[1][r] = 0.f;
+
+  const int nt = (T + TILE - 1) / TILE;
+  Tile<PREC> qt_, dt_;
+  qt_.load(rs, 0, a.ld, hc, t);
+  dt_.load(rd, 0, a.ldo, hc, t);
+  qt_.commit(smem, t, a.scale);
+  dt_.commit(smem + NIMG * IMG, t);
+  __syncthreads();
+
+  for (int it = 0; it < nt; ++it) {
+    const char* qimg = smem + (it & 1) * STAGE;
+    const char* dimg = qimg + NIMG * IMG;
+    if (it + 1 < nt) {
+      qt_.load(rs, (it + 1) * TILE, a.ld, hc, t);
+      dt_.load(rd, (it + 1) * TILE, a.ldo, hc, t);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {                          // two 32-query sub-tiles
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        u32x4_t qa[2], da[2];
+        frag_rows<PREC>(qimg, 32 * qb, ks, lane, qa);
+        frag_rows<PREC>(dimg, 32 * qb, ks, lane, da);
+        s = mac<PREC>(qa, kf[ks], s);
+        dp = mac<PREC>(da, vf[ks], dp);
+      }
+      // rows = queries it*64 + 32 qb + rho(r, h); P = exp(S - lse), dS = P (dP - delta); queries beyond T contribute nothing
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = it * TILE + 32 * qb + rho(r, h);
+        const bool ok = qq < T;
+        const float ls = ok ? lse[qq] : 0.f, de = ok ? dlt[qq] : 0.f;
+        const float p = ok ? __expf(s[r] - ls) : 0.f;
+        s[r] = p;
+        dp[r] = p * (dp[r] - de);
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        u32x4_t pf[2], sf[2];
+        acc_operand<PREC>(s, ss, pf);
+        acc_operand<PREC>(dp, ss, sf);
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+          u32x4_t oa[2], qa[2];
+          frag_cols<PREC>(dimg, 32 * qb, ss, 32 * dd, lane, oa);
+          frag_cols<PREC>(qimg, 32 * qb, ss, 32 * dd, lane, qa);
+          dv[dd] = mac<PREC>(oa, pf, dv[dd]);
+          dk[dd] = mac<PREC>(qa, sf, dk[dd]);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + 1 < nt) {
+      char* nq = smem + ((it + 1) & 1) * STAGE;
+      qt_.commit(nq, t, a.scale);
+      dt_.commit(nq + NIMG * IMG, t);
+    }
+    __syncthreads();
+  }
+  if (key < T) {
+    float* krow = a.dqkv + ((long long)seq * T + key) * a.ld + hc;
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const f32x4 x = {dk[dd][4 * gq], dk[dd][4 * gq + 1], dk[dd][4 * gq + 2], dk[dd][4 * gq + 3]};
+        const f32x4 y = {dv[dd][4 * gq], dv[dd][4 * gq + 1], dv[dd][4 * gq + 2], dv[dd][4 * gq + 3]};
+        *reinterpret_cast<f32x4*>(krow + a.koff + 32 * dd + 8 * gq + 4 * h) = x;
+        *reinterpret_cast<f32x4*>(krow + a.voff + 32 * dd + 8 * gq + 4 * h) = y;
+      }
+  }
+}
+
+// =====================================================================================================================
+// backward, dQ: wave = 32 queries (Qs, dO fragments in registers), streams K / V tiles of 64 keys
+//   S^T[key][q] = K Qs^T;  P^T = exp(S^T - lse[q]);  dP^T = V dO^T;  dS^T = P^T (dP^T - delta[q]);  dQ^T[d][q] += K^T dS^T
+//   dQ = scale * dQ^T^T
+// =====================================================================================================================
+template <int PREC>
+__global__ __launch_bounds__(THREADS, 2) void attn_bwd_dq_kernel(const Args a) {
+  constexpr int NIMG = PREC == 1 ? 2 : 1;
+  constexpr int STAGE = 2 * NIMG * IMG;                       // K images, V images
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5;
+  const int head = blockIdx.y, seq = blockIdx.z;
+  const int T = a.T;
+  const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const rsrc_t rs = seq_rsrc(a.qkv + (long long)seq * T * a.ld, (long long)T * a.ld * 4);
+  const rsrc_t rd = seq_rsrc(a.dctx + (long long)seq * T * a.ldo, (long long)T * a.ldo * 4);
+  const int hc = head * D;
+  const bool qok = q < T;
+  const float ls = qok ? a.lse[((long long)seq * a.H + head) * T + q] : 0.f;
+  const float de = qok ? a.delta[((long long)seq * a.H + head) * T + q] : 0.f;
+
+  u32x4_t qf[4][2], of[4][2];
+  reg_operand<PREC>(rs, q, a.ld, hc, lane, a.scale, qf);
+  reg_operand<PREC>(rd, q, a.ldo, hc, lane, 1.f, of);
+
+  f32x16 dq[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dq[0][r] = dq[1][r] = 0.f;
+
+  const int nt = (T + TILE - 1) / TILE;
+  Tile<PREC> kt_, vt_;
+  kt_.load(rs, 0, a.ld, a.koff + hc, t);
+  vt_.load(rs, 0, a.ld, a.voff + hc, t);
+  kt_.commit(smem, t);
+  vt_.commit(smem + NIMG * IMG, t);
+  __syncthreads();
+
+  for (int it = 0; it < nt; ++it) {
+    const char* kimg = smem + (it & 1) * STAGE;
+    const char* vimg = kimg + NIMG * IMG;
+    if (it + 1 < nt) {
+      kt_.load(rs, (it + 1) * TILE, a.ld, a.koff + hc, t);
+      vt_.load(rs, (it + 1) * TILE, a.ld, a.voff + hc, t);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        u32x4_t ka[2], va[2];
+        frag_rows<PREC>(kimg, 32 * kb, ks, lane, ka);
+        frag_rows<PREC>(vimg, 32 * kb, ks, lane, va);
+        s = mac<PREC>(ka, qf[ks], s);
+        dp = mac<PREC>(va, of[ks], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = qok && (it * TILE + 32 * kb + rho(r, h) < T);
+        const float p = ok ? __expf(s[r] - ls) : 0.f;
+        dp[r] = p * (dp[r] - de);
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        u32x4_t sf[2];
+        acc_operand<PREC>(dp, ss, sf);
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+          u32x4_t ka[2];
+          frag_cols<PREC>(kimg, 32 * kb, ss, 32 * dd, lane, ka);
+          dq[dd] = mac<PREC>(ka, sf, dq[dd]);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + 1 < nt) {
+      char* nk = smem + ((it + 1) & 1) * STAGE;
+      kt_.commit(nk, t);
+      vt_.commit(nk + NIMG * IMG, t);
+    }
+    __syncthreads();
+  }
+  if (qok) {
+    float* qrow = a.dqkv + ((long long)seq * T + q) * a.ld + hc;
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const f32x4 x = {dq[dd][4 * gq] * a.scale, dq[dd][4 * gq + 1] * a.scale, dq[dd][4 * gq + 2] * a.scale, dq[dd][4 * gq + 3] * a.scale};
+        *reinterpret_cast<f32x4*>(qrow + 32 * dd + 8 * gq + 4 * h) = x;
+      }
+  }
+}
+
+template <typename K>
+static int set_lds(K kern, int bytes, bool& done) {
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+      return set_err(A2F_ELAUNCH, "attention: cannot reserve %d bytes of LDS", bytes);
+    done = true;
+  }
+  return A2F_OK;
+}
+
+static int check_common(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, int64_t ldo, int precision) {
+  A2F_CHECK_ARG(qkv != nullptr, "attention: null qkv");
+  A2F_CHECK_ARG(S > 0 && T > 0 && H > 0 && H * 64 <= ldo && 3 * H * 64 <= ld, "attention: S=%lld T=%lld H=%lld ld=%lld ldo=%lld", (long long)S,
+                (long long)T, (long long)H, (long long)ld, (long long)ldo);
+  A2F_CHECK_ARG(ld % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)qkv & 15) == 0, "attention: strides must be multiples of 4 floats, buffers 16-byte aligned");
+  A2F_CHECK_ARG(T * ld * 4 < (1ll << 31) && H * 64 <= 1024, "attention: one sequence of the q|k|v buffer must span < 2 GiB");
+  A2F_CHECK_ARG(precision == 0 || precision == 1, "attention: precision %d", precision);
+  return A2F_OK;
+}
+
+}  // namespace attn
+}  // namespace a2f
+
+extern "C" int a2f_attn_fwd(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx, int64_t ldo,
+                            float* lse, a2f_stream_t stream) {
+  using namespace a2f;
+  using namespace a2f::attn;
+  int rc = check_common(qkv, S, T, H, ld, ldo, precision);
+  if (rc) return rc;
+  A2F_CHECK_ARG(ctx && lse && ((uintptr_t)ctx & 15) == 0, "attn_fwd: null / misaligned output");
+  Args a{};
+  a.qkv = qkv; a.out_ctx = ctx; a.out_lse = lse;
+  a.ld = (int)ld; a.ldo = (int)ldo; a.koff = (int)(H * 64); a.voff = (int)(2 * H * 64);
+  a.S = (int)S; a.T = (int)T; a.H = (int)H; a.scale = scale;
+  const dim3 grid((unsigned)cdiv(T, 128), (unsigned)H, (unsigned)S);
+  hipStream_t st = (hipStream_t)stream;
+  static bool d0 = false, d1 = false;
+  if (precision == 1) {
+    if ((rc = set_lds(attn_fwd_kernel<1>, 2 * 4 * IMG, d1))) return rc;
+    hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(THREADS), 2 * 4 * IMG, st, a);
+  } else {
+    if ((rc = set_lds(attn_fwd_kernel<0>, 2 * 2 * IMG, d0))) return rc;
+    hipLaunchKernelGGL(attn_fwd_kernel<0>, grid, dim3(THREADS), 2 * 2 * IMG, st, a);
+  }
+  A2F_CHECK_LAUNCH("attn_fwd");
+  return A2F_OK;
+}
+
+extern "C" int a2f_attn_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
+                            int64_t ldo, float scale, int32_t precision, float* dqkv, float* delta_ws, a2f_stream_t stream) {
+  using namespace a2f;
+  using namespace a2f::attn;
+  int rc = check_common(qkv, S, T, H, ld, ldo, precision);
+  if (rc) return rc;
+  A2F_CHECK_ARG(ctx && dctx && lse && dqkv && delta_ws, "attn_bwd: null pointer");
+  A2F_CHECK_ARG((((uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)dqkv) & 15) == 0, "attn_bwd: buffers must be 16-byte aligned");
+  Args a{};
+  a.qkv = qkv; a.ctx = ctx; a.dctx = dctx; a.lse = lse; a.delta = delta_ws; a.out_delta = delta_ws; a.dqkv = dqkv;
+  a.ld = (int)ld; a.ldo = (int)ldo; a.koff = (int)(H * 64); a.voff = (int)(2 * H * 64);
+  a.S = (int)S; a.T = (int)T; a.H = (int)H; a.scale = scale;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(S * T, THREADS / 64)), dim3(THREADS), 0, st, a);
+  A2F_CHECK_LAUNCH("attn_bwd delta");
+  const dim3 grid((unsigned)cdiv(T, 128), (unsigned)H, (unsigned)S);
+  static bool k0 = false, k1 = false, q0 = false, q1 = false;
+  if (precision == 1) {
+    if ((rc = set_lds(attn_bwd_dkv_kernel<1>, 2 * 4 * IMG, k1))) return rc;
+    if ((rc = set_lds(attn_bwd_dq_kernel<1>, 2 * 4 * IMG, q1))) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, grid, dim3(THREADS), 2 * 4 * IMG, st, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, grid, dim3(THREADS), 2 * 4 * IMG, st, a);
+  } else {
+    if ((rc = set_lds(attn_bwd_dkv_kernel<0>, 2 * 2 * IMG, k0))) return rc;
+    if ((rc = set_lds(attn_bwd_dq_kernel<0>, 2 * 2 * IMG, q0))) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<0>, grid, dim3(THREADS), 2 * 2 * IMG, st, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<0>, grid, dim3(THREADS), 2 * 2 * IMG, st, a);
+  }
+  A2F_CHECK_LAUNCH("attn_bwd");
+  return A2F_OK;
+}

@@ -155,6 +155,45 @@ class HipBackend:
             if pf is not None:
                 pf[tag] = pf.get(tag, 0.0) + 2.0 * M * N * K * batch
 
+    # ---- row-wise encoder kernels (csrc/rowops.hip) ----------------------------------------------
+    def layernorm_fwd(self, x, R, Cc, gamma, beta, eps, y, mean, rstd):
+        _chk(x, gamma, beta, y, mean, rstd)
+        _lib.check(self.lib.a2f_layernorm_fwd(_ptr(x), R, Cc, _ptr(gamma), _ptr(beta), eps, _ptr(y), _ptr(mean), _ptr(rstd), self._stream(x)),
+                   "a2f_layernorm_fwd")
+
+    def layernorm_bwd(self, dy, x, mean, rstd, gamma, R, Cc, dx, dgamma, dbeta, dx_colsum=None):
+        _chk(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, dx_colsum)
+        nb = self.lib.a2f_layernorm_bwd_ws_bytes(R, Cc)
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.a2f_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), R, Cc, _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+                                              _ptr(dx_colsum), _ptr(ws), nb, self._stream(x)), "a2f_layernorm_bwd")
+
+    def colsum(self, x, R, Cc, ld, out, x_off=0):
+        _chk(x, out)
+        nb = self.lib.a2f_colsum_ws_bytes(R, Cc)
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.a2f_colsum(_ptr(x, x_off), R, Cc, ld, _ptr(out), _ptr(ws), nb, self._stream(x)), "a2f_colsum")
+
+    def gelu_bwd(self, dy, z, out):
+        _chk(dy, z, out)
+        _lib.check(self.lib.a2f_gelu_bwd(_ptr(dy), _ptr(z), dy.numel(), _ptr(out), self._stream(dy)), "a2f_gelu_bwd")
+
+    # ---- MFMA flash attention (csrc/attention.hip) -----------------------------------------------
+    def attn_fwd(self, qkv, S, T, H, ld, scale, ctx, ldo, lse, precision=None):
+        _chk(qkv, ctx, lse)
+        ev = self._prof_begin("attn")
+        _lib.check(self.lib.a2f_attn_fwd(_ptr(qkv), S, T, H, ld, scale, self.mm_precision if precision is None else precision, _ptr(ctx), ldo,
+                                         _ptr(lse), self._stream(qkv)), "a2f_attn_fwd")
+        self._prof_end("attn", ev)
+
+    def attn_bwd(self, qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, dqkv, precision=None):
+        _chk(qkv, ctx, dctx, lse, dqkv)
+        ws = torch.empty(S * H * T, dtype=torch.float32, device=qkv.device)
+        ev = self._prof_begin("attn")
+        _lib.check(self.lib.a2f_attn_bwd(_ptr(qkv), _ptr(ctx), _ptr(dctx), _ptr(lse), S, T, H, ld, ldo, scale,
+                                         self.mm_precision if precision is None else precision, _ptr(dqkv), _ptr(ws), self._stream(qkv)), "a2f_attn_bwd")
+        self._prof_end("attn", ev)
+
     # ---- a2f_wgrad_f32 ------------------------------------------------------------------------
     def wgrad_supported(self, M, N):
         return bool(self.lib.a2f_wgrad_supported(M, N))

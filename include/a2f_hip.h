@@ -309,6 +309,41 @@ typedef struct a2f_mm_desc {
 
 int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Row-wise kernels of the wav2vec2 encoder path (csrc/rowops.hip; HF Wav2Vec2Model as wrapped by
+ * /root/reference/src/model/wav2vec.py:91-189: nn.LayerNorm of feature projection / encoder / the 12 post-norm layers,
+ * bias gradients, GELU derivative).  Rows of C floats, C % 4 == 0, C <= 1024, 16-byte aligned buffers.
+ *   layernorm_fwd: y = (x - mean) * rstd * gamma + beta (biased variance, eps inside the sqrt); saves mean / rstd per row.
+ *   layernorm_bwd: dx, dgamma = sum dy * xhat, dbeta = sum dy, and (optional, may be NULL) dx_colsum = column sums of dx
+ *                  (= the bias gradient of the Linear whose output was normalised); deterministic two-stage reductions.
+ *   colsum:        out[c] = sum_r x[r*ld + c]  (bias gradients), deterministic.
+ *   gelu_bwd:      out = dy * gelu'(z), erf form (may run in place, out == dy).
+ */
+int a2f_layernorm_fwd(const float* x, int64_t R, int64_t C, const float* gamma, const float* beta, float eps, float* y, float* mean,
+                      float* rstd, a2f_stream_t stream);
+size_t a2f_layernorm_bwd_ws_bytes(int64_t R, int64_t C);
+int a2f_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, int64_t R, int64_t C,
+                      float* dx, float* dgamma, float* dbeta, float* dx_colsum, void* ws, size_t ws_bytes, a2f_stream_t stream);
+size_t a2f_colsum_ws_bytes(int64_t R, int64_t C);
+int a2f_colsum(const float* x, int64_t R, int64_t C, int64_t ld, float* out, void* ws, size_t ws_bytes, a2f_stream_t stream);
+int a2f_gelu_bwd(const float* dy, const float* z, int64_t n, float* out, a2f_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * MFMA flash attention of the wav2vec2 encoder layers (csrc/attention.hip): H heads of 64, full self-attention inside each
+ * of the S sequences of T frames; replaces softmax(q k^T) v of HF Wav2Vec2Attention (the encoder layers called at
+ * /root/reference/src/model/wav2vec.py:174-180) and its backward.
+ *   qkv (S*T, ld): row = frame; q at column 0, k at column 64 H, v at column 128 H, head h at + 64 h (the output of the fused
+ *   q|k|v projection; q NOT yet scaled: `scale` = head_dim^-0.5 is applied on chip).
+ *   fwd: ctx (S*T, ldo) = softmax(scale q k^T) v per head; lse (S, H, T) = log-sum-exp of the scaled scores (saved for bwd).
+ *   bwd: dqkv (S*T, ld) from dctx (S*T, ldo), recomputing the probabilities from q, k and lse; delta_ws: S*H*T floats scratch.
+ *   precision 1 = bf16x3 split products (fp32-class), 0 = bf16 operands; fp32 softmax and accumulation in both.
+ * Deterministic (no atomics).  T*ld*4 must be < 2 GiB.
+ */
+int a2f_attn_fwd(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx, int64_t ldo,
+                 float* lse, a2f_stream_t stream);
+int a2f_attn_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
+                 int64_t ldo, float scale, int32_t precision, float* dqkv, float* delta_ws, a2f_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -151,6 +151,57 @@ class EmuBackend:
                 v = v + cflat[cidx].double()
             cflat[cidx] = v.float()
 
+    # ------------------------------------------------------------------ row-wise encoder kernels / attention (float64 contracts)
+    def layernorm_fwd(self, x, R, Cc, gamma, beta, eps, y, mean, rstd):
+        xd = x.reshape(R, Cc).double()
+        mu = xd.mean(dim=1, keepdim=True)
+        var = ((xd - mu) ** 2).mean(dim=1, keepdim=True)
+        rs = 1.0 / torch.sqrt(var + eps)
+        y.reshape(R, Cc).copy_(((xd - mu) * rs * gamma.double() + beta.double()).float())
+        mean.copy_(mu.reshape(-1).float()); rstd.copy_(rs.reshape(-1).float())
+
+    def layernorm_bwd(self, dy, x, mean, rstd, gamma, R, Cc, dx, dgamma, dbeta, dx_colsum=None):
+        xd, dyd = x.reshape(R, Cc).double(), dy.reshape(R, Cc).double()
+        xh = (xd - mean.double().view(-1, 1)) * rstd.double().view(-1, 1)
+        g = dyd * gamma.double()
+        d = rstd.double().view(-1, 1) * (g - g.mean(dim=1, keepdim=True) - xh * (g * xh).mean(dim=1, keepdim=True))
+        dx.reshape(R, Cc).copy_(d.float())
+        dgamma.copy_((dyd * xh).sum(0).float()); dbeta.copy_(dyd.sum(0).float())
+        if dx_colsum is not None:
+            dx_colsum.copy_(d.sum(0).float())
+
+    def colsum(self, x, R, Cc, ld, out, x_off=0):
+        flat = x.reshape(-1)[x_off:].double()
+        idx = torch.arange(R).view(-1, 1) * ld + torch.arange(Cc).view(1, -1)
+        out.copy_(flat[idx].sum(0).float())
+
+    def gelu_bwd(self, dy, z, out):
+        zd = z.double()
+        g = 0.5 * (1 + torch.erf(zd / math.sqrt(2.0))) + zd * torch.exp(-0.5 * zd * zd) / math.sqrt(2 * math.pi)
+        out.copy_((dy.double() * g).float())
+
+    @staticmethod
+    def _attn_split(qkv, S, T, H, ld):
+        m = qkv.reshape(S, T, ld).double()
+        take = lambda o: m[:, :, o:o + 64 * H].reshape(S, T, H, 64).permute(0, 2, 1, 3)      # (S,H,T,64)
+        return take(0), take(64 * H), take(128 * H)
+
+    def attn_fwd(self, qkv, S, T, H, ld, scale, ctx, ldo, lse, precision=None):
+        q, k, v = self._attn_split(qkv, S, T, H, ld)
+        s = torch.matmul(q * scale, k.transpose(-1, -2))
+        lse.reshape(S, H, T).copy_(torch.logsumexp(s, dim=-1).float())
+        o = torch.matmul(torch.softmax(s, dim=-1), v)                                        # (S,H,T,64)
+        ctx.reshape(S * T, ldo)[:, :64 * H].copy_(o.permute(0, 2, 1, 3).reshape(S * T, 64 * H).float())
+
+    def attn_bwd(self, qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, dqkv, precision=None):
+        q, k, v = (t.clone().requires_grad_(True) for t in self._attn_split(qkv, S, T, H, ld))
+        o = torch.matmul(torch.softmax(torch.matmul(q * scale, k.transpose(-1, -2)), dim=-1), v)
+        do = dctx.reshape(S, T, ldo)[:, :, :64 * H].double().reshape(S, T, H, 64).permute(0, 2, 1, 3)
+        o.backward(do)
+        out = dqkv.reshape(S, T, ld)
+        for t, off in ((q, 0), (k, 64 * H), (v, 128 * H)):
+            out[:, :, off:off + 64 * H] = t.grad.permute(0, 2, 1, 3).reshape(S, T, 64 * H).float()
+
     def wgrad_supported(self, M, N):
         mt, nt = (M + 31) // 32, (N + 1 + 31) // 32
         return (nt <= 7) if mt in (1, 2) else (nt <= 4) if mt == 3 else (nt <= 3) if mt == 4 else False

@@ -1,0 +1,80 @@
+"""GPU: the row-wise encoder kernels (csrc/rowops.hip) and the MFMA flash attention (csrc/attention.hip) against the float64
+emulator of their contracts (include/a2f_hip.h), through the C ABI."""
+import pytest
+import torch
+
+from a2f_amd import ops
+from emu_backend import EmuBackend
+from golden_util import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+@pytest.mark.parametrize("R,C", [(1, 64), (7, 512), (600, 768), (9601, 768), (130, 1024), (33, 4)])
+def test_layernorm_fwd_bwd(R, C):
+    x, dy = rnd(R, C, seed=1, scale=2.0) + 0.3, rnd(R, C, seed=2)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    res = []
+    for be, dev in ((ops.HipBackend(), DEV), (EmuBackend(), "cpu")):
+        new = lambda *s: torch.zeros(*s, device=dev)
+        y, mean, rstd, dx, dg, db, dc = new(R, C), new(R), new(R), new(R, C), new(C), new(C), new(C)
+        be.layernorm_fwd(x.to(dev), R, C, gamma.to(dev), beta.to(dev), 1e-5, y, mean, rstd)
+        be.layernorm_bwd(dy.to(dev), x.to(dev), mean, rstd, gamma.to(dev), R, C, dx, dg, db, dc)
+        res.append([t.cpu() for t in (y, mean, rstd, dx, dg, db, dc)])
+    for g, r, name in zip(res[0], res[1], ("y", "mean", "rstd", "dx", "dgamma", "dbeta", "dx_colsum")):
+        if name == "dx_colsum":                       # sums to ~0 by construction (dx is mean-free per row only, not per column): absolute scale
+            assert (g - r).abs().max() < 1e-4 * (res[1][3].abs().sum(0).max() + 1e-6), name
+        else:
+            assert rel_l2(g, r) < 2e-5, name
+
+
+def test_colsum_and_gelu_bwd():
+    R, C, ld = 9600, 768, 2304
+    x = rnd(R, ld, seed=1)
+    dy, z = rnd(R, C, seed=2), rnd(R, C, seed=3, scale=2.0)
+    res = []
+    for be, dev in ((ops.HipBackend(), DEV), (EmuBackend(), "cpu")):
+        out, out2 = torch.zeros(C, device=dev), torch.zeros(R, C, device=dev)
+        be.colsum(x.to(dev), R, C, ld, out, x_off=768)
+        be.gelu_bwd(dy.to(dev), z.to(dev), out2)
+        res.append((out.cpu(), out2.cpu()))
+    assert (res[0][0] - res[1][0]).abs().max() < 1e-3 * res[1][0].abs().max() + 1e-3
+    assert rel_l2(res[0][1], res[1][1]) < 1e-5
+
+
+@pytest.mark.parametrize("S,T,H", [(1, 30, 12), (2, 64, 2), (1, 600, 12), (3, 129, 4), (1, 1000, 1)])
+@pytest.mark.parametrize("precision,tol", [(1, 3e-5), (0, 2e-2)])
+def test_attention_fwd_bwd(S, T, H, precision, tol):
+    ld, ldo = 3 * 64 * H, 64 * H
+    qkv = rnd(S * T, ld, seed=1, scale=1.0)
+    qkv[:, :64 * H] *= 2.0                                       # sharper softmax than unit-variance scores
+    dctx = rnd(S * T, ldo, seed=2)
+    res = []
+    for be, dev in ((ops.HipBackend(), DEV), (EmuBackend(), "cpu")):
+        ctx, lse, dqkv = torch.zeros(S * T, ldo, device=dev), torch.zeros(S, H, T, device=dev), torch.zeros(S * T, ld, device=dev)
+        be.attn_fwd(qkv.to(dev), S, T, H, ld, 0.125, ctx, ldo, lse, precision=precision)
+        be.attn_bwd(qkv.to(dev), ctx, dctx.to(dev), lse, S, T, H, ld, ldo, 0.125, dqkv, precision=precision)
+        res.append([t.cpu() for t in (ctx, lse, dqkv[:, :64 * H], dqkv[:, 64 * H:128 * H], dqkv[:, 128 * H:])])
+    for g, r, name in zip(res[0], res[1], ("ctx", "lse", "dq", "dk", "dv")):
+        assert rel_l2(g, r) < tol, name
+
+
+def test_attention_forced_max_jump():
+    """Online-softmax rescale path: one key dominates late in the sequence (the running maximum jumps by ~40 at a chosen tile)."""
+    S, T, H = 1, 300, 1
+    qkv = rnd(T, 192, seed=5, scale=0.5)
+    qkv[:, 0:64] = 1.0                    # all queries equal
+    qkv[200, 64:128] = 40.0               # key 200 dominates: scaled score 0.125 * 64 * 40 = 320 ... bounded by scale below
+    qkv[200, 64:128] *= 0.125
+    res = []
+    for be, dev in ((ops.HipBackend(), DEV), (EmuBackend(), "cpu")):
+        ctx, lse = torch.zeros(T, 64, device=dev), torch.zeros(1, 1, T, device=dev)
+        be.attn_fwd(qkv.to(dev), S, T, H, 192, 0.125, ctx, 64, lse, precision=1)
+        res.append((ctx.cpu(), lse.cpu()))
+    assert rel_l2(res[0][0], res[1][0]) < 3e-5 and rel_l2(res[0][1], res[1][1]) < 1e-5

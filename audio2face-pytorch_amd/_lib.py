@@ -49,7 +49,7 @@ class MMDesc(C.Structure):
         ("C2", c_f32p),
         ("M", i64), ("N", i64), ("K", i64),
         ("bias", c_f32p),
-        ("aux", c_f32p), ("ldaux", i64),
+        ("aux", c_f32p), ("ldaux", i64), ("aux_bstride", i64),
         ("act", i32), ("aux_mode", i32), ("precision", i32), ("split_k", i32),
         ("ws", c_f32p),
         ("batch", i32), ("accumulate", i32),

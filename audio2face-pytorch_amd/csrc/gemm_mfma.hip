@@ -48,7 +48,7 @@ struct Args {
   const float* bias;
   const float* aux;
   float* ws;
-  long long ldc, c_seq_stride, c_bstride, bias_bstride, ldaux;
+  long long ldc, c_seq_stride, c_bstride, bias_bstride, ldaux, aux_bstride;
   int c_rps;
   int M, N, K;
   int act, aux_mode, accumulate, split_k, batch;
@@ -69,7 +69,7 @@ __device__ __forceinline__ void epilogue_store(const Args& a, int bz, int m, int
   if (a.act == 1) v = fmaxf(v, 0.f);
   else if (a.act == 3) v = gelu_f(v);
   if (a.aux_mode) {
-    const float x = a.aux[(long long)bz * a.M * a.ldaux + (long long)m * a.ldaux + n];
+    const float x = a.aux[bz * a.aux_bstride + (long long)m * a.ldaux + n];
     if (a.aux_mode == 1) v += x;
     else if (a.aux_mode == 2) v *= gelu_grad_f(x);
     else v *= (x > 0.f ? 1.f : 0.f);
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_mfma_kernel(const Args a) {
             if (a.act == 1) v = fmaxf(v, 0.f);
             else if (a.act == 3) v = gelu_f(v);
             if (a.aux_mode) {
-              const float x = a.aux[(long long)bz * a.M * a.ldaux + (long long)m * a.ldaux + ncol[j]];
+              const float x = a.aux[bz * a.aux_bstride + (long long)m * a.ldaux + ncol[j]];
               if (a.aux_mode == 1) v += x;
               else if (a.aux_mode == 2) v *= gelu_grad_f(x);
               else v *= (x > 0.f ? 1.f : 0.f);
@@ -511,6 +511,7 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   a.c_bstride = d->c_bstride;
   a.bias_bstride = d->bias_bstride;
   a.ldaux = d->ldaux;
+  a.aux_bstride = d->aux_bstride;
   a.c_rps = (int)d->c_rows_per_seq;
   a.M = (int)d->M;
   a.N = (int)d->N;

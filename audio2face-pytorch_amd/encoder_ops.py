@@ -1,0 +1,270 @@
+"""Autograd functions of the wav2vec2 encoder on the HIP path (HF Wav2Vec2Model as wrapped by
+/root/reference/src/model/wav2vec.py:91-189): every dense contraction runs on ``a2f_mm`` (bf16-MFMA GEMM family), attention
+on ``a2f_attn_*`` (MFMA flash attention), LayerNorm / bias gradients / GELU' on the row kernels - forward and hand-written
+backward, fixed launch sequences, deterministic reductions.
+
+Activations are channels-last rows: (sequence, frame, channel) flattened to (rows, channels).  Precision follows
+``ops.backend().mm_precision`` (1 = bf16x3 split products, fp32-class - the parity setting; 0 = bf16 operands for
+``percision: 16-mixed``); storage, softmax, LayerNorm statistics and every accumulation are fp32.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .ops import MM_ACT_GELU, MM_ACT_NONE, MM_AUX_ADD, MM_AUX_GELU_BWD, MMOp
+
+LN_EPS = 1e-5
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _new(ref, *shape):
+    return torch.empty(*shape, device=ref.device, dtype=torch.float32)
+
+
+# =================================================================================================
+# building blocks
+# =================================================================================================
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension of (R, C) rows."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        be = ops.backend()
+        xc, g, b = _f32c(x), _f32c(gamma), _f32c(beta)
+        R, C = xc.shape
+        y, mean, rstd = _new(xc, R, C), _new(xc, R), _new(xc, R)
+        be.layernorm_fwd(xc, R, C, g, b, LN_EPS, y, mean, rstd)
+        ctx.save_for_backward(xc, mean, rstd, g)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = ops.backend()
+        xc, mean, rstd, g = ctx.saved_tensors
+        R, C = xc.shape
+        dx, dg, db = _new(xc, R, C), _new(xc, C), _new(xc, C)
+        be.layernorm_bwd(_f32c(dy), xc, mean, rstd, g, R, C, dx, dg, db)
+        return dx, dg, db
+
+
+class LinearMMFn(torch.autograd.Function):
+    """y = x W^T + b on the bf16-MFMA GEMM; x (M,K), W (N,K), b (N)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        be = ops.backend()
+        xc, Wc, bc = _f32c(x), _f32c(W), _f32c(b)
+        M, K = xc.shape
+        N = Wc.shape[0]
+        y = _new(xc, M, N)
+        ops.mm_linear_fwd(be, xc, Wc, bc, y, M, N, K)
+        ctx.save_for_backward(xc, Wc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = ops.backend()
+        xc, Wc = ctx.saved_tensors
+        M, K = xc.shape
+        N = Wc.shape[0]
+        dy = _f32c(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _new(xc, M, K)
+            ops.mm_linear_dgrad(be, dy, Wc, dx, M, N, K)
+        dW, db = _new(xc, N, K), _new(xc, N)
+        ops.mm_linear_wgrad(be, dy, xc, dW, M, N, K)
+        be.colsum(dy, M, N, N, db)
+        return dx, dW, db
+
+
+# =================================================================================================
+# one post-norm Transformer layer (HF Wav2Vec2EncoderLayer): attention -> +res -> LN -> FFN(GELU) -> +res -> LN
+# =================================================================================================
+class EncoderLayerFn(torch.autograd.Function):
+    """x (S*T, d) -> (S*T, d).  Parameters in HF order: q, k, v, out projections (W, b), layer_norm (g, b),
+    intermediate_dense, output_dense (W, b), final_layer_norm (g, b).  19 launches forward, 31 backward."""
+
+    @staticmethod
+    def forward(ctx, x, S, T, heads, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2):
+        be = ops.backend()
+        xc = _f32c(x)
+        P = [_f32c(p) for p in (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2)]
+        Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2 = P
+        M, d = xc.shape
+        F = W1.shape[0]
+        keep = any(ctx.needs_input_grad)
+        qkv = _new(xc, M, 3 * d)
+        for i, (W, b) in enumerate(((Wq, bq), (Wk, bk), (Wv, bv))):
+            be.mm(MMOp(xc, d), MMOp(W, d), qkv, M, d, d, 3 * d, c_off=i * d, bias=b)
+        att, lse = _new(xc, M, d), _new(xc, S, heads, T)
+        scale = float((d // heads) ** -0.5)
+        be.attn_fwd(qkv, S, T, heads, 3 * d, scale, att, d, lse)
+        a1 = _new(xc, M, d)
+        be.mm(MMOp(att, d), MMOp(Wo, d), a1, M, d, d, d, bias=bo, aux=xc, ldaux=d, aux_mode=MM_AUX_ADD)
+        h1, m1, r1 = _new(xc, M, d), _new(xc, M), _new(xc, M)
+        be.layernorm_fwd(a1, M, d, g1, b1, LN_EPS, h1, m1, r1)
+        z = _new(xc, M, F) if keep else None
+        g = _new(xc, M, F)
+        be.mm(MMOp(h1, d), MMOp(W1, d), g, M, F, d, F, bias=c1, act=MM_ACT_GELU, C2=z)
+        a2 = _new(xc, M, d)
+        be.mm(MMOp(g, F), MMOp(W2, F), a2, M, d, F, d, bias=c2, aux=h1, ldaux=d, aux_mode=MM_AUX_ADD)
+        h2, m2, r2 = _new(xc, M, d), _new(xc, M), _new(xc, M)
+        be.layernorm_fwd(a2, M, d, g2, b2, LN_EPS, h2, m2, r2)
+        if keep:
+            ctx.save_for_backward(xc, qkv, att, lse, a1, m1, r1, h1, z, g, a2, m2, r2, Wq, Wk, Wv, Wo, g1, W1, W2, g2)
+            ctx.dims = (S, T, heads, scale)
+        return h2
+
+    @staticmethod
+    def backward(ctx, dh2):
+        be = ops.backend()
+        xc, qkv, att, lse, a1, m1, r1, h1, z, g, a2, m2, r2, Wq, Wk, Wv, Wo, g1, W1, W2, g2 = ctx.saved_tensors
+        S, T, heads, scale = ctx.dims
+        M, d = xc.shape
+        F = W1.shape[0]
+        new = lambda *s: _new(xc, *s)
+        dh2 = _f32c(dh2)
+        # final_layer_norm; the column sums of its input gradient are output_dense's bias gradient
+        da2, dg2, db2, dc2 = new(M, d), new(d), new(d), new(d)
+        be.layernorm_bwd(dh2, a2, m2, r2, g2, M, d, da2, dg2, db2, dc2)
+        dW2 = new(d, F)
+        ops.mm_linear_wgrad(be, da2, g, dW2, M, d, F)
+        dz = new(M, F)
+        ops.mm_linear_dgrad(be, da2, W2, dz, M, d, F, aux=z, aux_mode=MM_AUX_GELU_BWD)        # through GELU
+        dc1 = new(F)
+        be.colsum(dz, M, F, F, dc1)
+        dW1 = new(F, d)
+        ops.mm_linear_wgrad(be, dz, h1, dW1, M, F, d)
+        dh1 = new(M, d)
+        ops.mm_linear_dgrad(be, dz, W1, dh1, M, F, d, aux=da2, aux_mode=MM_AUX_ADD)           # + residual branch
+        # layer_norm after attention; colsum of its input gradient = out_proj's bias gradient
+        da1, dg1, db1, dbo = new(M, d), new(d), new(d), new(d)
+        be.layernorm_bwd(dh1, a1, m1, r1, g1, M, d, da1, dg1, db1, dbo)
+        dWo = new(d, d)
+        ops.mm_linear_wgrad(be, da1, att, dWo, M, d, d)
+        datt = new(M, d)
+        ops.mm_linear_dgrad(be, da1, Wo, datt, M, d, d)
+        dqkv = new(M, 3 * d)
+        be.attn_bwd(qkv, att, datt, lse, S, T, heads, 3 * d, d, scale, dqkv)
+        dbqkv = new(3 * d)
+        be.colsum(dqkv, M, 3 * d, 3 * d, dbqkv)
+        dWs = []
+        for i in range(3):
+            dW = new(d, d)
+            be.mm(MMOp(dqkv, 3 * d, trans=True, ptr_off=i * d), MMOp(xc, d, trans=True), dW, d, d, M, d, split_k=0)
+            dWs.append(dW)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = new(M, d)
+            be.mm(MMOp(dqkv, 3 * d), MMOp(Wq, d, trans=True), dx, M, d, d, d, aux=da1, ldaux=d, aux_mode=MM_AUX_ADD)   # + residual branch
+            be.mm(MMOp(dqkv, 3 * d, ptr_off=d), MMOp(Wk, d, trans=True), dx, M, d, d, d, accumulate=True)
+            be.mm(MMOp(dqkv, 3 * d, ptr_off=2 * d), MMOp(Wv, d, trans=True), dx, M, d, d, d, accumulate=True)
+        return (dx, None, None, None, dWs[0], dbqkv[0:d], dWs[1], dbqkv[d:2 * d], dWs[2], dbqkv[2 * d:], dWo, dbo, dg1, db1,
+                dW1, dc1, dW2, dc2, dg2, db2)
+
+
+# =================================================================================================
+# channels-last Conv1d + GELU (feature-encoder layers 1..6: bias-free, k = 3 or 2, stride 2)
+# =================================================================================================
+class ConvGeluFn(torch.autograd.Function):
+    """x (S, Lin, Ci) -> gelu(conv1d(x)) (S, Lout, Co); w is the nn.Conv1d weight (Co, Ci, KH), no bias, no padding."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        be = ops.backend()
+        xc, wc = _f32c(x), _f32c(w)
+        S, Lin, Ci = xc.shape
+        Co, _, KH = wc.shape
+        Lout = (Lin - KH) // stride + 1
+        wg = _new(xc, Co, KH * Ci)
+        be.conv_weight_pack(wc, wg, Co, Ci, KH, 0)
+        keep = any(ctx.needs_input_grad)
+        z = _new(xc, S, Lout, Co) if keep else None
+        y = _new(xc, S, Lout, Co)
+        ops.mm_conv_fwd(be, xc, wg, y, S, Lin, Lout, Ci, Co, KH, stride, act=MM_ACT_GELU, pre=z)
+        if keep:
+            ctx.save_for_backward(xc, wg, z)
+            ctx.dims = (S, Lin, Lout, Ci, Co, KH, stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = ops.backend()
+        xc, wg, z = ctx.saved_tensors
+        S, Lin, Lout, Ci, Co, KH, stride = ctx.dims
+        dz = _new(xc, S, Lout, Co)
+        be.gelu_bwd(_f32c(dy), z, dz)
+        dwg = _new(xc, Co, KH * Ci)
+        ops.mm_conv_wgrad(be, xc, dz, dwg, S, Lin, Lout, Ci, Co, KH, stride)
+        dw = _new(xc, Co, Ci, KH)
+        be.conv_weight_pack(dwg, dw, Co, Ci, KH, 1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros(S, Lin, Ci, device=xc.device, dtype=torch.float32)
+            ops.mm_conv_dgrad(be, dz, wg, dx, S, Lin, Lout, Ci, Co, KH, stride)
+        return dx, dw, None
+
+
+# =================================================================================================
+# grouped positional convolution (HF Wav2Vec2PositionalConvEmbedding): h + gelu(conv1d(h, k=128, pad=64, groups=16)[:-1])
+# =================================================================================================
+class PosConvFn(torch.autograd.Function):
+    """h (S, T, C) , w (C, C/groups, K) (weight-norm already applied), bias (C) -> h + gelu(grouped conv)  (S, T, C).
+
+    One batched a2f_mm per direction: the 16 groups are 16 independent GEMMs over group-major copies of the activations
+    (G, S, T, C/G), whose rows are contiguous K x C/G windows (left pad K/2, even kernel: the last output frame is dropped)."""
+
+    @staticmethod
+    def forward(ctx, h, w, bias, groups):
+        be = ops.backend()
+        hc, wc, bc = _f32c(h), _f32c(w), _f32c(bias)
+        S, T, C = hc.shape
+        Cg, K = wc.shape[1], wc.shape[2]
+        G = groups
+        pad = K // 2
+        hg = hc.view(S, T, G, Cg).permute(2, 0, 1, 3).contiguous()                       # (G,S,T,Cg)
+        wg = wc.view(G, Cg, Cg, K).permute(0, 1, 3, 2).contiguous().view(G, Cg, K * Cg)   # [g][co][kk*Cg+ci]
+        keep = any(ctx.needs_input_grad)
+        z = _new(hc, S * T, C) if keep else None
+        y = _new(hc, S * T, C)
+        A = MMOp(hg, Cg, lines_per_seq=T, seq_stride=T * Cg, off=-pad * Cg, seq_elems=T * Cg)
+        be.mm(A, MMOp(wg, K * Cg), y, S * T, Cg, K * Cg, C, bias=bc, act=MM_ACT_GELU, C2=z, aux=hc, ldaux=C, aux_mode=MM_AUX_ADD,
+              batch=G, a_bstride=S * T * Cg, b_bstride=Cg * K * Cg, c_bstride=Cg, bias_bstride=Cg, aux_bstride=Cg)
+        if keep:
+            ctx.save_for_backward(hg, wc, z)
+            ctx.dims = (S, T, C, Cg, K, G)
+        return y.view(S, T, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = ops.backend()
+        hg, wc, z = ctx.saved_tensors
+        S, T, C, Cg, K, G = ctx.dims
+        pad = K // 2
+        dy = _f32c(dy).view(S * T, C)
+        dz = _new(dy, S * T, C)
+        be.gelu_bwd(dy, z, dz)
+        db = _new(dy, C)
+        be.colsum(dz, S * T, C, C, db)
+        # weight gradient: dwg[g][co][kk*Cg+ci] = sum_rows dz[row, g*Cg+co] * window(hg[g])[row, kk*Cg+ci]
+        dwg = _new(dy, G, Cg, K * Cg)
+        B = MMOp(hg, Cg, trans=True, lines_per_seq=T, seq_stride=T * Cg, off=-pad * Cg, seq_elems=T * Cg)
+        be.mm(MMOp(dz, C, trans=True), B, dwg, Cg, K * Cg, S * T, K * Cg, batch=G, a_bstride=Cg, b_bstride=S * T * Cg, c_bstride=Cg * K * Cg,
+              split_k=0)
+        dw = dwg.view(G, Cg, K, Cg).permute(0, 1, 3, 2).reshape(C, Cg, K)
+        dh = None
+        if ctx.needs_input_grad[0]:
+            # data gradient: dh[s,t',g,ci] = sum_{kk',co} dz[s, t'-(K/2-1)+kk', g, co] * w[g*Cg+co, ci, K-1-kk']  (+ the residual branch)
+            dzg = dz.view(S, T, G, Cg).permute(2, 0, 1, 3).contiguous()
+            wd = wc.view(G, Cg, Cg, K).flip(-1).permute(0, 2, 3, 1).contiguous().view(G, Cg, K * Cg)   # [g][ci][kk'*Cg+co]
+            dh = _new(dy, S * T, C)
+            A = MMOp(dzg, Cg, lines_per_seq=T, seq_stride=T * Cg, off=-(pad - 1) * Cg, seq_elems=T * Cg)
+            be.mm(A, MMOp(wd, K * Cg), dh, S * T, Cg, K * Cg, C, aux=dy, ldaux=C, aux_mode=MM_AUX_ADD, batch=G, a_bstride=S * T * Cg,
+                  b_bstride=Cg * K * Cg, c_bstride=Cg, aux_bstride=Cg)
+            dh = dh.view(S, T, C)
+        return dh, dw, db, None

@@ -86,6 +86,16 @@ class Faceformer(nn.Module):
     def encode(self, audio, frame_num):
         wave = normalize_waveform(audio)                                     # audio_preprocessor, faceformer.py:142-144
         if self.encoder_autocast is not None and wave.is_cuda:
+            if getattr(self.audio_encoder, "use_hip", False):
+                # hand-written encoder: mixed precision = plain bf16 operands on the matrix pipe (fp32 accumulate / softmax /
+                # LayerNorm) instead of the bf16x3 split products
+                from .. import ops
+                be = ops.backend()
+                old, be.mm_precision = be.mm_precision, 0
+                try:
+                    return self.audio_encoder(wave, self.dataset, frame_num=frame_num).last_hidden_state
+                finally:
+                    be.mm_precision = old
             with torch.autocast("cuda", dtype=self.encoder_autocast):
                 h = self.audio_encoder(wave, self.dataset, frame_num=frame_num).last_hidden_state
             return h.float()

@@ -2,9 +2,10 @@
 subclasses HF ``transformers.Wav2Vec2Model``; this is a self-contained module with HF-compatible state-dict keys, so
 ``facebook/wav2vec2-base-960h`` weights load with ``load_state_dict``).
 
-Arithmetic: third-party (HF) architecture restated in torch ops, which on ROCm dispatch to MIOpen / rocBLAS / the SDPA
-kernel - SURVEY §8(a) A7 scopes this encoder as "torch-ops restatement first"; the hand-written HIP path starts at
-``audio_feature_map``.  ``forward(input_values, dataset, frame_num=...)`` keeps the reference wrapper's signature and
+Arithmetic: third-party (HF) architecture.  On HIP tensors ``forward`` runs the hand-written path (``encoder_ops``: every
+contraction on the bf16-MFMA GEMM family ``a2f_mm`` - feature-encoder convolutions 1..6 as implicit GEMMs, feature projection,
+grouped positional convolution, the 12 Transformer layers - MFMA flash attention, HIP LayerNorm / GELU' / bias-gradient
+kernels, forward and backward).  The torch-ops restatement below it is what host-side (CPU) tests of this module run.  ``forward(input_values, dataset, frame_num=...)`` keeps the reference wrapper's signature and
 returns an object with ``.last_hidden_state`` (1,T,768); the vocaset branch interpolates the 49 Hz conv features to
 ``frame_num`` frames with align_corners=True (wav2vec.py:76-84,125-128).  SpecAugment / layerdrop / dropout are
 train-only in the reference and stochastic; this module implements the deterministic (eval) function and raises if
@@ -141,12 +142,52 @@ class Wav2Vec2Model(nn.Module):
         self.feature_projection = _FeatureProjection(conv_dim, hidden)
         self.encoder = _Encoder(hidden, layers, ffn, heads)
         self.conv_autotune = True
+        self.heads = heads
+        self.use_hip = True          # HIP tensors -> hand-written path; False keeps the torch-ops restatement (A/B timing, debugging)
+
+    compute_path = "hand-written HIP (a2f_mm bf16-MFMA GEMMs, MFMA flash attention, HIP LayerNorm/GELU; layer-0 conv + GroupNorm in torch ops)"
+
+    @property
+    def dtype_note(self):
+        from .. import ops
+        return ("encoder products as bf16x3 split MFMA (fp32-class), fp32 accumulate / softmax / LayerNorm" if ops.backend().mm_precision == 1
+                else "encoder products as bf16 MFMA, fp32 accumulate / softmax / LayerNorm")
+
+    def _forward_hip(self, wave, frame_num):
+        """The encoder on the HIP path; wave (S, N) normalised -> (S, frame_num, hidden)."""
+        from ..encoder_ops import ConvGeluFn, EncoderLayerFn, LayerNormFn, LinearMMFn, PosConvFn
+        S = wave.shape[0]
+        fe = self.feature_extractor.conv_layers
+        # layer 0 (1 -> 512 channels, k = 10, stride 5) + GroupNorm(512 groups) + GELU: 10 MACs per output, memory-bound
+        z = F.conv1d(wave[:, None, :].float(), fe[0].conv.weight, None, stride=CONV_STRIDE[0])
+        z = F.gelu(F.group_norm(z, z.shape[1], fe[0].layer_norm.weight, fe[0].layer_norm.bias, 1e-5))
+        z = z.transpose(1, 2).contiguous()                                        # channels-last (S, L, 512)
+        for i in range(1, len(fe)):
+            z = ConvGeluFn.apply(z, fe[i].conv.weight, CONV_STRIDE[i])
+        z = linear_interpolation(z, frame_num)                                    # (S, T, 512)
+        T, C = z.shape[1], z.shape[2]
+        fp = self.feature_projection
+        h = LinearMMFn.apply(LayerNormFn.apply(z.reshape(S * T, C), fp.layer_norm.weight, fp.layer_norm.bias), fp.projection.weight, fp.projection.bias)
+        enc = self.encoder
+        pc = enc.pos_conv_embed
+        d = h.shape[1]
+        h = PosConvFn.apply(h.view(S, T, d), pc.conv.weight, pc.conv.bias, pc.conv.groups).reshape(S * T, d)
+        h = LayerNormFn.apply(h, enc.layer_norm.weight, enc.layer_norm.bias)
+        for layer in enc.layers:
+            a, f = layer.attention, layer.feed_forward
+            h = EncoderLayerFn.apply(h, S, T, self.heads, a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias, a.v_proj.weight,
+                                     a.v_proj.bias, a.out_proj.weight, a.out_proj.bias, layer.layer_norm.weight, layer.layer_norm.bias,
+                                     f.intermediate_dense.weight, f.intermediate_dense.bias, f.output_dense.weight, f.output_dense.bias,
+                                     layer.final_layer_norm.weight, layer.final_layer_norm.bias)
+        return h.view(S, T, d)
 
     def forward(self, input_values, dataset="vocaset", attention_mask=None, frame_num=None, **_):
         if dataset != "vocaset":
             raise NotImplementedError("only the vocaset branch (wav2vec.py:124-128) is on the hot path")
         if attention_mask is not None:
             raise NotImplementedError("attention_mask is never passed by the reference FaceFormer (faceformer.py:149-151)")
+        if input_values.is_cuda and self.use_hip:
+            return types.SimpleNamespace(last_hidden_state=self._forward_hip(input_values, frame_num))
         # conv_autotune: let MIOpen pick its fastest algorithm for the feature-encoder / positional convolutions of this
         # shape (find mode, first call only): 124 -> 114 ms per 16 x 600 FaceFormer step; its default choice is an im2col path
         old_benchmark = torch.backends.cudnn.benchmark

@@ -123,7 +123,7 @@ class HipBackend:
 
     def mm(self, A: "MMOp", B: "MMOp", Cout, M, N, K, ldc, *, c_off=0, c_rows_per_seq=0, c_seq_stride=0, C2=None, bias=None, aux=None,
            ldaux=0, act=MM_ACT_NONE, aux_mode=MM_AUX_NONE, precision=None, split_k=1, batch=1, a_bstride=0, b_bstride=0, c_bstride=0,
-           bias_bstride=0, accumulate=False, alpha=1.0, tag="gemm_mfma"):
+           bias_bstride=0, aux_bstride=0, accumulate=False, alpha=1.0, tag="gemm_mfma"):
         """C[m,n] = epi(alpha * sum_k A(m,k) B(k,n)) on the bf16 matrix pipe (contract: include/a2f_hip.h, a2f_mm)."""
         _chk(A.t, B.t, Cout, C2, bias, aux)
         d = MMDesc()
@@ -145,7 +145,7 @@ class HipBackend:
             ws = torch.empty(batch * split_k * M * N, device=Cout.device, dtype=torch.float32)
             d.ws = _ptr(ws)
         d.batch, d.accumulate = batch, int(accumulate)
-        d.a_bstride, d.b_bstride, d.c_bstride, d.bias_bstride = a_bstride, b_bstride, c_bstride, bias_bstride
+        d.a_bstride, d.b_bstride, d.c_bstride, d.bias_bstride, d.aux_bstride = a_bstride, b_bstride, c_bstride, bias_bstride, aux_bstride
         d.alpha = alpha
         ev = self._prof_begin(tag)
         _lib.check(self.lib.a2f_mm(C.byref(d), self._stream(Cout)), "a2f_mm")

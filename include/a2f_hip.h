@@ -283,7 +283,8 @@ int a2f_stream_triad(float* dst, const float* a, const float* b, int64_t n, a2f_
  * stored at C + (m / c_rows_per_seq)*c_seq_stride + (m % c_rows_per_seq)*ldc + n  (c_rows_per_seq = 0: C + m*ldc + n).
  * split_k > 1: the contraction is cut into split_k slabs stored in `ws` (>= batch*split_k*M*N floats) and folded in fixed
  * order by a second kernel that applies the epilogue (deterministic; how weight gradients with K = 10^4 rows fill the chip).
- * batch > 1: independent problems at p + b*{a,b,c,bias}_bstride (the 16 groups of the positional convolution).
+ * batch > 1: independent problems at p + b*{a,b,c,bias}_bstride, aux + b*aux_bstride (the 16 groups of the positional
+ * convolution; C2 follows C).
  */
 typedef struct a2f_mm_operand {
   const float* p;
@@ -299,7 +300,7 @@ typedef struct a2f_mm_desc {
   float* C2;
   int64_t M, N, K;
   const float* bias;
-  const float* aux; int64_t ldaux;
+  const float* aux; int64_t ldaux, aux_bstride;
   int32_t act, aux_mode, precision, split_k;
   float* ws;
   int32_t batch, accumulate;

@@ -115,8 +115,8 @@ class EmuBackend:
         return torch.where(ok, flat[idx.clamp(0, flat.numel() - 1)], torch.zeros((), dtype=torch.double))
 
     def mm(self, A, B, Cout, M, N, K, ldc, *, c_off=0, c_rows_per_seq=0, c_seq_stride=0, C2=None, bias=None, aux=None, ldaux=0, act=0,
-           aux_mode=0, precision=None, split_k=1, batch=1, a_bstride=0, b_bstride=0, c_bstride=0, bias_bstride=0, accumulate=False,
-           alpha=1.0, tag=None):
+           aux_mode=0, precision=None, split_k=1, batch=1, a_bstride=0, b_bstride=0, c_bstride=0, bias_bstride=0, aux_bstride=0,
+           accumulate=False, alpha=1.0, tag=None):
         import copy
         self.calls.append(("mm", M, N, K, batch))
         cflat = Cout.reshape(-1)
@@ -140,7 +140,7 @@ class EmuBackend:
             elif act == 3:
                 v = 0.5 * v * (1 + torch.erf(v / math.sqrt(2.0)))
             if aux_mode:
-                ax = aux.reshape(-1)[bz * M * ldaux + m * ldaux + torch.arange(N).view(1, -1)].double()
+                ax = aux.reshape(-1)[bz * aux_bstride + m * ldaux + torch.arange(N).view(1, -1)].double()
                 if aux_mode == 1:
                     v = v + ax
                 elif aux_mode == 2:
@@ -194,10 +194,11 @@ class EmuBackend:
         ctx.reshape(S * T, ldo)[:, :64 * H].copy_(o.permute(0, 2, 1, 3).reshape(S * T, 64 * H).float())
 
     def attn_bwd(self, qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, dqkv, precision=None):
-        q, k, v = (t.clone().requires_grad_(True) for t in self._attn_split(qkv, S, T, H, ld))
-        o = torch.matmul(torch.softmax(torch.matmul(q * scale, k.transpose(-1, -2)), dim=-1), v)
-        do = dctx.reshape(S, T, ldo)[:, :, :64 * H].double().reshape(S, T, H, 64).permute(0, 2, 1, 3)
-        o.backward(do)
+        with torch.enable_grad():                         # called from inside autograd.Function.backward (grad mode off there)
+            q, k, v = (t.clone().requires_grad_(True) for t in self._attn_split(qkv.detach(), S, T, H, ld))
+            o = torch.matmul(torch.softmax(torch.matmul(q * scale, k.transpose(-1, -2)), dim=-1), v)
+            do = dctx.detach().reshape(S, T, ldo)[:, :, :64 * H].double().reshape(S, T, H, 64).permute(0, 2, 1, 3)
+            o.backward(do)
         out = dqkv.reshape(S, T, ld)
         for t, off in ((q, 0), (k, 64 * H), (v, 128 * H)):
             out[:, :, off:off + 64 * H] = t.grad.permute(0, 2, 1, 3).reshape(S, T, 64 * H).float()

@@ -245,3 +245,31 @@ def test_voca_accepts_per_frame_features(emu):
     # window semantics: frame t of a sequence sees rows t-8 .. t+7 of ITS sequence, zeros outside
     w = feature_windows(feats)
     assert torch.equal(w[0, :, 8], feats[0, 0]) and torch.all(w[0, :, :8] == 0) and torch.equal(w[T, :, 8], feats[1, 0]) and torch.all(w[T, :, :8] == 0)
+
+
+def test_hip_encoder_composition_matches_oracle(emu):
+    """The hand-written encoder path (encoder_ops: a2f_mm windows / batches / epilogues, flash-attention and LayerNorm contracts,
+    fixed backward launch sequence) composed over the float64 emulator of the C ABI against the oracle's autograd: forward,
+    d/d(waveform) and every parameter gradient of the first layers (two sequences, T = 12)."""
+    from a2f_amd.model.wav2vec import Wav2Vec2Model
+    from oracle import wav2vec2 as o_w2v
+    m = Wav2Vec2Model(layers=2)
+    sd = {k: v for k, v in W.formula_state_dict(W.wav2vec2_shapes(layers=2), gains={"original0": 40.0}).items()}
+    m.load_state_dict(sd)
+    T = 12
+    wave = o_w2v.normalize_waveform(W.formula_input("enc.audio", (2, T * 16000 // 60 + 5), 0.1))
+    wg = wave.clone().requires_grad_(True)
+    h = m._forward_hip(wg, T)
+    E = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    wo = wave.clone().requires_grad_(True)
+    ref = torch.cat([o_w2v.wav2vec2_forward(E, wo[i:i + 1], T, n_layers=2) for i in range(2)], 0)
+    assert rel_l2(h, ref) < 1e-5
+    gout = W.formula_input("enc.gout", tuple(ref.shape))
+    h.backward(gout)
+    ref.backward(gout)
+    assert rel_l2(wg.grad, wo.grad) < 1e-4
+    P = dict(m.named_parameters())
+    for k, v in E.items():
+        if v.grad is None or k.endswith("k_proj.bias"):          # d/d(k bias) is identically zero in exact arithmetic (softmax shift invariance)
+            continue
+        assert rel_l2(P[k].grad, v.grad) < 1e-4, k

@@ -103,6 +103,10 @@ SIGNATURES = {
     "a2f_gelu_bwd": (C.c_int, [c_f32p, c_f32p, i64, c_f32p, C.c_void_p]),
     "a2f_attn_fwd": (C.c_int, [c_f32p, i64, i64, i64, i64, f32, i32, c_f32p, i64, c_f32p, C.c_void_p]),
     "a2f_attn_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, i64, i64, i64, f32, i32, c_f32p, c_f32p, C.c_void_p]),
+    "a2f_featenc0_ws_bytes": (sz, [i64, i64, i64]),
+    "a2f_featenc0_fwd": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, i64, f32, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
+    "a2f_featenc0_bwd": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, sz,
+                                   C.c_void_p]),
     "a2f_stream_copy": (C.c_int, [c_f32p, c_f32p, i64, C.c_void_p]),
     "a2f_stream_triad": (C.c_int, [c_f32p, c_f32p, c_f32p, i64, C.c_void_p]),
 }

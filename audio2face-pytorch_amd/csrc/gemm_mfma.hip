@@ -111,7 +111,12 @@ __device__ __forceinline__ u32x2_t tr_read(const char* lds_addr) {
   return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4_t*)(lds_addr)));
 }
 __device__ __forceinline__ f32x16 mfma(u32x4_t a, u32x4_t b, f32x16 c) {
+#ifdef MM_ABL_NOMFMA        // timing ablation only: operands stay live, no matrix instruction
+  asm volatile("" ::"v"(a), "v"(b));
+  return c;
+#else
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -182,7 +187,12 @@ struct Stage {
         const unsigned e = (unsigned)(e0[i] + k0);                       // negative offsets wrap to huge values: out of range
         const bool ok = kin & (((okmask >> i) & 1u) != 0) & (e < (unsigned)op.seq_elems);
         const unsigned off = boff[i] + (unsigned)k0 * 4u;
+#ifdef MM_ABL_NOLOAD      // timing ablation only (wrong results): no global traffic
+        reg[i] = u32x4_t{off, off, off, off};
+        (void)ok;
+#else
         reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : 0xFFFFFFFFu, 0, 0);
+#endif
       }
     } else {
       const unsigned sstep = (unsigned)(op.seq_stride * 4);
@@ -204,7 +214,12 @@ struct Stage {
         }
         const unsigned e = (unsigned)(q * op.ld + jx);
         const bool ok = (okmask != 0) & ((k0 + kl) < kend) & (e < (unsigned)op.seq_elems);
+#ifdef MM_ABL_NOLOAD
+        reg[i] = u32x4_t{e, e, e, e};
+        (void)ok;
+#else
         reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? sb + e * 4u : 0xFFFFFFFFu, 0, 0);
+#endif
       }
     }
   }
@@ -273,7 +288,19 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_mfma_kernel(const Args a) {
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-contiguous tile order: workgroups are dealt to the 8 XCDs round-robin (blockIdx.x % 8 labels the XCD group); remap
+  // so that every XCD owns one contiguous run of the row-major (m-tile, n-tile) order - the n-tiles that share an A panel
+  // then meet in ONE L2 instead of eight (speed only: any placement computes the same tiles).
+  const int tiles_n = (a.N + BN - 1) / BN;
+  int m0, n0;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    const int tm = wgid / tiles_n;
+    m0 = tm * BM;
+    n0 = (wgid - tm * tiles_n) * BN;
+  }
   // readfirstlane: the batch / split indices come out of an integer division (vector ALU); telling the compiler they are
   // wave-uniform keeps the buffer resources in SGPRs (otherwise every buffer load is wrapped in a waterfall loop)
   const int bz = __builtin_amdgcn_readfirstlane((int)(blockIdx.z / a.split_k));
@@ -313,14 +340,20 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_mfma_kernel(const Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  u32x4_t ra[SA::NL], rb[SB::NL];
-  // prologue: k-tile 0 -> stage 0 (with nkt == 0 every load is out of range and the images are zeros)
-  sa.load(opA, rsA, kbeg, kend, ra);
-  sb.load(opB, rsB, kbeg, kend, rb);
+  // Two register sets: while k-tile kt is multiplied, tile kt+1 (fetched one iteration earlier) is converted and written
+  // to the other LDS stage and the loads of tile kt+2 are issued - a fetch has two multiply phases to land (an L2 / HBM
+  // round trip is longer than one 32-deep multiply phase).
+  u32x4_t ra0[SA::NL], rb0[SB::NL], ra1[SA::NL], rb1[SB::NL];
+  sa.load(opA, rsA, kbeg, kend, ra0);
+  sb.load(opB, rsB, kbeg, kend, rb0);
   sa.advance(opA);
   sb.advance(opB);
-  sa.template commit<PREC>(smem, ra);
-  sb.template commit<PREC>(smem + A_BYTES, rb);
+  sa.load(opA, rsA, kbeg + BK, kend, ra1);                     // out of range (zeros) when there is no second tile
+  sb.load(opB, rsB, kbeg + BK, kend, rb1);
+  sa.advance(opA);
+  sb.advance(opB);
+  sa.template commit<PREC>(smem, ra0);
+  sb.template commit<PREC>(smem + A_BYTES, rb0);
   __syncthreads();
 
   auto compute = [&](const char* cur) {
@@ -350,23 +383,38 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_mfma_kernel(const Args a) {
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma(fa[0][i], fb[0][j], acc[i][j]);
     }
   };
-
-  // steady state: the loads of tile kt+1 fly while tile kt is multiplied; the last tile is peeled (no loads, no commit)
-  for (int kt = 0; kt + 1 < nkt; ++kt) {
-    const int k0 = kbeg + (kt + 1) * BK;
-    sa.load(opA, rsA, k0, kend, ra);
-    sb.load(opB, rsB, k0, kend, rb);
+  // one steady-state iteration: tile kt is multiplied, `cur` registers (tile kt+1) go to LDS, `nxt` registers receive tile kt+2
+  auto body = [&](int kt, u32x4_t (&ca)[SA::NL], u32x4_t (&cb)[SB::NL], u32x4_t (&na)[SA::NL], u32x4_t (&nb)[SB::NL]) {
+    char* nst = smem + ((kt + 1) & 1) * STAGE;
+    const int k2 = kbeg + (kt + 2) * BK;
+    sa.load(opA, rsA, k2, kend, na);                            // `nxt` held tile kt, which went to LDS one iteration ago
+    sb.load(opB, rsB, k2, kend, nb);
     sa.advance(opA);
     sb.advance(opB);
     // keep the load issue HERE: without the fence the machine scheduler sinks the buffer loads below the MFMA block, next
-    // to their first use, and the tile fetch no longer overlaps the multiplication
+    // to their first use, and the fetch no longer overlaps the multiplication.  Below it the conversion / LDS writes of
+    // tile kt+1 (other stage) and the MFMAs of tile kt are one scheduling region: the compiler interleaves VALU and MFMA.
     __builtin_amdgcn_sched_barrier(0);
+#ifdef MM_ABL_NOCOMMIT      // timing ablation only: loaded registers stay live, no conversion, no LDS writes
+#pragma unroll
+    for (int i = 0; i < SA::NL; ++i) asm volatile("" ::"v"(ca[i]));
+#pragma unroll
+    for (int i = 0; i < SB::NL; ++i) asm volatile("" ::"v"(cb[i]));
+#else
+    sa.template commit<PREC>(nst, ca);
+    sb.template commit<PREC>(nst + A_BYTES, cb);
+#endif
     compute(smem + (kt & 1) * STAGE);
-    __builtin_amdgcn_sched_barrier(0);
-    char* nxt = smem + ((kt + 1) & 1) * STAGE;
-    sa.template commit<PREC>(nxt, ra);
-    sb.template commit<PREC>(nxt + A_BYTES, rb);
     __syncthreads();
+  };
+  int kt = 0;
+  for (; kt + 2 < nkt; kt += 2) {
+    body(kt, ra1, rb1, ra0, rb0);
+    body(kt + 1, ra0, rb0, ra1, rb1);
+  }
+  if (kt + 1 < nkt) {
+    body(kt, ra1, rb1, ra0, rb0);
+    ++kt;
   }
   if (nkt > 0) compute(smem + ((nkt - 1) & 1) * STAGE);
 
@@ -447,7 +495,7 @@ static int launch(const Args& a, hipStream_t st) {
       return set_err(A2F_ELAUNCH, "a2f_mm: cannot reserve %d bytes of LDS", smem);
     attr_done = true;
   }
-  dim3 grid((unsigned)cdiv(a.N, BN), (unsigned)cdiv(a.M, BM), (unsigned)(a.batch * a.split_k));
+  dim3 grid((unsigned)(cdiv(a.N, BN) * cdiv(a.M, BM)), 1, (unsigned)(a.batch * a.split_k));
   hipLaunchKernelGGL(kern, grid, dim3(THREADS), smem, st, a);
   return A2F_OK;
 }

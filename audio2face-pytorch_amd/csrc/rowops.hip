@@ -134,16 +134,23 @@ __global__ __launch_bounds__(RO_THREADS) void layernorm_bwd_kernel(const float* 
   }
 }
 
-// out[k][c] = sum over blocks of part[b][k][c]   (k < nk), fixed order
+// out[k][c] = sum over blocks of part[b][k][c]   (k < nk), fixed order: one wave per group of 16 output elements, the 64 lanes
+// split as 4 block-phases x 16 elements (64-byte coalesced reads), lane partials folded by a butterfly (same order every run)
 __global__ __launch_bounds__(256) void slab_fold_kernel(const float* __restrict__ part, int nblocks, int nk, int C, float* __restrict__ o0,
                                                         float* __restrict__ o1, float* __restrict__ o2) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= nk * C) return;
-  const int k = idx / C, c = idx - k * C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int idx = (blockIdx.x * 4 + wave) * 16 + (lane & 15);
+  const int total = nk * C;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * nk * C + idx];
-  float* o = k == 0 ? o0 : (k == 1 ? o1 : o2);
-  if (o) o[c] = s;
+  if (idx < total)
+    for (int b = lane >> 4; b < nblocks; b += 4) s += part[(int64_t)b * total + idx];
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  if (idx < total && lane < 16) {
+    const int k = idx / C, c = idx - k * C;
+    float* o = k == 0 ? o0 : (k == 1 ? o1 : o2);
+    if (o) o[c] = s;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float4* __restrict_
 
 static int ln_blocks_bwd(int64_t R) {
   int64_t b = cdiv(R, RO_THREADS / 64);
-  return (int)(b > 512 ? 512 : b);
+  return (int)(b > 256 ? 256 : b);
 }
 
 }  // namespace a2f
@@ -209,7 +216,7 @@ extern "C" int a2f_layernorm_bwd(const float* dy, const float* x, const float* m
   else if (C <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nb), dim3(RO_THREADS), 0, st, dy, x, mean, rstd, gamma, R, (int)C, dx, part);
   else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nb), dim3(RO_THREADS), 0, st, dy, x, mean, rstd, gamma, R, (int)C, dx, part);
   A2F_CHECK_LAUNCH("layernorm_bwd");
-  hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)cdiv(3 * C, 256)), dim3(256), 0, st, part, nb, 3, (int)C, dgamma, dbeta, dx_colsum);
+  hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)cdiv(3 * C, 64)), dim3(256), 0, st, part, nb, 3, (int)C, dgamma, dbeta, dx_colsum);
   A2F_CHECK_LAUNCH("layernorm_bwd fold");
   return A2F_OK;
 }
@@ -229,7 +236,7 @@ extern "C" int a2f_colsum(const float* x, int64_t R, int64_t C, int64_t ld, floa
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, (unsigned)cdiv(C / 4, RO_THREADS)), dim3(RO_THREADS), 0, st, x, R, (int)C, ld, (float*)ws);
   A2F_CHECK_LAUNCH("colsum");
-  hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, (const float*)ws, nb, 1, (int)C, out, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, st, (const float*)ws, nb, 1, (int)C, out, (float*)nullptr, (float*)nullptr);
   A2F_CHECK_LAUNCH("colsum fold");
   return A2F_OK;
 }

@@ -169,6 +169,50 @@ class EncoderLayerFn(torch.autograd.Function):
 
 
 # =================================================================================================
+# feature-encoder layer 0: conv1d(1 -> C, k = 10, stride 5) + GroupNorm(C groups) + GELU, channels-last output
+# =================================================================================================
+class FeatEnc0Fn(torch.autograd.Function):
+    """wave (S, N), w (C, 1, 10), gamma (C), beta (C) -> (S, L, C), L = (N - 10) // 5 + 1   (csrc/featenc.hip)."""
+
+    @staticmethod
+    def forward(ctx, wave, w, gamma, beta):
+        be = ops.backend()
+        xc, wc, g, b = _f32c(wave), _f32c(w), _f32c(gamma), _f32c(beta)
+        S, N = xc.shape
+        C = wc.shape[0]
+        L = (N - 10) // 5 + 1
+        out, stats = _new(xc, S, L, C), _new(xc, S, 2, C)
+        be.featenc0_fwd(xc, S, N, wc, g, b, C, 1e-5, out, stats)
+        ctx.save_for_backward(xc, wc, g, b, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        be = ops.backend()
+        xc, wc, g, b, stats = ctx.saved_tensors
+        S, N = xc.shape
+        C = wc.shape[0]
+        L = (N - 10) // 5 + 1
+        need_dx = ctx.needs_input_grad[0]
+        dw, dg, db = _new(xc, C, 1, 10), _new(xc, C), _new(xc, C)
+        dy = _new(xc, S, L, C) if need_dx else None
+        be.featenc0_bwd(xc, S, N, wc, g, b, C, stats, _f32c(dout), dw, dg, db, dy)
+        dx = None
+        if need_dx:
+            # d/d(waveform) (only when the input itself requires a gradient - parity tests; training never asks for it):
+            # dcol[row, k] = sum_c dy[row, c] w[c, k] on the GEMM (N padded 10 -> 12), then the 10 strided taps are added up
+            wp = torch.zeros(12, C, device=xc.device, dtype=torch.float32)
+            wp[:10] = wc.view(C, 10).t()
+            dcol = _new(xc, S * L, 12)
+            be.mm(MMOp(dy, C), MMOp(wp, C), dcol, S * L, 12, C, 12)
+            dcol = dcol.view(S, L, 12)
+            dx = torch.zeros(S, N, device=xc.device, dtype=torch.float32)
+            for k in range(10):
+                dx[:, k:k + 5 * (L - 1) + 1:5] += dcol[:, :, k]
+        return dx, dw, dg, db
+
+
+# =================================================================================================
 # channels-last Conv1d + GELU (feature-encoder layers 1..6: bias-free, k = 3 or 2, stride 2)
 # =================================================================================================
 class ConvGeluFn(torch.autograd.Function):

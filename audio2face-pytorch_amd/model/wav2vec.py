@@ -145,7 +145,7 @@ class Wav2Vec2Model(nn.Module):
         self.heads = heads
         self.use_hip = True          # HIP tensors -> hand-written path; False keeps the torch-ops restatement (A/B timing, debugging)
 
-    compute_path = "hand-written HIP (a2f_mm bf16-MFMA GEMMs, MFMA flash attention, HIP LayerNorm/GELU; layer-0 conv + GroupNorm in torch ops)"
+    compute_path = "hand-written HIP (a2f_mm bf16-MFMA GEMMs, MFMA flash attention, HIP LayerNorm / GELU / GroupNorm kernels)"
 
     @property
     def dtype_note(self):
@@ -155,13 +155,11 @@ class Wav2Vec2Model(nn.Module):
 
     def _forward_hip(self, wave, frame_num):
         """The encoder on the HIP path; wave (S, N) normalised -> (S, frame_num, hidden)."""
-        from ..encoder_ops import ConvGeluFn, EncoderLayerFn, LayerNormFn, LinearMMFn, PosConvFn
+        from ..encoder_ops import ConvGeluFn, EncoderLayerFn, FeatEnc0Fn, LayerNormFn, LinearMMFn, PosConvFn
         S = wave.shape[0]
         fe = self.feature_extractor.conv_layers
         # layer 0 (1 -> 512 channels, k = 10, stride 5) + GroupNorm(512 groups) + GELU: 10 MACs per output, memory-bound
-        z = F.conv1d(wave[:, None, :].float(), fe[0].conv.weight, None, stride=CONV_STRIDE[0])
-        z = F.gelu(F.group_norm(z, z.shape[1], fe[0].layer_norm.weight, fe[0].layer_norm.bias, 1e-5))
-        z = z.transpose(1, 2).contiguous()                                        # channels-last (S, L, 512)
+        z = FeatEnc0Fn.apply(wave, fe[0].conv.weight, fe[0].layer_norm.weight, fe[0].layer_norm.bias)         # channels-last (S, L, 512)
         for i in range(1, len(fe)):
             z = ConvGeluFn.apply(z, fe[i].conv.weight, CONV_STRIDE[i])
         z = linear_interpolation(z, frame_num)                                    # (S, T, 512)

@@ -178,6 +178,21 @@ class HipBackend:
         _chk(dy, z, out)
         _lib.check(self.lib.a2f_gelu_bwd(_ptr(dy), _ptr(z), dy.numel(), _ptr(out), self._stream(dy)), "a2f_gelu_bwd")
 
+    # ---- feature-encoder layer 0 (csrc/featenc.hip) ----------------------------------------------
+    def featenc0_fwd(self, wave, S, N, w, gamma, beta, Cc, eps, out, stats):
+        _chk(wave, w, gamma, beta, out, stats)
+        nb = self.lib.a2f_featenc0_ws_bytes(S, N, Cc)
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=wave.device)
+        _lib.check(self.lib.a2f_featenc0_fwd(_ptr(wave), S, N, _ptr(w), _ptr(gamma), _ptr(beta), Cc, eps, _ptr(out), _ptr(stats), _ptr(ws), nb,
+                                             self._stream(wave)), "a2f_featenc0_fwd")
+
+    def featenc0_bwd(self, wave, S, N, w, gamma, beta, Cc, stats, dout, dw, dgamma, dbeta, dy=None):
+        _chk(wave, w, gamma, beta, stats, dout, dw, dgamma, dbeta, dy)
+        nb = self.lib.a2f_featenc0_ws_bytes(S, N, Cc)
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=wave.device)
+        _lib.check(self.lib.a2f_featenc0_bwd(_ptr(wave), S, N, _ptr(w), _ptr(gamma), _ptr(beta), Cc, _ptr(stats), _ptr(dout), _ptr(dw), _ptr(dgamma),
+                                             _ptr(dbeta), _ptr(dy), _ptr(ws), nb, self._stream(wave)), "a2f_featenc0_bwd")
+
     # ---- MFMA flash attention (csrc/attention.hip) -----------------------------------------------
     def attn_fwd(self, qkv, S, T, H, ld, scale, ctx, ldo, lse, precision=None):
         _chk(qkv, ctx, lse)

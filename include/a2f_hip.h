@@ -345,6 +345,23 @@ int a2f_attn_fwd(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, 
 int a2f_attn_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
                  int64_t ldo, float scale, int32_t precision, float* dqkv, float* delta_ws, a2f_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Layer 0 of the wav2vec2 feature encoder (csrc/featenc.hip; HF Wav2Vec2FeatureEncoder layer 0 as called at
+ * /root/reference/src/model/wav2vec.py:116): conv1d(1 -> C, k = 10, stride 5, no bias) -> GroupNorm(C groups: per sequence and
+ * channel statistics over time, biased variance, eps) -> GELU (erf), written channels-last.
+ *   wave (S, N) fp32, w (C, 1, 10), gamma / beta (C); L = (N - 10) / 5 + 1;  out (S, L, C);  stats (S, 2, C) = mean, rstd (saved).
+ *   bwd: dout (S, L, C) -> dw (C, 1, 10), dgamma (C), dbeta (C); dy (S, L, C), optional (NULL to skip) = the gradient w.r.t.
+ *   the convolution output, from which the caller forms d/d(wave) when the waveform itself needs a gradient.
+ * The convolution is recomputed from the waveform in every pass (10 multiply-adds per output) instead of being stored.
+ * C % 4 == 0 and 256 % (C / 4) == 0 (C = 512 here).  Deterministic.  ws: a2f_featenc0_ws_bytes(S, N, C) bytes.
+ */
+size_t a2f_featenc0_ws_bytes(int64_t S, int64_t N, int64_t C);
+int a2f_featenc0_fwd(const float* wave, int64_t S, int64_t N, const float* w, const float* gamma, const float* beta, int64_t C, float eps,
+                     float* out, float* stats, void* ws, size_t ws_bytes, a2f_stream_t stream);
+int a2f_featenc0_bwd(const float* wave, int64_t S, int64_t N, const float* w, const float* gamma, const float* beta, int64_t C,
+                     const float* stats, const float* dout, float* dw, float* dgamma, float* dbeta, float* dy, void* ws, size_t ws_bytes,
+                     a2f_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

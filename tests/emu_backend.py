@@ -180,6 +180,29 @@ class EmuBackend:
         g = 0.5 * (1 + torch.erf(zd / math.sqrt(2.0))) + zd * torch.exp(-0.5 * zd * zd) / math.sqrt(2 * math.pi)
         out.copy_((dy.double() * g).float())
 
+    def featenc0_fwd(self, wave, S, N, w, gamma, beta, Cc, eps, out, stats):
+        import torch.nn.functional as F
+        y = F.conv1d(wave.reshape(S, 1, N).double(), w.reshape(Cc, 1, 10).double(), stride=5)          # (S,C,L)
+        mu = y.mean(dim=2, keepdim=True)
+        var = ((y - mu) ** 2).mean(dim=2, keepdim=True)
+        rs = 1.0 / torch.sqrt(var + eps)
+        u = (y - mu) * rs * gamma.double().view(1, -1, 1) + beta.double().view(1, -1, 1)
+        out.copy_(F.gelu(u).transpose(1, 2).float())
+        stats.reshape(S, 2, Cc)[:, 0].copy_(mu.squeeze(2).float()); stats.reshape(S, 2, Cc)[:, 1].copy_(rs.squeeze(2).float())
+
+    def featenc0_bwd(self, wave, S, N, w, gamma, beta, Cc, stats, dout, dw, dgamma, dbeta, dy=None):
+        import torch.nn.functional as F
+        with torch.enable_grad():
+            wd = w.detach().reshape(Cc, 1, 10).double().requires_grad_(True)
+            gd, bd = gamma.detach().double().requires_grad_(True), beta.detach().double().requires_grad_(True)
+            y = F.conv1d(wave.detach().reshape(S, 1, N).double(), wd, stride=5)
+            y.retain_grad()
+            o = F.gelu(F.group_norm(y, Cc, gd, bd, 1e-5)).transpose(1, 2)
+            o.backward(dout.detach().double())
+        dw.copy_(wd.grad.reshape(dw.shape).float()); dgamma.copy_(gd.grad.float()); dbeta.copy_(bd.grad.float())
+        if dy is not None:
+            dy.copy_(y.grad.transpose(1, 2).float())
+
     @staticmethod
     def _attn_split(qkv, S, T, H, ld):
         m = qkv.reshape(S, T, ld).double()

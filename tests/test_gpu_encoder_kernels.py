@@ -80,7 +80,7 @@ def test_attention_forced_max_jump():
     assert rel_l2(res[0][0], res[1][0]) < 3e-5 and rel_l2(res[0][1], res[1][1]) < 1e-5
 
 
-@pytest.mark.parametrize("S,N", [(1, 10), (2, 1283), (3, 8013), (2, 160008)])
+@pytest.mark.parametrize("S,N", [(1, 15), (2, 1283), (3, 8013), (2, 160008)])
 def test_featenc0_fwd_bwd(S, N):
     """conv1d(1->512, k=10, s=5) + GroupNorm(512 groups) + GELU, channels-last, against torch's float64 ops (emulator)."""
     C = 512
@@ -96,6 +96,4 @@ def test_featenc0_fwd_bwd(S, N):
         be.featenc0_bwd(wave.to(dev), S, N, w.to(dev), gamma.to(dev), beta.to(dev), C, stats, dout.to(dev), dw, dg, db, dy)
         res.append([t.cpu() for t in (out, stats[:, 0], dw, dg, db, dy)])
     for g, r, name in zip(res[0], res[1], ("out", "mean", "dw", "dgamma", "dbeta", "dy")):
-        if L == 1 and name in ("dw", "dy", "dgamma"):
-            continue                                     # a single frame: xhat = 0 and the input gradient of the normalisation vanishes (noise / noise)
         assert rel_l2(g, r) < 2e-5, name

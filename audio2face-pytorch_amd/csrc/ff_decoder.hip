@@ -236,7 +236,7 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_fwd_kernel(const flo
 // backward (reverse time)
 // =====================================================================================================================
 __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dy, int T,
-                                                                        int period, float* __restrict__ save, float* __restrict__ dP,
+                                                                        int period, float* __restrict__ save,
                                                                         float* __restrict__ dcross, float* __restrict__ dstyle) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Wqkv = lds;                        // [192][64] row-major: lane = input index for the transposed products
@@ -478,37 +478,48 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
   }
   // demb_0 belongs to emb_0 = style only: it must not reach dA / dc (no feedback produced emb_0) - nothing to do.
 
-  // ---- flush accumulators (fp32 atomics into the caller-zeroed gradient block) ----
+  // ---- flush accumulators: this sequence's gradient block goes to its own slab (plain stores, every entry written exactly
+  // once); ff_decoder_fold_kernel sums the slabs in sequence order - deterministic, no atomics
+  float* dP = save + (int64_t)gridDim.x * T * SV_STRIDE + s * (int64_t)A2F_FF_PARAM_FLOATS;
   if (t < 192) {
-    atomicAdd(dP + A2F_FF_BQKV + t, gbA);
+    dP[A2F_FF_BQKV + t] = gbA;
 #pragma unroll
-    for (int k = 0; k < FD; ++k) atomicAdd(dP + A2F_FF_WQKV + t * FD + k, gA[k]);
+    for (int k = 0; k < FD; ++k) dP[A2F_FF_WQKV + t * FD + k] = gA[k];
   } else {
-    atomicAdd(dP + A2F_FF_BO + (t - 192), gbA);
+    dP[A2F_FF_BO + (t - 192)] = gbA;
 #pragma unroll
-    for (int k = 0; k < FD; ++k) atomicAdd(dP + A2F_FF_WO + (t - 192) * FD + k, gA[k]);
+    for (int k = 0; k < FD; ++k) dP[A2F_FF_WO + (t - 192) * FD + k] = gA[k];
   }
   if (t < FFF) {
-    atomicAdd(dP + A2F_FF_B1 + t, gbB);
+    dP[A2F_FF_B1 + t] = gbB;
 #pragma unroll
-    for (int k = 0; k < FD; ++k) atomicAdd(dP + A2F_FF_W1 + t * FD + k, gB[k]);
+    for (int k = 0; k < FD; ++k) dP[A2F_FF_W1 + t * FD + k] = gB[k];
   } else if (t < 192) {
-    atomicAdd(dP + A2F_FF_C + (t - 128), gbB);
+    dP[A2F_FF_C + (t - 128)] = gbB;
 #pragma unroll
-    for (int k = 0; k < FD; ++k) atomicAdd(dP + A2F_FF_A + (t - 128) * FD + k, gB[k]);
+    for (int k = 0; k < FD; ++k) dP[A2F_FF_A + (t - 128) * FD + k] = gB[k];
   }
 #pragma unroll
-  for (int k = 0; k < 32; ++k) atomicAdd(dP + A2F_FF_W2 + (t & 63) * FFF + (t >> 6) * 32 + k, gC[k]);
+  for (int k = 0; k < 32; ++k) dP[A2F_FF_W2 + (t & 63) * FFF + (t >> 6) * 32 + k] = gC[k];
   if (wave == 0) {
-    atomicAdd(dP + A2F_FF_B2 + lane, gb2);
-    atomicAdd(dP + A2F_FF_LN + 0 * FD + lane, gg1);
-    atomicAdd(dP + A2F_FF_LN + 1 * FD + lane, gb1n);
-    atomicAdd(dP + A2F_FF_LN + 2 * FD + lane, gg2);
-    atomicAdd(dP + A2F_FF_LN + 3 * FD + lane, gb2n);
-    atomicAdd(dP + A2F_FF_LN + 4 * FD + lane, gg3);
-    atomicAdd(dP + A2F_FF_LN + 5 * FD + lane, gb3n);
+    dP[A2F_FF_B2 + lane] = gb2;
+    dP[A2F_FF_LN + 0 * FD + lane] = gg1;
+    dP[A2F_FF_LN + 1 * FD + lane] = gb1n;
+    dP[A2F_FF_LN + 2 * FD + lane] = gg2;
+    dP[A2F_FF_LN + 3 * FD + lane] = gb2n;
+    dP[A2F_FF_LN + 4 * FD + lane] = gg3;
+    dP[A2F_FF_LN + 5 * FD + lane] = gb3n;
     dstyle[s * FD + lane] = gsty;
   }
+}
+
+// dparams[i] = sum over sequences (fixed order) of the per-sequence slabs the backward kernel left behind `save`
+__global__ __launch_bounds__(256) void ff_decoder_fold_kernel(const float* __restrict__ slabs, int S, float* __restrict__ dP) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= A2F_FF_PARAM_FLOATS) return;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += slabs[(int64_t)s * A2F_FF_PARAM_FLOATS + i];
+  dP[i] = acc;
 }
 
 constexpr size_t FF_FWD_LDS = (size_t)(FD * 192 + 2 * FD * FD + 4 * FD + FFF + 4 * FD + FD) * sizeof(float);
@@ -518,7 +529,8 @@ constexpr size_t FF_BWD_LDS = (size_t)(192 * FD + 2 * FD * FD + 2 * FD + FFF + 3
 
 extern "C" size_t a2f_ff_save_bytes(int64_t S, int64_t T) {
   if (S <= 0 || T <= 0) return 16;
-  return (size_t)S * (size_t)T * a2f::SV_STRIDE * sizeof(float);
+  // per-step save rows + one gradient slab per sequence (written by the backward kernel, folded in sequence order)
+  return ((size_t)S * (size_t)T * a2f::SV_STRIDE + (size_t)S * A2F_FF_PARAM_FLOATS) * sizeof(float);
 }
 
 extern "C" int a2f_ff_decoder_fwd(const float* params, const float* pe, const float* cross, const float* style, int64_t S, int64_t T,
@@ -554,7 +566,10 @@ extern "C" int a2f_ff_decoder_bwd(const float* params, const float* dy, int64_t 
     attr_set = true;
   }
   hipLaunchKernelGGL(ff_decoder_bwd_kernel, dim3((unsigned)S), dim3(FF_THREADS), FF_BWD_LDS, (hipStream_t)stream, params, dy, (int)T, (int)period,
-                     (float*)save, dparams, dcross, dstyle);
+                     (float*)save, dcross, dstyle);
   A2F_CHECK_LAUNCH("ff_decoder_bwd");
+  hipLaunchKernelGGL(ff_decoder_fold_kernel, dim3((unsigned)cdiv(A2F_FF_PARAM_FLOATS, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)save + (size_t)S * T * SV_STRIDE, (int)S, dparams);
+  A2F_CHECK_LAUNCH("ff_decoder_bwd fold");
   return A2F_OK;
 }

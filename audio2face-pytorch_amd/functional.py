@@ -566,7 +566,7 @@ class FFDecoderFn(torch.autograd.Function):
         pc, save = ctx.saved_tensors
         S, T, period = ctx.dims
         dy = _f32c(dy)
-        dparams = torch.zeros_like(pc)
+        dparams = torch.empty_like(pc)            # overwritten (per-sequence slabs folded in fixed order)
         dcross = torch.empty(S, T, 64, device=dy.device, dtype=torch.float32)
         dstyle = torch.empty(S, 64, device=dy.device, dtype=torch.float32)
         be.ff_decoder_bwd(pc, dy, S, T, period, save, dparams, dcross, dstyle)

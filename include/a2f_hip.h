@@ -227,8 +227,10 @@ size_t a2f_ff_save_bytes(int64_t S, int64_t T);
  * reference builds it. */
 int a2f_ff_decoder_fwd(const float* params, const float* pe, const float* cross, const float* style, int64_t S, int64_t T,
                        int32_t period, float* y, void* save, size_t save_bytes, a2f_stream_t stream);
-/* dy (S,T,64) -> dparams (A2F_FF_PARAM_FLOATS, accumulated with atomics: the caller zeroes it), dcross (S,T,64),
- * dstyle (S,64).  `save` is the forward's buffer; its dK/dV accumulator columns are scratch for this call. */
+/* dy (S,T,64) -> dparams (A2F_FF_PARAM_FLOATS, OVERWRITTEN: every sequence leaves its gradient block in a slab behind the
+ * per-step rows of `save`, a fold kernel sums the slabs in sequence order - deterministic, no atomics), dcross (S,T,64),
+ * dstyle (S,64).  `save` is the forward's buffer (a2f_ff_save_bytes covers the slabs); its dK/dV accumulator columns are
+ * scratch for this call. */
 int a2f_ff_decoder_bwd(const float* params, const float* dy, int64_t S, int64_t T, int32_t period, void* save,
                        size_t save_bytes, float* dparams, float* dcross, float* dstyle, a2f_stream_t stream);
 

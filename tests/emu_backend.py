@@ -410,7 +410,7 @@ class EmuBackend:
             st = style.detach().double().requires_grad_(True)
             out = self.ff_spec(p, pe.double(), cr, st, period)
             out.backward(dy.reshape(S, T, 64).double())
-        dparams.add_(p.grad.float()); dcross.reshape(S, T, 64).copy_(cr.grad.float()); dstyle.reshape(S, 64).copy_(st.grad.float())
+        dparams.copy_(p.grad.float()); dcross.reshape(S, T, 64).copy_(cr.grad.float()); dstyle.reshape(S, 64).copy_(st.grad.float())
 
     # ------------------------------------------------------------------ Adam
     def adam_step(self, p, g, m, v, n, lr, b1, b2, eps, wd, grad_scale, step):

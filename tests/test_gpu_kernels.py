@@ -349,8 +349,15 @@ def test_ff_decoder_kernels_vs_spec(S, T, period):
     y_e = torch.empty(S, T, 64)
     emu.ff_decoder_fwd(P, pe, cross, style, S, T, period, y_e, None)
     assert rel_l2(y_h.cpu(), y_e) < 2e-5
-    dP_h, dc_h, ds_h = torch.zeros(nP, device=DEV), torch.empty(S, T, 64, device=DEV), torch.empty(S, 64, device=DEV)
+    dP_h, dc_h, ds_h = torch.full((nP,), 7.0, device=DEV), torch.empty(S, T, 64, device=DEV), torch.empty(S, 64, device=DEV)   # dparams is OVERWRITTEN
     hip.ff_decoder_bwd(P.to(DEV), dy.to(DEV), S, T, period, save, dP_h, dc_h, ds_h)
+    # deterministic: per-sequence slabs folded in sequence order (no atomics) -> a second run is bitwise identical
+    save2 = torch.empty_like(save)
+    y2 = torch.empty_like(y_h)
+    hip.ff_decoder_fwd(P.to(DEV), pe.to(DEV), cross.to(DEV), style.to(DEV), S, T, period, y2, save2)
+    dP2, dc2, ds2 = torch.empty(nP, device=DEV), torch.empty(S, T, 64, device=DEV), torch.empty(S, 64, device=DEV)
+    hip.ff_decoder_bwd(P.to(DEV), dy.to(DEV), S, T, period, save2, dP2, dc2, ds2)
+    assert torch.equal(dP2, dP_h) and torch.equal(dc2, dc_h) and torch.equal(ds2, ds_h)
     dP_e, dc_e, ds_e = torch.zeros(nP), torch.empty(S, T, 64), torch.empty(S, 64)
     emu.ff_decoder_bwd(P, dy, S, T, period, None, dP_e, dc_e, ds_e)
     assert rel_l2(dc_h.cpu(), dc_e) < 1e-4

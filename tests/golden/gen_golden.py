@@ -395,7 +395,50 @@ def g8():
     save("g8_faceformer_e2e", out)
 
 
-ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8}
+# --------------------------------------------------------------------------------------- G10 training trajectory
+def g10():
+    """Three optimiser steps of the reference's training step on the reference VOCA model: unpack_batch x100
+    (lightning_model.py:145-148), model forward, VocaLoss, backward, torch.optim.Adam(lr, weight_decay = lr / 10)
+    (lightning_model.py:99,209-213), mse_error (lightning_model.py:119-125) - Lightning itself is absent here, so the step is the
+    reference's own modules driven by the three calls its training_step makes.  lr = 1e-3 so the trajectory moves visibly."""
+    from src.model.voca import Voca
+    from src.loss import VocaLoss
+    print("G10 VOCA 3-step training trajectory (reference model + loss + Adam)")
+    lr = 1e-3
+    m = Voca(n_verts=NV, n_onehot=12)
+    sd = W.formula_state_dict(W.voca_shapes(NV), gains={"decoder.4": 4.0})
+    m.load_state_dict(sd)
+    opt = torch.optim.Adam(m.parameters(), lr=lr, weight_decay=lr / 10)
+    loss_fn = VocaLoss()
+    B = 6
+    out = {"lr": np.float64(lr), "B": np.int64(B)}
+    one_hot = torch.zeros(B, 12); one_hot[torch.arange(B), torch.tensor([0, 3, 7, 9, 1, 5])] = 1.0
+    out["one_hot"] = one_hot.numpy()
+    for it in range(3):
+        batch = {"audio": W.formula_input(f"g10.x{it}", (B, 29, 16)), "one_hot": one_hot,
+                 "template_vert": W.formula_input(f"g10.template{it}", (B, 5023, 3), 0.05)}
+        batch["verts"] = batch["template_vert"] + W.formula_input(f"g10.gt{it}", (B, 5023, 3), 0.005)
+        batch["verts"] = batch["verts"] * 100                    # unpack_batch
+        batch["template_vert"] = batch["template_vert"] * 100
+        x, oh, gt, template = batch["audio"], batch["one_hot"], batch["verts"], batch["template_vert"]
+        opt.zero_grad()
+        with quiet():
+            pred = m(x, oh, template)
+        loss = loss_fn(pred, gt)
+        with torch.no_grad():
+            err = torch.mean(torch.mean((pred.view(-1, 5023 * 3) - gt.view(-1, 5023 * 3)) ** 2, axis=1))
+        loss["loss"].backward()
+        opt.step()
+        for k in loss:
+            out[f"step{it}::{k}"] = np.float64(float(loss[k].detach()))
+        out[f"step{it}::err"] = np.float64(float(err))
+        print(f"   step {it}: loss {float(loss['loss'].detach()):.6f} err {float(err):.6f}")
+    for k, p in m.named_parameters():
+        pack("final::" + k, p, out)
+    save("g10_voca_train_trajectory", out)
+
+
+ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G10": g10}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

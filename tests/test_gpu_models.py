@@ -604,3 +604,57 @@ def test_bench_secondary_lines_small():
     assert set(sec) == {"faceformer", "audio2mesh"}
     for e in sec.values():
         assert e["value"] > 0 and e["roofline"]["bound"] == "mfma" and 0 < e["roofline"]["frac"] < 1
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# N1: the Lightning-free trainer against the reference-generated training trajectory (G10) and the fit loop on the GPU
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_trainstep_training_trajectory_g10(use_graph):
+    """Three TrainStep steps on the HIP path (x100 unpack, fused forward / loss / backward, flat Adam, weight decay lr/10)
+    reproduce the loss / err trajectory and the final parameters of the reference VOCA model + VocaLoss + torch.optim.Adam
+    (fixture G10, generated by tests/golden/gen_golden.py from /root/reference)."""
+    from a2f_amd.trainer import TrainStep
+    g = load("g10_voca_train_trajectory")
+    m, _ = _voca()
+    step = TrainStep(m, a2f_amd.VocaLoss(), lr=float(g["lr"]), use_graph=use_graph)
+    B = int(g["B"])
+    static = None
+    for it in range(3):
+        tv = W.formula_input(f"g10.template{it}", (B, 5023, 3), 0.05)
+        batch = {"audio": W.formula_input(f"g10.x{it}", (B, 29, 16)).to(DEV), "one_hot": torch.from_numpy(g["one_hot"]).to(DEV),
+                 "template_vert": tv.to(DEV), "verts": (tv + W.formula_input(f"g10.gt{it}", (B, 5023, 3), 0.005)).to(DEV)}
+        ins = TrainStep.unpack_batch(batch)
+        if use_graph:                                   # graph replay: same input buffers every step
+            if static is None:
+                static = [t.clone() for t in ins]
+            for s_, t_ in zip(static, ins):
+                s_.copy_(t_)
+            ins = static
+        out = step(*ins)
+        for k in ("loss", "rec_loss", "vel_loss", "err"):
+            ref = float(g[f"step{it}::{k}"])
+            assert abs(float(out[k]) - ref) <= 5e-5 * abs(ref), (it, k, float(out[k]), ref)
+    for k, p in m.named_parameters():
+        assert packed_error(g, "final::" + k, p) < 1e-4, k
+
+
+def test_fit_loop_on_gpu_voca_and_faceformer(tmp_path):
+    """a2f_amd.fit on the GPU: VOCA two epochs (validation, best-only checkpoint, reload) and the FaceFormer branch of
+    train.py:30-34 (batch 1, whole clips) for one epoch on a 30-frame clip."""
+    from a2f_amd import fit as F
+    from a2f_amd.registry import ExpConfig
+    from a2f_amd.train import synthetic_batch
+    base = dict(batch_size=8, modelname="voca", vertex_count=NV, one_hot_size=12, split_frame=True, percision="32", lr=1e-3,
+                feature_extractor=None, sample_rate=22000, n_feature=16, out_dim=29, win_length=440)
+    for name, epochs in (("voca", 2), ("faceformer", 1)):
+        cfg = F.apply_model_overrides(ExpConfig(**dict(base, modelname=name)))
+        torch.manual_seed(0)
+        tr = lambda e: (synthetic_batch(cfg, cfg.batch_size, DEV, 100 + 3 * e + i, frames=30) for i in range(3))
+        va = lambda e: (synthetic_batch(cfg, cfg.batch_size, DEV, 7, frames=30),)
+        model, hist = F.fit(cfg, tr, va, DEV, str(tmp_path / name), max_epochs=epochs, log=lambda *_: None)
+        assert len(hist) == epochs and all(h["val/err"] == h["val/err"] and h["val/err"] > 0 for h in hist)
+        files = os.listdir(tmp_path / name / "checkpoints")
+        assert len(files) == 1 and files[0].startswith("epoch=")
+        ck = torch.load(tmp_path / name / "checkpoints" / files[0], weights_only=False)
+        assert ck["hyper_parameters"]["config"].modelname == name and all(k.startswith("model.") for k in ck["state_dict"])

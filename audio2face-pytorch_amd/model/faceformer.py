@@ -113,6 +113,19 @@ class Faceformer(nn.Module):
         style = LinearFn.apply(one_hot, self.obj_vector.weight, None)       # (S,64)  :148
         return FFDecoderFn.apply(self._packed_decoder_params(), self.PPE.table(), cross, style, self.period)
 
+    _warned_train_mode = False
+
+    def _note_train_mode(self):
+        """The reference's train mode adds stochastic regularisers that redraw their masks at EVERY step of its O(T^3) loop
+        (decoder / PPE dropout 0.1, faceformer.py:73,88,121-127) plus wav2vec2's dropout / layerdrop / SpecAugment
+        (wav2vec.py:25-72,149-173).  The incremental evaluation computes the deterministic function (what `.eval()` gives
+        the reference); training here is therefore un-regularised - say so once instead of silently differing."""
+        if self.training and not Faceformer._warned_train_mode:
+            import warnings
+            warnings.warn("a2f_amd.Faceformer in train mode: the reference's stochastic regularisers (decoder/PPE dropout, wav2vec2 "
+                          "dropout / layerdrop / SpecAugment) are not applied; gradients are those of the deterministic (eval-mode) function")
+            Faceformer._warned_train_mode = True
+
     # ------------------------------------------------------------------ reference surface
     def forward(self, audio, one_hot, template, **kwargs):
         frame_num = audio.shape[1] * 60 // 16000                             # faceformer.py:141
@@ -130,6 +143,7 @@ class Faceformer(nn.Module):
     def forward_with_loss(self, audio, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0, unit_grad: bool = False, **kwargs):
         """Training fast path = forward + FaceFormerLoss (loss.py:4-17) with the head, the loss and the head backward
         fused into one pass; the odd tail frame is predicted but left out of the loss, as the reference does."""
+        self._note_train_mode()
         frame_num = audio.shape[1] * 60 // 16000
         enc = kwargs.get("encoder_states")
         if enc is None:
@@ -147,6 +161,7 @@ class Faceformer(nn.Module):
         audio (S,N), one_hot (S,n_onehot), template (S,V,3), gt (S,T,V,3).  The encoder runs batched, the decoder
         recurrence launches one workgroup per sequence, the fused head runs once per sequence (its template is per
         sequence).  Returns (pred (S,T,V,3), mean loss dict)."""
+        self._note_train_mode()
         S = audio.shape[0]
         frame_num = audio.shape[1] * 60 // 16000
         enc = self.encode(audio, frame_num)

@@ -8,8 +8,8 @@ grouped positional convolution, the 12 Transformer layers - MFMA flash attention
 kernels, forward and backward).  The torch-ops restatement below it is what host-side (CPU) tests of this module run.  ``forward(input_values, dataset, frame_num=...)`` keeps the reference wrapper's signature and
 returns an object with ``.last_hidden_state`` (1,T,768); the vocaset branch interpolates the 49 Hz conv features to
 ``frame_num`` frames with align_corners=True (wav2vec.py:76-84,125-128).  SpecAugment / layerdrop / dropout are
-train-only in the reference and stochastic; this module implements the deterministic (eval) function and raises if
-asked to train with them enabled.
+train-only in the reference and stochastic; this module implements the deterministic (eval) function in both modes
+(``Faceformer`` warns once when it is trained without them).
 """
 from __future__ import annotations
 

@@ -80,7 +80,7 @@ def test_attention_forced_max_jump():
     assert rel_l2(res[0][0], res[1][0]) < 3e-5 and rel_l2(res[0][1], res[1][1]) < 1e-5
 
 
-@pytest.mark.parametrize("S,N", [(1, 15), (2, 1283), (3, 8013), (2, 160008)])
+@pytest.mark.parametrize("S,N", [(1, 110), (2, 1283), (3, 8013), (2, 160008)])
 def test_featenc0_fwd_bwd(S, N):
     """conv1d(1->512, k=10, s=5) + GroupNorm(512 groups) + GELU, channels-last, against torch's float64 ops (emulator)."""
     C = 512

@@ -37,6 +37,7 @@ struct Op {
   const float* p;
   unsigned bytes;
   int ld, lps, off, seq_elems;
+  int lps_shift;         // log2(lps) when lps is a power of two, else -1 (short sequences: division -> shift)
   long long seq_stride;
   long long bstride;
 };
@@ -206,8 +207,8 @@ struct Stage {
             const bool wrap = q >= op.lps;
             q = wrap ? q - op.lps : q;
             sb = wrap ? sb + sstep : sb;
-          } else {                                                        // very short sequences (tests): general form
-            const int w = q / op.lps;
+          } else {                                                        // short sequences (Audio2Mesh rows of 1..16 positions)
+            const int w = op.lps_shift >= 0 ? (q >> op.lps_shift) : q / op.lps;
             q -= w * op.lps;
             sb += (unsigned)w * sstep;
           }
@@ -233,7 +234,7 @@ struct Stage {
           q0 = wrap ? q0 - op.lps : q0;
           s0bytes = wrap ? s0bytes + (unsigned)(op.seq_stride * 4) : s0bytes;
         } else {
-          const int w = q0 / op.lps;
+          const int w = op.lps_shift >= 0 ? (q0 >> op.lps_shift) : q0 / op.lps;
           q0 -= w * op.lps;
           s0bytes += (unsigned)w * (unsigned)(op.seq_stride * 4);
         }
@@ -520,6 +521,11 @@ static int fill_op(const a2f_mm_operand& o, int64_t bstride, int64_t contiguous_
   k.bytes = (unsigned)o.bytes;
   k.ld = (int)o.ld;
   k.lps = (int)o.lines_per_seq;
+  k.lps_shift = -1;
+  if (k.lps > 0 && (k.lps & (k.lps - 1)) == 0) {
+    k.lps_shift = 0;
+    while ((1 << k.lps_shift) < k.lps) ++k.lps_shift;
+  }
   k.off = o.lines_per_seq > 0 ? (int)o.off : 0;
   k.seq_elems = o.lines_per_seq > 0 ? (int)(o.seq_elems < 0x7FFFFFF0ll ? o.seq_elems : 0x7FFFFFF0ll) : 0x7FFFFFF0;
   k.seq_stride = o.lines_per_seq > 0 ? o.seq_stride : 0;

@@ -434,6 +434,197 @@ class A2MTrunkFn(torch.autograd.Function):
 
 
 # =================================================================================================
+# Audio2Mesh trunk on the bf16-MFMA GEMM family (a2f_mm): same function as A2MTrunkFn, convolutions 1..9 as windowed implicit
+# GEMMs with bf16x3 split products.  Channel counts that are not multiples of 4 (162, 243) are stored with a padded channel
+# stride (164, 244; the pad channels are identically zero through conv / BatchNorm / ReLU and carry zero gradients), so every
+# window starts on a 16-byte boundary.
+# =================================================================================================
+A2M_CHP = (1, 72, 108, 164, 244, 256)          # padded analysis channels
+
+
+def _padv(v, n, value=0.0):
+    return v if v.shape[0] == n else torch.cat([v, v.new_full((n - v.shape[0],), value)])
+
+
+def _pack_conv_w(w3, Cop, Cip):
+    """w3 (Co, Ci, KH) -> (Cop, KH*Cip) with k = kh*Cip + ci, zero padded."""
+    Co, Ci, KH = w3.shape
+    out = w3.new_zeros(Cop, KH, Cip)
+    out[:Co, :, :Ci] = w3.permute(0, 2, 1)
+    return out.view(Cop, KH * Cip)
+
+
+def _unpack_conv_w(dwg, Co, Ci, KH, Cip):
+    return dwg.view(-1, KH, Cip)[:Co, :, :Ci].permute(0, 2, 1).contiguous()
+
+
+class A2MTrunkMMFn(torch.autograd.Function):
+    """Same signature / outputs as A2MTrunkFn (x, one_hot, training, 20 BN buffers, 46 parameters -> h3 (B,50))."""
+
+    @staticmethod
+    def forward(ctx, x, one_hot, training, *rest):
+        be = ops.backend()
+        bufs, params = rest[:20], rest[20:]
+        convs = [(_f32c(params[2 * i]), _f32c(params[2 * i + 1])) for i in range(10)]
+        bns = [(_f32c(params[20 + 2 * i]), _f32c(params[21 + 2 * i])) for i in range(10)]
+        fcs = [(_f32c(params[40 + 2 * i]), _f32c(params[41 + 2 * i])) for i in range(3)]
+        B, no = x.shape[0], one_hot.shape[1]
+        H0 = 52 + no
+        dev = x.device
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        ncat = 256 + no
+        a0, cat = new(B, H0, 32), new(B, ncat)
+        be.a2m_pack(_f32c(x), _f32c(one_hot), B, no, a0, cat, ncat, 256)
+        sv = {"wg": [None] * 10, "conv_in": [None] * 10, "bn_x": [None] * 10, "bn_y": [None] * 10, "stats": [None] * 10, "bn_g": [None] * 10}
+
+        def bn(i, xin, R, C, Cp, relu):
+            g, b = bns[i]
+            gp, bp = _padv(g, Cp, 1.0), _padv(b, Cp)
+            rm, rv = bufs[2 * i], bufs[2 * i + 1]
+            rmp, rvp = (rm, rv) if Cp == C else (_padv(rm, Cp), _padv(rv, Cp, 1.0))
+            y, mu, istd = new(R, Cp), new(Cp), new(Cp)
+            be.bn_fwd(xin, R, Cp, gp, bp, rmp, rvp, A2M_BN_MOMENTUM, A2M_BN_EPS, training, relu, y, mu, istd)
+            if Cp != C and training:
+                rm.copy_(rmp[:C]); rv.copy_(rvp[:C])
+            sv["bn_x"][i], sv["bn_y"][i], sv["stats"][i], sv["bn_g"][i] = xin, y, (mu, istd), gp
+            return y
+
+        # analysis layer 0 (one input channel, K = 3): the exact-fp32 generic GEMM (three multiply-adds per output)
+        w0, b0 = convs[0]
+        wg0 = new(72, 3)
+        be.conv_weight_pack(w0, wg0, 72, 1, 3, 0)
+        R = B * H0 * 16
+        z = new(R, 72)
+        ops.conv_fwd(be, a0, wg0, b0, z, R, 16, 1, 72, relu=False)
+        sv["wg"][0], sv["conv_in"][0] = wg0, a0
+        act = bn(0, z, R, 72, 72, True)
+        Wd = 16
+        for l in range(1, 5):                                  # analysis layers 1..4: windows over W, sequences = (frame, row)
+            ci, co, cip, cop = A2M_CH[l], A2M_CH[l + 1], A2M_CHP[l], A2M_CHP[l + 1]
+            w, b = convs[l]
+            wg = _pack_conv_w(w.view(co, ci, 3), cop, cip)
+            Wo = Wd // 2
+            R = B * H0 * Wo
+            z = new(R, cop)
+            ops.mm_conv_fwd(be, act, wg, z, B * H0, Wd, Wo, cip, cop, 3, 2, pad=1, bias=_padv(b, cop))
+            sv["wg"][l], sv["conv_in"][l] = wg, act
+            act = bn(l, z, R, co, cop, True)
+            Wd = Wo
+        Hd = H0
+        for l in range(5, 8):                                  # articulation: windows over H, sequences = frames
+            w, b = convs[l]
+            wg = _pack_conv_w(w.view(256, 256, 3), 256, 256)
+            Ho = Hd // 2
+            z = new(B * Ho, 256)
+            ops.mm_conv_fwd(be, act, wg, z, B, Hd, Ho, 256, 256, 3, 2, pad=1, bias=b)
+            sv["wg"][l], sv["conv_in"][l] = wg, act
+            act = bn(l, z, B * Ho, 256, 256, True)
+            Hd = Ho
+        act = bn(8, act, B * Hd, 256, 256, False)              # BN -> conv -> ReLU   (order flip, audio2face.py:41-43)
+        w, b = convs[8]
+        wg = _pack_conv_w(w.view(256, 256, 3), 256, 256)
+        Ho = Hd // 2
+        z8 = new(B * Ho, 256)
+        ops.mm_conv_fwd(be, act, wg, z8, B, Hd, Ho, 256, 256, 3, 2, pad=1, bias=b, act=ops.MM_ACT_RELU)
+        sv["wg"][8], sv["conv_in"][8] = wg, act
+        Hd = Ho
+        zb = bn(9, z8, B * Hd, 256, 256, False)                # BN -> conv(4,1)/s4 -> ReLU  (audio2face.py:44-46)
+        w, b = convs[9]
+        KH9 = w.shape[2]
+        wg = _pack_conv_w(w.view(256, 256, KH9), 256, 256)
+        be.mm(ops.MMOp(zb, KH9 * 256), ops.MMOp(wg, KH9 * 256), cat, B, 256, KH9 * 256, ncat, bias=b, act=ops.MM_ACT_RELU)
+        sv["wg"][9], sv["conv_in"][9] = wg, zb
+        z1, z2, h3 = new(B, 72), new(B, 128), new(B, 50)
+        ops.linear_fwd(be, cat, fcs[0][0], fcs[0][1], z1, B, 72, ncat)
+        ops.linear_fwd(be, z1, fcs[1][0], fcs[1][1], z2, B, 128, 72, act=ACT_TANH)
+        ops.linear_fwd(be, z2, fcs[2][0], fcs[2][1], h3, B, 50, 128)
+        ctx.sv = sv
+        ctx.misc = (B, no, H0, Hd, KH9, training, cat, z8, z1, z2, [f[0] for f in fcs])
+        return h3
+
+    @staticmethod
+    def backward(ctx, dh3):
+        be = ops.backend()
+        sv = ctx.sv
+        B, no, H0, Hlast, KH9, training, cat, z8, z1, z2, fw = ctx.misc
+        dev = cat.device
+        ncat = 256 + no
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        zeros = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
+        dh3 = _f32c(dh3)
+        g_conv, g_bn, g_fc = [None] * 20, [None] * 20, [None] * 6
+        dW, db = new(50, 128), new(50)
+        ops.linear_bwd_weight(be, dh3, z2, dW, db, B, 50, 128); g_fc[4], g_fc[5] = dW, db
+        dz2 = new(B, 128)
+        ops.linear_bwd_input(be, dh3, fw[2], dz2, B, 50, 128, aux=z2, ldaux=128, aux_mode=AUX_TANH_BWD)
+        dW, db = new(128, 72), new(128)
+        ops.linear_bwd_weight(be, dz2, z1, dW, db, B, 128, 72); g_fc[2], g_fc[3] = dW, db
+        dz1 = new(B, 72)
+        ops.linear_bwd_input(be, dz2, fw[1], dz1, B, 128, 72)
+        dW, db = new(72, ncat), new(72)
+        ops.linear_bwd_weight(be, dz1, cat, dW, db, B, 72, ncat); g_fc[0], g_fc[1] = dW, db
+        d = new(B, 256)                                       # grad w.r.t. conv-9 pre-activation (ReLU mask of cat fused)
+        ops.linear_bwd_input(be, dz1, fw[0], d, B, 72, ncat, n_cols=256, aux=cat, ldaux=ncat, aux_mode=AUX_RELU_BWD)
+
+        def bias_grad(dout, R, Cp, C):
+            dbv = new(Cp)
+            be.colsum(dout, R, Cp, Cp, dbv)
+            return dbv[:C]
+
+        def bn_bwd(i, dy, R, C, Cp, relu):
+            mu, istd = sv["stats"][i]
+            dx, dg, dbt = new(R, Cp), new(Cp), new(Cp)
+            be.bn_bwd(sv["bn_x"][i], sv["bn_y"][i], dy, R, Cp, sv["bn_g"][i], mu, istd, training, relu, dx, dg, dbt)
+            g_bn[2 * i], g_bn[2 * i + 1] = dg[:C], dbt[:C]
+            return dx
+
+        # conv 9: (KH9,1)/s KH9, no pad: a plain GEMM over the (B, KH9*256) rows of zb
+        dwg = new(256, KH9 * 256)
+        ops.mm_linear_wgrad(be, d, sv["conv_in"][9], dwg, B, 256, KH9 * 256)
+        g_conv[18], g_conv[19] = _unpack_conv_w(dwg, 256, 256, KH9, 256).view(256, 256, KH9, 1), bias_grad(d, B, 256, 256)
+        dzb = new(B, KH9 * 256)
+        ops.mm_linear_dgrad(be, d, sv["wg"][9], dzb, B, 256, KH9 * 256)
+        dz = bn_bwd(9, dzb, B * Hlast, 256, 256, False)
+        dz = torch.where(z8 > 0, dz, torch.zeros_like(dz))    # conv 8's ReLU
+        Hd = 2 * Hlast
+
+        def conv_bwd(i, dout, S, Lin, Lout, ci, co, cip, cop, shape, need_dx=True):
+            dwg = new(cop, 3 * cip)
+            ops.mm_conv_wgrad(be, sv["conv_in"][i], dout, dwg, S, Lin, Lout, cip, cop, 3, 2, pad=1)
+            g_conv[2 * i], g_conv[2 * i + 1] = _unpack_conv_w(dwg, co, ci, 3, cip).view(*shape), bias_grad(dout, S * Lout, cop, co)
+            if not need_dx:
+                return None
+            din = new(S * Lin, cip)                           # every position is written (Lin = 2 Lout, pad = 1)
+            ops.mm_conv_dgrad(be, dout, sv["wg"][i], din, S, Lin, Lout, cip, cop, 3, 2, pad=1)
+            return din
+
+        dact = conv_bwd(8, dz, B, Hd, Hlast, 256, 256, 256, 256, (256, 256, 3, 1))
+        d = bn_bwd(8, dact, B * Hd, 256, 256, False)
+        for l in (7, 6, 5):                                   # articulation conv -> BN -> ReLU blocks
+            draw = bn_bwd(l, d, B * Hd, 256, 256, True)
+            d = conv_bwd(l, draw, B, 2 * Hd, Hd, 256, 256, 256, 256, (256, 256, 3, 1))
+            Hd *= 2
+        Wd = 1
+        for l in (4, 3, 2, 1):                                # analysis layers on the MFMA GEMM
+            ci, co, cip, cop = A2M_CH[l], A2M_CH[l + 1], A2M_CHP[l], A2M_CHP[l + 1]
+            draw = bn_bwd(l, d, B * H0 * Wd, co, cop, True)
+            d = conv_bwd(l, draw, B * H0, 2 * Wd, Wd, ci, co, cip, cop, (co, ci, 1, 3))
+            Wd *= 2
+        # analysis layer 0 (Ci = 1): exact-fp32 generic kernels; no data gradient needed
+        draw = bn_bwd(0, d, B * H0 * Wd, 72, 72, True)
+        dwg0, dbias0 = new(72, 3), new(72)
+        ops.conv_bwd_weight(be, sv["conv_in"][0], draw, dwg0, dbias0, B * H0 * Wd, Wd, 1, 72)
+        dw0 = new(72, 1, 1, 3)
+        be.conv_weight_pack(dwg0, dw0, 72, 1, 3, 1)
+        g_conv[0], g_conv[1] = dw0, dbias0
+        ctx.sv = None
+        return (None, None, None) + (None,) * 20 + tuple(g_conv) + tuple(g_bn) + tuple(g_fc)
+
+
+A2M_USE_MM = os.environ.get("A2F_A2M_GEMM", "mm") != "legacy"      # "legacy": the round-1 split-precision generic GEMM path (A2MTrunkFn)
+
+
+# =================================================================================================
 # Fused head + loss + head backward (single pass over the frame matrix; see csrc/head_fused.hip)
 # =================================================================================================
 class HeadLossFusedFn(torch.autograd.Function):

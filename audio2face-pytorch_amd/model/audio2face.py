@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..functional import A2M_CH, A2MTrunkFn, HeadFn, HeadLossFusedFn
+from ..functional import A2M_CH, A2M_USE_MM, A2MTrunkFn, A2MTrunkMMFn, HeadFn, HeadLossFusedFn
 
 
 class Audio2Mesh(nn.Module):
@@ -51,7 +51,7 @@ class Audio2Mesh(nn.Module):
             params += [b.weight, b.bias]
         for i in (0, 1, 3):
             params += [self.output_net[i].weight, self.output_net[i].bias]
-        h3 = A2MTrunkFn.apply(x, one_hot, self.training, *bufs, *params)
+        h3 = (A2MTrunkMMFn if A2M_USE_MM else A2MTrunkFn).apply(x, one_hot, self.training, *bufs, *params)
         if self.training:
             for b in bns:
                 b.num_batches_tracked += 1

@@ -530,23 +530,23 @@ def mm_conv_wgrad(be, x, dy, dWg, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, ta
     be.mm(A, B, dWg, Co, KH * Ci, S * Lout, KH * Ci, split_k=0, tag=tag)
 
 
-def mm_conv_dgrad(be, dy, Wg, dx, S, Lin, Lout, Ci, Co, KH, stride, *, aux=None, aux_mode=MM_AUX_NONE, tag="gemm_mfma"):
+def mm_conv_dgrad(be, dy, Wg, dx, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, tag="gemm_mfma"):
     """dx (S,Lin,Ci) from dy (S,Lout,Co), gather form (no atomics, no col2im buffer); positions no window touches must be
-    zero in dx on entry.  Supported: KH == stride (non-overlapping windows) and KH = 3, stride = 2 (no padding).
-    aux / aux_mode: activation derivative evaluated on aux (S,Lin,Ci), fused into the store."""
-    if aux_mode != MM_AUX_NONE:
-        raise A2FError("mm_conv_dgrad: fused activation derivative is not supported on strided outputs")   # rows of C are remapped, aux rows are dense
-    if KH == stride:
+    zero in dx on entry.  Supported: KH == stride, pad = 0 (non-overlapping windows) and KH = 3, stride = 2 with pad = 0
+    (Lin >= 2 Lout + 1) or pad = 1 (Lin = 2 Lout)."""
+    if KH == stride and pad == 0:
         be.mm(MMOp(dy, Co), MMOp(Wg, KH * Ci, trans=True), dx, S * Lout, KH * Ci, Co, KH * Ci, c_rows_per_seq=Lout, c_seq_stride=Lin * Ci, tag=tag)
         return
-    if KH == 3 and stride == 2:
-        assert Lin >= 2 * Lout + 1
-        # even positions 2q, q = 0..Lout: window [dy[q-1], dy[q]] against [W_kh=2 ; W_kh=0]
-        A = MMOp(dy, Co, lines_per_seq=Lout + 1, seq_stride=Lout * Co, off=-Co, seq_elems=Lout * Co)
+    if KH == 3 and stride == 2 and pad in (0, 1):
+        # positions touched by two taps (pad 0: even j = 2q from dy[q-1] (kh=2), dy[q] (kh=0); pad 1: odd j = 2q+1 from dy[q] (kh=2),
+        # dy[q+1] (kh=0)): a two-row window of dy against [W_kh=2 ; W_kh=0]
+        assert Lin >= 2 * Lout + 1 if pad == 0 else Lin == 2 * Lout
+        rows = Lout + 1 if pad == 0 else Lout
+        A = MMOp(dy, Co, lines_per_seq=rows, seq_stride=Lout * Co, off=-Co if pad == 0 else 0, seq_elems=Lout * Co)
         B = MMOp(Wg, 3 * Ci, trans=True, lines_per_seq=Co, seq_stride=-2 * Ci, off=2 * Ci, seq_elems=_BIG)
-        be.mm(A, B, dx, S * (Lout + 1), Ci, 2 * Co, 2 * Ci, c_rows_per_seq=Lout + 1, c_seq_stride=Lin * Ci, tag=tag)
-        # odd positions 2q+1, q = 0..Lout-1: dy[q] against W_kh=1
-        be.mm(MMOp(dy, Co), MMOp(Wg, 3 * Ci, trans=True, ptr_off=Ci), dx, S * Lout, Ci, Co, 2 * Ci, c_off=Ci, c_rows_per_seq=Lout,
+        be.mm(A, B, dx, S * rows, Ci, 2 * Co, 2 * Ci, c_off=0 if pad == 0 else Ci, c_rows_per_seq=rows, c_seq_stride=Lin * Ci, tag=tag)
+        # positions touched by the middle tap only: dy[q] against W_kh=1
+        be.mm(MMOp(dy, Co), MMOp(Wg, 3 * Ci, trans=True, ptr_off=Ci), dx, S * Lout, Ci, Co, 2 * Ci, c_off=Ci if pad == 0 else 0, c_rows_per_seq=Lout,
               c_seq_stride=Lin * Ci, tag=tag)
         return
-    raise A2FError(f"mm_conv_dgrad: unsupported kernel/stride {KH}/{stride}")
+    raise A2FError(f"mm_conv_dgrad: unsupported kernel/stride/pad {KH}/{stride}/{pad}")

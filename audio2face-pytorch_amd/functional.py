@@ -621,7 +621,11 @@ class A2MTrunkMMFn(torch.autograd.Function):
         return (None, None, None) + (None,) * 20 + tuple(g_conv) + tuple(g_bn) + tuple(g_fc)
 
 
-A2M_USE_MM = os.environ.get("A2F_A2M_GEMM", "mm") != "legacy"      # "legacy": the round-1 split-precision generic GEMM path (A2MTrunkFn)
+# Which trunk Audio2Mesh uses.  Default "legacy" = A2MTrunkFn (bf16x6 split products on the generic GEMM: the setting that holds the
+# G2 fixture's weight gradients at 1.7e-5).  "mm" = A2MTrunkMMFn on a2f_mm with bf16x3 products: 1.28x faster per step (B = 1024:
+# 8.9 vs 11.4 ms) and the same predictions (9e-6), but the batch-statistics BatchNorm backward amplifies the 2^-16 product error
+# into 1e-2 on the deepest weight gradients of the B = 4 fixture - outside the parity bar, so it is opt-in.
+A2M_USE_MM = os.environ.get("A2F_A2M_GEMM", "legacy") == "mm"
 
 
 # =================================================================================================

@@ -49,7 +49,32 @@ def shape(M, N, K, name):
     print(json.dumps(res), flush=True)
 
 
+def attention(S, T, H=12):
+    """a2f_attn_fwd / a2f_attn_bwd at the encoder's shape: (TFLOP/s of 4 S H T^2 64 forward, 10 S H T^2 64 backward algorithmic flops)."""
+    ld, ldo = 3 * 64 * H, 64 * H
+    qkv = torch.randn(S * T, ld, device=dev)
+    dctx = torch.randn(S * T, ldo, device=dev)
+    ctx, lse, dqkv = torch.empty(S * T, ldo, device=dev), torch.empty(S, H, T, device=dev), torch.empty(S * T, ld, device=dev)
+    res = {"shape": f"attention S={S} T={T} H={H}"}
+    for prec, tag in ((1, "x3"), (0, "bf16")):
+        tf = timeit(lambda: be.attn_fwd(qkv, S, T, H, ld, 0.125, ctx, ldo, lse, precision=prec))
+        tb = timeit(lambda: be.attn_bwd(qkv, ctx, dctx, lse, S, T, H, ld, ldo, 0.125, dqkv, precision=prec))
+        res[f"fwd_{tag}_ms"], res[f"bwd_{tag}_ms"] = round(tf, 4), round(tb, 4)
+        res[f"fwd_{tag}_TF"] = round(4.0 * S * H * T * T * 64 / (tf * 1e-3) / 1e12, 1)
+        res[f"bwd_{tag}_TF"] = round(10.0 * S * H * T * T * 64 / (tb * 1e-3) / 1e12, 1)
+    q = qkv.view(S, T, 3, H, 64).permute(2, 0, 3, 1, 4).contiguous()
+    res["torch_sdpa_f32_fwd_ms"] = round(timeit(lambda: torch.nn.functional.scaled_dot_product_attention(q[0], q[1], q[2])), 4)
+    print(json.dumps(res), flush=True)
+
+
 if __name__ == "__main__":
+    if os.environ.get("MM_QUICK") == "1":                 # PMC / ablation runs: two GEMM shapes and the attention kernels only
+        shape(9600, 768, 768, "qkv/out projection, 16 x 600 frames")
+        shape(9600, 768, 3072, "ffn down")
+        attention(16, 600)
+        sys.exit(0)
+    attention(16, 600)
+    attention(2, 3000)
     shape(9600, 768, 768, "qkv/out projection, 16 x 600 frames")
     shape(9600, 3072, 768, "ffn up")
     shape(9600, 768, 3072, "ffn down")

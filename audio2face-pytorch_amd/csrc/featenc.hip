@@ -179,22 +179,26 @@ __global__ __launch_bounds__(THREADS) void conv0_bwd_reduce_kernel(const Args a)
   }
 }
 
-// sums[s][k][c] = sum over slabs (double); dgamma[c] = sum_s sums[s][1][c], dbeta[c] = sum_s sums[s][0][c]
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ part, int nslab, int S, int C, float* __restrict__ sums,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+// sums[s][k][c] = sum over this sequence's slabs (double accumulation), one thread per (s, c)
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ part, int nslab, int C, float* __restrict__ sums) {
+  const int c = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+  if (c >= C) return;
+  double sa = 0.0, sb = 0.0;
+  for (int b = 0; b < nslab; ++b) {
+    sa += (double)part[((long long)s * nslab + b) * 2 * C + c];
+    sb += (double)part[((long long)s * nslab + b) * 2 * C + C + c];
+  }
+  sums[((long long)s * 2) * C + c] = (float)sa;
+  sums[((long long)s * 2 + 1) * C + c] = (float)sb;
+}
+// dbeta[c] = sum_s sums[s][0][c], dgamma[c] = sum_s sums[s][1][c]  (sequence order)
+__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restrict__ sums, int S, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   double ga = 0.0, gb = 0.0;
   for (int s = 0; s < S; ++s) {
-    double sa = 0.0, sb = 0.0;
-    for (int b = 0; b < nslab; ++b) {
-      sa += (double)part[((long long)s * nslab + b) * 2 * C + c];
-      sb += (double)part[((long long)s * nslab + b) * 2 * C + C + c];
-    }
-    sums[((long long)s * 2) * C + c] = (float)sa;
-    sums[((long long)s * 2 + 1) * C + c] = (float)sb;
-    ga += sa;
-    gb += sb;
+    ga += (double)sums[((long long)s * 2) * C + c];
+    gb += (double)sums[((long long)s * 2 + 1) * C + c];
   }
   dbeta[c] = (float)ga;
   dgamma[c] = (float)gb;
@@ -256,12 +260,17 @@ __global__ __launch_bounds__(THREADS) void conv0_bwd_apply_kernel(const Args a) 
     for (int k = 0; k < KW; ++k) o[(c4 + j) * KW + k] = dw[j][k];
 }
 
+// out[i] = sum over slabs of part[b][i] (double accumulation): a wave owns 4 consecutive outputs, its lanes are 16 slab phases x 4
+// outputs; the phase partials are folded by a butterfly over the phase bits (same order every run)
 __global__ __launch_bounds__(256) void dw_fold_kernel(const float* __restrict__ part, int nslab, int n, float* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = (blockIdx.x * 4 + wave) * 4 + (lane & 3);
   double acc = 0.0;
-  for (int b = 0; b < nslab; ++b) acc += (double)part[(long long)b * n + i];
-  out[i] = (float)acc;
+  if (i < n)
+    for (int b = lane >> 2; b < nslab; b += 16) acc += (double)part[(long long)b * n + i];
+#pragma unroll
+  for (int off = 4; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
+  if (i < n && lane < 4) out[i] = (float)acc;
 }
 
 static int plan(int64_t L, int& nblk, int& cpb) {
@@ -333,12 +342,14 @@ extern "C" int a2f_featenc0_bwd(const float* wave, int64_t S, int64_t N, const f
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(conv0_bwd_reduce_kernel, dim3(nblk, (unsigned)S), dim3(THREADS), 0, st, a);
   A2F_CHECK_LAUNCH("featenc0 bwd reduce");
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, (const float*)a.part, nblk * PH, (int)S, (int)C, sums, dgamma, dbeta);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 256), (unsigned)S), dim3(256), 0, st, (const float*)a.part, nblk * PH, (int)C, sums);
   A2F_CHECK_LAUNCH("featenc0 bwd finalize");
+  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, (const float*)sums, (int)S, (int)C, dgamma, dbeta);
+  A2F_CHECK_LAUNCH("featenc0 bwd params");
   hipLaunchKernelGGL(conv0_bwd_apply_kernel, dim3(nblk, (unsigned)S), dim3(THREADS), 0, st, a);
   A2F_CHECK_LAUNCH("featenc0 bwd apply");
   const int n = (int)(C * KW);
-  hipLaunchKernelGGL(dw_fold_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const float*)a.part, (int)(S * nblk * PH), n, dw);
+  hipLaunchKernelGGL(dw_fold_kernel, dim3((unsigned)cdiv(n, 16)), dim3(256), 0, st, (const float*)a.part, (int)(S * nblk * PH), n, dw);
   A2F_CHECK_LAUNCH("featenc0 bwd fold");
   return A2F_OK;
 }

@@ -298,6 +298,9 @@ def main():
     ap.add_argument("--ff-frames", type=int, default=600)
     ap.add_argument("--a2m-batch", type=int, default=1024)
     ap.add_argument("--secondary-steps", type=int, default=10)
+    ap.add_argument("--encoder-precision", default="split", choices=["split", "bf16"],
+                    help="FaceFormer encoder products: split = bf16x3 (fp32-class, the parity setting); bf16 = plain bf16 operands "
+                         "(the reference's `percision: 16-mixed`)")
     ap.add_argument("--input", default="windows", choices=["windows", "features"],
                     help="windows: x = (B,29,16) as the reference's Voca.forward takes it (default, the headline); features: x = (S,T,29), "
                          "the 16-frame windows are built inside the trunk kernel (SURVEY §8(f) N4)")
@@ -401,6 +404,8 @@ def main():
         with torch.no_grad():                                    # the reference zero-initialises both vertice maps (faceformer.py:132-135):
             model.vertice_map_r.weight.normal_(0, 0.1)           # non-zero values so the recurrence and its backward do real work
             model.vertice_map.weight.normal_(0, 0.001)
+        if args.encoder_precision == "bf16":
+            model.encoder_autocast = torch.bfloat16
         step = TrainStep(model, a2f_amd.FaceFormerLoss(), lr=1e-4)
         audio, one_hot, gt, templ = make_ff_batch(S, T, rank, device)
         elapsed, loss_val = timed(lambda: step(audio, one_hot, gt, templ), steps, max(warmup, 2), barrier, world, device)
@@ -408,7 +413,8 @@ def main():
         enc_path = getattr(model.audio_encoder, "compute_path", "torch ops (rocBLAS / MIOpen / SDPA)")
         res = {
             "value": round(fps, 1), "unit": "mesh-frames/s", "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 3),
-            "dtype": "f32 storage; " + getattr(model.audio_encoder, "dtype_note", "encoder in fp32 torch ops") ,
+            "dtype": "f32 storage; " + ("encoder products as bf16 MFMA (16-mixed), fp32 accumulate / softmax / LayerNorm" if args.encoder_precision == "bf16"
+                                        else getattr(model.audio_encoder, "dtype_note", "encoder in fp32 torch ops")),
             "config": {"workload": f"FaceFormer train step (wav2vec2-base encoder + incremental decoder + fused head/FaceFormerLoss, bwd, Adam over 96.4 M "
                                    f"parameters), {S} independent batch-1 sequences x {T} frames per GPU per step, BASELINE configs[2]",
                        "frames_per_gpu_step": S * T, "parallelism": f"dp{world}", "final_loss": round(loss_val, 6), "encoder": enc_path},

@@ -55,3 +55,39 @@ out["one_hot"] = np.stack([ref.get_human_id_one_hot(h) for h in ids])
 assert np.array_equal(out["one_hot"], np.stack([mine.human_id_one_hot(h) for h in ids]))
 np.savez_compressed(os.path.join(HERE, "g9_vocaset_helpers.npz"), **out)
 print("wrote g9_vocaset_helpers.npz:", len(cases), "fragment cases,", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# G11: the loader classes (DataSplitRecorder, ClipVocaSet per-frame path) of the reference on a synthetic VOCASET directory
+# ---------------------------------------------------------------------------------------------------------------------------
+import tempfile                                    # noqa: E402
+import contextlib, io                              # noqa: E402,E401
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import vocaset_synth                               # noqa: E402
+from a2f_amd import vocaset as mine_vs             # noqa: E402
+
+out = {}
+with tempfile.TemporaryDirectory() as d_ref, tempfile.TemporaryDirectory() as d_mine:
+    vocaset_synth.build(d_ref)
+    vocaset_synth.build(d_mine)
+    for phase in ("train", "val", "test", "all"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = ref.ClipVocaSet(d_ref, phase=phase, split_frame=True)
+        q = mine_vs.ClipVocaSet(d_mine, phase=phase, split_frame=True)
+        assert [tuple(x) for x in r.datalist] == [tuple(x) for x in q.datalist], phase
+        out[f"{phase}::human_id"] = np.array([x[0] for x in r.datalist])
+        out[f"{phase}::sentence_id"] = np.array([x[1] for x in r.datalist])
+        out[f"{phase}::index"] = np.array([[x[2], x[3]] for x in r.datalist], dtype=np.int64)
+        for i in sorted({0, len(r) // 2, len(r) - 1}):
+            a, b = r[i], q[i]
+            for k in ("audio", "verts", "template_vert", "one_hot"):
+                assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), (phase, i, k)
+                out[f"{phase}::item{i}::{k}"] = a[k]
+    with contextlib.redirect_stdout(io.StringIO()):
+        r = ref.ClipVocaSet(d_ref, phase="test", split_frame=True)
+    q = mine_vs.ClipVocaSet(d_mine, phase="test", split_frame=True)
+    fr, fq = r.get_framedatas("FaceTalk_170809_00138_TA", "sentence21"), q.get_framedatas("FaceTalk_170809_00138_TA", "sentence21")
+    assert len(fr) == len(fq) and all(np.array_equal(x["audio"], y["audio"]) for x, y in zip(fr, fq))
+    out["framedatas::count"] = np.int64(len(fr))
+    out["framedatas::audio0"] = fr[0]["audio"]
+np.savez_compressed(os.path.join(HERE, "g11_vocaset_loader.npz"), **out)
+print("wrote g11_vocaset_loader.npz:", len(out), "arrays,", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")

@@ -14,8 +14,10 @@ is no torchaudio build, reference test or fixture here to check it against; test
     AmplitudeToDB("power", top_db=80): 10 log10(max(x, 1e-10)), floored at (max over the whole (batch, mel, time) input) - 80
                     (torchaudio treats a 3-D input as one packed item; per item only for 4-D input)
     DCT-II, norm="ortho", first n_mfcc coefficients
-``Wav2VecExtractor`` (extractor.py:62-96) is the wav2vec2 encoder of ``model/wav2vec.py`` behind torchaudio's resampler
-(``data.resample_sinc_hann``); it needs the pretrained weights, which are not available offline, and is not restated.
+``Wav2VecExtractor`` (extractor.py:62-96) is the wav2vec2 encoder of ``model/wav2vec.py`` (HF key names: load
+``facebook/wav2vec2-base-960h`` with ``extractor.model.load_state_dict``; nothing is downloaded here) behind the resampler
+(``data.resample_sinc_hann``, parity-unpinned) and the HF processor's normalisation; everything after the resampler is pinned
+against the installed HF modules by fixture G12 (tests/golden/gen_golden.py).
 """
 from __future__ import annotations
 
@@ -93,8 +95,42 @@ class MFCCExtractor(nn.Module):
         return mfcc
 
 
+class Wav2VecExtractor(nn.Module):
+    """Input (batch, time) at ``sample_rate`` -> (batch, out_dim, n_feature); same constructor as extractor.py:63-83.
+
+    forward (extractor.py:84-96): resample to 16 kHz; the HF processor's zero-mean / unit-variance normalisation - computed over
+    the WHOLE (batch, time) tensor, because the processor receives one tensor, wraps it as a single example and the reference
+    then takes ``input_values[0]``; the plain wav2vec2 forward (49 Hz frames, no interpolation); transpose to (batch, 768, L);
+    bilinear resize to (out_dim, n_feature) unless out_dim == 768.  The convolutional feature encoder is frozen
+    (``freeze_feature_encoder``).  On HIP tensors the encoder runs the hand-written path of ``model/wav2vec.py``."""
+
+    def __init__(self, sample_rate: int, n_feature: int, out_dim: int, *args, **kwargs):
+        super().__init__()
+        from .model.wav2vec import Wav2Vec2Model
+        self.ori_sample_rate = sample_rate
+        self.sample_rate = 16000
+        self.out_dim = out_dim
+        self.n_feature = n_feature
+        self.model = Wav2Vec2Model()
+        for p in self.model.feature_extractor.parameters():               # freeze_feature_encoder()
+            p.requires_grad_(False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        from .data import resample_sinc_hann
+        x = resample_sinc_hann(x, self.ori_sample_rate, self.sample_rate)
+        x = x.to(torch.float32)
+        x = (x - x.mean()) / torch.sqrt(x.var(unbiased=False) + 1e-7)      # Wav2Vec2FeatureExtractor.zero_mean_unit_var_norm on one example
+        h = self.model(x, None).last_hidden_state                          # (batch, L, 768)
+        h = h.transpose(1, 2)
+        if self.out_dim != h.shape[1]:
+            h = F.interpolate(h.unsqueeze(1), size=(self.out_dim, self.n_feature), mode="bilinear").squeeze(1)
+        return h
+
+
 def get_extractor(extractor: str):
     """lightning_model.py:61-67."""
     if extractor == "mfcc":
         return MFCCExtractor
-    raise KeyError(f"feature extractor '{extractor}' is not restated here (wav2vec needs the pretrained facebook/wav2vec2-base-960h weights)")
+    if extractor == "wav2vec":
+        return Wav2VecExtractor
+    raise KeyError(f"unknown feature extractor '{extractor}' (available: mfcc, wav2vec)")

@@ -162,7 +162,8 @@ class Wav2Vec2Model(nn.Module):
         z = FeatEnc0Fn.apply(wave, fe[0].conv.weight, fe[0].layer_norm.weight, fe[0].layer_norm.bias)         # channels-last (S, L, 512)
         for i in range(1, len(fe)):
             z = ConvGeluFn.apply(z, fe[i].conv.weight, CONV_STRIDE[i])
-        z = linear_interpolation(z, frame_num)                                    # (S, T, 512)
+        if frame_num is not None:
+            z = linear_interpolation(z, frame_num)                                # (S, T, 512)
         T, C = z.shape[1], z.shape[2]
         fp = self.feature_projection
         h = LinearMMFn.apply(LayerNormFn.apply(z.reshape(S * T, C), fp.layer_norm.weight, fp.layer_norm.bias), fp.projection.weight, fp.projection.bias)
@@ -180,8 +181,10 @@ class Wav2Vec2Model(nn.Module):
         return h.view(S, T, d)
 
     def forward(self, input_values, dataset="vocaset", attention_mask=None, frame_num=None, **_):
-        if dataset != "vocaset":
-            raise NotImplementedError("only the vocaset branch (wav2vec.py:124-128) is on the hot path")
+        if dataset not in ("vocaset", None):
+            raise NotImplementedError("only the vocaset branch (wav2vec.py:124-128) and the plain HF forward (dataset=None) are restated")
+        if dataset is None:
+            frame_num = None                                   # plain HF Wav2Vec2Model.forward: 49 Hz frames, no interpolation
         if attention_mask is not None:
             raise NotImplementedError("attention_mask is never passed by the reference FaceFormer (faceformer.py:149-151)")
         if input_values.is_cuda and self.use_hip:
@@ -192,7 +195,8 @@ class Wav2Vec2Model(nn.Module):
         torch.backends.cudnn.benchmark = old_benchmark or (bool(self.conv_autotune) and input_values.is_cuda)
         try:
             z = self.feature_extractor(input_values).transpose(1, 2)
-            z = linear_interpolation(z, frame_num)
+            if frame_num is not None:
+                z = linear_interpolation(z, frame_num)
             fp = self.feature_projection
             h = fp.projection(fp.layer_norm(z))
             return types.SimpleNamespace(last_hidden_state=self.encoder(h))

@@ -438,7 +438,35 @@ def g10():
     save("g10_voca_train_trajectory", out)
 
 
-ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G10": g10}
+# --------------------------------------------------------------------------------------- G12 Wav2VecExtractor (after the resampler)
+def g12():
+    """extractor.py:84-96 with the installed HF modules, fed 16 kHz audio (the torchaudio resampler in front is absent here and
+    stays unpinned): HF processor on ONE (batch, time) tensor -> input_values[0] -> HF Wav2Vec2Model (formula weights, eval) ->
+    transpose -> bilinear resize to (out_dim, n_feature).  src/model/extractor.py itself imports torchaudio at module level, so
+    its forward is driven here line by line with the same HF objects it constructs."""
+    import transformers
+    print("G12 Wav2VecExtractor.forward after the resampler (HF processor + HF Wav2Vec2Model + resize)")
+    model = transformers.Wav2Vec2Model(transformers.Wav2Vec2Config(attn_implementation="eager")).eval()
+    sd = W.formula_state_dict(W.wav2vec2_shapes(), gains={"original0": 40.0})
+    model.load_state_dict(sd)
+    processor = transformers.Wav2Vec2FeatureExtractor()                   # == the preprocessor of facebook/wav2vec2-base-960h
+    out = {}
+    for name, (B, n, out_dim, n_feature) in {"a": (2, 8320, 52, 32), "b": (3, 4000, 768, 12)}.items():
+        x = W.formula_input(f"g12.audio.{name}", (B, n), 0.1) + 0.02 * torch.arange(B).view(B, 1)     # different means per clip
+        px = processor(x, return_tensors="pt", padding=True, sampling_rate=16000)
+        with torch.no_grad():
+            h = model(px.input_values[0]).last_hidden_state
+            h = h.transpose(1, 2)
+            if out_dim != h.shape[1]:
+                h = torch.nn.functional.interpolate(h.unsqueeze(1), size=(out_dim, n_feature), mode="bilinear").squeeze(1)
+        out[f"{name}::dims"] = np.asarray([B, n, out_dim, n_feature], dtype=np.int64)
+        pack(f"{name}::features", h, out, big=10 ** 9)
+        pack(f"{name}::input_values", px.input_values[0], out, big=10 ** 9)
+        print(f"   case {name}: features {tuple(h.shape)}")
+    save("g12_wav2vec_extractor", out)
+
+
+ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G10": g10, "G12": g12}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

@@ -658,3 +658,20 @@ def test_fit_loop_on_gpu_voca_and_faceformer(tmp_path):
         assert len(files) == 1 and files[0].startswith("epoch=")
         ck = torch.load(tmp_path / name / "checkpoints" / files[0], weights_only=False)
         assert ck["hyper_parameters"]["config"].modelname == name and all(k.startswith("model.") for k in ck["state_dict"])
+
+
+def test_wav2vec_extractor_on_gpu_g12():
+    """N2: Wav2VecExtractor with its encoder on the hand-written HIP path (plain 49 Hz forward, no interpolation) against the
+    HF-generated fixture G12."""
+    from a2f_amd.extractor import Wav2VecExtractor
+    g = load("g12_wav2vec_extractor")
+    for name in ("a", "b"):
+        B, n, out_dim, n_feature = (int(v) for v in g[f"{name}::dims"])
+        ex = Wav2VecExtractor(sample_rate=16000, n_feature=n_feature, out_dim=out_dim).eval()
+        ex.model.load_state_dict(W.formula_state_dict(W.wav2vec2_shapes(), gains={"original0": 40.0}))
+        ex.to(DEV)
+        x = (W.formula_input(f"g12.audio.{name}", (B, n), 0.1) + 0.02 * torch.arange(B).view(B, 1)).to(DEV)
+        with torch.no_grad():
+            y = ex(x)
+        assert y.is_cuda and tuple(y.shape) == (B, out_dim, n_feature)
+        assert packed_error(g, f"{name}::features", y) < TOL

@@ -127,3 +127,26 @@ def test_mfcc_top_db_floor_is_batch_wide():
     mel = ex.mel_spectrogram(torch.cat([loud, quiet], 0))
     db = 10.0 * torch.log10(torch.clamp(mel, min=1e-10))
     assert float(db[1].max()) < float(db.max()) - 80.0                # i.e. the whole quiet clip sits below the batch-wide floor
+
+
+def test_wav2vec_extractor_matches_hf_golden_g12():
+    """N2: Wav2VecExtractor (extractor.py:63-96) after the resampler against fixture G12 = the installed HF processor + HF
+    Wav2Vec2Model + the reference's resize, formula weights: the joint (batch, time) normalisation quirk, the plain 49 Hz
+    forward, transpose and bilinear resize."""
+    import numpy as np
+    import torch
+    from a2f_amd.extractor import Wav2VecExtractor, get_extractor
+    from golden_util import load, packed_error
+    from oracle import weights as W
+    g = load("g12_wav2vec_extractor")
+    assert get_extractor("wav2vec") is Wav2VecExtractor
+    for name in ("a", "b"):
+        B, n, out_dim, n_feature = (int(v) for v in g[f"{name}::dims"])
+        ex = Wav2VecExtractor(sample_rate=16000, n_feature=n_feature, out_dim=out_dim).eval()     # 16 kHz in: the resampler is the identity
+        ex.model.load_state_dict(W.formula_state_dict(W.wav2vec2_shapes(), gains={"original0": 40.0}))
+        assert not any(p.requires_grad for p in ex.model.feature_extractor.parameters())          # freeze_feature_encoder
+        x = W.formula_input(f"g12.audio.{name}", (B, n), 0.1) + 0.02 * torch.arange(B).view(B, 1)
+        with torch.no_grad():
+            y = ex(x)
+        assert tuple(y.shape) == (B, out_dim, n_feature)
+        assert packed_error(g, f"{name}::features", y) < 2e-5

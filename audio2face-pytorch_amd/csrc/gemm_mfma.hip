@@ -18,6 +18,7 @@
 //     8 (6) fragment reads for 12 (6) MFMAs in bf16x3;
 //   * split-K slabs + fixed-order fold for weight gradients (K = rows of the batch), batch index for grouped convolutions.
 #include "a2f_common.h"
+#include <stdlib.h>
 
 namespace a2f {
 namespace mm {
@@ -31,7 +32,7 @@ using i16x4_t = __attribute__((ext_vector_type(4))) short;
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 
 constexpr int BK = 32;
-constexpr int THREADS = 256;
+constexpr int THREADS = 256;           // CFG 0 / 1; CFG 2 runs 512 threads (see gemm_mfma_kernel)
 
 struct Op {
   const float* p;
@@ -123,9 +124,9 @@ __device__ __forceinline__ f32x16 mfma(u32x4_t a, u32x4_t b, f32x16 c) {
 // ---------------------------------------------------------------------------------------------------------------------
 // One operand's staging: X = number of lines (R) or contiguous extent (T) a tile spans (BM for A, BN for B).
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool T, int X>
+template <bool T, int X, int TH = THREADS>
 struct Stage {
-  static constexpr int NL = T ? (BK * X / 4) / THREADS : (X * 8) / THREADS;      // float4 units per thread
+  static constexpr int NL = T ? (BK * X / 4) / TH : (X * 8) / TH;                // float4 units per thread
   static constexpr int PITCH = T ? (2 * X + 64) : 64;                            // bytes
   static constexpr int IMG = T ? BK * PITCH : X * 64;                            // bytes of one bf16 image
   // R: fixed lines, the loads walk along k.  T: fixed contiguous offset, the lines (= k) advance with the k-tiles.
@@ -147,7 +148,7 @@ struct Stage {
       kq4 = kq * 4;
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
-        const int ll = (t >> 3) + 32 * i;
+        const int ll = (t >> 3) + (TH / 8) * i;
         const int line = x0 + ll;
         int s = 0, q = line;
         if (op.lps > 0) { s = line / op.lps; q = line - s * op.lps; }
@@ -165,7 +166,7 @@ struct Stage {
       jx += op.off;
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
-        const int kl = t / PER_ROW + (THREADS / PER_ROW) * i;
+        const int kl = t / PER_ROW + (TH / PER_ROW) * i;
         e0[i] = kl;
         lds_w[i] = kl * PITCH + nq * 8;
       }
@@ -274,15 +275,25 @@ struct Stage {
   }
 };
 
-// CFG 0: 128 x 128 tile, waves 2 x 2, 2 x 2 accumulator tiles per wave.  CFG 1: 128 x 64 tile, waves 4 x 1, 1 x 2 tiles.
+// CFG 0: 128 x 128 tile, 4 waves as 2 x 2, 2 x 2 accumulator tiles per wave.  CFG 1: 128 x 64 tile, waves 4 x 1, 1 x 2 tiles.
+// CFG 2: 256 x 128 tile, 8 waves as 4 x 2 (512 threads, one workgroup per CU): the same two waves per SIMD as two CFG-0
+// workgroups, but 384 instead of 512 operand rows are fetched / converted / written to LDS per 32 768 outputs and k-tile.
+template <int CFG>
+struct Cfg {
+  static constexpr int BM = CFG == 2 ? 256 : 128, BN = CFG == 1 ? 64 : 128;
+  static constexpr int TH = CFG == 2 ? 512 : 256;
+  static constexpr int WGN = CFG == 1 ? 1 : 2;
+  static constexpr int TM = CFG == 1 ? 1 : 2, TN = 2;
+};
+
 template <bool AT, bool BT, int PREC, int CFG>
-__global__ __launch_bounds__(THREADS, 2) void gemm_mfma_kernel(const Args a) {
-  constexpr int BM = 128, BN = CFG == 0 ? 128 : 64;
-  constexpr int WGN = CFG == 0 ? 2 : 1;
-  constexpr int TM = CFG == 0 ? 2 : 1, TN = 2;
+__global__ __launch_bounds__(Cfg<CFG>::TH, CFG == 2 ? 1 : 2) void gemm_mfma_kernel(const Args a) {
+  constexpr int BM = Cfg<CFG>::BM, BN = Cfg<CFG>::BN, TH = Cfg<CFG>::TH;
+  constexpr int WGN = Cfg<CFG>::WGN;
+  constexpr int TM = Cfg<CFG>::TM, TN = Cfg<CFG>::TN;
   constexpr int NIMG = PREC == 1 ? 2 : 1;
-  using SA = Stage<AT, BM>;
-  using SB = Stage<BT, BN>;
+  using SA = Stage<AT, BM, TH>;
+  using SB = Stage<BT, BN, TH>;
   constexpr int A_BYTES = NIMG * SA::IMG, B_BYTES = NIMG * SB::IMG;
   constexpr int STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];          // two stages
@@ -486,9 +497,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_fold_kernel(const Args a) {
 
 template <bool AT, bool BT, int PREC, int CFG>
 static int launch(const Args& a, hipStream_t st) {
-  constexpr int BM = 128, BN = CFG == 0 ? 128 : 64;
+  constexpr int BM = Cfg<CFG>::BM, BN = Cfg<CFG>::BN, TH = Cfg<CFG>::TH;
   constexpr int NIMG = PREC == 1 ? 2 : 1;
-  constexpr int smem = 2 * NIMG * (Stage<AT, BM>::IMG + Stage<BT, BN>::IMG);
+  constexpr int smem = 2 * NIMG * (Stage<AT, BM, TH>::IMG + Stage<BT, BN, TH>::IMG);
   auto kern = gemm_mfma_kernel<AT, BT, PREC, CFG>;
   static bool attr_done = false;                        // set-once per instantiation (idempotent; safe to repeat)
   if (!attr_done) {
@@ -497,7 +508,7 @@ static int launch(const Args& a, hipStream_t st) {
     attr_done = true;
   }
   dim3 grid((unsigned)(cdiv(a.N, BN) * cdiv(a.M, BM)), 1, (unsigned)(a.batch * a.split_k));
-  hipLaunchKernelGGL(kern, grid, dim3(THREADS), smem, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3(TH), smem, st, a);
   return A2F_OK;
 }
 
@@ -577,10 +588,16 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   a.batch = batch;
   a.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   const bool at = d->A.trans != 0, bt = d->B.trans != 0;
-  const int cfg = d->N <= 64 ? 1 : 0;
+  // tile choice: narrow outputs -> 128 x 64; tall problems with enough 256-row tiles to fill the chip -> 256 x 128; else 128 x 128
+  int cfg = d->N <= 64 ? 1 : 0;
+  if (cfg == 0 && d->N >= 128 && cdiv(d->M, 256) * cdiv(d->N, 128) * batch * split >= 200) cfg = 2;
+  {
+    const char* force = getenv("A2F_MM_CFG");                 // tuning / A-B hook: 0 | 1 | 2
+    if (force && force[0] >= '0' && force[0] <= '2' && !(force[0] == '1' && d->N > 64)) cfg = force[0] - '0';
+  }
   hipStream_t st = (hipStream_t)stream;
-  if (d->precision == 1) rc = cfg == 0 ? dispatch_layout<1, 0>(a, at, bt, st) : dispatch_layout<1, 1>(a, at, bt, st);
-  else rc = cfg == 0 ? dispatch_layout<0, 0>(a, at, bt, st) : dispatch_layout<0, 1>(a, at, bt, st);
+  if (d->precision == 1) rc = cfg == 0 ? dispatch_layout<1, 0>(a, at, bt, st) : cfg == 1 ? dispatch_layout<1, 1>(a, at, bt, st) : dispatch_layout<1, 2>(a, at, bt, st);
+  else rc = cfg == 0 ? dispatch_layout<0, 0>(a, at, bt, st) : cfg == 1 ? dispatch_layout<0, 1>(a, at, bt, st) : dispatch_layout<0, 2>(a, at, bt, st);
   if (rc) return rc;
   A2F_CHECK_LAUNCH("a2f_mm");
   if (split > 1) {

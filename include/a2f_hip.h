@@ -12,8 +12,11 @@
  * Conventions
  *  - every pointer is a DEVICE pointer owned by the caller (torch tensor .data_ptr()), fp32 unless noted,
  *    dense row-major unless a stride is given; nothing is retained after the call returns;
- *  - work is enqueued asynchronously on `stream` (a hipStream_t, passed as void*); no entry point
- *    synchronises, allocates device memory, or keeps mutable global state (hipGraph-capturable);
+ *  - work is enqueued asynchronously on `stream` (a hipStream_t, passed as void*); no entry point synchronises or
+ *    allocates device memory (hipGraph-capturable).  Process-wide state the library does keep, all of it idempotent or
+ *    opt-in: one "LDS attribute set" flag per kernel instantiation (hipFuncSetAttribute is issued once), the head-kernel
+ *    shape selected by the environment variable A2F_HEAD_CFG (read once), the tile override A2F_MM_CFG (read per call), and
+ *    the measurement ring of a2f_profile_enable (off by default).  Nothing else survives a call;
  *  - return value: 0 on success, negative A2F_E* on failure; a2f_last_error() gives a thread-local message;
  *  - `ws` is caller-provided scratch of at least the matching *_ws_bytes(); contents are undefined on entry.
  */

@@ -281,13 +281,16 @@ struct Stage {
 template <int CFG>
 struct Cfg {
   static constexpr int BM = CFG == 2 ? 256 : 128, BN = CFG == 1 ? 64 : 128;
-  static constexpr int TH = CFG == 2 ? 512 : 256;
+  static constexpr int TH = CFG >= 2 ? 512 : 256;
   static constexpr int WGN = CFG == 1 ? 1 : 2;
-  static constexpr int TM = CFG == 1 ? 1 : 2, TN = 2;
+  static constexpr int TM = (CFG == 1 || CFG == 3) ? 1 : 2, TN = 2;
+  // waves per SIMD the register budget is set for: CFG 3 = 128 x 128 tile on 8 waves (32 x 64 per wave), two workgroups per CU
+  // -> four waves per SIMD (<= 128 VGPRs) to cover the LDS-read / barrier latencies of one another
+  static constexpr int WPS = CFG == 3 ? 4 : (CFG == 2 ? 2 : 2);
 };
 
 template <bool AT, bool BT, int PREC, int CFG>
-__global__ __launch_bounds__(Cfg<CFG>::TH, CFG == 2 ? 1 : 2) void gemm_mfma_kernel(const Args a) {
+__global__ __launch_bounds__(Cfg<CFG>::TH, Cfg<CFG>::WPS) void gemm_mfma_kernel(const Args a) {
   constexpr int BM = Cfg<CFG>::BM, BN = Cfg<CFG>::BN, TH = Cfg<CFG>::TH;
   constexpr int WGN = Cfg<CFG>::WGN;
   constexpr int TM = Cfg<CFG>::TM, TN = Cfg<CFG>::TN;
@@ -588,16 +591,22 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   a.batch = batch;
   a.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   const bool at = d->A.trans != 0, bt = d->B.trans != 0;
-  // tile choice: narrow outputs -> 128 x 64; tall problems with enough 256-row tiles to fill the chip -> 256 x 128; else 128 x 128
-  int cfg = d->N <= 64 ? 1 : 0;
-  if (cfg == 0 && d->N >= 128 && cdiv(d->M, 256) * cdiv(d->N, 128) * batch * split >= 200) cfg = 2;
+  // tile choice (measured, tools/bench_mm.py): narrow outputs -> 128 x 64; weight-gradient layout (both operands k-strided: 80 KB of
+  // LDS per 128 x 128 workgroup, so only one 8-wave workgroup would fit) -> 256 x 128 on 8 waves when there are enough tiles, else
+  // 128 x 128 on 4 waves; everything else -> 128 x 128 on 8 waves, two workgroups per CU = four waves per SIMD (+10-25 % over 4 waves)
+  int cfg = d->N <= 64 ? 1 : 3;
+  if (cfg == 3 && at && bt) cfg = (cdiv(d->M, 256) * cdiv(d->N, 128) * batch * split >= 200) ? 2 : 0;
   {
     const char* force = getenv("A2F_MM_CFG");                 // tuning / A-B hook: 0 | 1 | 2
-    if (force && force[0] >= '0' && force[0] <= '2' && !(force[0] == '1' && d->N > 64)) cfg = force[0] - '0';
+    if (force && force[0] >= '0' && force[0] <= '3' && !(force[0] == '1' && d->N > 64)) cfg = force[0] - '0';
   }
   hipStream_t st = (hipStream_t)stream;
-  if (d->precision == 1) rc = cfg == 0 ? dispatch_layout<1, 0>(a, at, bt, st) : cfg == 1 ? dispatch_layout<1, 1>(a, at, bt, st) : dispatch_layout<1, 2>(a, at, bt, st);
-  else rc = cfg == 0 ? dispatch_layout<0, 0>(a, at, bt, st) : cfg == 1 ? dispatch_layout<0, 1>(a, at, bt, st) : dispatch_layout<0, 2>(a, at, bt, st);
+  if (d->precision == 1)
+    rc = cfg == 0 ? dispatch_layout<1, 0>(a, at, bt, st) : cfg == 1 ? dispatch_layout<1, 1>(a, at, bt, st) : cfg == 2 ? dispatch_layout<1, 2>(a, at, bt, st)
+                                                                                                              : dispatch_layout<1, 3>(a, at, bt, st);
+  else
+    rc = cfg == 0 ? dispatch_layout<0, 0>(a, at, bt, st) : cfg == 1 ? dispatch_layout<0, 1>(a, at, bt, st) : cfg == 2 ? dispatch_layout<0, 2>(a, at, bt, st)
+                                                                                                              : dispatch_layout<0, 3>(a, at, bt, st);
   if (rc) return rc;
   A2F_CHECK_LAUNCH("a2f_mm");
   if (split > 1) {

@@ -158,10 +158,19 @@ class Wav2Vec2Model(nn.Module):
         from ..encoder_ops import ConvGeluFn, EncoderLayerFn, FeatEnc0Fn, LayerNormFn, LinearMMFn, PosConvFn
         S = wave.shape[0]
         fe = self.feature_extractor.conv_layers
-        # layer 0 (1 -> 512 channels, k = 10, stride 5) + GroupNorm(512 groups) + GELU: 10 MACs per output, memory-bound
-        z = FeatEnc0Fn.apply(wave, fe[0].conv.weight, fe[0].layer_norm.weight, fe[0].layer_norm.bias)         # channels-last (S, L, 512)
-        for i in range(1, len(fe)):
-            z = ConvGeluFn.apply(z, fe[i].conv.weight, CONV_STRIDE[i])
+        # feature encoder, in chunks of sequences: the sequences are independent there and an a2f_mm operand spans < 4 GiB (the layer-0
+        # output of 32 sequences of 160 000 samples is 2.1 GB); the chunks are concatenated once the frame rate is down to 49 Hz
+        n = wave.shape[1]
+        per = max(1, int((3 << 30) // (max((n - 10) // 5 + 1, 1) * 512 * 4)))
+        per = -(-S // -(-S // per))                               # balanced chunks
+        outs = []
+        for s0 in range(0, S, per):
+            # layer 0 (1 -> 512 channels, k = 10, stride 5) + GroupNorm(512 groups) + GELU: 10 MACs per output, memory-bound
+            z = FeatEnc0Fn.apply(wave[s0:s0 + per], fe[0].conv.weight, fe[0].layer_norm.weight, fe[0].layer_norm.bias)      # channels-last (s, L, 512)
+            for i in range(1, len(fe)):
+                z = ConvGeluFn.apply(z, fe[i].conv.weight, CONV_STRIDE[i])
+            outs.append(z)
+        z = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
         if frame_num is not None:
             z = linear_interpolation(z, frame_num)                                # (S, T, 512)
         T, C = z.shape[1], z.shape[2]

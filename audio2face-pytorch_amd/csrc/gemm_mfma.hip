@@ -32,6 +32,9 @@ using i16x4_t = __attribute__((ext_vector_type(4))) short;
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 
 constexpr int BK = 32;
+#ifndef MM_TPAD
+#define MM_TPAD 64            // bytes of padding per row of a [k][lines] image (64: transposing reads conflict-free)
+#endif
 constexpr int THREADS = 256;           // CFG 0 / 1; CFG 2 runs 512 threads (see gemm_mfma_kernel)
 
 struct Op {
@@ -127,7 +130,7 @@ __device__ __forceinline__ f32x16 mfma(u32x4_t a, u32x4_t b, f32x16 c) {
 template <bool T, int X, int TH = THREADS>
 struct Stage {
   static constexpr int NL = T ? (BK * X / 4) / TH : (X * 8) / TH;                // float4 units per thread
-  static constexpr int PITCH = T ? (2 * X + 64) : 64;                            // bytes
+  static constexpr int PITCH = T ? (2 * X + MM_TPAD) : 64;                       // bytes
   static constexpr int IMG = T ? BK * PITCH : X * 64;                            // bytes of one bf16 image
   // R: fixed lines, the loads walk along k.  T: fixed contiguous offset, the lines (= k) advance with the k-tiles.
   // All address arithmetic is 32-bit and branch-free (selects): byte offsets are taken modulo 2^32 from the operand base

@@ -10,7 +10,7 @@ Headline (``metric``/``value``) = BASELINE.json configs[1]: VOCA (DeepSpeech-29 
 VOCASET batch 32 sequences x 600 frames = 19 200 frame windows (29,16) per GPU per step, 5023-vertex meshes, weak scaling
 (every rank runs the same per-GPU batch on its own shard, seed 1234+rank; the only data-path exchange is the gradient
 all-reduce).  ``secondary`` carries the other two model families on their BASELINE configurations, same step definition:
-  * FaceFormer (configs[2]): wav2vec2-base encoder + autoregressive decoder, 32 sequences x 600 frames per GPU per step, fp32 storage
+  * FaceFormer (configs[2]): wav2vec2-base encoder + autoregressive decoder, 64 sequences x 600 frames per GPU per step, fp32 storage
   * Audio2Mesh: B = 1024 windows (52,32) per GPU per step
 each with its own ``roofline`` and ``cpu_baseline``.  ``--workload faceformer|audio2mesh`` makes one of them the headline.
 
@@ -294,7 +294,7 @@ def main():
     ap.add_argument("--workload", default="voca", choices=["voca", "faceformer", "audio2mesh"])
     ap.add_argument("--seqs", type=int, default=32)
     ap.add_argument("--frames", type=int, default=600)
-    ap.add_argument("--ff-seqs", type=int, default=32)
+    ap.add_argument("--ff-seqs", type=int, default=64)
     ap.add_argument("--ff-frames", type=int, default=600)
     ap.add_argument("--a2m-batch", type=int, default=1024)
     ap.add_argument("--secondary-steps", type=int, default=10)

@@ -675,3 +675,30 @@ def test_wav2vec_extractor_on_gpu_g12():
             y = ex(x)
         assert y.is_cuda and tuple(y.shape) == (B, out_dim, n_feature)
         assert packed_error(g, f"{name}::features", y) < TOL
+
+
+def test_trainstep_falls_back_to_eager_when_graph_capture_fails(monkeypatch):
+    """TrainStep(use_graph=True): a failed hipGraph capture must not abort training - the step continues with eager launches
+    of the same kernels and produces the same numbers as a step that never tried to capture."""
+    from a2f_amd.trainer import TrainStep
+    gen = torch.Generator().manual_seed(11)
+    B = 6
+    x = torch.randn(B, 29, 16, generator=gen).to(DEV)
+    oh = torch.zeros(B, 12); oh[torch.arange(B), torch.arange(B) % 8] = 1
+    t = (torch.randn(B, 5023, 3, generator=gen) * 5).to(DEV)
+    gt = t + (torch.randn(B, 5023, 3, generator=gen) * 0.5).to(DEV)
+    losses = {}
+    for mode in ("eager", "broken_graph"):
+        m, _ = _voca()
+        step = TrainStep(m, a2f_amd.VocaLoss(), lr=1e-3, use_graph=(mode != "eager"))
+        if mode == "broken_graph":
+            class Boom:
+                def __init__(self, *a, **k):
+                    raise RuntimeError("capture refused (test)")
+            monkeypatch.setattr(torch.cuda, "graph", Boom)
+        with (pytest.warns(UserWarning, match="capture") if mode == "broken_graph" else __import__("contextlib").nullcontext()):
+            losses[mode] = [float(step(x, oh.to(DEV), gt, t)["loss"]) for _ in range(4)]      # steps 1-2 warm up, step 3 tries to capture
+        if mode == "broken_graph":
+            assert step.use_graph is False
+            monkeypatch.undo()
+    assert losses["eager"] == losses["broken_graph"]

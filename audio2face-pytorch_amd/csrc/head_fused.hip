@@ -36,6 +36,8 @@ struct HeadArgs {
   float* pred; float* dH_slab; float* dW_slab; float* db_slab; double* loss_part;
   unsigned long long* dbg;             // diagnostic build only (HF_STAMPS): per-wave phase cycle totals
   int64_t ldt;                         // template row stride: n, or 0 for one broadcast row
+  int rpt, ntempl;                     // head_x3 only: rpt > 0 = frame r takes template row r / rpt of ntempl rows (one per sequence)
+  float inv_rpt;
   int ldh;                             // dH slab row pitch in floats: HF_KP, or K rounded up to 4 (rows back to back: only whole lines are written)
   int B, Bloss, n, CG, RG, NRB;
   int CW;                              // head_x3: column-group stride (<= 256, multiple of 4): group cg owns columns [cg CW, (cg+1) CW)
@@ -649,17 +651,22 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
   const int qcol_ok = ((c0 + 4 * lane) - cend) >> 31;                                    // -1: this lane's first column exists
   auto issue_q = [&](int rb, int m) {
     const int row0 = rb * HF_ROWS;
-    const int64_t gfirst = (int64_t)row0 * n + c0, tfirst = (int64_t)row0 * a.ldt + c0;
+    const int row = 4 * wave + m;
+    int64_t gfirst = (int64_t)row0 * n + c0, tfirst = (int64_t)row0 * a.ldt + c0;
     int64_t grec = ((int64_t)B * n - gfirst) * 4, trec = (a.ldt ? ((int64_t)B * a.ldt - tfirst) : (int64_t)(n - c0)) * 4;
+    int trow = row * (int)a.ldt;
+    if (a.rpt) {                                                                      // one template row per sequence of rpt frames (wave-uniform)
+      const int tr = (int)(((float)(row0 + row) + 0.5f) * a.inv_rpt);                 // exact floor((row0 + row) / rpt) below 2^22 rows
+      tfirst = c0; trec = ((int64_t)a.ntempl * n - c0) * 4; trow = tr * n;
+    }
     grec = grec < 0 ? 0 : grec > 0x7FFFFFF0 ? 0x7FFFFFF0 : grec;                      // loads past the tensors' last element return 0
     trec = trec < 0 ? 0 : trec > 0x7FFFFFF0 ? 0x7FFFFFF0 : trec;
     const rsrc_t gb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gt + gfirst), 0, (int)grec, 0x00020000);
     const rsrc_t tb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.templ + tfirst), 0, (int)trec, 0x00020000);
-    const int row = 4 * wave + m;
     int l4 = 4 * lane;
     asm volatile("" : "+v"(l4));
     const int ok = qcol_ok & ((rb - rb1) >> 31) & ((row0 + row - B) >> 31);
-    tq[m] = __builtin_amdgcn_raw_buffer_load_b128(tb, (4 * (row * (int)a.ldt + l4)) | ~ok, 0, X3_STREAM_LD);
+    tq[m] = __builtin_amdgcn_raw_buffer_load_b128(tb, (4 * (trow + l4)) | ~ok, 0, X3_STREAM_LD);
     gq[m] = __builtin_amdgcn_raw_buffer_load_b128(gb, (4 * (row * n + l4)) | ~ok, 0, X3_STREAM_LD);
   };
 #pragma unroll
@@ -1214,7 +1221,11 @@ extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias,
   A2F_CHECK_ARG(B >= 2 && B < (1 << 30), "head_fused: B=%lld", (long long)B);
   A2F_CHECK_ARG(Bloss >= 2 && (Bloss % 2) == 0 && Bloss <= B, "head_fused: Bloss=%lld must be even, >= 2 and <= B (loss.py:13-15,33-35)", (long long)Bloss);
   A2F_CHECK_ARG(n >= 3 && (n % 3) == 0 && n < (1 << 30), "head_fused: n=%lld must be a multiple of 3", (long long)n);
-  A2F_CHECK_ARG(template_rows == 1 || template_rows == B, "head_fused: template_rows must be 1 or B");
+  A2F_CHECK_ARG(template_rows >= 1 && template_rows <= B && B % template_rows == 0, "head_fused: template_rows=%lld must divide B=%lld",
+                (long long)template_rows, (long long)B);
+  const bool per_seq = template_rows != 1 && template_rows != B;          // one template row per run of B / template_rows frames
+  A2F_CHECK_ARG(!per_seq || (cfg_is_x3(K) && B < (1 << 22) && template_rows * n < (1 << 28)),
+                "head_fused: per-sequence template rows need the bf16x3 kernel (A2F_HEAD_CFG unset or 5), B < 2^22");
   const HeadPlan p = head_plan_for(B, n, K);
   if (ws_bytes < p.total) return set_err(A2F_EWORKSPACE, "head_fused: workspace %zu < %zu", ws_bytes, p.total);
   hipStream_t s = (hipStream_t)stream;
@@ -1224,7 +1235,9 @@ extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias,
   a.dH_slab = (float*)(w8 + p.off_dH); a.dW_slab = (float*)(w8 + p.off_dW); a.db_slab = (float*)(w8 + p.off_db);
   a.loss_part = (double*)(w8 + p.off_loss);
   a.dbg = (unsigned long long*)(w8 + p.off_dbg);
-  a.ldt = template_rows == 1 ? 0 : n;
+  a.ldt = template_rows == B ? n : 0;
+  a.rpt = per_seq ? (int)(B / template_rows) : 0; a.ntempl = (int)template_rows;
+  a.inv_rpt = per_seq ? 1.0f / (float)a.rpt : 0.f;
   a.ldh = cfg_is_x3(K) ? (int)((K + 3) & ~(int64_t)3) : HF_KP;
   a.B = (int)B; a.Bloss = (int)Bloss; a.n = (int)n; a.CG = p.CG; a.RG = p.RG; a.NRB = p.NRB; a.CW = p.CW;
   const double V = (double)(n / 3);

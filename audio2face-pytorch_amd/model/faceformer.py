@@ -159,14 +159,20 @@ class Faceformer(nn.Module):
     def forward_with_loss_batch(self, audio, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0):
         """S independent batch-1 problems in one step (the reference trains batch = 1, train.py:33):
         audio (S,N), one_hot (S,n_onehot), template (S,V,3), gt (S,T,V,3).  The encoder runs batched, the decoder
-        recurrence launches one workgroup per sequence, the fused head runs once per sequence (its template is per
-        sequence).  Returns (pred (S,T,V,3), mean loss dict)."""
+        recurrence launches one workgroup per sequence, and the fused head takes all S * T frames in ONE launch with one
+        template row per sequence (even T: the velocity pairs (2k, 2k+1) then never straddle two sequences and the mean over
+        S * T frames equals the mean of the per-sequence means; odd T falls back to one launch per sequence, each dropping its
+        own tail frame as loss.py:13-15 does).  Returns (pred (S,T,V,3), mean loss dict)."""
         self._note_train_mode()
         S = audio.shape[0]
         frame_num = audio.shape[1] * 60 // 16000
         enc = self.encode(audio, frame_num)
         y = self.decode_hidden(enc, one_hot)                                  # (S,T,64)
         T = y.shape[1]
+        if T % 2 == 0:
+            p, tot = HeadLossFusedFn.apply(y.reshape(S * T, -1), self.vertice_map_r.weight, self.vertice_map_r.bias, template.reshape(S, -1),
+                                           gt.reshape(S * T, -1), S * T, k_rec, k_vel)
+            return p.view(S, T, -1, 3), {"loss": tot[0], "rec_loss": tot[1].detach(), "vel_loss": tot[2].detach()}
         preds, tot = [], None
         for s in range(S):
             p, o3 = HeadLossFusedFn.apply(y[s], self.vertice_map_r.weight, self.vertice_map_r.bias, template[s].reshape(1, -1),

@@ -120,7 +120,9 @@ int a2f_vocaloss_bwd(const float* pred, const float* gt, const float* g3, int64_
  *   pred[b,:] = H[b,:] Wt + bias + template[b or 0,:]              (written once)
  *   partial sums of rec / vel                                      -> out3 = {loss, rec, vel}
  *   G = dloss/dpred (never stored);  dH = G W ; dW = G^T H ; dbias = colsum G
- * H (B,K) K<=64; W (n,K) torch Linear layout; template (B,n) or (1,n) when template_rows == 1;
+ * H (B,K) K<=64; W (n,K) torch Linear layout; template (template_rows, n): template_rows == 1 (one row for all frames),
+ * == B (one row per frame) or a divisor S of B - frame b takes row b / (B / S): the S sequences of a FaceFormer step
+ * (batch = 1 each in the reference, train.py:33) in one launch, each with its own subject template;
  * gt (B,n).  B must be even.  dH (B,K), dW (n,K), dbias (n) are overwritten.
  * `Bloss` frames (even, <= B) enter the loss (FaceFormerLoss drops an odd tail frame, loss.py:13-15);
  * all B rows of pred are written.

@@ -273,7 +273,8 @@ class EmuBackend:
     def head_fused(self, H, W, bias, templ, template_rows, gt, B, Bloss, n, K, k_rec, k_vel, pred, out3, dH, dW, dbias):
         Hd, Wd = H.reshape(B, K).double(), W.reshape(n, K).double()
         t = templ.reshape(template_rows, n).double()
-        p = Hd @ Wd.t() + bias.double().view(1, -1) + (t if template_rows == B else t[:1])
+        assert B % template_rows == 0
+        p = Hd @ Wd.t() + bias.double().view(1, -1) + t.repeat_interleave(B // template_rows, dim=0)
         pred.reshape(B, n).copy_(p.float())
         V = n // 3
         d = (p - gt.reshape(B, n).double())[:Bloss]

@@ -265,12 +265,17 @@ def test_adam_matches_torch_optim():
 
 @pytest.mark.parametrize("B_,n,K,trows,Bloss", [(4, 15069, 50, 4, 4), (70, 1536, 50, 70, 70), (64, 999, 64, 1, 64), (33, 600, 64, 1, 32),
                                                  (2, 3, 50, 2, 2), (130, 15069, 64, 1, 130), (256, 15069, 50, 256, 256),
-                                                 (601, 15069, 64, 1, 600), (1031, 4002, 50, 1031, 1030)])
+                                                 (601, 15069, 64, 1, 600), (1031, 4002, 50, 1031, 1030),
+                                                 # one template row per sequence (FaceFormer: S sequences of T frames in one launch)
+                                                 (120, 15069, 64, 3, 120), (1200, 4002, 64, 2, 1200), (96, 15069, 50, 6, 96), (38, 999, 64, 19, 38),
+                                                 (130, 1536, 64, 5, 104)])
 def test_head_fused_vs_contract(B_, n, K, trows, Bloss):
+    if trows not in (1, B_) and os.environ.get("A2F_HEAD_CFG", "5") != "5":
+        pytest.skip("per-sequence template rows exist in the bf16x3 kernel only")
     hip, emu = ops.HipBackend(), EmuBackend()
     H, Wt, bias = rnd(B_, K, seed=50), rnd(n, K, seed=51, scale=0.3), rnd(n, seed=52)
     templ = rnd(trows, n, seed=53, scale=5.0)
-    gt = (templ if trows == B_ else templ.expand(B_, n)) + rnd(B_, n, seed=54, scale=0.5)
+    gt = templ.repeat_interleave(B_ // trows, dim=0) + rnd(B_, n, seed=54, scale=0.5)
     outs = []
     for be, dev in ((hip, DEV), (emu, "cpu")):
         pred = torch.full((B_, n), float("nan"), device=dev)
@@ -307,6 +312,8 @@ def test_head_fused_rejects_bad_arguments():
     z = lambda *s: torch.zeros(*s, device=DEV)
     with pytest.raises(a2f_amd.A2FError):       # unsupported K
         be.head_fused(z(4, 32), z(30, 32), z(30), z(4, 30), 4, z(4, 30), 4, 4, 30, 32, 1.0, 10.0, z(4, 30), z(3), z(4, 32), z(30, 32), z(30))
+    with pytest.raises(a2f_amd.A2FError):       # template rows must divide B
+        be.head_fused(z(4, 50), z(30, 50), z(30), z(3, 30), 3, z(4, 30), 4, 4, 30, 50, 1.0, 10.0, z(4, 30), z(3), z(4, 50), z(30, 50), z(30))
     with pytest.raises(a2f_amd.A2FError):       # odd Bloss
         be.head_fused(z(4, 50), z(30, 50), z(30), z(4, 30), 4, z(4, 30), 4, 3, 30, 50, 1.0, 10.0, z(4, 30), z(3), z(4, 50), z(30, 50), z(30))
 

@@ -702,3 +702,44 @@ def test_trainstep_falls_back_to_eager_when_graph_capture_fails(monkeypatch):
             assert step.use_graph is False
             monkeypatch.undo()
     assert losses["eager"] == losses["broken_graph"]
+
+
+@pytest.mark.parametrize("T", [40, 41])
+def test_faceformer_batch_step_one_head_launch_equals_per_sequence_steps(T):
+    """forward_with_loss_batch: S sequences with S different subject templates through ONE fused-head launch (even T; template row
+    = frame // T inside the kernel) against the mean of S batch-1 `forward_with_loss` calls, the reference's own formulation
+    (train.py:33 batch = 1; loss.py:4-17).  Odd T takes the per-sequence launches (each drops its own tail frame)."""
+    import types
+    S = 3
+
+    class _Enc(torch.nn.Module):
+        def forward(self, wave, dataset, frame_num=None):
+            return types.SimpleNamespace(last_hidden_state=self.states[: wave.shape[0]] if wave.shape[0] == S else self.states[self.pick:self.pick + 1])
+
+    m = a2f_amd.Faceformer(n_verts=NV, n_onehot=12, audio_encoder=_Enc())
+    m.load_state_dict(W.formula_state_dict(W.faceformer_decoder_shapes(NV, 12, 64), gains=FF_GAINS), strict=False)
+    m.to(DEV)
+    enc = W.formula_input("batchhead.enc", (S, T, 768)).to(DEV).requires_grad_(True)
+    m.audio_encoder.states = enc
+    audio = torch.zeros(S, T * 16000 // 60 + 8, device=DEV)
+    oh = torch.zeros(S, 12, device=DEV); oh[0, 1] = oh[1, 7] = oh[2, 4] = 1
+    template = W.formula_input("batchhead.template", (S, 5023, 3), 5.0).to(DEV)
+    gt = template.view(S, 1, 5023, 3) + W.formula_input("batchhead.gt", (S, T, 5023, 3), 0.5).to(DEV)
+    pred_b, loss_b = m.forward_with_loss_batch(audio, oh, template, gt)
+    loss_b["loss"].backward()
+    gb = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    ge_b = enc.grad.clone()
+    m.zero_grad(); enc.grad = None
+    tot, preds = 0.0, []
+    for s in range(S):
+        m.audio_encoder.pick = s
+        p, l = m.forward_with_loss(audio[s:s + 1], oh[s:s + 1], template[s:s + 1], gt[s:s + 1])
+        (l["loss"] / S).backward()
+        tot = tot + l["loss"].detach() / S
+        preds.append(p)
+    assert rel_l2(pred_b.cpu(), torch.cat(preds).cpu()) < 1e-6
+    assert abs(float(loss_b["loss"]) - float(tot)) <= 2e-5 * abs(float(tot))
+    assert rel_l2(ge_b.cpu(), enc.grad.cpu()) < TOL
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            assert rel_l2(gb[k].cpu(), p.grad.cpu()) < TOL, k

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_fwd_kernel(const flo
                                                                         const float* __restrict__ cross, const float* __restrict__ style,
                                                                         int T, int period, float* __restrict__ y, float* __restrict__ save) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  __builtin_amdgcn_s_setprio(3);          // a latency-bound chain: when it shares a CU with GEMM waves of another stream (the pipelined step), its waves issue first
   float* WqkvT = lds;                       // [64][192]  WqkvT[k*192 + o] = Wqkv[o][k]
   float* WoT = WqkvT + FD * 192;            // [64][64]
   float* AT = WoT + FD * FD;                // [64][64]
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
                                                                         int period, float* __restrict__ save,
                                                                         float* __restrict__ dcross, float* __restrict__ dstyle) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  __builtin_amdgcn_s_setprio(3);          // a latency-bound chain: when it shares a CU with GEMM waves of another stream (the pipelined step), its waves issue first
   float* Wqkv = lds;                        // [192][64] row-major: lane = input index for the transposed products
   float* Wo = Wqkv + 192 * FD;              // [64][64]
   float* Am = Wo + FD * FD;                 // [64][64]

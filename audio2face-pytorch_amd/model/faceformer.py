@@ -156,28 +156,87 @@ class Faceformer(nn.Module):
                                            template.reshape(1, -1), gt.reshape(T, -1), T - (T % 2), k_rec, k_vel, unit_grad)
         return pred.view(1, T, -1, 3), {"loss": out3[0], "rec_loss": out3[1].detach(), "vel_loss": out3[2].detach()}
 
-    def forward_with_loss_batch(self, audio, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0):
-        """S independent batch-1 problems in one step (the reference trains batch = 1, train.py:33; SURVEY §8(d) C3):
-        audio (S,N), one_hot (S,n_onehot), template (S,V,3), gt (S,T,V,3).  The encoder runs batched, the decoder
-        recurrence launches one workgroup per sequence, and the fused head takes all S * T frames in ONE launch with one
-        template row per sequence (even T: the velocity pairs (2k, 2k+1) then never straddle two sequences and the mean over
-        S * T frames equals the mean of the per-sequence means; odd T falls back to one launch per sequence, each dropping its
-        own tail frame as loss.py:13-15 does).  Returns (pred (S,T,V,3), mean loss dict)."""
-        self._note_train_mode()
-        S = audio.shape[0]
-        frame_num = audio.shape[1] * 60 // 16000
-        enc = self.encode(audio, frame_num)
-        y = self.decode_hidden(enc, one_hot)                                  # (S,T,64)
-        T = y.shape[1]
+    def _head_loss_batch(self, y, template, gt, k_rec, k_vel):
+        """y (S,T,64) -> (pred (S,T,V,3), out3 = [loss, rec, vel] averaged over the S sequences).  Even T: all S * T frames in ONE
+        fused-head launch with one template row per sequence (the velocity pairs (2k, 2k+1) never straddle two sequences and the
+        mean over S * T frames equals the mean of the per-sequence means); odd T: one launch per sequence, each dropping its own
+        tail frame as loss.py:13-15 does."""
+        S, T = y.shape[0], y.shape[1]
         if T % 2 == 0:
             p, tot = HeadLossFusedFn.apply(y.reshape(S * T, -1), self.vertice_map_r.weight, self.vertice_map_r.bias, template.reshape(S, -1),
                                            gt.reshape(S * T, -1), S * T, k_rec, k_vel)
-            return p.view(S, T, -1, 3), {"loss": tot[0], "rec_loss": tot[1].detach(), "vel_loss": tot[2].detach()}
+            return p.view(S, T, -1, 3), tot
         preds, tot = [], None
         for s in range(S):
             p, o3 = HeadLossFusedFn.apply(y[s], self.vertice_map_r.weight, self.vertice_map_r.bias, template[s].reshape(1, -1),
                                           gt[s].reshape(T, -1), T - (T % 2), k_rec, k_vel)
             preds.append(p)
             tot = o3 if tot is None else tot + o3
-        tot = tot / S
-        return torch.stack(preds).view(S, T, -1, 3), {"loss": tot[0], "rec_loss": tot[1].detach(), "vel_loss": tot[2].detach()}
+        return torch.stack(preds).view(S, T, -1, 3), tot / S
+
+    def forward_with_loss_batch(self, audio, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0):
+        """S independent batch-1 problems in one step (the reference trains batch = 1, train.py:33; SURVEY §8(d) C3):
+        audio (S,N), one_hot (S,n_onehot), template (S,V,3), gt (S,T,V,3).  The encoder runs batched, the decoder
+        recurrence launches one workgroup per sequence, the fused head takes all frames at once (`_head_loss_batch`).
+        Returns (pred (S,T,V,3), mean loss dict)."""
+        self._note_train_mode()
+        frame_num = audio.shape[1] * 60 // 16000
+        enc = self.encode(audio, frame_num)
+        y = self.decode_hidden(enc, one_hot)                                  # (S,T,64)
+        pred, tot = self._head_loss_batch(y, template, gt, k_rec, k_vel)
+        return pred, {"loss": tot[0], "rec_loss": tot[1].detach(), "vel_loss": tot[2].detach()}
+
+    _pipe_stream = None
+
+    def train_step_pipelined(self, audio, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0):
+        """forward + FaceFormerLoss + backward of S >= 2 sequences (gradients ACCUMULATE into .grad, as loss.backward() does) with
+        the latency-bound decoder recurrence hidden under encoder work.  The recurrence occupies one workgroup per sequence for
+        ~17 ms (forward + backward at T = 600) whatever S is; run back to back with the encoder it leaves >= 75 % of the CUs idle
+        for that time.  Here the step is cut into two half-batches A, B and issued on two HIP streams:
+
+            main stream : encoder fwd A | encoder fwd B |     encoder bwd A      | encoder bwd B
+            side stream :               | decoder fwd + head + decoder bwd of A  | ... of B |
+
+        so A's recurrence runs beside B's encoder forward and B's beside A's encoder backward.  To issue a half's decoder backward
+        BEFORE the other half's encoder launches (the host issues ~2 500 launches per step; what is issued late starts late) the
+        autograd graph of a half is cut at the encoder output: the decoder side runs on a detached copy and is differentiated
+        right after its forward (`backward(inputs=...)` on the side stream); d loss / d encoder-output then seeds the encoder
+        backward on the main stream.  The arithmetic per sequence is that of `forward_with_loss_batch` (same kernels); only the order
+        in which the two halves' gradients are added differs.  Returns the loss dict (detached values, mean over the S sequences)."""
+        self._note_train_mode()
+        S = audio.shape[0]
+        assert S >= 2 and audio.is_cuda
+        frame_num = audio.shape[1] * 60 // 16000
+        cur = torch.cuda.current_stream()
+        if Faceformer._pipe_stream is None or Faceformer._pipe_stream.device != audio.device:
+            Faceformer._pipe_stream = torch.cuda.Stream(device=audio.device, priority=-1)     # the short dependent chain goes first in dispatch
+        side = Faceformer._pipe_stream
+        cuts = (0, (S + 1) // 2, S)
+        enc_params = {id(p) for p in self.audio_encoder.parameters()}
+        dec_params = [p for p in self.parameters() if p.requires_grad and id(p) not in enc_params]
+        halves, outs = [], []
+        for g in range(2):
+            lo, hi = cuts[g], cuts[g + 1]
+            enc = self.encode(audio[lo:hi], frame_num)                          # main stream
+            ready = cur.record_event()
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                enc.record_stream(side)
+                enc_d = enc.detach().requires_grad_(True)
+                y = self.decode_hidden(enc_d, one_hot[lo:hi])
+                _pred, out3 = self._head_loss_batch(y, template[lo:hi], gt[lo:hi], k_rec, k_vel)
+                w = (hi - lo) / S
+                torch.autograd.backward(out3[0] * w, inputs=[enc_d] + dec_params)
+                outs.append(out3.detach() * w)
+                halves.append((enc, enc_d.grad, side.record_event()))
+                del y, _pred, out3, enc_d
+        for enc, d_enc, done in halves:
+            cur.wait_event(done)
+            d_enc.record_stream(cur)
+            enc.backward(d_enc)                                                 # main stream: encoder backward of this half
+        halves.clear()
+        cur.wait_stream(side)
+        for o in outs:
+            o.record_stream(cur)
+        tot = outs[0] + outs[1]
+        return {"loss": tot[0], "rec_loss": tot[1], "vel_loss": tot[2]}

@@ -743,3 +743,48 @@ def test_faceformer_batch_step_one_head_launch_equals_per_sequence_steps(T):
     for k, p in m.named_parameters():
         if p.grad is not None:
             assert rel_l2(gb[k].cpu(), p.grad.cpu()) < TOL, k
+
+
+@pytest.mark.parametrize("S,T", [(3, 30), (4, 61)])
+def test_faceformer_pipelined_step_equals_single_stream_step(S, T):
+    """Faceformer.train_step_pipelined (two half-batches on two HIP streams, decoder recurrence under the other half's encoder work):
+    BITWISE equal to the same two half-batches run one after the other on one stream (same kernels, same accumulation order - any
+    missing stream dependency or allocator reuse hazard shows as a difference), twice in a row (the second step reuses freed
+    blocks); and equal within the summation-order noise of the weight-gradient GEMMs to the unsplit batch step."""
+    m, _, _ = _faceformer_full()
+    m.train()
+    gen = torch.Generator().manual_seed(77)
+    audio = (torch.randn(S, T * 16000 // 60 + 8, generator=gen) * 0.1).to(DEV)
+    oh = torch.zeros(S, 12); oh[torch.arange(S), torch.arange(S) % 8] = 1
+    template = torch.randn(S, 5023, 3, generator=gen) * 5
+    gt = (template.view(S, 1, 5023, 3) + torch.randn(S, T, 5023, 3, generator=gen) * 0.5).to(DEV)
+    oh, template = oh.to(DEV), template.to(DEV)
+    m.zero_grad()
+    _p, loss = m.forward_with_loss_batch(audio, oh, template, gt)
+    loss["loss"].backward()
+    whole = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad()
+    h = (S + 1) // 2
+    seq_loss = 0.0
+    for lo, hi in ((0, h), (h, S)):
+        _p, l = m.forward_with_loss_batch(audio[lo:hi], oh[lo:hi], template[lo:hi], gt[lo:hi])
+        (l["loss"] * ((hi - lo) / S)).backward()
+        seq_loss = seq_loss + l["loss"].detach() * ((hi - lo) / S)
+    halves = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    for _rep in range(2):
+        m.zero_grad()
+        lp = m.train_step_pipelined(audio, oh, template, gt)
+        torch.cuda.synchronize()
+        assert float(lp["loss"]) == float(seq_loss)
+        assert abs(float(lp["loss"]) - float(loss["loss"].detach())) <= 1e-5 * abs(float(loss["loss"].detach()))
+        got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+        assert set(got) == set(halves)
+        for k in halves:
+            assert torch.equal(got[k], halves[k]), k
+            # against the unsplit step: q / k projection gradients of the deeper layers are ~1e-5 in magnitude with this synthetic
+            # model (near-uniform attention; k_proj.bias is analytically zero) and carry only summation-order noise - held as part of
+            # the whole gradient vector below, every other tensor individually
+            if ".q_proj." not in k and ".k_proj." not in k:
+                assert rel_l2(got[k].cpu(), whole[k].cpu()) < TOL, k
+        keys = sorted(halves)
+        assert rel_l2(torch.cat([got[k].flatten() for k in keys]).cpu(), torch.cat([whole[k].flatten() for k in keys]).cpu()) < 2e-5

@@ -183,6 +183,49 @@ struct Stage {
     }
   }
 
+  // ---- plain operands (no sequence windows: lines_per_seq == 0, K a multiple of the k-tile): every per-thread offset is
+  // loop-invariant.  The k-tile is selected by re-basing the buffer resource (scalar ALU: base += k0 (* ld), size -= the same;
+  // size 0 past the end of the k-range), the vector offsets stay put: ZERO vector instructions per load in the steady state
+  // (the windowed path spends ~25 per load on positions, sequence wraps and range masks).
+  __device__ __forceinline__ void init_plain(const Op& op, int x0, int xcount, int t) {
+    okmask = 0;
+    if constexpr (!T) {
+      const int kq = t & 7;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int ll = (t >> 3) + (TH / 8) * i;
+        const int line = x0 + ll;
+        boff[i] = line < xcount ? ((unsigned)line * (unsigned)op.ld + (unsigned)(kq * 4)) * 4u : 0xFFFFFFFFu;
+        lds_w[i] = ll * 64 + ((((kq >> 1) ^ ((ll >> 2) & 3))) << 4) + ((kq & 1) << 3);
+      }
+    } else {
+      constexpr int PER_ROW = X / 4;
+      const int nq = t % PER_ROW;
+      const int j = x0 + nq * 4;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int kl = t / PER_ROW + (TH / PER_ROW) * i;
+        boff[i] = j < xcount ? ((unsigned)kl * (unsigned)op.ld + (unsigned)j) * 4u : 0xFFFFFFFFu;
+        lds_w[i] = kl * PITCH + nq * 8;
+      }
+    }
+  }
+  __device__ __forceinline__ static rsrc_t tile_rsrc(const Op& op, int k0, int kend) {
+    const long long adv = T ? (long long)k0 * op.ld : (long long)k0;                    // elements; wave-uniform
+    const unsigned left = k0 < kend ? op.bytes - (unsigned)(adv * 4) : 0u;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.p + adv), 0, (int)left, 0x00020000);
+  }
+  __device__ __forceinline__ void load_plain(rsrc_t rs, u32x4_t (&reg)[NL]) const {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+#ifdef MM_ABL_NOLOAD
+      reg[i] = u32x4_t{boff[i], boff[i], boff[i], boff[i]};
+#else
+      reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[i], 0, 0);
+#endif
+    }
+  }
+
   // issue the loads of the k-tile starting at k0 (kend = end of this split's k-range); T operands: call advance() after it
   __device__ __forceinline__ void load(const Op& op, rsrc_t rs, int k0, int kend, u32x4_t (&reg)[NL]) {
     if constexpr (!T) {
@@ -292,7 +335,7 @@ struct Cfg {
   static constexpr int WPS = CFG == 3 ? 4 : (CFG == 2 ? 2 : 2);
 };
 
-template <bool AT, bool BT, int PREC, int CFG>
+template <bool AT, bool BT, int PREC, int CFG, bool PLAIN>
 __global__ __launch_bounds__(Cfg<CFG>::TH, Cfg<CFG>::WPS) void gemm_mfma_kernel(const Args a) {
   constexpr int BM = Cfg<CFG>::BM, BN = Cfg<CFG>::BN, TH = Cfg<CFG>::TH;
   constexpr int WGN = Cfg<CFG>::WGN;
@@ -347,8 +390,25 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, Cfg<CFG>::WPS) void gemm_mfma_kernel(
 
   SA sa;
   SB sb;
-  sa.init(opA, m0, a.M, kbeg, t);
-  sb.init(opB, n0, a.N, kbeg, t);
+  if constexpr (PLAIN) {
+    sa.init_plain(opA, m0, a.M, t);
+    sb.init_plain(opB, n0, a.N, t);
+  } else {
+    sa.init(opA, m0, a.M, kbeg, t);
+    sb.init(opB, n0, a.N, kbeg, t);
+  }
+  // the loads of the k-tile that starts at k0 into one register set
+  auto fetch = [&](int k0, u32x4_t (&qa)[SA::NL], u32x4_t (&qb)[SB::NL]) {
+    if constexpr (PLAIN) {
+      sa.load_plain(SA::tile_rsrc(opA, k0, kend), qa);
+      sb.load_plain(SB::tile_rsrc(opB, k0, kend), qb);
+    } else {
+      sa.load(opA, rsA, k0, kend, qa);
+      sb.load(opB, rsB, k0, kend, qb);
+      sa.advance(opA);
+      sb.advance(opB);
+    }
+  };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -362,14 +422,8 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, Cfg<CFG>::WPS) void gemm_mfma_kernel(
   // to the other LDS stage and the loads of tile kt+2 are issued - a fetch has two multiply phases to land (an L2 / HBM
   // round trip is longer than one 32-deep multiply phase).
   u32x4_t ra0[SA::NL], rb0[SB::NL], ra1[SA::NL], rb1[SB::NL];
-  sa.load(opA, rsA, kbeg, kend, ra0);
-  sb.load(opB, rsB, kbeg, kend, rb0);
-  sa.advance(opA);
-  sb.advance(opB);
-  sa.load(opA, rsA, kbeg + BK, kend, ra1);                     // out of range (zeros) when there is no second tile
-  sb.load(opB, rsB, kbeg + BK, kend, rb1);
-  sa.advance(opA);
-  sb.advance(opB);
+  fetch(kbeg, ra0, rb0);
+  fetch(kbeg + BK, ra1, rb1);                                  // out of range (zeros) when there is no second tile
   sa.template commit<PREC>(smem, ra0);
   sb.template commit<PREC>(smem + A_BYTES, rb0);
   __syncthreads();
@@ -405,10 +459,7 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, Cfg<CFG>::WPS) void gemm_mfma_kernel(
   auto body = [&](int kt, u32x4_t (&ca)[SA::NL], u32x4_t (&cb)[SB::NL], u32x4_t (&na)[SA::NL], u32x4_t (&nb)[SB::NL]) {
     char* nst = smem + ((kt + 1) & 1) * STAGE;
     const int k2 = kbeg + (kt + 2) * BK;
-    sa.load(opA, rsA, k2, kend, na);                            // `nxt` held tile kt, which went to LDS one iteration ago
-    sb.load(opB, rsB, k2, kend, nb);
-    sa.advance(opA);
-    sb.advance(opB);
+    fetch(k2, na, nb);                                          // `nxt` held tile kt, which went to LDS one iteration ago
     // keep the load issue HERE: without the fence the machine scheduler sinks the buffer loads below the MFMA block, next
     // to their first use, and the fetch no longer overlaps the multiplication.  Below it the conversion / LDS writes of
     // tile kt+1 (other stage) and the MFMAs of tile kt are one scheduling region: the compiler interleaves VALU and MFMA.
@@ -501,12 +552,12 @@ __global__ __launch_bounds__(256) void gemm_mfma_fold_kernel(const Args a) {
   }
 }
 
-template <bool AT, bool BT, int PREC, int CFG>
+template <bool AT, bool BT, int PREC, int CFG, bool PLAIN>
 static int launch(const Args& a, hipStream_t st) {
   constexpr int BM = Cfg<CFG>::BM, BN = Cfg<CFG>::BN, TH = Cfg<CFG>::TH;
   constexpr int NIMG = PREC == 1 ? 2 : 1;
   constexpr int smem = 2 * NIMG * (Stage<AT, BM, TH>::IMG + Stage<BT, BN, TH>::IMG);
-  auto kern = gemm_mfma_kernel<AT, BT, PREC, CFG>;
+  auto kern = gemm_mfma_kernel<AT, BT, PREC, CFG, PLAIN>;
   static bool attr_done = false;                        // set-once per instantiation (idempotent; safe to repeat)
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -519,11 +570,20 @@ static int launch(const Args& a, hipStream_t st) {
 }
 
 template <int PREC, int CFG>
-static int dispatch_layout(const Args& a, bool at, bool bt, hipStream_t st) {
-  if (!at && !bt) return launch<false, false, PREC, CFG>(a, st);
-  if (!at && bt) return launch<false, true, PREC, CFG>(a, st);
-  if (at && bt) return launch<true, true, PREC, CFG>(a, st);
-  return launch<true, false, PREC, CFG>(a, st);
+static int dispatch_layout(const Args& a, bool at, bool bt, bool plain, hipStream_t st) {
+  // plain operands (the Transformer layers' Linear forward / data gradient / weight gradient): the loop-invariant addressing path, built
+  // for the tile shapes those layouts run with
+  if constexpr (CFG == 3) {
+    if (plain && !at && !bt) return launch<false, false, PREC, CFG, true>(a, st);
+    if (plain && !at && bt) return launch<false, true, PREC, CFG, true>(a, st);
+  }
+  if constexpr (CFG == 0 || CFG == 2) {
+    if (plain && at && bt) return launch<true, true, PREC, CFG, true>(a, st);
+  }
+  if (!at && !bt) return launch<false, false, PREC, CFG, false>(a, st);
+  if (!at && bt) return launch<false, true, PREC, CFG, false>(a, st);
+  if (at && bt) return launch<true, true, PREC, CFG, false>(a, st);
+  return launch<true, false, PREC, CFG, false>(a, st);
 }
 
 static int fill_op(const a2f_mm_operand& o, int64_t bstride, int64_t contiguous_extent, Op& k, const char* name) {
@@ -604,12 +664,14 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
     if (force && force[0] >= '0' && force[0] <= '3' && !(force[0] == '1' && d->N > 64)) cfg = force[0] - '0';
   }
   hipStream_t st = (hipStream_t)stream;
+  static const bool no_plain = [] { const char* e = getenv("A2F_MM_PLAIN"); return e && e[0] == '0'; }();     // A-B hook
+  const bool plain = !no_plain && a.A.lps == 0 && a.B.lps == 0 && (d->K % BK) == 0;
   if (d->precision == 1)
-    rc = cfg == 0 ? dispatch_layout<1, 0>(a, at, bt, st) : cfg == 1 ? dispatch_layout<1, 1>(a, at, bt, st) : cfg == 2 ? dispatch_layout<1, 2>(a, at, bt, st)
-                                                                                                              : dispatch_layout<1, 3>(a, at, bt, st);
+    rc = cfg == 0 ? dispatch_layout<1, 0>(a, at, bt, plain, st) : cfg == 1 ? dispatch_layout<1, 1>(a, at, bt, plain, st)
+       : cfg == 2 ? dispatch_layout<1, 2>(a, at, bt, plain, st) : dispatch_layout<1, 3>(a, at, bt, plain, st);
   else
-    rc = cfg == 0 ? dispatch_layout<0, 0>(a, at, bt, st) : cfg == 1 ? dispatch_layout<0, 1>(a, at, bt, st) : cfg == 2 ? dispatch_layout<0, 2>(a, at, bt, st)
-                                                                                                              : dispatch_layout<0, 3>(a, at, bt, st);
+    rc = cfg == 0 ? dispatch_layout<0, 0>(a, at, bt, plain, st) : cfg == 1 ? dispatch_layout<0, 1>(a, at, bt, plain, st)
+       : cfg == 2 ? dispatch_layout<0, 2>(a, at, bt, plain, st) : dispatch_layout<0, 3>(a, at, bt, plain, st);
   if (rc) return rc;
   A2F_CHECK_LAUNCH("a2f_mm");
   if (split > 1) {

@@ -55,6 +55,8 @@ class MMDesc(C.Structure):
         ("batch", i32), ("accumulate", i32),
         ("a_bstride", i64), ("b_bstride", i64), ("c_bstride", i64), ("bias_bstride", i64),
         ("alpha", f32), ("reserved", i32),
+        ("keep_bits", c_f32p), ("keep_wpr", i64),
+        ("keep_scale", f32), ("reserved2", i32),
     ]
 
 
@@ -103,6 +105,13 @@ SIGNATURES = {
     "a2f_gelu_bwd": (C.c_int, [c_f32p, c_f32p, i64, c_f32p, C.c_void_p]),
     "a2f_attn_fwd": (C.c_int, [c_f32p, i64, i64, i64, i64, f32, i32, c_f32p, i64, c_f32p, C.c_void_p]),
     "a2f_attn_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, i64, i64, i64, f32, i32, c_f32p, c_f32p, C.c_void_p]),
+    "a2f_attn_fwd_drop": (C.c_int, [c_f32p, i64, i64, i64, i64, f32, i32, c_f32p, i64, c_f32p, c_f32p, f32, C.c_void_p]),
+    "a2f_attn_bwd_drop": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, i64, i64, i64, f32, i32, c_f32p, c_f32p, c_f32p, c_f32p, f32,
+                                    C.c_void_p]),
+    "a2f_keep_bits": (C.c_int, [C.c_uint64, C.c_uint32, i64, i64, f32, c_f32p, i64, C.c_void_p]),
+    "a2f_attn_keep_words": (i64, [i64]),
+    "a2f_keep_bits_attn": (C.c_int, [C.c_uint64, C.c_uint32, i64, i64, f32, c_f32p, c_f32p, C.c_void_p]),
+    "a2f_dropout_apply": (C.c_int, [c_f32p, c_f32p, i64, i64, i64, i64, f32, c_f32p, C.c_void_p]),
     "a2f_featenc0_ws_bytes": (sz, [i64, i64, i64]),
     "a2f_featenc0_fwd": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, i64, f32, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
     "a2f_featenc0_bwd": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, sz,

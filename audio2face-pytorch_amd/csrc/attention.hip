@@ -48,6 +48,12 @@ struct Args {
   int ld, ldo, koff, voff;
   int S, T, H;
   float scale;
+  // train-mode dropout of the probabilities (HF Wav2Vec2Attention: nn.functional.dropout(attn_weights, p = attention_dropout)): keep bits,
+  // query-major words [sh][q][TW] / key-major words [sh][TW][32 TW] (csrc/dropout.hip), kept values are multiplied by keep_scale = 1 / (1 - p)
+  const unsigned* keep_q;
+  const unsigned* keep_k;
+  int TW;
+  float keep_scale;
 };
 
 __device__ __forceinline__ int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -194,7 +200,7 @@ __device__ __forceinline__ void reg_operand(rsrc_t rs, int row, int ld, int col0
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
-template <int PREC>
+template <int PREC, bool DROP>
 __global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
   constexpr int NIMG = PREC == 1 ? 2 : 1;
   constexpr int STAGE = 2 * NIMG * IMG;                       // K images, V images
@@ -213,6 +219,8 @@ __global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[0][r] = o[1][r] = 0.f;
   float m = -INFINITY, l = 0.f;
+  const unsigned* keepq = nullptr;                             // this lane's query: TW words, bit = key
+  if constexpr (DROP) keepq = a.keep_q + (((long long)seq * a.H + head) * T + min(q, T - 1)) * a.TW;
 
   const int nt = (T + TILE - 1) / TILE;
   Tile<PREC> kt_, vt_;
@@ -229,6 +237,8 @@ __global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
       kt_.load(rs, (it + 1) * TILE, a.ld, a.koff + hc, t);
       vt_.load(rs, (it + 1) * TILE, a.ld, a.voff + hc, t);
     }
+    u32x2_t keep = {0u, 0u};
+    if constexpr (DROP) keep = *reinterpret_cast<const u32x2_t*>(keepq + 2 * it) >> (unsigned)(4 * h);     // bit (r & 3) + 8 (r >> 2) <-> register r
     __builtin_amdgcn_sched_barrier(0);
     // ---- S^T = K Q^T: keys on the registers, this lane's query on the lane
     f32x16 st[2];
@@ -274,6 +284,13 @@ __global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
       o[0][r] *= alpha;
       o[1][r] *= alpha;
     }
+    if constexpr (DROP) {                                       // the normaliser l keeps every key; only the value sum is thinned
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[0][r] = ((keep.x >> ((r & 3) + 8 * (r >> 2))) & 1u) ? st[0][r] : 0.f;
+        st[1][r] = ((keep.y >> ((r & 3) + 8 * (r >> 2))) & 1u) ? st[1][r] : 0.f;
+      }
+    }
     // ---- O^T += V^T P: P straight from the accumulator registers
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
 
   // ---- epilogue: O = O^T / l, rows = this lane's query, 4 consecutive d per register quad
   const float lt = l + __shfl_xor(l, 32, 64);
-  const float inv = 1.f / lt;
+  const float inv = (DROP ? a.keep_scale : 1.f) / lt;
   if (q < T) {
     float* orow = a.out_ctx + ((long long)seq * T + q) * a.ldo + hc;
 #pragma unroll
@@ -338,7 +355,7 @@ __global__ __launch_bounds__(THREADS) void attn_delta_kernel(const Args a) {
 //   S[q][key] = Qs K^T (query on the registers, key on the lane);  P = exp(S - lse[q]);  dP = dO V^T;  dS = P (dP - delta[q])
 //   dV^T[d][key] += dO^T P;   dK^T[d][key] += Qs^T dS           (Qs = scale * Q, so dK needs no further factor)
 // =====================================================================================================================
-template <int PREC>
+template <int PREC, bool DROP>
 __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) {
   constexpr int NIMG = PREC == 1 ? 2 : 1;
   constexpr int STAGE = 2 * NIMG * IMG;                       // Q images, dO images
@@ -352,6 +369,8 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) 
   const int hc = head * D;
   const float* lse = a.lse + ((long long)seq * a.H + head) * T;
   const float* dlt = a.delta + ((long long)seq * a.H + head) * T;
+  const unsigned* keepk = nullptr;                             // this lane's key: word (qw) at + qw * 32 TW, bit = query 32 qw + b
+  if constexpr (DROP) keepk = a.keep_k + ((long long)seq * a.H + head) * a.TW * (32ll * a.TW) + min(key, 32 * a.TW - 1);
 
   u32x4_t kf[4][2], vf[4][2];
   reg_operand<PREC>(rs, key, a.ld, a.koff + hc, lane, 1.f, kf);
@@ -391,14 +410,22 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) 
         dp = mac<PREC>(da, vf[ks], dp);
       }
       // rows = queries it*64 + 32 qb + rho(r, h); P = exp(S - lse), dS = P (dP - delta); queries beyond T contribute nothing
+      unsigned keep = 0u;
+      if constexpr (DROP) keep = keepk[(long long)(2 * it + qb) * (32ll * a.TW)] >> (unsigned)(4 * h);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qq = it * TILE + 32 * qb + rho(r, h);
         const bool ok = qq < T;
         const float ls = ok ? lse[qq] : 0.f, de = ok ? dlt[qq] : 0.f;
         const float p = ok ? __expf(s[r] - ls) : 0.f;
-        s[r] = p;
-        dp[r] = p * (dp[r] - de);
+        if constexpr (DROP) {                                  // ctx = (P o D) V: dV sees the thinned P (its 1/(1-p) at the end), dP = (dO V^T) o D
+          const bool kp = ((keep >> ((r & 3) + 8 * (r >> 2))) & 1u) != 0u;
+          s[r] = kp ? p : 0.f;
+          dp[r] = p * ((kp ? dp[r] * a.keep_scale : 0.f) - de);
+        } else {
+          s[r] = p;
+          dp[r] = p * (dp[r] - de);
+        }
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
@@ -430,7 +457,8 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) 
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const f32x4 x = {dk[dd][4 * gq], dk[dd][4 * gq + 1], dk[dd][4 * gq + 2], dk[dd][4 * gq + 3]};
-        const f32x4 y = {dv[dd][4 * gq], dv[dd][4 * gq + 1], dv[dd][4 * gq + 2], dv[dd][4 * gq + 3]};
+        const float vs = DROP ? a.keep_scale : 1.f;
+        const f32x4 y = {dv[dd][4 * gq] * vs, dv[dd][4 * gq + 1] * vs, dv[dd][4 * gq + 2] * vs, dv[dd][4 * gq + 3] * vs};
         *reinterpret_cast<f32x4*>(krow + a.koff + 32 * dd + 8 * gq + 4 * h) = x;
         *reinterpret_cast<f32x4*>(krow + a.voff + 32 * dd + 8 * gq + 4 * h) = y;
       }
@@ -442,7 +470,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) 
 //   S^T[key][q] = K Qs^T;  P^T = exp(S^T - lse[q]);  dP^T = V dO^T;  dS^T = P^T (dP^T - delta[q]);  dQ^T[d][q] += K^T dS^T
 //   dQ = scale * dQ^T^T
 // =====================================================================================================================
-template <int PREC>
+template <int PREC, bool DROP>
 __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dq_kernel(const Args a) {
   constexpr int NIMG = PREC == 1 ? 2 : 1;
   constexpr int STAGE = 2 * NIMG * IMG;                       // K images, V images
@@ -457,6 +485,8 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dq_kernel(const Args a) {
   const bool qok = q < T;
   const float ls = qok ? a.lse[((long long)seq * a.H + head) * T + q] : 0.f;
   const float de = qok ? a.delta[((long long)seq * a.H + head) * T + q] : 0.f;
+  const unsigned* keepq = nullptr;
+  if constexpr (DROP) keepq = a.keep_q + (((long long)seq * a.H + head) * T + min(q, T - 1)) * a.TW;
 
   u32x4_t qf[4][2], of[4][2];
   reg_operand<PREC>(rs, q, a.ld, hc, lane, a.scale, qf);
@@ -481,6 +511,8 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dq_kernel(const Args a) {
       kt_.load(rs, (it + 1) * TILE, a.ld, a.koff + hc, t);
       vt_.load(rs, (it + 1) * TILE, a.ld, a.voff + hc, t);
     }
+    u32x2_t keep2 = {0u, 0u};
+    if constexpr (DROP) keep2 = *reinterpret_cast<const u32x2_t*>(keepq + 2 * it) >> (unsigned)(4 * h);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -499,7 +531,13 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dq_kernel(const Args a) {
       for (int r = 0; r < 16; ++r) {
         const bool ok = qok && (it * TILE + 32 * kb + rho(r, h) < T);
         const float p = ok ? __expf(s[r] - ls) : 0.f;
-        dp[r] = p * (dp[r] - de);
+        if constexpr (DROP) {
+          const unsigned kw = kb == 0 ? keep2.x : keep2.y;
+          const bool kp = ((kw >> ((r & 3) + 8 * (r >> 2))) & 1u) != 0u;
+          dp[r] = p * ((kp ? dp[r] * a.keep_scale : 0.f) - de);
+        } else {
+          dp[r] = p * (dp[r] - de);
+        }
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
@@ -556,8 +594,8 @@ static int check_common(const float* qkv, int64_t S, int64_t T, int64_t H, int64
 }  // namespace attn
 }  // namespace a2f
 
-extern "C" int a2f_attn_fwd(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx, int64_t ldo,
-                            float* lse, a2f_stream_t stream) {
+static int attn_fwd_impl(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx, int64_t ldo,
+                         float* lse, const uint32_t* keep_q, float keep_scale, a2f_stream_t stream) {
   using namespace a2f;
   using namespace a2f::attn;
   int rc = check_common(qkv, S, T, H, ld, ldo, precision);
@@ -567,48 +605,77 @@ extern "C" int a2f_attn_fwd(const float* qkv, int64_t S, int64_t T, int64_t H, i
   a.qkv = qkv; a.out_ctx = ctx; a.out_lse = lse;
   a.ld = (int)ld; a.ldo = (int)ldo; a.koff = (int)(H * 64); a.voff = (int)(2 * H * 64);
   a.S = (int)S; a.T = (int)T; a.H = (int)H; a.scale = scale;
+  a.keep_q = keep_q; a.TW = (int)a2f_attn_keep_words(T); a.keep_scale = keep_scale;
   const dim3 grid((unsigned)cdiv(T, 128), (unsigned)H, (unsigned)S);
   hipStream_t st = (hipStream_t)stream;
-  static bool d0 = false, d1 = false;
-  if (precision == 1) {
-    if ((rc = set_lds(attn_fwd_kernel<1>, 2 * 4 * IMG, d1))) return rc;
-    hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(THREADS), 2 * 4 * IMG, st, a);
-  } else {
-    if ((rc = set_lds(attn_fwd_kernel<0>, 2 * 2 * IMG, d0))) return rc;
-    hipLaunchKernelGGL(attn_fwd_kernel<0>, grid, dim3(THREADS), 2 * 2 * IMG, st, a);
-  }
+  static bool done[4] = {false, false, false, false};
+  const int lds = precision == 1 ? 2 * 4 * IMG : 2 * 2 * IMG;
+#define A2F_ATTN_FWD(P, D)                                                        \
+  do {                                                                            \
+    if ((rc = set_lds(attn_fwd_kernel<P, D>, lds, done[2 * P + D]))) return rc;   \
+    hipLaunchKernelGGL((attn_fwd_kernel<P, D>), grid, dim3(THREADS), lds, st, a); \
+  } while (0)
+  if (precision == 1) { if (keep_q) A2F_ATTN_FWD(1, true); else A2F_ATTN_FWD(1, false); }
+  else { if (keep_q) A2F_ATTN_FWD(0, true); else A2F_ATTN_FWD(0, false); }
+#undef A2F_ATTN_FWD
   A2F_CHECK_LAUNCH("attn_fwd");
   return A2F_OK;
 }
 
-extern "C" int a2f_attn_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
-                            int64_t ldo, float scale, int32_t precision, float* dqkv, float* delta_ws, a2f_stream_t stream) {
+static int attn_bwd_impl(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
+                         int64_t ldo, float scale, int32_t precision, float* dqkv, float* delta_ws, const uint32_t* keep_q, const uint32_t* keep_k,
+                         float keep_scale, a2f_stream_t stream) {
   using namespace a2f;
   using namespace a2f::attn;
   int rc = check_common(qkv, S, T, H, ld, ldo, precision);
   if (rc) return rc;
   A2F_CHECK_ARG(ctx && dctx && lse && dqkv && delta_ws, "attn_bwd: null pointer");
   A2F_CHECK_ARG((((uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)dqkv) & 15) == 0, "attn_bwd: buffers must be 16-byte aligned");
+  A2F_CHECK_ARG((keep_q == nullptr) == (keep_k == nullptr), "attn_bwd: both keep-bit layouts or neither");
   Args a{};
   a.qkv = qkv; a.ctx = ctx; a.dctx = dctx; a.lse = lse; a.delta = delta_ws; a.out_delta = delta_ws; a.dqkv = dqkv;
   a.ld = (int)ld; a.ldo = (int)ldo; a.koff = (int)(H * 64); a.voff = (int)(2 * H * 64);
   a.S = (int)S; a.T = (int)T; a.H = (int)H; a.scale = scale;
+  a.keep_q = keep_q; a.keep_k = keep_k; a.TW = (int)a2f_attn_keep_words(T); a.keep_scale = keep_scale;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(S * T, THREADS / 64)), dim3(THREADS), 0, st, a);
   A2F_CHECK_LAUNCH("attn_bwd delta");
   const dim3 grid((unsigned)cdiv(T, 128), (unsigned)H, (unsigned)S);
-  static bool k0 = false, k1 = false, q0 = false, q1 = false;
-  if (precision == 1) {
-    if ((rc = set_lds(attn_bwd_dkv_kernel<1>, 2 * 4 * IMG, k1))) return rc;
-    if ((rc = set_lds(attn_bwd_dq_kernel<1>, 2 * 4 * IMG, q1))) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, grid, dim3(THREADS), 2 * 4 * IMG, st, a);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, grid, dim3(THREADS), 2 * 4 * IMG, st, a);
-  } else {
-    if ((rc = set_lds(attn_bwd_dkv_kernel<0>, 2 * 2 * IMG, k0))) return rc;
-    if ((rc = set_lds(attn_bwd_dq_kernel<0>, 2 * 2 * IMG, q0))) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<0>, grid, dim3(THREADS), 2 * 2 * IMG, st, a);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<0>, grid, dim3(THREADS), 2 * 2 * IMG, st, a);
-  }
+  static bool dk[4] = {false, false, false, false}, dq[4] = {false, false, false, false};
+  const int lds = precision == 1 ? 2 * 4 * IMG : 2 * 2 * IMG;
+#define A2F_ATTN_BWD(P, D)                                                            \
+  do {                                                                                \
+    if ((rc = set_lds(attn_bwd_dkv_kernel<P, D>, lds, dk[2 * P + D]))) return rc;     \
+    if ((rc = set_lds(attn_bwd_dq_kernel<P, D>, lds, dq[2 * P + D]))) return rc;      \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, D>), grid, dim3(THREADS), lds, st, a); \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<P, D>), grid, dim3(THREADS), lds, st, a);  \
+  } while (0)
+  if (precision == 1) { if (keep_q) A2F_ATTN_BWD(1, true); else A2F_ATTN_BWD(1, false); }
+  else { if (keep_q) A2F_ATTN_BWD(0, true); else A2F_ATTN_BWD(0, false); }
+#undef A2F_ATTN_BWD
   A2F_CHECK_LAUNCH("attn_bwd");
   return A2F_OK;
+}
+
+extern "C" int a2f_attn_fwd(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx, int64_t ldo,
+                            float* lse, a2f_stream_t stream) {
+  return attn_fwd_impl(qkv, S, T, H, ld, scale, precision, ctx, ldo, lse, nullptr, 1.f, stream);
+}
+
+extern "C" int a2f_attn_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
+                            int64_t ldo, float scale, int32_t precision, float* dqkv, float* delta_ws, a2f_stream_t stream) {
+  return attn_bwd_impl(qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, precision, dqkv, delta_ws, nullptr, nullptr, 1.f, stream);
+}
+
+extern "C" int a2f_attn_fwd_drop(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx, int64_t ldo,
+                                 float* lse, const uint32_t* keep_qmajor, float keep_scale, a2f_stream_t stream) {
+  if (!keep_qmajor) return a2f::set_err(A2F_EINVAL, "attn_fwd_drop: null keep bits");
+  return attn_fwd_impl(qkv, S, T, H, ld, scale, precision, ctx, ldo, lse, keep_qmajor, keep_scale, stream);
+}
+
+extern "C" int a2f_attn_bwd_drop(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
+                                 int64_t ldo, float scale, int32_t precision, float* dqkv, float* delta_ws, const uint32_t* keep_qmajor,
+                                 const uint32_t* keep_kmajor, float keep_scale, a2f_stream_t stream) {
+  if (!keep_qmajor || !keep_kmajor) return a2f::set_err(A2F_EINVAL, "attn_bwd_drop: null keep bits");
+  return attn_bwd_impl(qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, precision, dqkv, delta_ws, keep_qmajor, keep_kmajor, keep_scale, stream);
 }

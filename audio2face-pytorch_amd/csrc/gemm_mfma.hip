@@ -58,6 +58,9 @@ struct Args {
   int M, N, K;
   int act, aux_mode, accumulate, split_k, batch;
   float alpha;
+  const unsigned* keep;          // dropout keep bits of C (csrc/dropout.hip: word (m, n >> 5), bit n & 31), applied after the activation
+  long long keep_wpr;
+  float keep_scale;
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
@@ -73,6 +76,7 @@ __device__ __forceinline__ void epilogue_store(const Args& a, int bz, int m, int
   if (a.C2) a.C2[ci] = v;
   if (a.act == 1) v = fmaxf(v, 0.f);
   else if (a.act == 3) v = gelu_f(v);
+  if (a.keep) v = ((a.keep[(long long)m * a.keep_wpr + (n >> 5)] >> (n & 31)) & 1u) ? v * a.keep_scale : 0.f;
   if (a.aux_mode) {
     const float x = a.aux[bz * a.aux_bstride + (long long)m * a.ldaux + n];
     if (a.aux_mode == 1) v += x;
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, Cfg<CFG>::WPS) void gemm_mfma_kernel(
     ncol[j] = n0 + (wn * TN + j) * 32 + (lane & 31);
     bv[j] = (a.bias && a.split_k <= 1 && ncol[j] < a.N) ? a.bias[bz * a.bias_bstride + ncol[j]] : 0.f;
   }
-  const bool generic = a.C2 || a.act || a.aux_mode || a.accumulate;     // wave-uniform
+  const bool generic = a.C2 || a.act || a.aux_mode || a.accumulate || a.keep;     // wave-uniform
   if (a.split_k > 1) {
     float* wsz = a.ws + (long long)blockIdx.z * a.M * a.N;
 #pragma unroll
@@ -525,6 +529,7 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, Cfg<CFG>::WPS) void gemm_mfma_kernel(
             if (a.C2) a.C2[bz * a.c_bstride + crow + ncol[j]] = v;
             if (a.act == 1) v = fmaxf(v, 0.f);
             else if (a.act == 3) v = gelu_f(v);
+            if (a.keep) v = ((a.keep[(long long)m * a.keep_wpr + (ncol[j] >> 5)] >> (ncol[j] & 31)) & 1u) ? v * a.keep_scale : 0.f;
             if (a.aux_mode) {
               const float x = a.aux[bz * a.aux_bstride + (long long)m * a.ldaux + ncol[j]];
               if (a.aux_mode == 1) v += x;
@@ -653,6 +658,10 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   a.split_k = split;
   a.batch = batch;
   a.alpha = d->alpha == 0.f ? 1.f : d->alpha;
+  A2F_CHECK_ARG(d->keep_bits == nullptr || (batch == 1 && d->keep_wpr * 32 >= d->N), "a2f_mm: keep_bits need batch == 1 and keep_wpr * 32 >= N");
+  a.keep = d->keep_bits;
+  a.keep_wpr = d->keep_wpr;
+  a.keep_scale = d->keep_scale;
   const bool at = d->A.trans != 0, bt = d->B.trans != 0;
   // tile choice (measured, tools/bench_mm.py): narrow outputs -> 128 x 64; weight-gradient layout (both operands k-strided: 80 KB of
   // LDS per 128 x 128 workgroup, so only one 8-wave workgroup would fit) -> 256 x 128 on 8 waves when there are enough tiles, else

@@ -1,0 +1,157 @@
+"""Train-mode stochastic regularisers of the wav2vec2 encoder (host side): which masks a step needs, how they are drawn, how
+recorded masks are injected.
+
+What the reference does in train mode (HF ``Wav2Vec2Model`` under ``/root/reference/src/model/wav2vec.py:87-189`` with the
+configuration of ``facebook/wav2vec2-base-960h``): dropout 0.1 after the feature projection, after the encoder's first
+LayerNorm, on the attention probabilities, on the attention block's output, on GELU(intermediate_dense) and on the
+feed-forward output of each of the 12 layers; LayerDrop 0.1 (one uniform draw per layer, the layer is skipped when it falls
+below); SpecAugment along time (``_compute_mask_indices``, wav2vec.py:25-72: ``mask_time_prob`` 0.05, spans of 10 frames, at
+least 2 spans - the masked frames are replaced by the learned ``masked_spec_embed``, wav2vec.py:149-162).
+
+The kernels consume bit-packed keep masks (csrc/dropout.hip).  ``draw_encoder_masks`` fills them on the device from one
+64-bit step seed (Philox4x32-10: a mask is a pure function of (seed, site, element)); ``EncoderMasks.from_recorded`` packs
+boolean masks recorded elsewhere - the parity tests record every mask the reference drew in one train-mode forward and feed
+exactly those (tests/golden/gen_golden.py, G13), which pins the train-mode function although it is stochastic.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+
+def pack_keep_bits(mask: torch.Tensor) -> torch.Tensor:
+    """bool (R, C) -> int32 (R, ceil(C / 32)): bit b of word w <-> column 32 w + b (layout of a2f_keep_bits)."""
+    R, C = mask.shape
+    wpr = (C + 31) // 32
+    m = torch.zeros(R, wpr * 32, dtype=torch.int64, device=mask.device)
+    m[:, :C] = mask.to(torch.int64)
+    w = (m.view(R, wpr, 32) << torch.arange(32, dtype=torch.int64, device=mask.device)).sum(-1)
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+
+
+def unpack_keep_bits(bits: torch.Tensor, C: int) -> torch.Tensor:
+    """int32 (R, wpr) -> bool (R, C)."""
+    w = bits.to(torch.int64) & 0xFFFFFFFF
+    sh = torch.arange(32, dtype=torch.int64, device=bits.device)
+    return (((w.unsqueeze(-1) >> sh) & 1) != 0).reshape(bits.shape[0], -1)[:, :C]
+
+
+def attn_keep_words(T: int) -> int:
+    return 2 * ((T + 63) // 64)
+
+
+def pack_keep_bits_attn(mask: torch.Tensor):
+    """bool (SH, T, T) [sh][query][key] -> (query-major int32 (SH*T, TW), key-major int32 (SH, TW, 32 TW)) as a2f_keep_bits_attn
+    lays them out (TW = 2 ceil(T / 64); key-major word (qw, key): bit b <-> query 32 qw + b)."""
+    SH, T, _ = mask.shape
+    TW = attn_keep_words(T)
+    full = torch.zeros(SH, 32 * TW, 32 * TW, dtype=torch.bool, device=mask.device)
+    full[:, :T, :T] = mask
+    qmaj = pack_keep_bits(full[:, :T].reshape(SH * T, 32 * TW))
+    kmaj = pack_keep_bits(full.transpose(1, 2).reshape(SH * 32 * TW, 32 * TW)).view(SH, 32 * TW, TW).transpose(1, 2).contiguous()
+    return qmaj, kmaj
+
+
+def compute_mask_indices(shape, mask_prob: float, mask_length: int, min_masks: int = 0, rng=None) -> np.ndarray:
+    """SpecAugment span mask, restated from /root/reference/src/model/wav2vec.py:25-72 (no attention_mask: FaceFormer never passes
+    one).  Consumes the random stream exactly as the reference does - one ``rand()``, one ``choice`` of span starts per row, one
+    ``choice`` per row that is thinned to the shortest row - so the same numpy seed gives the same mask (pinned by fixture G13).
+    ``rng``: a ``np.random.RandomState``; default = numpy's global state, which is what the reference draws from."""
+    rng = np.random if rng is None else rng
+    rows, size = shape
+    n_spans = max(min_masks, int(mask_prob * size / float(mask_length) + rng.rand()))
+    picked = []
+    for _ in range(rows):
+        lengths = np.full(n_spans, mask_length)
+        if lengths.sum() == 0:
+            lengths[0] = min(mask_length, size - 1)
+        shortest = lengths.min()
+        if size - shortest <= n_spans:
+            shortest = size - n_spans - 1
+        starts = rng.choice(size - shortest, n_spans, replace=False)
+        idx = (starts[:, None] + np.arange(mask_length)[None, :]).reshape(-1) if n_spans else np.zeros(0, dtype=np.int64)
+        picked.append(np.unique(idx[idx < size]))
+    keep_n = min(len(p) for p in picked)
+    mask = np.zeros((rows, size), dtype=bool)
+    for r, idx in enumerate(picked):
+        if len(idx) > keep_n:
+            idx = rng.choice(idx, keep_n, replace=False)
+        mask[r, idx] = True
+    return mask
+
+
+class EncoderMasks:
+    """The masks of one train-mode forward of the encoder: ``featproj`` / ``enc`` = (bits, scale) or None; ``layers`` = one dict per
+    Transformer layer as EncoderLayerFn takes it; ``layer_skip`` = LayerDrop decisions; ``spec`` = bool (S, T) rows replaced by
+    ``masked_spec_embed`` (or None)."""
+
+    def __init__(self):
+        self.featproj = None
+        self.enc = None
+        self.layers: List[Dict] = []
+        self.layer_skip: List[bool] = []
+        self.spec: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def from_recorded(rec: Dict, device, p_feat=0.1, p_hidden=0.1, p_attn=0.1, p_act=0.1) -> "EncoderMasks":
+        """rec: {"featproj": bool (M, d), "enc": bool (M, d), "layer{l}.attn": bool (S*H, T, T), "layer{l}.hid1" / ".act" / ".hid2": bool
+        (M, ·), "layer_skip": bool (L,), "spec": bool (S, T)} (numpy or torch); missing entries = no dropout at that site."""
+        t = lambda a: torch.as_tensor(np.asarray(a)).to(device)
+        m = EncoderMasks()
+        if "featproj" in rec:
+            m.featproj = (pack_keep_bits(t(rec["featproj"])), 1.0 / (1.0 - p_feat))
+        if "enc" in rec:
+            m.enc = (pack_keep_bits(t(rec["enc"])), 1.0 / (1.0 - p_hidden))
+        skip = [bool(x) for x in np.asarray(rec["layer_skip"]).reshape(-1)] if "layer_skip" in rec else []
+        L = len(skip) if skip else 1 + max([int(k.split(".")[0][5:]) for k in rec if k.startswith("layer") and "." in k], default=-1)
+        for l in range(L):
+            d = {}
+            if f"layer{l}.attn" in rec:
+                q, k = pack_keep_bits_attn(t(rec[f"layer{l}.attn"]))
+                d["attn"] = (q, k, 1.0 / (1.0 - p_attn))
+            for name, p in (("hid1", p_hidden), ("act", p_act), ("hid2", p_hidden)):
+                if f"layer{l}.{name}" in rec:
+                    d[name] = (pack_keep_bits(t(rec[f"layer{l}.{name}"])), 1.0 / (1.0 - p))
+            m.layers.append(d)
+        m.layer_skip = skip or [False] * L
+        if "spec" in rec:
+            m.spec = t(rec["spec"]).bool()
+        return m
+
+
+def draw_encoder_masks(be, S: int, T: int, n_layers: int, heads: int, hidden: int, ffn: int, cfg, seed: int, device) -> EncoderMasks:
+    """The masks of one step, drawn on the device from ``seed`` (sites: 0 feature projection, 1 encoder, 2 + 4 l + {0 attention,
+    1 attention output, 2 activation, 3 feed-forward output}); LayerDrop and SpecAugment draw from a numpy stream seeded with it."""
+    M = S * T
+    m = EncoderMasks()
+    words = lambda c: torch.empty(M, (c + 31) // 32, dtype=torch.int32, device=device)
+
+    def site(idx, cols, p):
+        if p <= 0.0:
+            return None
+        b = words(cols)
+        be.keep_bits(seed, idx, M, cols, p, b)
+        return (b, 1.0 / (1.0 - p))
+
+    m.featproj = site(0, hidden, cfg.feat_proj_dropout)
+    m.enc = site(1, hidden, cfg.hidden_dropout)
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    TW = attn_keep_words(T)
+    for l in range(n_layers):
+        d = {}
+        if cfg.attention_dropout > 0.0:
+            q = torch.empty(S * heads * T, TW, dtype=torch.int32, device=device)
+            k = torch.empty(S * heads, TW, 32 * TW, dtype=torch.int32, device=device)
+            be.keep_bits_attn(seed, 2 + 4 * l, S * heads, T, cfg.attention_dropout, q, k)
+            d["attn"] = (q, k, 1.0 / (1.0 - cfg.attention_dropout))
+        for j, (name, cols, p) in enumerate((("hid1", hidden, cfg.hidden_dropout), ("act", ffn, cfg.activation_dropout), ("hid2", hidden, cfg.hidden_dropout))):
+            s_ = site(2 + 4 * l + 1 + j, cols, p)
+            if s_ is not None:
+                d[name] = s_
+        m.layers.append(d)
+        m.layer_skip.append(bool(rng.rand() < cfg.layerdrop))              # HF Wav2Vec2Encoder: skip when the draw is below layerdrop
+    if cfg.apply_spec_augment and cfg.mask_time_prob > 0.0 and T > cfg.mask_time_length:
+        m.spec = torch.from_numpy(compute_mask_indices((S, T), cfg.mask_time_prob, cfg.mask_time_length, min_masks=2, rng=rng)).to(device)
+    return m

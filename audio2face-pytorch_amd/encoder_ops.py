@@ -52,17 +52,18 @@ class LayerNormFn(torch.autograd.Function):
 
 
 class LinearMMFn(torch.autograd.Function):
-    """y = x W^T + b on the bf16-MFMA GEMM; x (M,K), W (N,K), b (N)."""
+    """y = x W^T + b on the bf16-MFMA GEMM; x (M,K), W (N,K), b (N).  keep = (bits, scale): dropout of y in the epilogue."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, keep=None):
         be = ops.backend()
         xc, Wc, bc = _f32c(x), _f32c(W), _f32c(b)
         M, K = xc.shape
         N = Wc.shape[0]
         y = _new(xc, M, N)
-        ops.mm_linear_fwd(be, xc, Wc, bc, y, M, N, K)
+        be.mm(MMOp(xc, K), MMOp(Wc, K), y, M, N, K, N, bias=bc, keep=keep)
         ctx.save_for_backward(xc, Wc)
+        ctx.keep = keep
         return y
 
     @staticmethod
@@ -72,6 +73,10 @@ class LinearMMFn(torch.autograd.Function):
         M, K = xc.shape
         N = Wc.shape[0]
         dy = _f32c(dy)
+        if ctx.keep is not None:
+            dm = _new(dy, M, N)
+            be.dropout_apply(dy, ctx.keep[0], M, N, N, ctx.keep[1], dm)
+            dy = dm
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _new(xc, M, K)
@@ -79,7 +84,7 @@ class LinearMMFn(torch.autograd.Function):
         dW, db = _new(xc, N, K), _new(xc, N)
         ops.mm_linear_wgrad(be, dy, xc, dW, M, N, K)
         be.colsum(dy, M, N, N, db)
-        return dx, dW, db
+        return dx, dW, db, None
 
 
 # =================================================================================================
@@ -87,14 +92,21 @@ class LinearMMFn(torch.autograd.Function):
 # =================================================================================================
 class EncoderLayerFn(torch.autograd.Function):
     """x (S*T, d) -> (S*T, d).  Parameters in HF order: q, k, v, out projections (W, b), layer_norm (g, b),
-    intermediate_dense, output_dense (W, b), final_layer_norm (g, b).  19 launches forward, 31 backward."""
+    intermediate_dense, output_dense (W, b), final_layer_norm (g, b).  19 launches forward, 31 backward.
+
+    ``masks`` (train mode, else None): the keep bits of the layer's four dropout sites (HF Wav2Vec2EncoderLayer /
+    Wav2Vec2FeedForward / eager attention): {"attn": (query-major, key-major, scale), "hid1": (bits, scale) on the out-projection
+    output, "act": (bits, scale) on GELU(intermediate_dense), "hid2": (bits, scale) on the output_dense output}; absent keys = no
+    dropout there.  Forward applies them inside the producing kernels (attention kernel, a2f_mm epilogues); backward masks the
+    incoming gradient of the two hidden sites with one streaming pass each and the activation site in the data-gradient epilogue."""
 
     @staticmethod
-    def forward(ctx, x, S, T, heads, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2):
+    def forward(ctx, x, S, T, heads, masks, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2):
         be = ops.backend()
         xc = _f32c(x)
         P = [_f32c(p) for p in (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2)]
         Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2 = P
+        mk = masks or {}
         M, d = xc.shape
         F = W1.shape[0]
         keep = any(ctx.needs_input_grad)
@@ -103,21 +115,25 @@ class EncoderLayerFn(torch.autograd.Function):
             be.mm(MMOp(xc, d), MMOp(W, d), qkv, M, d, d, 3 * d, c_off=i * d, bias=b)
         att, lse = _new(xc, M, d), _new(xc, S, heads, T)
         scale = float((d // heads) ** -0.5)
-        be.attn_fwd(qkv, S, T, heads, 3 * d, scale, att, d, lse)
+        if "attn" in mk:
+            be.attn_fwd_drop(qkv, S, T, heads, 3 * d, scale, att, d, lse, mk["attn"][0], mk["attn"][2])
+        else:
+            be.attn_fwd(qkv, S, T, heads, 3 * d, scale, att, d, lse)
         a1 = _new(xc, M, d)
-        be.mm(MMOp(att, d), MMOp(Wo, d), a1, M, d, d, d, bias=bo, aux=xc, ldaux=d, aux_mode=MM_AUX_ADD)
+        be.mm(MMOp(att, d), MMOp(Wo, d), a1, M, d, d, d, bias=bo, aux=xc, ldaux=d, aux_mode=MM_AUX_ADD, keep=mk.get("hid1"))
         h1, m1, r1 = _new(xc, M, d), _new(xc, M), _new(xc, M)
         be.layernorm_fwd(a1, M, d, g1, b1, LN_EPS, h1, m1, r1)
         z = _new(xc, M, F) if keep else None
         g = _new(xc, M, F)
-        be.mm(MMOp(h1, d), MMOp(W1, d), g, M, F, d, F, bias=c1, act=MM_ACT_GELU, C2=z)
+        be.mm(MMOp(h1, d), MMOp(W1, d), g, M, F, d, F, bias=c1, act=MM_ACT_GELU, C2=z, keep=mk.get("act"))
         a2 = _new(xc, M, d)
-        be.mm(MMOp(g, F), MMOp(W2, F), a2, M, d, F, d, bias=c2, aux=h1, ldaux=d, aux_mode=MM_AUX_ADD)
+        be.mm(MMOp(g, F), MMOp(W2, F), a2, M, d, F, d, bias=c2, aux=h1, ldaux=d, aux_mode=MM_AUX_ADD, keep=mk.get("hid2"))
         h2, m2, r2 = _new(xc, M, d), _new(xc, M), _new(xc, M)
         be.layernorm_fwd(a2, M, d, g2, b2, LN_EPS, h2, m2, r2)
         if keep:
             ctx.save_for_backward(xc, qkv, att, lse, a1, m1, r1, h1, z, g, a2, m2, r2, Wq, Wk, Wv, Wo, g1, W1, W2, g2)
             ctx.dims = (S, T, heads, scale)
+            ctx.masks = mk
         return h2
 
     @staticmethod
@@ -125,19 +141,27 @@ class EncoderLayerFn(torch.autograd.Function):
         be = ops.backend()
         xc, qkv, att, lse, a1, m1, r1, h1, z, g, a2, m2, r2, Wq, Wk, Wv, Wo, g1, W1, W2, g2 = ctx.saved_tensors
         S, T, heads, scale = ctx.dims
+        mk = ctx.masks
         M, d = xc.shape
         F = W1.shape[0]
         new = lambda *s: _new(xc, *s)
         dh2 = _f32c(dh2)
         # final_layer_norm; the column sums of its input gradient are output_dense's bias gradient
         da2, dg2, db2, dc2 = new(M, d), new(d), new(d), new(d)
-        be.layernorm_bwd(dh2, a2, m2, r2, g2, M, d, da2, dg2, db2, dc2)
+        if "hid2" in mk:                 # the residual branch keeps da2; output_dense sees it through its dropout mask
+            be.layernorm_bwd(dh2, a2, m2, r2, g2, M, d, da2, dg2, db2, None)
+            dy2 = new(M, d)
+            be.dropout_apply(da2, mk["hid2"][0], M, d, d, mk["hid2"][1], dy2)
+            be.colsum(dy2, M, d, d, dc2)
+        else:
+            be.layernorm_bwd(dh2, a2, m2, r2, g2, M, d, da2, dg2, db2, dc2)
+            dy2 = da2
         dW2 = new(d, F)
-        ops.mm_linear_wgrad(be, da2, g, dW2, M, d, F)
+        ops.mm_linear_wgrad(be, dy2, g, dW2, M, d, F)
         dz = new(M, F)
         # through GELU: the derivative runs as its own streaming pass - fused into the GEMM epilogue (aux_mode GELU') the erf / exp
         # per element ran at matrix-pipe-idle time and the K = 768 product dropped from 245 to 122 TFLOP/s (rocprofv3, 32 x 600)
-        ops.mm_linear_dgrad(be, da2, W2, dz, M, d, F)
+        be.mm(MMOp(dy2, d), MMOp(W2, F, trans=True), dz, M, F, d, F, keep=mk.get("act"))
         be.gelu_bwd(dz, z, dz)
         dc1 = new(F)
         be.colsum(dz, M, F, F, dc1)
@@ -147,13 +171,23 @@ class EncoderLayerFn(torch.autograd.Function):
         ops.mm_linear_dgrad(be, dz, W1, dh1, M, F, d, aux=da2, aux_mode=MM_AUX_ADD)           # + residual branch
         # layer_norm after attention; colsum of its input gradient = out_proj's bias gradient
         da1, dg1, db1, dbo = new(M, d), new(d), new(d), new(d)
-        be.layernorm_bwd(dh1, a1, m1, r1, g1, M, d, da1, dg1, db1, dbo)
+        if "hid1" in mk:
+            be.layernorm_bwd(dh1, a1, m1, r1, g1, M, d, da1, dg1, db1, None)
+            dy1 = new(M, d)
+            be.dropout_apply(da1, mk["hid1"][0], M, d, d, mk["hid1"][1], dy1)
+            be.colsum(dy1, M, d, d, dbo)
+        else:
+            be.layernorm_bwd(dh1, a1, m1, r1, g1, M, d, da1, dg1, db1, dbo)
+            dy1 = da1
         dWo = new(d, d)
-        ops.mm_linear_wgrad(be, da1, att, dWo, M, d, d)
+        ops.mm_linear_wgrad(be, dy1, att, dWo, M, d, d)
         datt = new(M, d)
-        ops.mm_linear_dgrad(be, da1, Wo, datt, M, d, d)
+        ops.mm_linear_dgrad(be, dy1, Wo, datt, M, d, d)
         dqkv = new(M, 3 * d)
-        be.attn_bwd(qkv, att, datt, lse, S, T, heads, 3 * d, d, scale, dqkv)
+        if "attn" in mk:
+            be.attn_bwd_drop(qkv, att, datt, lse, S, T, heads, 3 * d, d, scale, dqkv, mk["attn"][0], mk["attn"][1], mk["attn"][2])
+        else:
+            be.attn_bwd(qkv, att, datt, lse, S, T, heads, 3 * d, d, scale, dqkv)
         dbqkv = new(3 * d)
         be.colsum(dqkv, M, 3 * d, 3 * d, dbqkv)
         dWs = []
@@ -167,8 +201,31 @@ class EncoderLayerFn(torch.autograd.Function):
             be.mm(MMOp(dqkv, 3 * d), MMOp(Wq, d, trans=True), dx, M, d, d, d, aux=da1, ldaux=d, aux_mode=MM_AUX_ADD)   # + residual branch
             be.mm(MMOp(dqkv, 3 * d, ptr_off=d), MMOp(Wk, d, trans=True), dx, M, d, d, d, accumulate=True)
             be.mm(MMOp(dqkv, 3 * d, ptr_off=2 * d), MMOp(Wv, d, trans=True), dx, M, d, d, d, accumulate=True)
-        return (dx, None, None, None, dWs[0], dbqkv[0:d], dWs[1], dbqkv[d:2 * d], dWs[2], dbqkv[2 * d:], dWo, dbo, dg1, db1,
+        return (dx, None, None, None, None, dWs[0], dbqkv[0:d], dWs[1], dbqkv[d:2 * d], dWs[2], dbqkv[2 * d:], dWo, dbo, dg1, db1,
                 dW1, dc1, dW2, dc2, dg2, db2)
+
+
+class DropoutFn(torch.autograd.Function):
+    """y = keep ? x * scale : 0 on (R, C) rows with bit-packed keep masks (csrc/dropout.hip); the backward is the same map."""
+
+    @staticmethod
+    def forward(ctx, x, bits, scale):
+        be = ops.backend()
+        xc = _f32c(x)
+        R, C = xc.shape
+        y = _new(xc, R, C)
+        be.dropout_apply(xc, bits, R, C, C, scale, y)
+        ctx.bits, ctx.scale = bits, scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = ops.backend()
+        dyc = _f32c(dy)
+        R, C = dyc.shape
+        dx = _new(dyc, R, C)
+        be.dropout_apply(dyc, ctx.bits, R, C, C, ctx.scale, dx)
+        return dx, None, None
 
 
 # =================================================================================================

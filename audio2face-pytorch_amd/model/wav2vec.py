@@ -7,9 +7,13 @@ contraction on the bf16-MFMA GEMM family ``a2f_mm`` - feature-encoder convolutio
 grouped positional convolution, the 12 Transformer layers - MFMA flash attention, HIP LayerNorm / GELU' / bias-gradient
 kernels, forward and backward).  The torch-ops restatement below it is what host-side (CPU) tests of this module run.  ``forward(input_values, dataset, frame_num=...)`` keeps the reference wrapper's signature and
 returns an object with ``.last_hidden_state`` (1,T,768); the vocaset branch interpolates the 49 Hz conv features to
-``frame_num`` frames with align_corners=True (wav2vec.py:76-84,125-128).  SpecAugment / layerdrop / dropout are
-train-only in the reference and stochastic; this module implements the deterministic (eval) function in both modes
-(``Faceformer`` warns once when it is trained without them).
+``frame_num`` frames with align_corners=True (wav2vec.py:76-84,125-128).
+
+Train mode (``.train()``, as Lightning puts the reference's module): the stochastic regularisers of the reference's encoder are
+applied - dropout at the six kinds of sites of HF's modules, LayerDrop, SpecAugment along time (wav2vec.py:149-162) - with the
+probabilities of ``facebook/wav2vec2-base-960h`` (``self.config``).  Masks are drawn per forward from torch's CPU generator
+(``dropout.draw_encoder_masks``) or injected (``self.injected_masks``: how the parity test feeds the masks recorded from the
+reference, fixture G13).  ``self.train_regularisers = False`` keeps the deterministic function in train mode.
 """
 from __future__ import annotations
 
@@ -86,17 +90,24 @@ class _EncoderLayer(nn.Module):
         self.final_layer_norm = nn.LayerNorm(hidden, eps=1e-5)
         self.heads = heads
 
-    def forward(self, h):
+    def forward(self, h, masks=None):
         B, T, d = h.shape
         hd = d // self.heads
         a = self.attention
         q = a.q_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
         k = a.k_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
         v = a.v_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
-        ctx = F.scaled_dot_product_attention(q, k, v)                       # softmax(q k^T / sqrt(hd)) v
-        h = self.layer_norm(h + a.out_proj(ctx.transpose(1, 2).reshape(B, T, d)))
+        mk = masks or {}
+        drop = lambda x, key: x * (_unpack(mk[key][0], x.shape[-1]).view(x.shape) * mk[key][1]).to(x.dtype) if key in mk else x
+        if "attn" in mk:                                                    # HF eager attention: softmax -> dropout -> @ v
+            pr = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * hd ** -0.5, dim=-1)
+            pr = pr * (_unpack(mk["attn"][0], T).view(B, self.heads, T, T) * mk["attn"][2]).to(pr.dtype)
+            ctx = torch.matmul(pr, v)
+        else:
+            ctx = F.scaled_dot_product_attention(q, k, v)                   # softmax(q k^T / sqrt(hd)) v
+        h = self.layer_norm(h + drop(a.out_proj(ctx.transpose(1, 2).reshape(B, T, d)), "hid1"))
         f = self.feed_forward
-        return self.final_layer_norm(h + f.output_dense(F.gelu(f.intermediate_dense(h))))
+        return self.final_layer_norm(h + drop(f.output_dense(drop(F.gelu(f.intermediate_dense(h)), "act")), "hid2"))
 
 
 class _Encoder(nn.Module):
@@ -106,14 +117,23 @@ class _Encoder(nn.Module):
         self.layer_norm = nn.LayerNorm(hidden, eps=1e-5)
         self.layers = nn.ModuleList(_EncoderLayer(hidden, ffn, heads) for _ in range(layers))
 
-    def forward(self, h):
+    def forward(self, h, masks=None):
         pc = self.pos_conv_embed
         z = pc.conv(h.transpose(1, 2))
         z = z[:, :, :-1] if pc.k % 2 == 0 else z
         h = self.layer_norm(h + F.gelu(z).transpose(1, 2))
-        for layer in self.layers:
-            h = layer(h)
+        if masks is not None and masks.enc is not None:
+            h = h * (_unpack(masks.enc[0], h.shape[-1]).view(h.shape) * masks.enc[1]).to(h.dtype)
+        for l, layer in enumerate(self.layers):
+            if masks is not None and masks.layer_skip[l]:
+                continue                                                     # LayerDrop
+            h = layer(h, masks.layers[l] if masks is not None else None)
         return h
+
+
+def _unpack(bits, C):
+    from ..dropout import unpack_keep_bits
+    return unpack_keep_bits(bits, C)
 
 
 def linear_interpolation(features, output_len):
@@ -144,6 +164,12 @@ class Wav2Vec2Model(nn.Module):
         self.conv_autotune = True
         self.heads = heads
         self.use_hip = True          # HIP tensors -> hand-written path; False keeps the torch-ops restatement (A/B timing, debugging)
+        # the train-mode probabilities of facebook/wav2vec2-base-960h's configuration (what the reference's from_pretrained loads)
+        self.config = types.SimpleNamespace(feat_proj_dropout=0.1, hidden_dropout=0.1, attention_dropout=0.1, activation_dropout=0.1,
+                                            layerdrop=0.1, apply_spec_augment=True, mask_time_prob=0.05, mask_time_length=10)
+        self.train_regularisers = True
+        self.injected_masks = None   # an EncoderMasks to use instead of drawing (parity tests: masks recorded from the reference)
+        self.last_masks = None
 
     compute_path = "hand-written HIP (a2f_mm bf16-MFMA GEMMs, MFMA flash attention, HIP LayerNorm / GELU / GroupNorm kernels)"
 
@@ -153,9 +179,29 @@ class Wav2Vec2Model(nn.Module):
         return ("encoder products as bf16x3 split MFMA (fp32-class), fp32 accumulate / softmax / LayerNorm" if ops.backend().mm_precision == 1
                 else "encoder products as bf16 MFMA, fp32 accumulate / softmax / LayerNorm")
 
+    def _step_masks(self, S, T, device):
+        """The masks of this forward: None outside train mode; injected ones if set; else drawn from torch's CPU generator."""
+        if not (self.training and self.train_regularisers):
+            return None
+        if self.injected_masks is not None:
+            return self.injected_masks
+        from .. import ops
+        from ..dropout import draw_encoder_masks
+        enc = self.encoder
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        lay = enc.layers[0]
+        return draw_encoder_masks(ops.backend(), S, T, len(enc.layers), self.heads, lay.layer_norm.normalized_shape[0],
+                                  lay.feed_forward.intermediate_dense.out_features, self.config, seed, device)
+
+    def _spec_augment(self, h, masks):
+        """wav2vec.py:149-162: the frames SpecAugment picked are replaced by the learned masked_spec_embed (h: (S, T, d))."""
+        if masks is None or masks.spec is None:
+            return h
+        return torch.where(masks.spec.view(h.shape[0], h.shape[1], 1), self.masked_spec_embed.to(h.dtype).view(1, 1, -1), h)
+
     def _forward_hip(self, wave, frame_num):
         """The encoder on the HIP path; wave (S, N) normalised -> (S, frame_num, hidden)."""
-        from ..encoder_ops import ConvGeluFn, EncoderLayerFn, FeatEnc0Fn, LayerNormFn, LinearMMFn, PosConvFn
+        from ..encoder_ops import ConvGeluFn, DropoutFn, EncoderLayerFn, FeatEnc0Fn, LayerNormFn, LinearMMFn, PosConvFn
         S = wave.shape[0]
         fe = self.feature_extractor.conv_layers
         # feature encoder, in chunks of sequences: the sequences are independent there and an a2f_mm operand spans < 4 GiB (the layer-0
@@ -175,15 +221,23 @@ class Wav2Vec2Model(nn.Module):
             z = linear_interpolation(z, frame_num)                                # (S, T, 512)
         T, C = z.shape[1], z.shape[2]
         fp = self.feature_projection
-        h = LinearMMFn.apply(LayerNormFn.apply(z.reshape(S * T, C), fp.layer_norm.weight, fp.layer_norm.bias), fp.projection.weight, fp.projection.bias)
+        masks = self.last_masks = self._step_masks(S, T, z.device)
+        h = LinearMMFn.apply(LayerNormFn.apply(z.reshape(S * T, C), fp.layer_norm.weight, fp.layer_norm.bias), fp.projection.weight, fp.projection.bias,
+                             masks.featproj if masks is not None else None)
         enc = self.encoder
         pc = enc.pos_conv_embed
         d = h.shape[1]
-        h = PosConvFn.apply(h.view(S, T, d), pc.conv.weight, pc.conv.bias, pc.conv.groups).reshape(S * T, d)
+        h = self._spec_augment(h.view(S, T, d), masks)
+        h = PosConvFn.apply(h, pc.conv.weight, pc.conv.bias, pc.conv.groups).reshape(S * T, d)
         h = LayerNormFn.apply(h, enc.layer_norm.weight, enc.layer_norm.bias)
-        for layer in enc.layers:
+        if masks is not None and masks.enc is not None:
+            h = DropoutFn.apply(h, masks.enc[0], masks.enc[1])
+        for l, layer in enumerate(enc.layers):
+            if masks is not None and masks.layer_skip[l]:
+                continue                                                     # LayerDrop (HF Wav2Vec2Encoder.forward)
             a, f = layer.attention, layer.feed_forward
-            h = EncoderLayerFn.apply(h, S, T, self.heads, a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias, a.v_proj.weight,
+            h = EncoderLayerFn.apply(h, S, T, self.heads, masks.layers[l] if masks is not None else None,
+                                     a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias, a.v_proj.weight,
                                      a.v_proj.bias, a.out_proj.weight, a.out_proj.bias, layer.layer_norm.weight, layer.layer_norm.bias,
                                      f.intermediate_dense.weight, f.intermediate_dense.bias, f.output_dense.weight, f.output_dense.bias,
                                      layer.final_layer_norm.weight, layer.final_layer_norm.bias)
@@ -208,6 +262,10 @@ class Wav2Vec2Model(nn.Module):
                 z = linear_interpolation(z, frame_num)
             fp = self.feature_projection
             h = fp.projection(fp.layer_norm(z))
-            return types.SimpleNamespace(last_hidden_state=self.encoder(h))
+            masks = self.last_masks = self._step_masks(h.shape[0], h.shape[1], h.device)
+            if masks is not None and masks.featproj is not None:
+                h = h * (_unpack(masks.featproj[0], h.shape[-1]).view(h.shape) * masks.featproj[1]).to(h.dtype)
+            h = self._spec_augment(h, masks)
+            return types.SimpleNamespace(last_hidden_state=self.encoder(h, masks))
         finally:
             torch.backends.cudnn.benchmark = old_benchmark

@@ -57,6 +57,12 @@ def _chk(*ts):
             raise A2FError("a2f ops need contiguous tensors")
 
 
+def _chk_bits(*ts):
+    for t in ts:
+        if t.device.type != "cuda" or t.dtype != torch.int32 or not t.is_contiguous():
+            raise A2FError("keep-bit masks are contiguous int32 HIP tensors (32 elements per word)")
+
+
 class HipBackend:
     name = "hip"
 
@@ -123,8 +129,9 @@ class HipBackend:
 
     def mm(self, A: "MMOp", B: "MMOp", Cout, M, N, K, ldc, *, c_off=0, c_rows_per_seq=0, c_seq_stride=0, C2=None, bias=None, aux=None,
            ldaux=0, act=MM_ACT_NONE, aux_mode=MM_AUX_NONE, precision=None, split_k=1, batch=1, a_bstride=0, b_bstride=0, c_bstride=0,
-           bias_bstride=0, aux_bstride=0, accumulate=False, alpha=1.0, tag="gemm_mfma"):
-        """C[m,n] = epi(alpha * sum_k A(m,k) B(k,n)) on the bf16 matrix pipe (contract: include/a2f_hip.h, a2f_mm)."""
+           bias_bstride=0, aux_bstride=0, accumulate=False, alpha=1.0, tag="gemm_mfma", keep=None):
+        """C[m,n] = epi(alpha * sum_k A(m,k) B(k,n)) on the bf16 matrix pipe (contract: include/a2f_hip.h, a2f_mm).
+        keep = (bits int32 (M, wpr), scale): train-mode dropout of C in the epilogue."""
         _chk(A.t, B.t, Cout, C2, bias, aux)
         d = MMDesc()
         A.fill(d.A)
@@ -147,6 +154,10 @@ class HipBackend:
         d.batch, d.accumulate = batch, int(accumulate)
         d.a_bstride, d.b_bstride, d.c_bstride, d.bias_bstride, d.aux_bstride = a_bstride, b_bstride, c_bstride, bias_bstride, aux_bstride
         d.alpha = alpha
+        if keep is not None:
+            bits, scale = keep
+            _chk_bits(bits)
+            d.keep_bits, d.keep_wpr, d.keep_scale = bits.data_ptr(), bits.shape[-1], float(scale)
         ev = self._prof_begin(tag)
         _lib.check(self.lib.a2f_mm(C.byref(d), self._stream(Cout)), "a2f_mm")
         self._prof_end(tag, ev)
@@ -208,6 +219,43 @@ class HipBackend:
         _lib.check(self.lib.a2f_attn_bwd(_ptr(qkv), _ptr(ctx), _ptr(dctx), _ptr(lse), S, T, H, ld, ldo, scale,
                                          self.mm_precision if precision is None else precision, _ptr(dqkv), _ptr(ws), self._stream(qkv)), "a2f_attn_bwd")
         self._prof_end("attn", ev)
+
+    def attn_fwd_drop(self, qkv, S, T, H, ld, scale, ctx, ldo, lse, keep_q, keep_scale, precision=None):
+        _chk(qkv, ctx, lse)
+        _chk_bits(keep_q)
+        ev = self._prof_begin("attn")
+        _lib.check(self.lib.a2f_attn_fwd_drop(_ptr(qkv), S, T, H, ld, scale, self.mm_precision if precision is None else precision, _ptr(ctx), ldo,
+                                              _ptr(lse), keep_q.data_ptr(), float(keep_scale), self._stream(qkv)), "a2f_attn_fwd_drop")
+        self._prof_end("attn", ev)
+
+    def attn_bwd_drop(self, qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, dqkv, keep_q, keep_k, keep_scale, precision=None):
+        _chk(qkv, ctx, dctx, lse, dqkv)
+        _chk_bits(keep_q, keep_k)
+        ws = torch.empty(S * H * T, dtype=torch.float32, device=qkv.device)
+        ev = self._prof_begin("attn")
+        _lib.check(self.lib.a2f_attn_bwd_drop(_ptr(qkv), _ptr(ctx), _ptr(dctx), _ptr(lse), S, T, H, ld, ldo, scale,
+                                              self.mm_precision if precision is None else precision, _ptr(dqkv), _ptr(ws), keep_q.data_ptr(),
+                                              keep_k.data_ptr(), float(keep_scale), self._stream(qkv)), "a2f_attn_bwd_drop")
+        self._prof_end("attn", ev)
+
+    # ---- dropout keep masks (csrc/dropout.hip) ---------------------------------------------------
+    def attn_keep_words(self, T):
+        return 2 * ((T + 63) // 64)
+
+    def keep_bits(self, seed, site, R, Cc, p, bits):
+        _chk_bits(bits)
+        _lib.check(self.lib.a2f_keep_bits(int(seed), int(site), R, Cc, float(p), bits.data_ptr(), bits.shape[-1], self._stream(bits)), "a2f_keep_bits")
+
+    def keep_bits_attn(self, seed, site, SH, T, p, qmajor, kmajor):
+        _chk_bits(qmajor, kmajor)
+        _lib.check(self.lib.a2f_keep_bits_attn(int(seed), int(site), SH, T, float(p), qmajor.data_ptr(), kmajor.data_ptr(), self._stream(qmajor)),
+                   "a2f_keep_bits_attn")
+
+    def dropout_apply(self, x, bits, R, Cc, ld, scale, y):
+        _chk(x, y)
+        _chk_bits(bits)
+        _lib.check(self.lib.a2f_dropout_apply(_ptr(x), bits.data_ptr(), R, Cc, ld, bits.shape[-1], float(scale), _ptr(y), self._stream(x)),
+                   "a2f_dropout_apply")
 
     # ---- a2f_wgrad_f32 ------------------------------------------------------------------------
     def wgrad_supported(self, M, N):

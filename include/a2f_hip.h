@@ -286,6 +286,8 @@ int a2f_stream_triad(float* dst, const float* a, const float* b, int64_t n, a2f_
  * anything beyond reads as zero.  All of p, ld, off, seq_stride and the contiguous extent must be multiples of 4 elements
  * (16-byte vector loads).
  * Epilogue, per element: v = alpha*acc; if bias: v += bias[n]; C2 (optional) = v;  act: 0 none, 1 ReLU, 3 GELU (erf form);
+ * keep_bits (optional, batch == 1): v = bit (m, n) of the keep mask ? v * keep_scale : 0 (train-mode dropout of the layer's output,
+ * a2f_keep_bits layout with keep_wpr words per row);
  * aux_mode 1: v += aux[m*ldaux+n]; 2: v *= gelu'(aux); 3: v *= (aux > 0); accumulate: v += C_old.  Row m of C (and C2) is
  * stored at C + (m / c_rows_per_seq)*c_seq_stride + (m % c_rows_per_seq)*ldc + n  (c_rows_per_seq = 0: C + m*ldc + n).
  * split_k > 1: the contraction is cut into split_k slabs stored in `ws` (>= batch*split_k*M*N floats) and folded in fixed
@@ -313,6 +315,8 @@ typedef struct a2f_mm_desc {
   int32_t batch, accumulate;
   int64_t a_bstride, b_bstride, c_bstride, bias_bstride;
   float alpha; int32_t reserved;
+  const uint32_t* keep_bits; int64_t keep_wpr;     /* optional dropout of C: see a2f_keep_bits */
+  float keep_scale; int32_t reserved2;
 } a2f_mm_desc;
 
 int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream);
@@ -337,6 +341,24 @@ int a2f_colsum(const float* x, int64_t R, int64_t C, int64_t ld, float* out, voi
 int a2f_gelu_bwd(const float* dy, const float* z, int64_t n, float* out, a2f_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Train-mode dropout of the wav2vec2 encoder (csrc/dropout.hip; HF Wav2Vec2Model in train mode as the reference runs it:
+ * feat_proj_dropout / hidden_dropout / attention_dropout / activation_dropout, /root/reference/src/model/wav2vec.py:87-189 and
+ * HF modeling_wav2vec2 Wav2Vec2FeatureProjection / Wav2Vec2Encoder / Wav2Vec2EncoderLayer / Wav2Vec2FeedForward / eager attention).
+ * A dropout site is a bit-packed KEEP mask: (R, C) elements = R rows of `wpr` 32-bit words (wpr * 32 >= C), bit b of word (r, w)
+ * <-> element (r, 32 w + b), 1 = keep.  a2f_keep_bits fills one from Philox4x32-10: key = seed, counter = (element / 4 within the row,
+ * row, site, 0), element e of the group keeps iff output[e % 4] >= p * 2^32 - a pure function of (seed, site, row, column).
+ * a2f_keep_bits_attn: the (SH, T, T) mask of the attention probabilities in the two layouts the kernels read: query-major words
+ * [sh][q][TW] (bit = key) and key-major words [sh][TW][32 TW] (word (qw, key): bit b = query 32 qw + b); TW = a2f_attn_keep_words(T)
+ * = 2 ceil(T / 64); row index of the counter = sh * T + q.  a2f_dropout_apply: y = keep ? x * scale : 0 (streaming; y may be x).
+ * The consumers never generate masks themselves, so tests inject the masks recorded from the reference's own dropout calls.
+ */
+int a2f_keep_bits(uint64_t seed, uint32_t site, int64_t R, int64_t C, float p, uint32_t* bits, int64_t wpr, a2f_stream_t stream);
+int64_t a2f_attn_keep_words(int64_t T);
+int a2f_keep_bits_attn(uint64_t seed, uint32_t site, int64_t SH, int64_t T, float p, uint32_t* qmajor, uint32_t* kmajor, a2f_stream_t stream);
+int a2f_dropout_apply(const float* x, const uint32_t* bits, int64_t R, int64_t C, int64_t ld, int64_t wpr, float scale, float* y,
+                      a2f_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * MFMA flash attention of the wav2vec2 encoder layers (csrc/attention.hip): H heads of 64, full self-attention inside each
  * of the S sequences of T frames; replaces softmax(q k^T) v of HF Wav2Vec2Attention (the encoder layers called at
  * /root/reference/src/model/wav2vec.py:174-180) and its backward.
@@ -351,6 +373,13 @@ int a2f_attn_fwd(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, 
                  float* lse, a2f_stream_t stream);
 int a2f_attn_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
                  int64_t ldo, float scale, int32_t precision, float* dqkv, float* delta_ws, a2f_stream_t stream);
+/* The same with dropout on the probabilities (HF eager attention: softmax -> nn.functional.dropout(p = attention_dropout) -> @ v):
+ * ctx = (P o D) v with D = keep ? keep_scale : 0; lse is that of the un-thinned scores.  keep bits as a2f_keep_bits_attn lays them out. */
+int a2f_attn_fwd_drop(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx, int64_t ldo,
+                      float* lse, const uint32_t* keep_qmajor, float keep_scale, a2f_stream_t stream);
+int a2f_attn_bwd_drop(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
+                      int64_t ldo, float scale, int32_t precision, float* dqkv, float* delta_ws, const uint32_t* keep_qmajor,
+                      const uint32_t* keep_kmajor, float keep_scale, a2f_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Layer 0 of the wav2vec2 feature encoder (csrc/featenc.hip; HF Wav2Vec2FeatureEncoder layer 0 as called at

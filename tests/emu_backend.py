@@ -27,6 +27,48 @@ def _window(t, off, rs, cs, R, Ccols):
     return torch.where(ok, flat[idx.clamp(0, flat.numel() - 1)], torch.zeros((), dtype=torch.double)), ok
 
 
+def pack_keep_bits(mask):
+    """bool (R, C) -> int32 (R, ceil(C/32)) words, bit b of word w <-> column 32 w + b."""
+    R, Cc = mask.shape
+    wpr = (Cc + 31) // 32
+    m = torch.zeros(R, wpr * 32, dtype=torch.int64)
+    m[:, :Cc] = mask.to(torch.int64)
+    w = (m.reshape(R, wpr, 32) << torch.arange(32, dtype=torch.int64)).sum(-1)
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+
+
+def unpack_keep_bits(bits, Cc):
+    """int32 (R, wpr) words -> bool (R, Cc)."""
+    w = bits.to(torch.int64) & 0xFFFFFFFF
+    return (((w.unsqueeze(-1) >> torch.arange(32, dtype=torch.int64)) & 1) != 0).reshape(bits.shape[0], -1)[:, :Cc]
+
+
+def philox_keep_words(seed, site, R, Cc, p, wpr):
+    """numpy restatement of a2f_keep_bits (include/a2f_hip.h): Philox4x32-10, key = seed, counter = (column / 4, row, site, 0);
+    element keeps iff its output word >= p * 2^32.  Returns int32 (R, wpr)."""
+    import numpy as np
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
+    mask32 = np.uint64(0xFFFFFFFF)
+    ng = wpr * 8
+    c0 = np.broadcast_to(np.arange(ng, dtype=np.uint64)[None, :], (R, ng)).copy()
+    c1 = np.broadcast_to(np.arange(R, dtype=np.uint64)[:, None], (R, ng)).copy()
+    c2 = np.full((R, ng), site, dtype=np.uint64)
+    c3 = np.zeros((R, ng), dtype=np.uint64)
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask32, p1 >> np.uint64(32), p1 & mask32
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0, k1 = (k0 + W0) & mask32, (k1 + W1) & mask32
+    t = float(p) * 4294967296.0
+    thresh = np.uint64(0 if t <= 0 else min(int(t), 4294967295))
+    keep = np.stack([c0, c1, c2, c3], axis=-1) >= thresh                     # (R, ng, 4): element 4 g + e
+    keep = keep.reshape(R, ng * 4)
+    keep[:, Cc:] = False
+    words = (keep.reshape(R, wpr, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32)
+    return words.view(np.int32)
+
+
 class EmuBackend:
     name = "emu"
 
@@ -116,7 +158,7 @@ class EmuBackend:
 
     def mm(self, A, B, Cout, M, N, K, ldc, *, c_off=0, c_rows_per_seq=0, c_seq_stride=0, C2=None, bias=None, aux=None, ldaux=0, act=0,
            aux_mode=0, precision=None, split_k=1, batch=1, a_bstride=0, b_bstride=0, c_bstride=0, bias_bstride=0, aux_bstride=0,
-           accumulate=False, alpha=1.0, tag=None):
+           accumulate=False, alpha=1.0, tag=None, keep=None):
         import copy
         self.calls.append(("mm", M, N, K, batch))
         cflat = Cout.reshape(-1)
@@ -139,6 +181,9 @@ class EmuBackend:
                 v = v.clamp_min(0)
             elif act == 3:
                 v = 0.5 * v * (1 + torch.erf(v / math.sqrt(2.0)))
+            if keep is not None:
+                assert batch == 1
+                v = torch.where(unpack_keep_bits(keep[0], N)[:M], v * float(keep[1]), torch.zeros_like(v))
             if aux_mode:
                 ax = aux.reshape(-1)[bz * aux_bstride + m * ldaux + torch.arange(N).view(1, -1)].double()
                 if aux_mode == 1:
@@ -225,6 +270,51 @@ class EmuBackend:
         out = dqkv.reshape(S, T, ld)
         for t, off in ((q, 0), (k, 64 * H), (v, 128 * H)):
             out[:, :, off:off + 64 * H] = t.grad.permute(0, 2, 1, 3).reshape(S, T, 64 * H).float()
+
+    def attn_fwd_drop(self, qkv, S, T, H, ld, scale, ctx, ldo, lse, keep_q, keep_scale, precision=None):
+        q, k, v = self._attn_split(qkv, S, T, H, ld)
+        s = torch.matmul(q * scale, k.transpose(-1, -2))
+        lse.reshape(S, H, T).copy_(torch.logsumexp(s, dim=-1).float())
+        d = unpack_keep_bits(keep_q.reshape(S * H * T, -1), T).reshape(S, H, T, T).double() * float(keep_scale)
+        o = torch.matmul(torch.softmax(s, dim=-1) * d, v)
+        ctx.reshape(S * T, ldo)[:, :64 * H].copy_(o.permute(0, 2, 1, 3).reshape(S * T, 64 * H).float())
+
+    def attn_bwd_drop(self, qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, dqkv, keep_q, keep_k, keep_scale, precision=None):
+        TW = keep_q.reshape(S * H * T, -1).shape[1]
+        dq_ = unpack_keep_bits(keep_q.reshape(S * H * T, -1), T).reshape(S, H, T, T)
+        # the key-major copy must describe the same mask: word (qw, key), bit b <-> query 32 qw + b
+        dk_ = unpack_keep_bits(keep_k.reshape(S * H, TW, 32 * TW).permute(0, 2, 1).reshape(S * H * 32 * TW, TW), T).reshape(S * H, 32 * TW, T)[:, :T]
+        assert torch.equal(dq_.reshape(S * H, T, T), dk_.transpose(1, 2)), "attn_bwd_drop emu: the two keep-bit layouts disagree"
+        with torch.enable_grad():
+            q, k, v = (t.clone().requires_grad_(True) for t in self._attn_split(qkv.detach(), S, T, H, ld))
+            pr = torch.softmax(torch.matmul(q * scale, k.transpose(-1, -2)), dim=-1)
+            o = torch.matmul(pr * (dq_.double() * float(keep_scale)), v)
+            do = dctx.detach().reshape(S, T, ldo)[:, :, :64 * H].double().reshape(S, T, H, 64).permute(0, 2, 1, 3)
+            o.backward(do)
+        out = dqkv.reshape(S, T, ld)
+        for t, off in ((q, 0), (k, 64 * H), (v, 128 * H)):
+            out[:, :, off:off + 64 * H] = t.grad.permute(0, 2, 1, 3).reshape(S, T, 64 * H).float()
+
+    # ------------------------------------------------------------------ dropout keep masks (contract of csrc/dropout.hip)
+    def attn_keep_words(self, T):
+        return 2 * ((T + 63) // 64)
+
+    def keep_bits(self, seed, site, R, Cc, p, bits):
+        bits.copy_(torch.from_numpy(philox_keep_words(seed, site, R, Cc, p, bits.shape[-1])))
+
+    def keep_bits_attn(self, seed, site, SH, T, p, qmajor, kmajor):
+        TW = self.attn_keep_words(T)
+        words = philox_keep_words(seed, site, SH * T, T, p, TW)
+        qmajor.reshape(SH * T, TW).copy_(torch.from_numpy(words))
+        keep = unpack_keep_bits(torch.from_numpy(words), T).reshape(SH, T, T)                      # [sh][q][k]
+        full = torch.zeros(SH, 32 * TW, 32 * TW, dtype=torch.bool)
+        full[:, :T, :T] = keep
+        kmajor.reshape(SH, TW, 32 * TW).copy_(pack_keep_bits(full.transpose(1, 2).reshape(SH * 32 * TW, 32 * TW)).reshape(SH, 32 * TW, TW).transpose(1, 2))
+
+    def dropout_apply(self, x, bits, R, Cc, ld, scale, y):
+        k = unpack_keep_bits(bits.reshape(R, -1), Cc)
+        xv = x.reshape(-1)[: R * ld].reshape(R, ld)[:, :Cc]
+        y.reshape(-1)[: R * ld].reshape(R, ld)[:, :Cc] = torch.where(k, xv * float(scale), torch.zeros_like(xv))
 
     def wgrad_supported(self, M, N):
         mt, nt = (M + 31) // 32, (N + 1 + 31) // 32

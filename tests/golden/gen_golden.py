@@ -466,7 +466,92 @@ def g12():
     save("g12_wav2vec_extractor", out)
 
 
-ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G10": g10, "G12": g12}
+# --------------------------------------------------------------------------------------- G13 train-mode encoder, masks recorded
+def g13():
+    """The reference's wav2vec2 wrapper in TRAIN mode (wav2vec.py:87-189 over the installed HF modules, configuration values of
+    facebook/wav2vec2-base-960h): every stochastic decision is recorded or preset and stored with the outputs, so the train-mode
+    function is a fixture.  ``torch.nn.functional.dropout`` is replaced by a recorder (same arithmetic: x * keep / (1 - p), the
+    keep mask drawn from a seeded torch generator and logged in call order: feature projection, encoder, then per executed layer
+    attention probabilities / attention output / activation / feed-forward output); ``torch.rand([])`` (LayerDrop) returns preset
+    draws that skip layers 3 and 8; SpecAugment runs the reference's own ``_compute_mask_indices`` from ``np.random.seed(1234)``
+    and its result is recorded (and compared with a2f_amd.dropout.compute_mask_indices from the same seed)."""
+    import transformers
+    import torch.nn.functional as F
+    from src.model import wav2vec as ref_mod
+    from a2f_amd.dropout import compute_mask_indices
+    print("G13 wav2vec2 wrapper in train mode with recorded masks (dropout x 6 kinds of sites, LayerDrop, SpecAugment)")
+    cfg = transformers.Wav2Vec2Config(attn_implementation="eager", feat_proj_dropout=0.1, hidden_dropout=0.1, attention_dropout=0.1,
+                                      activation_dropout=0.1, layerdrop=0.1, apply_spec_augment=True, mask_time_prob=0.05, mask_time_length=10)
+    m = ref_mod.Wav2Vec2Model(cfg).train()
+    sd = W.formula_state_dict(W.wav2vec2_shapes(), gains={"original0": 40.0})
+    m.load_state_dict(sd)
+    S, T = 2, 30
+    n = T * 16000 // 60 + 3
+    wave = o_w2v.normalize_waveform(W.formula_input("g13.audio", (S, n), 0.1) + 0.01)      # no grad: HF's train-mode feature encoder marks its input itself
+    log = []
+    gen = torch.Generator().manual_seed(1313)
+    skip = [l in (3, 8) for l in range(12)]
+    draws = iter([0.05 if s_ else 0.5 for s_ in skip])
+
+    def rec_dropout(x, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return x
+        keep = torch.rand(x.shape, generator=gen) >= p
+        log.append(keep)
+        return x * keep.to(x.dtype) / (1.0 - p)
+
+    real_rand, real_dropout, real_cmi = torch.rand, F.dropout, ref_mod._compute_mask_indices
+
+    def rec_rand(*a, **k):
+        if len(a) == 1 and isinstance(a[0], (list, tuple)) and len(a[0]) == 0:
+            return torch.tensor(next(draws))
+        return real_rand(*a, **k)
+
+    spec = {}
+
+    def rec_cmi(*a, **k):
+        spec["mask"] = real_cmi(*a, **k)
+        return spec["mask"]
+
+    np.random.seed(1234)
+    F.dropout, torch.rand, ref_mod._compute_mask_indices = rec_dropout, rec_rand, rec_cmi
+    try:
+        hs = m(wave, "vocaset", frame_num=T).last_hidden_state
+    finally:
+        F.dropout, torch.rand, ref_mod._compute_mask_indices = real_dropout, real_rand, real_cmi
+    assert len(log) == 2 + 4 * (12 - sum(skip)), len(log)
+    mine = compute_mask_indices((S, T), 0.05, 10, min_masks=2, rng=np.random.RandomState(1234))
+    assert np.array_equal(mine, spec["mask"]), "SpecAugment port differs from the reference's _compute_mask_indices"
+    out = {"dims": np.asarray([S, T, n], dtype=np.int64), "layer_skip": np.asarray(skip), "spec": spec["mask"]}
+    it = iter(log)
+    bits = lambda t: np.packbits(t.numpy().reshape(-1))
+    out["featproj"], out["enc"] = bits(next(it)), bits(next(it))
+    for l in range(12):
+        if skip[l]:
+            continue
+        for name, shape in (("attn", (S, 12, T, T)), ("hid1", (S, T, 768)), ("act", (S, T, 3072)), ("hid2", (S, T, 768))):
+            k = next(it)
+            assert tuple(k.shape) == shape, (l, name, tuple(k.shape))
+            out[f"layer{l}.{name}"] = bits(k)
+    wgt = W.formula_input("g13.cotangent", (S, T, 768), 1.0)
+    (hs * wgt).sum().backward()
+    pack("last_hidden_state", hs, out, big=10 ** 9)
+    named = dict(m.named_parameters())
+    for k in ("masked_spec_embed", "feature_projection.projection.weight", "feature_projection.projection.bias", "encoder.layers.0.attention.q_proj.weight",
+              "encoder.layers.0.attention.v_proj.bias", "encoder.layers.5.feed_forward.intermediate_dense.weight",
+              "encoder.layers.11.feed_forward.output_dense.weight", "encoder.layers.11.final_layer_norm.weight", "encoder.layers.3.attention.out_proj.weight",
+              "feature_extractor.conv_layers.0.conv.weight", "encoder.layer_norm.bias"):
+        g = named[k].grad
+        if k.startswith("encoder.layers.3."):
+            assert g is None or float(g.abs().max()) == 0.0          # a dropped layer takes no part in the step
+            continue
+        pack(f"grad::{k}", g, out)
+    print(f"   S={S} T={T}: {len(log)} dropout calls recorded, layers {[l for l in range(12) if skip[l]]} skipped, "
+          f"{int(spec['mask'].sum())} frames replaced by masked_spec_embed, |h| = {float(hs.norm()):.3f}")
+    save("g13_wav2vec2_train_masks", out)
+
+
+ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G10": g10, "G12": g12, "G13": g13}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

@@ -97,3 +97,82 @@ def test_featenc0_fwd_bwd(S, N):
         res.append([t.cpu() for t in (out, stats[:, 0], dw, dg, db, dy)])
     for g, r, name in zip(res[0], res[1], ("out", "mean", "dw", "dgamma", "dbeta", "dy")):
         assert rel_l2(g, r) < 2e-5, name
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# train-mode dropout: the keep-mask generator, the streaming apply pass, the a2f_mm epilogue and the attention kernels
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,C,p", [(1, 4, 0.1), (77, 768, 0.1), (600, 3072, 0.25), (5, 100, 0.0)])
+def test_keep_bits_is_philox_bit_for_bit(R, C, p):
+    """a2f_keep_bits against the numpy restatement of its contract (Philox4x32-10, counter = (column / 4, row, site), keep iff
+    word >= p 2^32): every word equal; the bits beyond C are zero."""
+    from emu_backend import philox_keep_words
+    wpr = (C + 31) // 32 + (1 if R == 77 else 0)                # a padded row pitch is allowed
+    seed, site = 0x1234_5678_9ABC_DEF0 >> 1, 9
+    bits = torch.full((R, wpr), -1, dtype=torch.int32, device=DEV)
+    ops.HipBackend().keep_bits(seed, site, R, C, p, bits)
+    assert torch.equal(bits.cpu(), torch.from_numpy(philox_keep_words(seed, site, R, C, p, wpr)))
+
+
+@pytest.mark.parametrize("SH,T", [(3, 30), (2, 64), (24, 600), (1, 129)])
+def test_keep_bits_attn_two_layouts_describe_one_mask(SH, T):
+    from emu_backend import philox_keep_words, unpack_keep_bits
+    be = ops.HipBackend()
+    TW = be.attn_keep_words(T)
+    q = torch.zeros(SH * T, TW, dtype=torch.int32, device=DEV)
+    k = torch.zeros(SH, TW, 32 * TW, dtype=torch.int32, device=DEV)
+    be.keep_bits_attn(77, 6, SH, T, 0.1, q, k)
+    assert torch.equal(q.cpu(), torch.from_numpy(philox_keep_words(77, 6, SH * T, T, 0.1, TW)))
+    mq = unpack_keep_bits(q.cpu(), T).view(SH, T, T)                                                       # [sh][query][key]
+    mk = unpack_keep_bits(k.cpu().transpose(1, 2).reshape(SH * 32 * TW, TW), 32 * TW).view(SH, 32 * TW, 32 * TW)     # [sh][key][query]
+    assert torch.equal(mk[:, :T, :T].transpose(1, 2), mq)
+    assert not bool(mk[:, T:].any()) and not bool(mk[:, :, T:].any())
+    assert abs(float(mq.float().mean()) - 0.9) < 0.02
+
+
+def test_dropout_apply_and_mm_epilogue_keep():
+    from a2f_amd.dropout import pack_keep_bits
+    from a2f_amd.ops import MM_ACT_GELU, MM_AUX_ADD, MMOp
+    M, N, K = 333, 200, 96
+    gen = torch.Generator().manual_seed(3)
+    mask = torch.rand(M, N, generator=gen) > 0.2
+    x, W, b, res = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=0.2), rnd(N, seed=6), rnd(M, N, seed=7)
+    outs = []
+    for be, dev in ((ops.HipBackend(), DEV), (EmuBackend(), "cpu")):
+        bits = pack_keep_bits(mask).to(dev)
+        y = torch.zeros(M, N, device=dev)
+        be.dropout_apply(res.to(dev), bits, M, N, N, 1.25, y)
+        c, c2 = torch.zeros(M, N, device=dev), torch.zeros(M, N, device=dev)
+        be.mm(MMOp(x.to(dev), K), MMOp(W.to(dev), K), c, M, N, K, N, bias=b.to(dev), act=MM_ACT_GELU, C2=c2, aux=res.to(dev), ldaux=N, aux_mode=MM_AUX_ADD,
+              keep=(bits, 1.25))
+        cs = torch.zeros(N, K, device=dev)                     # the same through the split-K fold kernel's epilogue
+        be.mm(MMOp(res.to(dev), N, trans=True), MMOp(x.to(dev), K, trans=True), cs, N, K, M, K, split_k=3, keep=(pack_keep_bits(mask[:N, :K].contiguous()).to(dev), 2.0))
+        outs.append([t.cpu() for t in (y, c, c2, cs)])
+    assert torch.equal(outs[0][0], torch.where(mask, res * 1.25, torch.zeros(())))
+    for a, e, name in zip(outs[0][1:], outs[1][1:], ("C", "C2", "split-K C")):
+        assert rel_l2(a, e) < 3e-5, name
+    assert bool((outs[0][1] == res)[~mask].all())              # dropped elements: exactly the residual
+
+
+@pytest.mark.parametrize("S,T,H", [(1, 30, 12), (2, 64, 2), (1, 600, 12), (3, 129, 4)])
+@pytest.mark.parametrize("precision,tol", [(1, 3e-5), (0, 2e-2)])
+def test_attention_with_probability_dropout(S, T, H, precision, tol):
+    """a2f_attn_fwd_drop / a2f_attn_bwd_drop against softmax -> mask / (1 - p) -> @ v and its autograd in float64, with an
+    injected (torch-drawn) mask packed in both layouts."""
+    from a2f_amd.dropout import pack_keep_bits_attn
+    ld, ldo = 3 * 64 * H, 64 * H
+    qkv = rnd(S * T, ld, seed=1, scale=1.0)
+    qkv[:, :64 * H] *= 2.0
+    dctx = rnd(S * T, ldo, seed=2)
+    mask = torch.rand(S * H, T, T, generator=torch.Generator().manual_seed(8)) >= 0.1
+    kq, kk = pack_keep_bits_attn(mask)
+    res = []
+    for be, dev in ((ops.HipBackend(), DEV), (EmuBackend(), "cpu")):
+        ctx, lse, dqkv = torch.zeros(S * T, ldo, device=dev), torch.zeros(S, H, T, device=dev), torch.zeros(S * T, ld, device=dev)
+        be.attn_fwd_drop(qkv.to(dev), S, T, H, ld, 0.125, ctx, ldo, lse, kq.to(dev), 1 / 0.9, precision=precision)
+        be.attn_bwd_drop(qkv.to(dev), ctx, dctx.to(dev), lse, S, T, H, ld, ldo, 0.125, dqkv, kq.to(dev), kk.to(dev), 1 / 0.9, precision=precision)
+        res.append([t.cpu() for t in (ctx, lse, dqkv)])
+    for a, e, name in zip(res[0], res[1], ("ctx", "lse", "dqkv")):
+        assert rel_l2(a, e) < tol, name
+    for off, name in ((0, "dq"), (64 * H, "dk"), (128 * H, "dv")):
+        assert rel_l2(res[0][2][:, off:off + 64 * H], res[1][2][:, off:off + 64 * H]) < tol, name

@@ -753,6 +753,7 @@ def test_faceformer_pipelined_step_equals_single_stream_step(S, T):
     blocks); and equal within the summation-order noise of the weight-gradient GEMMs to the unsplit batch step."""
     m, _, _ = _faceformer_full()
     m.train()
+    m.audio_encoder.train_regularisers = False          # every call of this comparison must compute the same function
     gen = torch.Generator().manual_seed(77)
     audio = (torch.randn(S, T * 16000 // 60 + 8, generator=gen) * 0.1).to(DEV)
     oh = torch.zeros(S, 12); oh[torch.arange(S), torch.arange(S) % 8] = 1
@@ -788,3 +789,37 @@ def test_faceformer_pipelined_step_equals_single_stream_step(S, T):
                 assert rel_l2(got[k].cpu(), whole[k].cpu()) < TOL, k
         keys = sorted(halves)
         assert rel_l2(torch.cat([got[k].flatten() for k in keys]).cpu(), torch.cat([whole[k].flatten() for k in keys]).cpu()) < 2e-5
+
+
+def test_wav2vec2_train_mode_with_reference_masks_g13():
+    """The hand-written encoder in TRAIN mode on the GPU, fed every mask the reference drew in its own train-mode forward (fixture
+    G13: dropout at the 6 kinds of sites, LayerDrop of layers 3 and 8, SpecAugment rows): last_hidden_state and the recorded
+    parameter gradients of the reference within the parity bar."""
+    from test_train_regularisers_cpu import check_against_g13, g13_model_and_input
+    g, m, wave, S, T = g13_model_and_input(DEV)
+    hs = m(wave, "vocaset", frame_num=T).last_hidden_state
+    assert m.last_masks is m.injected_masks
+    check_against_g13(g, m, hs, T, TOL, TOL)
+
+
+def test_wav2vec2_drawn_masks_on_gpu():
+    """Masks drawn on the device from torch's generator: reproducible from the seed, different between steps, absent in eval mode;
+    about one element in ten is dropped at each site."""
+    from a2f_amd.dropout import unpack_keep_bits
+    m, _, _ = _faceformer_full()
+    enc = m.audio_encoder.train()
+    T = 30
+    wave = torch.randn(2, T * 16000 // 60 + 8, generator=torch.Generator().manual_seed(3)).to(DEV)
+    torch.manual_seed(5)
+    a = enc(wave, "vocaset", frame_num=T).last_hidden_state.detach()
+    masks = enc.last_masks
+    torch.manual_seed(5)
+    b = enc(wave, "vocaset", frame_num=T).last_hidden_state.detach()
+    c = enc(wave, "vocaset", frame_num=T).last_hidden_state.detach()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    for bits, cols in ((masks.featproj[0], 768), (masks.layers[0]["act"][0], 3072), (masks.layers[5]["attn"][0], T)):
+        assert abs(float(unpack_keep_bits(bits, cols).float().mean()) - 0.9) < 0.02
+    assert masks.spec is not None and int(masks.spec.sum()) >= 2 * 10
+    enc.eval()
+    d = enc(wave, "vocaset", frame_num=T).last_hidden_state.detach()
+    assert enc.last_masks is None and rel_l2(a, d) > 1e-3

@@ -253,7 +253,7 @@ def test_hip_encoder_composition_matches_oracle(emu):
     d/d(waveform) and every parameter gradient of the first layers (two sequences, T = 12)."""
     from a2f_amd.model.wav2vec import Wav2Vec2Model
     from oracle import wav2vec2 as o_w2v
-    m = Wav2Vec2Model(layers=2)
+    m = Wav2Vec2Model(layers=2).eval()                 # the deterministic function (train mode: tests/test_train_regularisers_cpu.py)
     sd = {k: v for k, v in W.formula_state_dict(W.wav2vec2_shapes(layers=2), gains={"original0": 40.0}).items()}
     m.load_state_dict(sd)
     T = 12

@@ -58,12 +58,31 @@ __device__ __forceinline__ float wave_layernorm_bwd(float dxhat, float xhat, flo
   return rstd * (dxhat - m1 - xhat * m2);
 }
 
+// Train-mode dropout (DROP variants).  The reference's decoder / PPE dropout (p = 0.1: faceformer.py:73,88; nn.TransformerDecoderLayer's
+// dropout, dropout1..3 and the attention-probability dropout of its MultiheadAttention) redraws every mask at EVERY step of the O(T^3)
+// loop, for all rows of the growing prefix - row j at step i then differs from row j at step j, and that function has no incremental
+// evaluation.  Here a mask belongs to its ROW (frame), not to the loop step: the frame keeps the mask it drew when it was first computed.
+// Per step the marginal distribution is the reference's; with masks fixed per row the reference's own loop is causal-consistent again and
+// equals this recurrence, which is how the variant is pinned (tests/golden/gen_golden.py G14: the reference run with its dropout calls
+// replaced by per-row masks, the same masks injected here).  Keep bits (csrc/dropout.hip layout): `row` (S*T, 10 words): columns 0..63 PPE
+// output, 64..127 self-attention output (dropout1), 128..255 feed-forward activation, 256..319 feed-forward output (dropout3); `attn`
+// (S*4*T, TW words): frame i, head h -> bit j = key j.  Cross-attention dropout and dropout2 act on the `cross` rows before this kernel.
+struct FFDrop {
+  const unsigned* row;
+  const unsigned* attn;
+  int TW;
+  float scale;
+};
+constexpr int FF_ROW_WORDS = 10;
+
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
+template <bool DROP>
 __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_fwd_kernel(const float* __restrict__ P, const float* __restrict__ pe,
                                                                         const float* __restrict__ cross, const float* __restrict__ style,
-                                                                        int T, int period, float* __restrict__ y, float* __restrict__ save) {
+                                                                        int T, int period, float* __restrict__ y, float* __restrict__ save,
+                                                                        const FFDrop dm) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __builtin_amdgcn_s_setprio(3);          // a latency-bound chain: when it shares a CU with GEMM waves of another stream (the pipelined step), its waves issue first
   float* WqkvT = lds;                       // [64][192]  WqkvT[k*192 + o] = Wqkv[o][k]
@@ -109,8 +128,10 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_fwd_kernel(const flo
 
   for (int i = 0; i < T; ++i) {
     float* sv = svbase + (int64_t)i * SV_STRIDE;
+    const unsigned* rowbits = DROP ? dm.row + (s * T + i) * FF_ROW_WORDS : nullptr;
     if (wave == 0) {
-      const float x = emb + pe[(i % period) * FD + lane];       // periodic positional encoding, dropout off
+      float x = emb + pe[(i % period) * FD + lane];             // periodic positional encoding
+      if constexpr (DROP) x = ((rowbits[lane >> 5] >> (lane & 31)) & 1u) ? x * dm.scale : 0.f;
       xs[lane] = x;
       sv[SV_X + lane] = x;
     }
@@ -134,13 +155,17 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_fwd_kernel(const flo
       // A slot past i re-reads row i (always valid memory) and is masked out.
       float mrun = -INFINITY, lsum = 0.f;
       float4 cacc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const unsigned* abits = DROP ? dm.attn + ((s * FH + wave) * T + i) * dm.TW : nullptr;     // this frame's, this head's keys
       for (int j0 = js; j0 <= i; j0 += 16 * FA_U) {
         float4 kk[FA_U], vv[FA_U];
+        unsigned kw[FA_U];
 #pragma unroll
         for (int u = 0; u < FA_U; ++u) {
-          const int64_t off = (int64_t)min(j0 + 16 * u, i) * SV_STRIDE;
+          const int jj = min(j0 + 16 * u, i);
+          const int64_t off = (int64_t)jj * SV_STRIDE;
           kk[u] = *reinterpret_cast<const float4*>(kbase + off);
           vv[u] = *reinterpret_cast<const float4*>(vbase + off);
+          if constexpr (DROP) kw[u] = abits[jj >> 5];
         }
 #pragma unroll
         for (int u = 0; u < FA_U; ++u) {
@@ -153,9 +178,11 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_fwd_kernel(const flo
           const float mnew = fmaxf(mrun, p);
           const float sc = mnew == -INFINITY ? 1.f : expf(mrun - mnew);
           const float e = valid ? expf(p - mnew) : 0.f;
-          lsum = lsum * sc + e;
-          cacc.x = cacc.x * sc + e * vv[u].x; cacc.y = cacc.y * sc + e * vv[u].y;
-          cacc.z = cacc.z * sc + e * vv[u].z; cacc.w = cacc.w * sc + e * vv[u].w;
+          lsum = lsum * sc + e;                                    // the normaliser keeps every key; only the value sum is thinned
+          float ev = e;
+          if constexpr (DROP) ev = ((kw[u] >> (j & 31)) & 1u) ? e * dm.scale : 0.f;
+          cacc.x = cacc.x * sc + ev * vv[u].x; cacc.y = cacc.y * sc + ev * vv[u].y;
+          cacc.z = cacc.z * sc + ev * vv[u].z; cacc.w = cacc.w * sc + ev * vv[u].w;
           mrun = mnew;
         }
       }
@@ -185,6 +212,7 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_fwd_kernel(const flo
       float sa = bo;
 #pragma unroll 16
       for (int k = 0; k < FD; ++k) sa += WoT[k * FD + lane] * cs[k];
+      if constexpr (DROP) sa = ((rowbits[2 + (lane >> 5)] >> (lane & 31)) & 1u) ? sa * dm.scale : 0.f;     // dropout1
       float rstd;
       float xh = wave_layernorm(xs[lane] + sa, rstd);                       // norm1(x + self_attn)
       sv[SV_XH1 + lane] = xh;
@@ -202,6 +230,7 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_fwd_kernel(const flo
 #pragma unroll
       for (int k = 0; k < FD; ++k) acc += w1r[k] * y2s[k];
       acc = fmaxf(acc, 0.f);
+      if constexpr (DROP) acc = ((rowbits[4 + (t >> 5)] >> (t & 31)) & 1u) ? acc * dm.scale : 0.f;          // dropout after the activation
       hs[t] = acc;
       sv[SV_H + t] = acc;
     }
@@ -214,7 +243,8 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_fwd_kernel(const flo
     }
     __syncthreads();
     if (wave == 0) {
-      const float f = b2 + part[lane] + part[FD + lane] + part[2 * FD + lane] + part[3 * FD + lane];
+      float f = b2 + part[lane] + part[FD + lane] + part[2 * FD + lane] + part[3 * FD + lane];
+      if constexpr (DROP) f = ((rowbits[8 + (lane >> 5)] >> (lane & 31)) & 1u) ? f * dm.scale : 0.f;         // dropout3
       float rstd;
       const float xh = wave_layernorm(y2 + f, rstd);                        // norm3(y2 + ffn)
       sv[SV_XH3 + lane] = xh;
@@ -236,9 +266,10 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_fwd_kernel(const flo
 // =====================================================================================================================
 // backward (reverse time)
 // =====================================================================================================================
+template <bool DROP>
 __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dy, int T,
                                                                         int period, float* __restrict__ save,
-                                                                        float* __restrict__ dcross, float* __restrict__ dstyle) {
+                                                                        float* __restrict__ dcross, float* __restrict__ dstyle, const FFDrop dm) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __builtin_amdgcn_s_setprio(3);          // a latency-bound chain: when it shares a CU with GEMM waves of another stream (the pipelined step), its waves issue first
   float* Wqkv = lds;                        // [192][64] row-major: lane = input index for the transposed products
@@ -300,6 +331,7 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
   for (int i = T - 1; i >= 0; --i) {
     float* sv = svbase + (int64_t)i * SV_STRIDE;
     float dy2 = 0.f, xh2 = 0.f, xh1 = 0.f;
+    const unsigned* rowbits = DROP ? dm.row + (s * T + i) * FF_ROW_WORDS : nullptr;
     // ---- S1: stage saved vectors; wave 0: LayerNorm-3 backward ----
     if (wave == 0) {
       const float xh3 = sv[SV_XH3 + lane];
@@ -309,8 +341,10 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
       gb3n += dy3;
       const float du3 = wave_layernorm_bwd(dy3 * ln_g3, xh3, rstd3);
       dy2 = du3;                                       // residual branch of norm3(y2 + ffn)
-      dfs[lane] = du3;
-      gb2 += du3;
+      float df = du3;                                  // the feed-forward branch sees it through dropout3
+      if constexpr (DROP) df = ((rowbits[8 + (lane >> 5)] >> (lane & 31)) & 1u) ? du3 * dm.scale : 0.f;
+      dfs[lane] = df;
+      gb2 += df;
       ys[lane] = xh3 * ln_g3 + ln_b3;
       xh2 = sv[SV_XH2 + lane];
       y2s[lane] = xh2 * ln_g2 + ln_b2;
@@ -345,7 +379,8 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
     // ---- S3: ReLU backward ; dW1 += dhp (x) y2 ----
     if (t < FFF) {
       const float dh = pbuf[t] + pbuf[FFF + t];
-      const float dhp = hs[t] > 0.f ? dh : 0.f;
+      // hs is the activation AFTER its dropout: a dropped unit is 0 there, a kept one relu * scale - so (hs > 0) is both masks at once
+      const float dhp = hs[t] > 0.f ? (DROP ? dh * dm.scale : dh) : 0.f;
       dhps[t] = dhp;
       gbB += dhp;
 #pragma unroll
@@ -374,8 +409,10 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
       gg1 += du2 * xh1;
       gb1n += du2;
       const float du1 = wave_layernorm_bwd(du2 * ln_g1, xh1, rstd1);
-      dx = du1;                                        // u1 = x + self_attn(x)
-      dsas[lane] = du1;
+      dx = du1;                                        // u1 = x + dropout1(self_attn(x))
+      float dsa = du1;
+      if constexpr (DROP) dsa = ((rowbits[2 + (lane >> 5)] >> (lane & 31)) & 1u) ? du1 * dm.scale : 0.f;
+      dsas[lane] = dsa;
     }
     __syncthreads();
     // ---- S6: out-projection: dWo += dsa (x) ctx (wave 3) ; dctx = Wo^T dsa (wave 0) ----
@@ -408,15 +445,19 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
       rowsum += __shfl_xor(rowsum, 1, 64);
       rowsum += __shfl_xor(rowsum, 2, 64);
       float4 dqa = make_float4(0.f, 0.f, 0.f, 0.f);
+      const unsigned* abits = DROP ? dm.attn + ((s * FH + wave) * T + i) * dm.TW : nullptr;
       for (int j0 = js; j0 <= i; j0 += 16 * FB_U) {
         float4 kk[FB_U], vv[FB_U], dk[FB_U], dv[FB_U];
+        unsigned kw[FB_U];
 #pragma unroll
         for (int u = 0; u < FB_U; ++u) {
-          const int64_t off = (int64_t)min(j0 + 16 * u, i) * SV_STRIDE;
+          const int jj = min(j0 + 16 * u, i);
+          const int64_t off = (int64_t)jj * SV_STRIDE;
           kk[u] = *reinterpret_cast<const float4*>(kbase + off);
           vv[u] = *reinterpret_cast<const float4*>(vbase + off);
           dk[u] = *reinterpret_cast<const float4*>(dkbase + off);
           dv[u] = *reinterpret_cast<const float4*>(dvbase + off);
+          if constexpr (DROP) kw[u] = abits[jj >> 5];
         }
 #pragma unroll
         for (int u = 0; u < FB_U; ++u) {
@@ -429,12 +470,18 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
           da += __shfl_xor(da, 1, 64);
           da += __shfl_xor(da, 2, 64);
           const float a = valid ? expf(p - slope * (float)((i - min(j, i)) / period) - m) * invl : 0.f;
+          float ad = a;                                // ctx = sum_j a_j D_j v_j: dV sees a D, da_j = D_j (dctx . v_j); sum_j a_j da_j = dctx . ctx still
+          if constexpr (DROP) {
+            const float dj = ((kw[u] >> (min(j, i) & 31)) & 1u) ? dm.scale : 0.f;
+            ad = a * dj;
+            da *= dj;
+          }
           const float ds = a * (da - rowsum);
           dqa.x += ds * kk[u].x; dqa.y += ds * kk[u].y; dqa.z += ds * kk[u].z; dqa.w += ds * kk[u].w;
           if (valid) {
             const int64_t off = (int64_t)j * SV_STRIDE;
             *reinterpret_cast<float4*>(dkbase + off) = make_float4(dk[u].x + ds * qv.x, dk[u].y + ds * qv.y, dk[u].z + ds * qv.z, dk[u].w + ds * qv.w);
-            *reinterpret_cast<float4*>(dvbase + off) = make_float4(dv[u].x + a * dcv.x, dv[u].y + a * dcv.y, dv[u].z + a * dcv.z, dv[u].w + a * dcv.w);
+            *reinterpret_cast<float4*>(dvbase + off) = make_float4(dv[u].x + ad * dcv.x, dv[u].y + ad * dcv.y, dv[u].z + ad * dcv.z, dv[u].w + ad * dcv.w);
           }
         }
       }
@@ -465,7 +512,8 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
     __syncthreads();
     // ---- S10: wave 0: gradient w.r.t. emb_i; carry A^T demb to step i-1 ----
     if (wave == 0) {
-      const float demb = dx + pbuf[lane] + pbuf[FD + lane] + pbuf[2 * FD + lane] + pbuf[3 * FD + lane];
+      float demb = dx + pbuf[lane] + pbuf[FD + lane] + pbuf[2 * FD + lane] + pbuf[3 * FD + lane];
+      if constexpr (DROP) demb = ((rowbits[lane >> 5] >> (lane & 31)) & 1u) ? demb * dm.scale : 0.f;      // through the PPE dropout
       gsty += demb;                                    // style enters every emb (emb_0 = style, emb_i = A y + c + style)
       dembs[lane] = demb;
     }
@@ -535,43 +583,89 @@ extern "C" size_t a2f_ff_save_bytes(int64_t S, int64_t T) {
   return ((size_t)S * (size_t)T * a2f::SV_STRIDE + (size_t)S * A2F_FF_PARAM_FLOATS) * sizeof(float);
 }
 
-extern "C" int a2f_ff_decoder_fwd(const float* params, const float* pe, const float* cross, const float* style, int64_t S, int64_t T,
-                                  int32_t period, float* y, void* save, size_t save_bytes, a2f_stream_t stream) {
+static int ff_check_drop(const uint32_t* row_bits, const uint32_t* attn_bits, float keep_scale, const char* who) {
+  using namespace a2f;
+  A2F_CHECK_ARG(row_bits && attn_bits && keep_scale >= 1.f, "%s: null keep bits / keep_scale %g", who, (double)keep_scale);
+  return A2F_OK;
+}
+
+static int ff_fwd_impl(const float* params, const float* pe, const float* cross, const float* style, int64_t S, int64_t T, int32_t period, float* y,
+                       void* save, size_t save_bytes, const uint32_t* row_bits, const uint32_t* attn_bits, float keep_scale, a2f_stream_t stream) {
   using namespace a2f;
   A2F_CHECK_ARG(params && pe && cross && style && y && save, "ff_decoder_fwd: null pointer");
   A2F_CHECK_ARG(S > 0 && S < (1 << 20) && T > 0 && T < (1 << 20) && period > 0, "ff_decoder_fwd: S=%lld T=%lld period=%d", (long long)S, (long long)T, period);
   A2F_CHECK_ARG((((uintptr_t)save) & 255) == 0, "ff_decoder_fwd: save buffer must be 256-byte aligned");
   if (save_bytes < a2f_ff_save_bytes(S, T)) return set_err(A2F_EWORKSPACE, "ff_decoder_fwd: save buffer %zu < %zu", save_bytes, a2f_ff_save_bytes(S, T));
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_decoder_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FF_FWD_LDS);
+  static bool attr_set[2] = {false, false};
+  const bool drop = row_bits != nullptr;
+  if (!attr_set[drop]) {
+    const void* k = drop ? reinterpret_cast<const void*>(&ff_decoder_fwd_kernel<true>) : reinterpret_cast<const void*>(&ff_decoder_fwd_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FF_FWD_LDS);
     if (e != hipSuccess) return set_err(A2F_ELAUNCH, "ff_decoder_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
+    attr_set[drop] = true;
   }
-  hipLaunchKernelGGL(ff_decoder_fwd_kernel, dim3((unsigned)S), dim3(FF_THREADS), FF_FWD_LDS, (hipStream_t)stream, params, pe, cross, style, (int)T,
-                     (int)period, y, (float*)save);
+  const FFDrop dm{row_bits, attn_bits, (int)a2f_attn_keep_words(T), keep_scale};
+  if (drop)
+    hipLaunchKernelGGL(ff_decoder_fwd_kernel<true>, dim3((unsigned)S), dim3(FF_THREADS), FF_FWD_LDS, (hipStream_t)stream, params, pe, cross, style, (int)T,
+                       (int)period, y, (float*)save, dm);
+  else
+    hipLaunchKernelGGL(ff_decoder_fwd_kernel<false>, dim3((unsigned)S), dim3(FF_THREADS), FF_FWD_LDS, (hipStream_t)stream, params, pe, cross, style, (int)T,
+                       (int)period, y, (float*)save, dm);
   A2F_CHECK_LAUNCH("ff_decoder_fwd");
   return A2F_OK;
 }
 
-extern "C" int a2f_ff_decoder_bwd(const float* params, const float* dy, int64_t S, int64_t T, int32_t period, void* save, size_t save_bytes,
-                                  float* dparams, float* dcross, float* dstyle, a2f_stream_t stream) {
+static int ff_bwd_impl(const float* params, const float* dy, int64_t S, int64_t T, int32_t period, void* save, size_t save_bytes, float* dparams,
+                       float* dcross, float* dstyle, const uint32_t* row_bits, const uint32_t* attn_bits, float keep_scale, a2f_stream_t stream) {
   using namespace a2f;
   A2F_CHECK_ARG(params && dy && save && dparams && dcross && dstyle, "ff_decoder_bwd: null pointer");
   A2F_CHECK_ARG(S > 0 && S < (1 << 20) && T > 0 && T < (1 << 20) && period > 0, "ff_decoder_bwd: S=%lld T=%lld period=%d", (long long)S, (long long)T, period);
   A2F_CHECK_ARG((((uintptr_t)save) & 255) == 0, "ff_decoder_bwd: save buffer must be 256-byte aligned");
   if (save_bytes < a2f_ff_save_bytes(S, T)) return set_err(A2F_EWORKSPACE, "ff_decoder_bwd: save buffer %zu < %zu", save_bytes, a2f_ff_save_bytes(S, T));
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_decoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FF_BWD_LDS);
+  static bool attr_set[2] = {false, false};
+  const bool drop = row_bits != nullptr;
+  if (!attr_set[drop]) {
+    const void* k = drop ? reinterpret_cast<const void*>(&ff_decoder_bwd_kernel<true>) : reinterpret_cast<const void*>(&ff_decoder_bwd_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FF_BWD_LDS);
     if (e != hipSuccess) return set_err(A2F_ELAUNCH, "ff_decoder_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
+    attr_set[drop] = true;
   }
-  hipLaunchKernelGGL(ff_decoder_bwd_kernel, dim3((unsigned)S), dim3(FF_THREADS), FF_BWD_LDS, (hipStream_t)stream, params, dy, (int)T, (int)period,
-                     (float*)save, dcross, dstyle);
+  const FFDrop dm{row_bits, attn_bits, (int)a2f_attn_keep_words(T), keep_scale};
+  if (drop)
+    hipLaunchKernelGGL(ff_decoder_bwd_kernel<true>, dim3((unsigned)S), dim3(FF_THREADS), FF_BWD_LDS, (hipStream_t)stream, params, dy, (int)T, (int)period,
+                       (float*)save, dcross, dstyle, dm);
+  else
+    hipLaunchKernelGGL(ff_decoder_bwd_kernel<false>, dim3((unsigned)S), dim3(FF_THREADS), FF_BWD_LDS, (hipStream_t)stream, params, dy, (int)T, (int)period,
+                       (float*)save, dcross, dstyle, dm);
   A2F_CHECK_LAUNCH("ff_decoder_bwd");
   hipLaunchKernelGGL(ff_decoder_fold_kernel, dim3((unsigned)cdiv(A2F_FF_PARAM_FLOATS, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)save + (size_t)S * T * SV_STRIDE, (int)S, dparams);
   A2F_CHECK_LAUNCH("ff_decoder_bwd fold");
   return A2F_OK;
+}
+
+extern "C" int a2f_ff_decoder_fwd(const float* params, const float* pe, const float* cross, const float* style, int64_t S, int64_t T,
+                                  int32_t period, float* y, void* save, size_t save_bytes, a2f_stream_t stream) {
+  return ff_fwd_impl(params, pe, cross, style, S, T, period, y, save, save_bytes, nullptr, nullptr, 1.f, stream);
+}
+
+extern "C" int a2f_ff_decoder_bwd(const float* params, const float* dy, int64_t S, int64_t T, int32_t period, void* save, size_t save_bytes,
+                                  float* dparams, float* dcross, float* dstyle, a2f_stream_t stream) {
+  return ff_bwd_impl(params, dy, S, T, period, save, save_bytes, dparams, dcross, dstyle, nullptr, nullptr, 1.f, stream);
+}
+
+extern "C" int a2f_ff_decoder_fwd_drop(const float* params, const float* pe, const float* cross, const float* style, int64_t S, int64_t T,
+                                       int32_t period, float* y, void* save, size_t save_bytes, const uint32_t* row_bits, const uint32_t* attn_bits,
+                                       float keep_scale, a2f_stream_t stream) {
+  int rc = ff_check_drop(row_bits, attn_bits, keep_scale, "ff_decoder_fwd_drop");
+  if (rc) return rc;
+  return ff_fwd_impl(params, pe, cross, style, S, T, period, y, save, save_bytes, row_bits, attn_bits, keep_scale, stream);
+}
+
+extern "C" int a2f_ff_decoder_bwd_drop(const float* params, const float* dy, int64_t S, int64_t T, int32_t period, void* save, size_t save_bytes,
+                                       float* dparams, float* dcross, float* dstyle, const uint32_t* row_bits, const uint32_t* attn_bits,
+                                       float keep_scale, a2f_stream_t stream) {
+  int rc = ff_check_drop(row_bits, attn_bits, keep_scale, "ff_decoder_bwd_drop");
+  if (rc) return rc;
+  return ff_bwd_impl(params, dy, S, T, period, save, save_bytes, dparams, dcross, dstyle, row_bits, attn_bits, keep_scale, stream);
 }

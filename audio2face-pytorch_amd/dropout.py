@@ -155,3 +155,45 @@ def draw_encoder_masks(be, S: int, T: int, n_layers: int, heads: int, hidden: in
     if cfg.apply_spec_augment and cfg.mask_time_prob > 0.0 and T > cfg.mask_time_length:
         m.spec = torch.from_numpy(compute_mask_indices((S, T), cfg.mask_time_prob, cfg.mask_time_length, min_masks=2, rng=rng)).to(device)
     return m
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# FaceFormer decoder / PPE dropout (faceformer.py:73,88; nn.TransformerDecoderLayer(dropout = 0.1 default) at faceformer.py:121-127)
+# ---------------------------------------------------------------------------------------------------------------------------
+class DecoderMasks:
+    """Per-row keep masks of the decoder recurrence (one mask per frame row - see csrc/ff_decoder.hip for why not per loop step):
+    ``row`` int32 (S*T, 10): columns 0..63 PPE output, 64..127 dropout1, 128..255 feed-forward activation, 256..319 dropout3;
+    ``attn`` int32 (S*4*T, TW): self-attention probabilities of (sequence, head, frame), bit = key; ``cross_v`` int32 (S*T, 2): the
+    cross-attention probability dropout - the diagonal memory mask (faceformer.py:58-66) leaves ONE key per frame, so that dropout
+    keeps or drops a whole head's value vector: one decision per (frame, head) spread over the head's 16 columns; ``cross_out`` int32
+    (S*T, 2): dropout2.  ``scale`` = 1 / (1 - p)."""
+
+    def __init__(self, row, attn, cross_v, cross_out, scale):
+        self.row, self.attn, self.cross_v, self.cross_out, self.scale = row, attn, cross_v, cross_out, float(scale)
+
+    @staticmethod
+    def from_recorded(rec: Dict, device, p: float = 0.1) -> "DecoderMasks":
+        """rec: bool arrays "ppe" (S*T, 64), "d1" (S*T, 64), "act" (S*T, 128), "d3" (S*T, 64), "attn" (S*4, T, T) [head-major rows s*4 + h],
+        "cross_head" (S*T, 4), "d2" (S*T, 64)."""
+        t = lambda a: torch.as_tensor(np.asarray(a)).to(device).bool()
+        row = pack_keep_bits(torch.cat([t(rec["ppe"]), t(rec["d1"]), t(rec["act"]), t(rec["d3"])], dim=1))
+        a = t(rec["attn"])
+        SH, T, _ = a.shape
+        attn = pack_keep_bits(torch.nn.functional.pad(a.reshape(SH * T, T), (0, 32 * attn_keep_words(T) - T)))
+        cross_v = pack_keep_bits(t(rec["cross_head"]).repeat_interleave(16, dim=1))
+        return DecoderMasks(row, attn, cross_v, pack_keep_bits(t(rec["d2"])), 1.0 / (1.0 - p))
+
+
+def draw_decoder_masks(be, S: int, T: int, p: float, seed: int, device) -> DecoderMasks:
+    """Masks of one step from ``seed`` (sites 1000 row block, 1001 self-attention, 1002 cross-attention heads, 1003 dropout2)."""
+    M = S * T
+    row = torch.empty(M, 10, dtype=torch.int32, device=device)
+    be.keep_bits(seed, 1000, M, 320, p, row)
+    attn = torch.empty(S * 4 * T, attn_keep_words(T), dtype=torch.int32, device=device)
+    be.keep_bits(seed, 1001, S * 4 * T, T, p, attn)
+    heads = torch.empty(M, 1, dtype=torch.int32, device=device)
+    be.keep_bits(seed, 1002, M, 4, p, heads)
+    cross_v = pack_keep_bits(unpack_keep_bits(heads, 4).repeat_interleave(16, dim=1))
+    cross_out = torch.empty(M, 2, dtype=torch.int32, device=device)
+    be.keep_bits(seed, 1003, M, 64, p, cross_out)
+    return DecoderMasks(row, attn, cross_v, cross_out, 1.0 / (1.0 - p))

@@ -744,15 +744,20 @@ class FFDecoderFn(torch.autograd.Function):
     """(params block (A2F_FF_PARAM_FLOATS,), pe (period,64), cross (S,T,64), style (S,64)) -> y (S,T,64)."""
 
     @staticmethod
-    def forward(ctx, params, pe, cross, style, period):
+    def forward(ctx, params, pe, cross, style, period, drop=None):
+        """drop = (row_bits, attn_bits, keep_scale): train-mode variant with one dropout mask per frame row (a2f_ff_decoder_fwd_drop)."""
         be = ops.backend()
         pc, pec, cc, sc = _f32c(params), _f32c(pe), _f32c(cross), _f32c(style)
         S, T, _ = cc.shape
         y = torch.empty(S, T, 64, device=cc.device, dtype=torch.float32)
         save = torch.empty(be.ff_save_floats(S, T), device=cc.device, dtype=torch.float32)
-        be.ff_decoder_fwd(pc, pec, cc, sc, S, T, int(period), y, save)
+        if drop is None:
+            be.ff_decoder_fwd(pc, pec, cc, sc, S, T, int(period), y, save)
+        else:
+            be.ff_decoder_fwd(pc, pec, cc, sc, S, T, int(period), y, save, drop=drop)
         ctx.save_for_backward(pc, save)
         ctx.dims = (S, T, int(period))
+        ctx.drop = drop
         return y
 
     @staticmethod
@@ -764,8 +769,11 @@ class FFDecoderFn(torch.autograd.Function):
         dparams = torch.empty_like(pc)            # overwritten (per-sequence slabs folded in fixed order)
         dcross = torch.empty(S, T, 64, device=dy.device, dtype=torch.float32)
         dstyle = torch.empty(S, 64, device=dy.device, dtype=torch.float32)
-        be.ff_decoder_bwd(pc, dy, S, T, period, save, dparams, dcross, dstyle)
-        return dparams, None, dcross, dstyle, None
+        if ctx.drop is None:
+            be.ff_decoder_bwd(pc, dy, S, T, period, save, dparams, dcross, dstyle)
+        else:
+            be.ff_decoder_bwd(pc, dy, S, T, period, save, dparams, dcross, dstyle, drop=ctx.drop)
+        return dparams, None, dcross, dstyle, None, None
 
 
 # =================================================================================================

@@ -9,8 +9,13 @@ What differs is how the same function is evaluated: the reference
 kernel per sequence with a K/V cache, the diagonal cross-attention is a per-frame vector computed by two GEMMs, the
 feedback ``vertice_map(vertice_map_r(y))`` is the collapsed 64x64 map ``A y + c``, and the 15069-wide head runs once
 per frame (fused with the loss in training).  Closed forms replace the materialised (4,600,600) bias table and the
-660-row PPE buffer, so T is not limited to 600.  Dropout is not applied (the reference is stochastic in train mode;
-parity is defined for dropout off) - see DESIGN.md.
+660-row PPE buffer, so T is not limited to 600.
+
+Train mode (what Lightning puts the reference's module in): the encoder applies the reference's dropout / LayerDrop / SpecAugment
+(model/wav2vec.py, pinned by fixture G13); the decoder / PPE dropout 0.1 is applied with one mask per frame ROW instead of a fresh
+mask per loop step (the reference's redraw makes row j at step i differ from row j at step j - a function with no incremental
+evaluation; per-row masks keep the per-step distribution and make the reference's own loop equal this recurrence: fixture G14).
+`.eval()` - and `decoder_regularisers = False` / `audio_encoder.train_regularisers = False` - give the deterministic function.
 
 The constructor does not download anything: the reference's ``from_pretrained`` calls need the network; load
 pretrained wav2vec2 weights with ``model.audio_encoder.load_state_dict(...)`` (HF key names).
@@ -101,30 +106,42 @@ class Faceformer(nn.Module):
             return h.float()
         return self.audio_encoder(wave, self.dataset, frame_num=frame_num).last_hidden_state
 
+    # Train mode: decoder / PPE dropout 0.1 (faceformer.py:73,88,121-127) with one mask per frame row (csrc/ff_decoder.hip explains why
+    # not per loop step; fixture G14 pins it), drawn per forward from torch's CPU generator or injected (tests);
+    # `decoder_regularisers = False` keeps the deterministic function in train mode.  The encoder's own regularisers: model/wav2vec.py.
+    decoder_dropout = 0.1
+    decoder_regularisers = True
+    injected_decoder_masks = None
+
+    def _decoder_masks(self, S, T, device):
+        if not (self.training and self.decoder_regularisers and self.decoder_dropout > 0.0):
+            return None
+        if self.injected_decoder_masks is not None:
+            return self.injected_decoder_masks
+        from .. import ops
+        from ..dropout import draw_decoder_masks
+        return draw_decoder_masks(ops.backend(), S, T, self.decoder_dropout, int(torch.randint(0, 2 ** 62, (1,)).item()), device)
+
     def decode_hidden(self, enc, one_hot):
         """enc (S,T,768), one_hot (S,n_onehot) -> decoder rows y (S,T,64)."""
         S, T, _ = enc.shape
         L = self.transformer_decoder.layers[0]
         d = self.feature_dim
+        dm = self.last_decoder_masks = self._decoder_masks(S, T, enc.device)
         mem = LinearFn.apply(enc.reshape(S * T, -1), self.audio_feature_map.weight, self.audio_feature_map.bias)     # :152
         mw, mb = L.multihead_attn.in_proj_weight, L.multihead_attn.in_proj_bias
         v = LinearFn.apply(mem, mw[2 * d:], mb[2 * d:])                      # diagonal enc-dec mask: softmax over one key
-        cross = LinearFn.apply(v, L.multihead_attn.out_proj.weight, L.multihead_attn.out_proj.bias).view(S, T, d)
+        if dm is not None:                                                    # ... whose probability (1) the attention dropout keeps or drops per head
+            from ..encoder_ops import DropoutFn
+            v = DropoutFn.apply(v, dm.cross_v, dm.scale)
+        cross = LinearFn.apply(v, L.multihead_attn.out_proj.weight, L.multihead_attn.out_proj.bias)
+        if dm is not None:
+            cross = DropoutFn.apply(cross, dm.cross_out, dm.scale)            # dropout2
         style = LinearFn.apply(one_hot, self.obj_vector.weight, None)       # (S,64)  :148
-        return FFDecoderFn.apply(self._packed_decoder_params(), self.PPE.table(), cross, style, self.period)
+        return FFDecoderFn.apply(self._packed_decoder_params(), self.PPE.table(), cross.view(S, T, d), style, self.period,
+                                 (dm.row, dm.attn, dm.scale) if dm is not None else None)
 
-    _warned_train_mode = False
-
-    def _note_train_mode(self):
-        """The reference's train mode adds stochastic regularisers that redraw their masks at EVERY step of its O(T^3) loop
-        (decoder / PPE dropout 0.1, faceformer.py:73,88,121-127) plus wav2vec2's dropout / layerdrop / SpecAugment
-        (wav2vec.py:25-72,149-173).  The incremental evaluation computes the deterministic function (what `.eval()` gives
-        the reference); training here is therefore un-regularised - say so once instead of silently differing."""
-        if self.training and not Faceformer._warned_train_mode:
-            import warnings
-            warnings.warn("a2f_amd.Faceformer in train mode: the reference's stochastic regularisers (decoder/PPE dropout, wav2vec2 "
-                          "dropout / layerdrop / SpecAugment) are not applied; gradients are those of the deterministic (eval-mode) function")
-            Faceformer._warned_train_mode = True
+    last_decoder_masks = None
 
     # ------------------------------------------------------------------ reference surface
     def forward(self, audio, one_hot, template, **kwargs):
@@ -143,7 +160,6 @@ class Faceformer(nn.Module):
     def forward_with_loss(self, audio, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0, unit_grad: bool = False, **kwargs):
         """Training fast path = forward + FaceFormerLoss (loss.py:4-17) with the head, the loss and the head backward
         fused into one pass; the odd tail frame is predicted but left out of the loss, as the reference does."""
-        self._note_train_mode()
         frame_num = audio.shape[1] * 60 // 16000
         enc = kwargs.get("encoder_states")
         if enc is None:
@@ -179,7 +195,6 @@ class Faceformer(nn.Module):
         audio (S,N), one_hot (S,n_onehot), template (S,V,3), gt (S,T,V,3).  The encoder runs batched, the decoder
         recurrence launches one workgroup per sequence, the fused head takes all frames at once (`_head_loss_batch`).
         Returns (pred (S,T,V,3), mean loss dict)."""
-        self._note_train_mode()
         frame_num = audio.shape[1] * 60 // 16000
         enc = self.encode(audio, frame_num)
         y = self.decode_hidden(enc, one_hot)                                  # (S,T,64)
@@ -203,7 +218,6 @@ class Faceformer(nn.Module):
         right after its forward (`backward(inputs=...)` on the side stream); d loss / d encoder-output then seeds the encoder
         backward on the main stream.  The arithmetic per sequence is that of `forward_with_loss_batch` (same kernels); only the order
         in which the two halves' gradients are added differs.  Returns the loss dict (detached values, mean over the S sequences)."""
-        self._note_train_mode()
         S = audio.shape[0]
         assert S >= 2 and audio.is_cuda
         frame_num = audio.shape[1] * 60 // 16000

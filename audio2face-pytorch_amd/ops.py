@@ -391,13 +391,26 @@ class HipBackend:
     def ff_save_floats(self, S, T):
         return self.lib.a2f_ff_save_bytes(S, T) // 4
 
-    def ff_decoder_fwd(self, params, pe, cross, style, S, T, period, y, save):
+    def ff_decoder_fwd(self, params, pe, cross, style, S, T, period, y, save, drop=None):
+        """drop = (row_bits int32 (S*T, 10), attn_bits int32 (S*4*T, TW), keep_scale): the train-mode variant (per-row masks)."""
         _chk(params, pe, cross, style, y, save)
+        if drop is not None:
+            _chk_bits(drop[0], drop[1])
+            _lib.check(self.lib.a2f_ff_decoder_fwd_drop(_ptr(params), _ptr(pe), _ptr(cross), _ptr(style), S, T, period, _ptr(y), _ptr(save),
+                                                        save.numel() * 4, drop[0].data_ptr(), drop[1].data_ptr(), float(drop[2]), self._stream(y)),
+                       "a2f_ff_decoder_fwd_drop")
+            return
         _lib.check(self.lib.a2f_ff_decoder_fwd(_ptr(params), _ptr(pe), _ptr(cross), _ptr(style), S, T, period, _ptr(y), _ptr(save),
                                                save.numel() * 4, self._stream(y)), "a2f_ff_decoder_fwd")
 
-    def ff_decoder_bwd(self, params, dy, S, T, period, save, dparams, dcross, dstyle):
+    def ff_decoder_bwd(self, params, dy, S, T, period, save, dparams, dcross, dstyle, drop=None):
         _chk(params, dy, save, dparams, dcross, dstyle)
+        if drop is not None:
+            _chk_bits(drop[0], drop[1])
+            _lib.check(self.lib.a2f_ff_decoder_bwd_drop(_ptr(params), _ptr(dy), S, T, period, _ptr(save), save.numel() * 4, _ptr(dparams), _ptr(dcross),
+                                                        _ptr(dstyle), drop[0].data_ptr(), drop[1].data_ptr(), float(drop[2]), self._stream(dy)),
+                       "a2f_ff_decoder_bwd_drop")
+            return
         _lib.check(self.lib.a2f_ff_decoder_bwd(_ptr(params), _ptr(dy), S, T, period, _ptr(save), save.numel() * 4,
                                                _ptr(dparams), _ptr(dcross), _ptr(dstyle), self._stream(dy)), "a2f_ff_decoder_bwd")
 

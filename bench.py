@@ -438,7 +438,7 @@ def main():
             hev = be.prof.get("head_fused", [])
             if hev:
                 hms = sum(a.elapsed_time(b) for a, b in hev) / len(hev)
-                hb = ALGO_BYTES_PER_FRAME["head_fused_ff"] * (T if len(hev) > 2 else S * T)
+                hb = ALGO_BYTES_PER_FRAME["head_fused_ff"] * (2 * S * T / len(hev))          # frames per launch over the 2 profiled steps
                 roof["head_hbm"] = {"kernel": "head_x3_kernel<64> + fold", "achieved": round(hb / (hms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(hb / (hms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(hms, 4), "launches_timed": len(hev)}
             be.prof = None

@@ -238,6 +238,19 @@ int a2f_ff_decoder_fwd(const float* params, const float* pe, const float* cross,
  * scratch for this call. */
 int a2f_ff_decoder_bwd(const float* params, const float* dy, int64_t S, int64_t T, int32_t period, void* save,
                        size_t save_bytes, float* dparams, float* dcross, float* dstyle, a2f_stream_t stream);
+/* Train-mode variants: dropout 0.1 of the PPE output (faceformer.py:73,88) and of nn.TransformerDecoderLayer's self-attention
+ * probabilities, dropout1, feed-forward activation dropout and dropout3, with ONE mask per frame row (the reference redraws the
+ * masks of all prefix rows at every loop step, which has no incremental evaluation; per-row masks keep its per-step distribution
+ * and make its own loop causal-consistent - fixture G14 pins this variant on the reference run with per-row masks injected).
+ * Keep bits (a2f_keep_bits layout): row_bits (S*T, 10 words): columns 0..63 PPE output, 64..127 dropout1, 128..255 activation,
+ * 256..319 dropout3; attn_bits (S*4*T, a2f_attn_keep_words(T) words): row (s*4 + head)*T + frame, bit j = key j.  Cross-attention
+ * dropout / dropout2 act on the `cross` rows before the call.  keep_scale = 1 / (1 - p). */
+int a2f_ff_decoder_fwd_drop(const float* params, const float* pe, const float* cross, const float* style, int64_t S, int64_t T,
+                            int32_t period, float* y, void* save, size_t save_bytes, const uint32_t* row_bits, const uint32_t* attn_bits,
+                            float keep_scale, a2f_stream_t stream);
+int a2f_ff_decoder_bwd_drop(const float* params, const float* dy, int64_t S, int64_t T, int32_t period, void* save, size_t save_bytes,
+                            float* dparams, float* dcross, float* dstyle, const uint32_t* row_bits, const uint32_t* attn_bits,
+                            float keep_scale, a2f_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Linear interpolation along time (align_corners = True) of channels-last feature rows: x (N, L_in, C) -> y (N, L_out, C),

@@ -454,8 +454,9 @@ class EmuBackend:
         return Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, ln, A, c
 
     @classmethod
-    def ff_spec(cls, params, pe, cross, style, period):
-        """Differentiable torch statement of the recurrence the HIP kernel implements (double precision)."""
+    def ff_spec(cls, params, pe, cross, style, period, drop=None):
+        """Differentiable torch statement of the recurrence the HIP kernel implements (double precision).  drop = (row keep (S*T, 320)
+        bool: columns 0..63 PPE, 64..127 dropout1, 128..255 activation, 256..319 dropout3; attn keep (S*4*T, T) bool; scale)."""
         import torch.nn.functional as F
         Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, ln, A, c = cls._ff_unpack(params)
         S, T, D = cross.shape
@@ -467,6 +468,10 @@ class EmuBackend:
             emb = style[s]
             for i in range(T):
                 x = emb + pe[i % period]
+                if drop is not None:
+                    rk, ak, dsc = drop
+                    rb = rk[s * T + i].to(params.dtype) * dsc
+                    x = x * rb[:64]
                 qkv = F.linear(x, Wqkv, bqkv)
                 q = qkv[:D].view(H, hd) * 0.25
                 ks.append(qkv[D:2 * D]); vs.append(qkv[2 * D:])
@@ -475,10 +480,15 @@ class EmuBackend:
                 steps = torch.div(i - torch.arange(i + 1), period, rounding_mode="floor").to(params.dtype)
                 sc = sc - slopes.view(-1, 1) * steps.view(1, -1)
                 a = torch.softmax(sc, dim=-1)
+                if drop is not None:
+                    a = a * torch.stack([ak[(s * H + h) * T + i, : i + 1] for h in range(H)]).to(params.dtype) * dsc
                 ctx = torch.einsum("hj,jhd->hd", a, Vc).reshape(D)
-                y = F.layer_norm(x + F.linear(ctx, Wo, bo), (D,), ln[0], ln[1], 1e-5)
+                sa = F.linear(ctx, Wo, bo)
+                y = F.layer_norm(x + (sa * rb[64:128] if drop is not None else sa), (D,), ln[0], ln[1], 1e-5)
                 y = F.layer_norm(y + cross[s, i], (D,), ln[2], ln[3], 1e-5)
-                y = F.layer_norm(y + F.linear(F.relu(F.linear(y, W1, b1)), W2, b2), (D,), ln[4], ln[5], 1e-5)
+                hid = F.relu(F.linear(y, W1, b1))
+                ff = F.linear(hid * rb[128:256] if drop is not None else hid, W2, b2)
+                y = F.layer_norm(y + (ff * rb[256:320] if drop is not None else ff), (D,), ln[4], ln[5], 1e-5)
                 rows.append(y)
                 emb = A @ y + c + style[s]
             ys.append(torch.stack(rows))
@@ -487,19 +497,26 @@ class EmuBackend:
     def ff_save_floats(self, S, T):
         return S * T * 64 * 2 + 8          # the emulator keeps (cross, style-free) inputs it needs for its autograd replay
 
-    def ff_decoder_fwd(self, params, pe, cross, style, S, T, period, y, save):
+    @staticmethod
+    def _ff_drop(drop, S, T):
+        if drop is None:
+            return None
+        return (unpack_keep_bits(drop[0].reshape(S * T, -1), 320), unpack_keep_bits(drop[1].reshape(S * 4 * T, -1), T), float(drop[2]))
+
+    def ff_decoder_fwd(self, params, pe, cross, style, S, T, period, y, save, drop=None):
         with torch.no_grad():
-            out = self.ff_spec(params.double(), pe.double(), cross.reshape(S, T, 64).double(), style.reshape(S, 64).double(), period)
+            out = self.ff_spec(params.double(), pe.double(), cross.reshape(S, T, 64).double(), style.reshape(S, 64).double(), period,
+                               self._ff_drop(drop, S, T))
         y.reshape(S, T, 64).copy_(out.float())
         self._ff_ctx = (pe.clone(), cross.reshape(S, T, 64).clone(), style.reshape(S, 64).clone())
 
-    def ff_decoder_bwd(self, params, dy, S, T, period, save, dparams, dcross, dstyle):
+    def ff_decoder_bwd(self, params, dy, S, T, period, save, dparams, dcross, dstyle, drop=None):
         pe, cross, style = self._ff_ctx
         with torch.enable_grad():                       # we are called from inside an autograd backward
             p = params.detach().double().requires_grad_(True)
             cr = cross.detach().double().requires_grad_(True)
             st = style.detach().double().requires_grad_(True)
-            out = self.ff_spec(p, pe.double(), cr, st, period)
+            out = self.ff_spec(p, pe.double(), cr, st, period, self._ff_drop(drop, S, T))
             out.backward(dy.reshape(S, T, 64).double())
         dparams.copy_(p.grad.float()); dcross.reshape(S, T, 64).copy_(cr.grad.float()); dstyle.reshape(S, 64).copy_(st.grad.float())
 

@@ -18,6 +18,7 @@ FaceFormer (train mode is stochastic).  Nothing here travels to the GPU box exce
 from __future__ import annotations
 
 import contextlib
+import math
 import io
 import os
 import sys
@@ -551,7 +552,81 @@ def g13():
     save("g13_wav2vec2_train_masks", out)
 
 
-ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G10": g10, "G12": g12, "G13": g13}
+# --------------------------------------------------------------------------------------- G14 train-mode decoder, per-row masks
+def g14():
+    """The reference FaceFormer (pinned encoder output) in TRAIN mode with its dropout calls replaced by PER-ROW masks: every nn.Dropout
+    of the PPE / decoder layer (faceformer.py:73,88 and nn.TransformerDecoderLayer's dropout1 / dropout2 / dropout / dropout3) and the
+    attention-probability dropout inside both nn.MultiheadAttention calls draws, for frame row r, the SAME mask at every step of the
+    O(T^3) loop (masks fixed up front from a seeded generator and sliced to the prefix).  With row-consistent masks the loop is
+    causal-consistent, so its result is what the incremental recurrence computes with those masks injected - the train-mode variant
+    a2f_amd implements (the reference itself redraws per step; see csrc/ff_decoder.hip).  Arithmetic of the patched calls is
+    torch's: x * keep / (1 - p), and softmax(q k^T / sqrt(d) + mask) * keep / (1 - p) @ v."""
+    import torch.nn.functional as F
+    from src.loss import FaceFormerLoss
+    print("G14 FaceFormer decoder in train mode, per-row dropout masks, T in {7,61}")
+    m = build_reference_faceformer(stub_encoder=True)
+    sd = decoder_state(m, FF_GAINS)
+    m.load_state_dict(sd, strict=False)
+    m.train()
+    out = {}
+    real_dropout, real_sdpa = F.dropout, F.scaled_dot_product_attention
+    for T in (7, 61):
+        gen = torch.Generator().manual_seed(1400 + T)
+        draw = lambda *shape: torch.rand(*shape, generator=gen) >= 0.1
+        masks = {"ppe": draw(T, 64), "d1": draw(T, 64), "d2": draw(T, 64), "act": draw(T, 128), "d3": draw(T, 64), "attn": draw(4, T, T),
+                 "cross": draw(4, T, T)}
+        order, calls = ("ppe", "d1", "d2", "act", "d3"), {"drop": 0, "sdpa": 0}
+
+        def row_dropout(x, p=0.5, training=True, inplace=False):
+            assert training and abs(p - 0.1) < 1e-12 and x.dim() == 3 and x.shape[0] == 1
+            site = order[calls["drop"] % 5]
+            calls["drop"] += 1
+            k = masks[site][: x.shape[1]]
+            assert k.shape == x.shape[1:], (site, tuple(x.shape))
+            return x * k.to(x.dtype) / 0.9
+
+        def row_sdpa(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, **kw):
+            assert abs(dropout_p - 0.1) < 1e-12 and not is_causal and attn_mask is not None and attn_mask.dtype == q.dtype
+            site = ("attn", "cross")[calls["sdpa"] % 2]
+            calls["sdpa"] += 1
+            n, nk = q.shape[-2], k.shape[-2]
+            pr = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(q.shape[-1]) + attn_mask, dim=-1)
+            pr = pr * masks[site][:, :n, :nk].to(q.dtype).view(1, 4, n, nk) / 0.9
+            return torch.matmul(pr, v)
+
+        enc = W.formula_input(f"g14.enc{T}", (1, T, 768)).requires_grad_(True)
+        m.audio_encoder.enc = enc
+        audio = torch.zeros(1, T * 16000 // 60 + 8)
+        one_hot = torch.zeros(1, 12); one_hot[0, (T + 5) % 12] = 1.0
+        template = W.formula_input(f"g14.template{T}", (1, 5023, 3), 5.0)
+        gt = template.view(1, 1, 5023, 3) + W.formula_input(f"g14.gt{T}", (1, T, 5023, 3), 0.5)
+        m.zero_grad()
+        F.dropout, F.scaled_dot_product_attention = row_dropout, row_sdpa
+        try:
+            pred = m(audio, one_hot, template)
+        finally:
+            F.dropout, F.scaled_dot_product_attention = real_dropout, real_sdpa
+        assert calls == {"drop": 5 * T, "sdpa": 2 * T}, calls
+        loss = FaceFormerLoss()(pred, gt)
+        loss["loss"].backward()
+        pre = f"T{T}::"
+        out[pre + "one_hot"] = one_hot.numpy()
+        for k_, v_ in masks.items():
+            out[pre + "mask::" + k_] = np.packbits(v_.numpy().reshape(-1))
+        pack(pre + "pred", pred, out, big=7 * NV + 1)
+        out[pre + "pred::frame_l2"] = pred.detach().double().reshape(T, -1).norm(dim=1).numpy()
+        for k_ in loss:
+            out[pre + "loss::" + k_] = np.float64(float(loss[k_].detach()))
+        for k_, p_ in m.named_parameters():
+            if k_.startswith("audio_encoder.") or p_.grad is None:
+                continue
+            pack(pre + "grad::" + k_, p_.grad, out)
+        pack(pre + "grad::enc", enc.grad, out)
+        print(f"   T={T}: loss {float(loss['loss'].detach()):.6f}, {calls['drop']} dropout and {calls['sdpa']} attention calls replaced")
+    save("g14_faceformer_decoder_train_masks", out)
+
+
+ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G10": g10, "G12": g12, "G13": g13, "G14": g14}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

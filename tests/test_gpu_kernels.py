@@ -377,6 +377,50 @@ def test_ff_decoder_kernels_vs_spec(S, T, period):
         o += sz_
 
 
+@pytest.mark.parametrize("S,T,period", [(1, 5, 60), (3, 70, 60), (2, 133, 7)])
+def test_ff_decoder_dropout_kernels_vs_spec(S, T, period):
+    """a2f_ff_decoder_fwd_drop / bwd_drop (one keep mask per frame row at the PPE output, the self-attention probabilities, dropout1, the
+    feed-forward activation and dropout3) against autograd on the float64 statement of the same masked recurrence; masks come from
+    a2f_keep_bits as the model draws them; a second run is bitwise identical."""
+    nP = 192 * 64 + 192 + 64 * 64 + 64 + 128 * 64 + 128 + 64 * 128 + 64 + 6 * 64 + 64 * 64 + 64
+    P = rnd(nP, seed=70, scale=0.12)
+    o_ln = 192 * 64 + 192 + 64 * 64 + 64 + 128 * 64 + 128 + 64 * 128 + 64
+    P[o_ln:o_ln + 64] += 1.0; P[o_ln + 128:o_ln + 192] += 1.0; P[o_ln + 256:o_ln + 320] += 1.0
+    P[o_ln + 384:o_ln + 384 + 64 * 64] *= 0.3
+    pe = rnd(period, 64, seed=71)
+    cross, style, dy = rnd(S, T, 64, seed=72), rnd(S, 64, seed=73), rnd(S, T, 64, seed=74)
+    hip, emu = ops.HipBackend(), EmuBackend()
+    row = torch.empty(S * T, 10, dtype=torch.int32, device=DEV)
+    attn = torch.empty(S * 4 * T, hip.attn_keep_words(T), dtype=torch.int32, device=DEV)
+    hip.keep_bits(4242, 1000, S * T, 320, 0.1, row)
+    hip.keep_bits(4242, 1001, S * 4 * T, T, 0.1, attn)
+    drop_h, drop_e = (row, attn, 1 / 0.9), (row.cpu(), attn.cpu(), 1 / 0.9)
+    outs = []
+    for _rep in range(2):
+        y_h = torch.empty(S, T, 64, device=DEV)
+        save = torch.empty(hip.ff_save_floats(S, T), device=DEV)
+        hip.ff_decoder_fwd(P.to(DEV), pe.to(DEV), cross.to(DEV), style.to(DEV), S, T, period, y_h, save, drop=drop_h)
+        dP_h, dc_h, ds_h = torch.full((nP,), 7.0, device=DEV), torch.empty(S, T, 64, device=DEV), torch.empty(S, 64, device=DEV)
+        hip.ff_decoder_bwd(P.to(DEV), dy.to(DEV), S, T, period, save, dP_h, dc_h, ds_h, drop=drop_h)
+        outs.append((y_h, dP_h, dc_h, ds_h))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    y_e = torch.empty(S, T, 64)
+    emu.ff_decoder_fwd(P, pe, cross, style, S, T, period, y_e, None, drop=drop_e)
+    dP_e, dc_e, ds_e = torch.zeros(nP), torch.empty(S, T, 64), torch.empty(S, 64)
+    emu.ff_decoder_bwd(P, dy, S, T, period, None, dP_e, dc_e, ds_e, drop=drop_e)
+    y_h, dP_h, dc_h, ds_h = outs[0]
+    assert rel_l2(y_h.cpu(), y_e) < 2e-5
+    y_plain = torch.empty(S, T, 64)
+    emu.ff_decoder_fwd(P, pe, cross, style, S, T, period, y_plain, None)
+    assert rel_l2(y_h.cpu(), y_plain) > 1e-2                      # the masks do something
+    assert rel_l2(dc_h.cpu(), dc_e) < 1e-4 and rel_l2(ds_h.cpu(), ds_e) < 1e-4
+    o = 0
+    for nm, sz_ in [("Wqkv", 192 * 64), ("bqkv", 192), ("Wo", 4096), ("bo", 64), ("W1", 8192), ("b1", 128), ("W2", 8192), ("b2", 64), ("ln", 384),
+                    ("A", 4096), ("c", 64)]:
+        assert rel_l2(dP_h.cpu()[o:o + sz_], dP_e[o:o + sz_]) < 1e-4, nm
+        o += sz_
+
+
 @pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("M,N,K", [(32, 111, 5000), (32, 96, 777), (64, 96, 3001), (64, 192, 1200), (72, 72, 640), (128, 72, 19), (50, 128, 2048), (1, 1, 3)])
 def test_wgrad_kernel_vs_contract(M, N, K, prec):

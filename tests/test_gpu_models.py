@@ -230,7 +230,7 @@ FF_GAINS = {"vertice_map_r.weight": 4.0, "vertice_map.weight": 0.05, "obj_vector
 def _faceformer(stub=True):
     m = a2f_amd.Faceformer(n_verts=NV, n_onehot=12, audio_encoder=torch.nn.Identity() if stub else None)
     m.load_state_dict(W.formula_state_dict(W.faceformer_decoder_shapes(NV, 12, 64), gains=FF_GAINS), strict=False)
-    return m.to(DEV)
+    return m.to(DEV).eval()          # the deterministic function; the train-mode tests call .train() and inject / seed their masks
 
 
 @pytest.mark.parametrize("T", [7, 61, 130])
@@ -334,7 +334,7 @@ def test_faceformer_encoder_autocast_close_to_fp32():
     """`percision: 16-mixed`: the wav2vec2 encoder under bf16 autocast, decoder / head / loss in fp32 - same function to
     mixed-precision accuracy (the 1e-4 parity bar is defined on the fp32 setting)."""
     torch.manual_seed(0)
-    m = a2f_amd.Faceformer(n_verts=NV, n_onehot=12).to(DEV)
+    m = a2f_amd.Faceformer(n_verts=NV, n_onehot=12).to(DEV).eval()
     with torch.no_grad():
         m.vertice_map_r.weight.normal_(0, 0.1); m.vertice_map.weight.normal_(0, 0.001)
     T = 30
@@ -718,7 +718,7 @@ def test_faceformer_batch_step_one_head_launch_equals_per_sequence_steps(T):
 
     m = a2f_amd.Faceformer(n_verts=NV, n_onehot=12, audio_encoder=_Enc())
     m.load_state_dict(W.formula_state_dict(W.faceformer_decoder_shapes(NV, 12, 64), gains=FF_GAINS), strict=False)
-    m.to(DEV)
+    m.to(DEV).eval()
     enc = W.formula_input("batchhead.enc", (S, T, 768)).to(DEV).requires_grad_(True)
     m.audio_encoder.states = enc
     audio = torch.zeros(S, T * 16000 // 60 + 8, device=DEV)
@@ -753,7 +753,7 @@ def test_faceformer_pipelined_step_equals_single_stream_step(S, T):
     blocks); and equal within the summation-order noise of the weight-gradient GEMMs to the unsplit batch step."""
     m, _, _ = _faceformer_full()
     m.train()
-    m.audio_encoder.train_regularisers = False          # every call of this comparison must compute the same function
+    m.audio_encoder.train_regularisers = m.decoder_regularisers = False          # every call of this comparison must compute the same function
     gen = torch.Generator().manual_seed(77)
     audio = (torch.randn(S, T * 16000 // 60 + 8, generator=gen) * 0.1).to(DEV)
     oh = torch.zeros(S, 12); oh[torch.arange(S), torch.arange(S) % 8] = 1
@@ -823,3 +823,44 @@ def test_wav2vec2_drawn_masks_on_gpu():
     enc.eval()
     d = enc(wave, "vocaset", frame_num=T).last_hidden_state.detach()
     assert enc.last_masks is None and rel_l2(a, d) > 1e-3
+
+
+@pytest.mark.parametrize("T", [7, 61])
+def test_faceformer_decoder_train_mode_per_row_masks_g14(T):
+    """ff_decoder_fwd_drop / bwd_drop + the masked cross rows + the head on the GPU in train mode, fed the per-row masks of fixture G14
+    (the reference's O(T^3) loop run with its dropout calls replaced by row-consistent masks): predictions, loss terms, every
+    decoder-side gradient and d loss / d encoder-output within the parity bar; plain forward + loss module and the fused-loss path."""
+    from test_train_regularisers_cpu import check_against_g14, g14_case
+    for fused in (False, True):
+        g, m, pre, enc, audio, one_hot, template, gt = g14_case(T, DEV)
+        if fused:
+            pred, loss = m.forward_with_loss(audio, one_hot, template, gt, encoder_states=enc)
+        else:
+            pred = m(audio, one_hot, template, encoder_states=enc)
+            loss = a2f_amd.FaceFormerLoss()(pred, gt)
+        assert m.last_decoder_masks is m.injected_decoder_masks
+        check_against_g14(g, m, pre, enc, pred, loss, TOL)
+
+
+def test_faceformer_decoder_drawn_masks_on_gpu():
+    """Decoder masks drawn on the device: reproducible from torch's seed, new every step, none in eval mode, keep rate 0.9; the
+    decoder kernels with masks stay bitwise deterministic run to run."""
+    from a2f_amd.dropout import unpack_keep_bits
+    m = _faceformer().train()
+    S, T = 3, 40
+    enc = W.formula_input("drawn.enc", (S, T, 768)).to(DEV)
+    oh = torch.zeros(S, 12, device=DEV); oh[:, 2] = 1
+    torch.manual_seed(9)
+    a = m.decode_hidden(enc, oh).detach()
+    dm = m.last_decoder_masks
+    torch.manual_seed(9)
+    b = m.decode_hidden(enc, oh).detach()
+    c = m.decode_hidden(enc, oh).detach()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(float(unpack_keep_bits(dm.row, 320).float().mean()) - 0.9) < 0.02
+    assert abs(float(unpack_keep_bits(dm.attn, T).float().mean()) - 0.9) < 0.02
+    heads = unpack_keep_bits(dm.cross_v, 64).view(S * T, 4, 16)
+    assert bool((heads == heads[:, :, :1]).all())                    # one decision per (frame, head)
+    m.eval()
+    d = m.decode_hidden(enc, oh).detach()
+    assert m.last_decoder_masks is None and rel_l2(a.cpu(), d.cpu()) > 1e-3

@@ -140,7 +140,7 @@ def _faceformer(stub=True):
     sd = W.formula_state_dict(W.faceformer_decoder_shapes(NV, 12, 64), gains=FF_GAINS)
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected and all(k == "PPE.pe" or k.startswith("audio_encoder.") for k in missing), (missing, unexpected)
-    return m, sd
+    return m.eval(), sd              # the deterministic function (train mode: tests/test_train_regularisers_cpu.py)
 
 
 @pytest.mark.parametrize("T", [7, 61])

@@ -139,3 +139,62 @@ def test_drawn_masks_are_reproducible_and_eval_is_deterministic():
         assert torch.equal(d, e) and rel_l2(a, e) > 1e-3
     finally:
         ops.set_backend(old)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# FaceFormer decoder / PPE dropout with per-row masks (fixture G14)
+# ---------------------------------------------------------------------------------------------------------------------------
+NV = 15069
+FF_GAINS = {"vertice_map_r.weight": 4.0, "vertice_map.weight": 0.05, "obj_vector": 2.0, "in_proj_weight": 1.5}
+
+
+def g14_recorded(g, T):
+    pre = f"T{T}::mask::"
+    un = lambda key, shape: np.unpackbits(g[pre + key])[: int(np.prod(shape))].reshape(shape).astype(bool)
+    cross = un("cross", (4, T, T))
+    return {"ppe": un("ppe", (T, 64)), "d1": un("d1", (T, 64)), "d2": un("d2", (T, 64)), "act": un("act", (T, 128)), "d3": un("d3", (T, 64)),
+            "attn": un("attn", (4, T, T)),
+            # the diagonal memory mask leaves key i for frame i: only that probability's keep decision matters
+            "cross_head": np.stack([cross[h, np.arange(T), np.arange(T)] for h in range(4)], axis=1)}
+
+
+def g14_case(T, device="cpu"):
+    g = load("g14_faceformer_decoder_train_masks")
+    m = a2f_amd.Faceformer(n_verts=NV, n_onehot=12, audio_encoder=torch.nn.Identity())
+    m.load_state_dict(W.formula_state_dict(W.faceformer_decoder_shapes(NV, 12, 64), gains=FF_GAINS), strict=False)
+    m.to(device).train()
+    m.injected_decoder_masks = D.DecoderMasks.from_recorded(g14_recorded(g, T), device)
+    pre = f"T{T}::"
+    enc = W.formula_input(f"g14.enc{T}", (1, T, 768)).to(device).requires_grad_(True)
+    audio = torch.zeros(1, T * 16000 // 60 + 8, device=device)
+    one_hot = torch.from_numpy(g[pre + "one_hot"]).to(device)
+    template = W.formula_input(f"g14.template{T}", (1, 5023, 3), 5.0)
+    gt = (template.view(1, 1, 5023, 3) + W.formula_input(f"g14.gt{T}", (1, T, 5023, 3), 0.5)).to(device)
+    return g, m, pre, enc, audio, one_hot, template.to(device), gt
+
+
+def check_against_g14(g, m, pre, enc, pred, loss, tol):
+    assert packed_error(g, pre + "pred", pred) < tol
+    for k in ("loss", "rec_loss", "vel_loss"):
+        assert abs(float(loss[k].detach()) - float(g[pre + "loss::" + k])) <= 1e-4 * abs(float(g[pre + "loss::" + k]))
+    loss["loss"].backward()
+    seen = 0
+    for k, p in m.named_parameters():
+        if (pre + "grad::" + k) in g or (pre + "grad::" + k + "::sample") in g:
+            assert packed_error(g, pre + "grad::" + k, p.grad) < tol, k
+            seen += 1
+    assert seen >= 20
+    assert packed_error(g, pre + "grad::enc", enc.grad) < tol
+
+
+@pytest.mark.parametrize("T", [7, 61])
+def test_faceformer_decoder_train_mode_matches_reference_with_per_row_masks_g14(T):
+    """Decoder recurrence + cross rows + head in train mode over the float64 emulator of the C ABI, fed the per-row masks fixture G14
+    was generated with (the reference's O(T^3) loop with its dropout calls replaced by row-consistent masks)."""
+    g, m, pre, enc, audio, one_hot, template, gt = g14_case(T)
+    old = ops.set_backend(EmuBackend())
+    try:
+        pred = m(audio, one_hot, template, encoder_states=enc)
+        check_against_g14(g, m, pre, enc, pred, a2f_amd.FaceFormerLoss()(pred, gt), 1e-4)
+    finally:
+        ops.set_backend(old)

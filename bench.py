@@ -307,6 +307,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--ff-deterministic", action="store_true", help="FaceFormer: switch the train-mode regularisers off (A/B timing)")
     ap.add_argument("--no-graph", action="store_true", help="launch the ~90 kernels of a step eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
@@ -406,6 +407,9 @@ def main():
             model.vertice_map.weight.normal_(0, 0.001)
         if args.encoder_precision == "bf16":
             model.encoder_autocast = torch.bfloat16
+        model.train()                                            # Lightning's fit puts the reference's module in train mode
+        if args.ff_deterministic:                                # A/B: the deterministic (eval-mode) function under the same step
+            model.audio_encoder.train_regularisers = model.decoder_regularisers = False
         step = TrainStep(model, a2f_amd.FaceFormerLoss(), lr=1e-4)
         audio, one_hot, gt, templ = make_ff_batch(S, T, rank, device)
         elapsed, loss_val = timed(lambda: step(audio, one_hot, gt, templ), steps, max(warmup, 2), barrier, world, device)
@@ -417,7 +421,10 @@ def main():
                                         else getattr(model.audio_encoder, "dtype_note", "encoder in fp32 torch ops")),
             "config": {"workload": f"FaceFormer train step (wav2vec2-base encoder + incremental decoder + fused head/FaceFormerLoss, bwd, Adam over 96.4 M "
                                    f"parameters), {S} independent batch-1 sequences x {T} frames per GPU per step, BASELINE configs[2]",
-                       "frames_per_gpu_step": S * T, "parallelism": f"dp{world}", "final_loss": round(loss_val, 6), "encoder": enc_path},
+                       "frames_per_gpu_step": S * T, "parallelism": f"dp{world}", "final_loss": round(loss_val, 6), "encoder": enc_path,
+                       "train_mode": ("deterministic function (regularisers off, --ff-deterministic)" if args.ff_deterministic else
+                                      "reference train mode: wav2vec2 dropout x6 kinds of sites / LayerDrop 0.1 / SpecAugment, decoder + PPE dropout 0.1 "
+                                      "(one mask per frame row), masks drawn on the device every step")},
         }
         if want_roof:
             # whole step against the matrix peak (857 MFLOP/frame algorithmic) + the tagged GEMM launches alone

@@ -73,11 +73,19 @@ __device__ __forceinline__ void epilogue_store(const Args& a, int bz, int m, int
   v *= a.alpha;
   if (a.bias) v += a.bias[bz * a.bias_bstride + n];
   const long long ci = bz * a.c_bstride + crow + n;
-  if (a.C2) a.C2[ci] = v;
-  if (a.act == 1) v = fmaxf(v, 0.f);
-  else if (a.act == 3) v = gelu_f(v);
+  if (a.act == 4) {                        // GELU with its derivative saved for the backward (C2 = gelu'(v) instead of v)
+    const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+    if (a.C2) a.C2[ci] = cdf + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+    v *= cdf;
+  } else {
+    if (a.C2) a.C2[ci] = v;
+    if (a.act == 1) v = fmaxf(v, 0.f);
+    else if (a.act == 3) v = gelu_f(v);
+  }
   if (a.keep) v = ((a.keep[(long long)m * a.keep_wpr + (n >> 5)] >> (n & 31)) & 1u) ? v * a.keep_scale : 0.f;
-  if (a.aux_mode) {
+  if (a.aux_mode == 4) {
+    v *= a.aux[ci];                        // aux laid out like C (same row map): a saved activation derivative
+  } else if (a.aux_mode) {
     const float x = a.aux[bz * a.aux_bstride + (long long)m * a.ldaux + n];
     if (a.aux_mode == 1) v += x;
     else if (a.aux_mode == 2) v *= gelu_grad_f(x);
@@ -526,11 +534,19 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, Cfg<CFG>::WPS) void gemm_mfma_kernel(
           if (ncol[j] >= a.N) continue;
           float v = acc[i][j][r] * a.alpha + bv[j];
           if (generic) {
-            if (a.C2) a.C2[bz * a.c_bstride + crow + ncol[j]] = v;
-            if (a.act == 1) v = fmaxf(v, 0.f);
-            else if (a.act == 3) v = gelu_f(v);
+            if (a.act == 4) {
+              const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+              if (a.C2) a.C2[bz * a.c_bstride + crow + ncol[j]] = cdf + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+              v *= cdf;
+            } else {
+              if (a.C2) a.C2[bz * a.c_bstride + crow + ncol[j]] = v;
+              if (a.act == 1) v = fmaxf(v, 0.f);
+              else if (a.act == 3) v = gelu_f(v);
+            }
             if (a.keep) v = ((a.keep[(long long)m * a.keep_wpr + (ncol[j] >> 5)] >> (ncol[j] & 31)) & 1u) ? v * a.keep_scale : 0.f;
-            if (a.aux_mode) {
+            if (a.aux_mode == 4) {
+              v *= a.aux[bz * a.c_bstride + crow + ncol[j]];
+            } else if (a.aux_mode) {
               const float x = a.aux[bz * a.aux_bstride + (long long)m * a.ldaux + ncol[j]];
               if (a.aux_mode == 1) v += x;
               else if (a.aux_mode == 2) v *= gelu_grad_f(x);
@@ -626,8 +642,8 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
                 "a2f_mm: M=%lld N=%lld K=%lld", (long long)d->M, (long long)d->N, (long long)d->K);
   A2F_CHECK_ARG(d->C != nullptr, "a2f_mm: C is null");
   A2F_CHECK_ARG(d->precision == 0 || d->precision == 1, "a2f_mm: precision %d (0 = bf16, 1 = bf16x3)", d->precision);
-  A2F_CHECK_ARG(d->act == 0 || d->act == 1 || d->act == 3, "a2f_mm: act %d", d->act);
-  A2F_CHECK_ARG(d->aux_mode >= 0 && d->aux_mode <= 3 && (d->aux_mode == 0 || d->aux != nullptr), "a2f_mm: aux_mode %d / aux", d->aux_mode);
+  A2F_CHECK_ARG(d->act == 0 || d->act == 1 || d->act == 3 || d->act == 4, "a2f_mm: act %d", d->act);
+  A2F_CHECK_ARG(d->aux_mode >= 0 && d->aux_mode <= 4 && (d->aux_mode == 0 || d->aux != nullptr), "a2f_mm: aux_mode %d / aux", d->aux_mode);
   const int batch = d->batch > 0 ? d->batch : 1;
   const int split = d->split_k > 1 ? d->split_k : 1;
   A2F_CHECK_ARG(split == 1 || d->ws != nullptr, "a2f_mm: split_k needs a workspace");

@@ -12,9 +12,11 @@ from __future__ import annotations
 import torch
 
 from . import ops
-from .ops import MM_ACT_GELU, MM_ACT_NONE, MM_AUX_ADD, MM_AUX_GELU_BWD, MMOp
+from .ops import MM_ACT_GELU, MM_ACT_GELU_SAVE_GRAD, MM_ACT_NONE, MM_AUX_ADD, MM_AUX_GELU_BWD, MM_AUX_MUL_LIKE_C, MMOp
 
 LN_EPS = 1e-5
+import os as _os
+GELU_SAVED = _os.environ.get("A2F_GELU_SAVED", "1") != "0"       # A-B hook: 0 = pre-activation saved + streaming GELU' pass in the backward
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -123,9 +125,9 @@ class EncoderLayerFn(torch.autograd.Function):
         be.mm(MMOp(att, d), MMOp(Wo, d), a1, M, d, d, d, bias=bo, aux=xc, ldaux=d, aux_mode=MM_AUX_ADD, keep=mk.get("hid1"))
         h1, m1, r1 = _new(xc, M, d), _new(xc, M), _new(xc, M)
         be.layernorm_fwd(a1, M, d, g1, b1, LN_EPS, h1, m1, r1)
-        z = _new(xc, M, F) if keep else None
+        z = _new(xc, M, F) if keep else None                     # gelu'(pre-activation): what the backward multiplies by
         g = _new(xc, M, F)
-        be.mm(MMOp(h1, d), MMOp(W1, d), g, M, F, d, F, bias=c1, act=MM_ACT_GELU, C2=z, keep=mk.get("act"))
+        be.mm(MMOp(h1, d), MMOp(W1, d), g, M, F, d, F, bias=c1, act=MM_ACT_GELU_SAVE_GRAD if (keep and GELU_SAVED) else MM_ACT_GELU, C2=z, keep=mk.get("act"))
         a2 = _new(xc, M, d)
         be.mm(MMOp(g, F), MMOp(W2, F), a2, M, d, F, d, bias=c2, aux=h1, ldaux=d, aux_mode=MM_AUX_ADD, keep=mk.get("hid2"))
         h2, m2, r2 = _new(xc, M, d), _new(xc, M), _new(xc, M)
@@ -159,10 +161,13 @@ class EncoderLayerFn(torch.autograd.Function):
         dW2 = new(d, F)
         ops.mm_linear_wgrad(be, dy2, g, dW2, M, d, F)
         dz = new(M, F)
-        # through GELU: the derivative runs as its own streaming pass - fused into the GEMM epilogue (aux_mode GELU') the erf / exp
-        # per element ran at matrix-pipe-idle time and the K = 768 product dropped from 245 to 122 TFLOP/s (rocprofv3, 32 x 600)
-        be.mm(MMOp(dy2, d), MMOp(W2, F, trans=True), dz, M, F, d, F, keep=mk.get("act"))
-        be.gelu_bwd(dz, z, dz)
+        # through GELU: the forward epilogue saved gelu'(pre-activation), so this epilogue only multiplies (evaluating erf / exp here
+        # per element dropped the K = 768 product from 245 to 122 TFLOP/s; a separate streaming GELU' pass cost 3 % of the step)
+        if GELU_SAVED:
+            be.mm(MMOp(dy2, d), MMOp(W2, F, trans=True), dz, M, F, d, F, keep=mk.get("act"), aux=z, aux_mode=MM_AUX_MUL_LIKE_C)
+        else:
+            be.mm(MMOp(dy2, d), MMOp(W2, F, trans=True), dz, M, F, d, F, keep=mk.get("act"))
+            be.gelu_bwd(dz, z, dz)
         dc1 = new(F)
         be.colsum(dz, M, F, F, dc1)
         dW1 = new(F, d)
@@ -312,6 +317,63 @@ class ConvGeluFn(torch.autograd.Function):
             dx = torch.zeros(S, Lin, Ci, device=xc.device, dtype=torch.float32)
             ops.mm_conv_dgrad(be, dz, wg, dx, S, Lin, Lout, Ci, Co, KH, stride)
         return dx, dw, None
+
+
+class ConvStackFn(torch.autograd.Function):
+    """Feature-encoder layers 1..n in one autograd node: x (S, L0, C0) -> gelu(conv_n(... gelu(conv_1(x)))) channels-last; weights are
+    the nn.Conv1d weights (Co, Ci, KH), no bias, no padding; ``strides`` a tuple.  Forward epilogues save gelu'(pre-activation) of every
+    layer; in the backward the data-gradient epilogue of layer i + 1 multiplies by layer i's saved derivative, so the gradient arrives at
+    layer i already as its pre-activation gradient - one streaming GELU' multiply (the top layer's) instead of one per layer."""
+
+    @staticmethod
+    def forward(ctx, x, strides, *weights):
+        be = ops.backend()
+        cur = _f32c(x)
+        keep = any(ctx.needs_input_grad)
+        saved, dims = [], []
+        for w, stride in zip(weights, strides):
+            wc = _f32c(w)
+            S, Lin, Ci = cur.shape
+            Co, _, KH = wc.shape
+            Lout = (Lin - KH) // stride + 1
+            wg = _new(cur, Co, KH * Ci)
+            be.conv_weight_pack(wc, wg, Co, Ci, KH, 0)
+            gp = _new(cur, S, Lout, Co) if keep else None
+            y = _new(cur, S, Lout, Co)
+            ops.mm_conv_fwd(be, cur, wg, y, S, Lin, Lout, Ci, Co, KH, stride, act=MM_ACT_GELU_SAVE_GRAD if keep else MM_ACT_GELU, pre=gp)
+            saved += [cur, wg, gp]
+            dims.append((S, Lin, Lout, Ci, Co, KH, stride))
+            cur = y
+        if keep:
+            ctx.save_for_backward(*saved)
+            ctx.dims = dims
+        return cur
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = ops.backend()
+        saved, dims = ctx.saved_tensors, ctx.dims
+        n = len(dims)
+        dz = _f32c(dy) * saved[3 * (n - 1) + 2]                   # top layer: dy o gelu'
+        dws = [None] * n
+        dx = None
+        for i in range(n - 1, -1, -1):
+            xc, wg, _gp = saved[3 * i: 3 * i + 3]
+            S, Lin, Lout, Ci, Co, KH, stride = dims[i]
+            dwg = _new(xc, Co, KH * Ci)
+            ops.mm_conv_wgrad(be, xc, dz, dwg, S, Lin, Lout, Ci, Co, KH, stride)
+            dw = _new(xc, Co, Ci, KH)
+            be.conv_weight_pack(dwg, dw, Co, Ci, KH, 1)
+            dws[i] = dw
+            if i == 0 and not ctx.needs_input_grad[0]:
+                break
+            dxi = torch.zeros(S, Lin, Ci, device=xc.device, dtype=torch.float32)
+            ops.mm_conv_dgrad(be, dz, wg, dxi, S, Lin, Lout, Ci, Co, KH, stride, mul=saved[3 * (i - 1) + 2] if i > 0 else None)
+            if i > 0:
+                dz = dxi                                           # already layer (i - 1)'s pre-activation gradient
+            else:
+                dx = dxi
+        return (dx, None, *dws)
 
 
 # =================================================================================================

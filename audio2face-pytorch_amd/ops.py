@@ -19,8 +19,8 @@ from ._lib import A2FError, GemmDesc, MMDesc, MMOperand
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 AUX_NONE, AUX_RELU_BWD, AUX_TANH_BWD, AUX_ADD = 0, 1, 2, 3
 # a2f_mm (bf16-MFMA GEMM family) epilogue codes
-MM_ACT_NONE, MM_ACT_RELU, MM_ACT_GELU = 0, 1, 3
-MM_AUX_NONE, MM_AUX_ADD, MM_AUX_GELU_BWD, MM_AUX_RELU_BWD = 0, 1, 2, 3
+MM_ACT_NONE, MM_ACT_RELU, MM_ACT_GELU, MM_ACT_GELU_SAVE_GRAD = 0, 1, 3, 4
+MM_AUX_NONE, MM_AUX_ADD, MM_AUX_GELU_BWD, MM_AUX_RELU_BWD, MM_AUX_MUL_LIKE_C = 0, 1, 2, 3, 4
 
 
 class MMOp:
@@ -140,7 +140,7 @@ class HipBackend:
         d.C2 = _ptr(C2, c_off)
         d.M, d.N, d.K = M, N, K
         d.bias = _ptr(bias)
-        d.aux, d.ldaux = _ptr(aux), ldaux
+        d.aux, d.ldaux = _ptr(aux, c_off if aux_mode == MM_AUX_MUL_LIKE_C else 0), ldaux
         d.act, d.aux_mode = act, aux_mode
         d.precision = self.mm_precision if precision is None else precision
         if split_k == 0:                                        # auto: enough workgroups for the chip, slabs stay small
@@ -591,12 +591,14 @@ def mm_conv_wgrad(be, x, dy, dWg, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, ta
     be.mm(A, B, dWg, Co, KH * Ci, S * Lout, KH * Ci, split_k=0, tag=tag)
 
 
-def mm_conv_dgrad(be, dy, Wg, dx, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, tag="gemm_mfma"):
+def mm_conv_dgrad(be, dy, Wg, dx, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, tag="gemm_mfma", mul=None):
     """dx (S,Lin,Ci) from dy (S,Lout,Co), gather form (no atomics, no col2im buffer); positions no window touches must be
     zero in dx on entry.  Supported: KH == stride, pad = 0 (non-overlapping windows) and KH = 3, stride = 2 with pad = 0
-    (Lin >= 2 Lout + 1) or pad = 1 (Lin = 2 Lout)."""
+    (Lin >= 2 Lout + 1) or pad = 1 (Lin = 2 Lout).  mul (S,Lin,Ci), optional: every written element is multiplied by it in the
+    epilogue (the saved activation derivative of the layer below: dx then IS that layer's pre-activation gradient)."""
+    ex = dict(aux=mul, aux_mode=MM_AUX_MUL_LIKE_C) if mul is not None else {}
     if KH == stride and pad == 0:
-        be.mm(MMOp(dy, Co), MMOp(Wg, KH * Ci, trans=True), dx, S * Lout, KH * Ci, Co, KH * Ci, c_rows_per_seq=Lout, c_seq_stride=Lin * Ci, tag=tag)
+        be.mm(MMOp(dy, Co), MMOp(Wg, KH * Ci, trans=True), dx, S * Lout, KH * Ci, Co, KH * Ci, c_rows_per_seq=Lout, c_seq_stride=Lin * Ci, tag=tag, **ex)
         return
     if KH == 3 and stride == 2 and pad in (0, 1):
         # positions touched by two taps (pad 0: even j = 2q from dy[q-1] (kh=2), dy[q] (kh=0); pad 1: odd j = 2q+1 from dy[q] (kh=2),
@@ -605,9 +607,9 @@ def mm_conv_dgrad(be, dy, Wg, dx, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, ta
         rows = Lout + 1 if pad == 0 else Lout
         A = MMOp(dy, Co, lines_per_seq=rows, seq_stride=Lout * Co, off=-Co if pad == 0 else 0, seq_elems=Lout * Co)
         B = MMOp(Wg, 3 * Ci, trans=True, lines_per_seq=Co, seq_stride=-2 * Ci, off=2 * Ci, seq_elems=_BIG)
-        be.mm(A, B, dx, S * rows, Ci, 2 * Co, 2 * Ci, c_off=0 if pad == 0 else Ci, c_rows_per_seq=rows, c_seq_stride=Lin * Ci, tag=tag)
+        be.mm(A, B, dx, S * rows, Ci, 2 * Co, 2 * Ci, c_off=0 if pad == 0 else Ci, c_rows_per_seq=rows, c_seq_stride=Lin * Ci, tag=tag, **ex)
         # positions touched by the middle tap only: dy[q] against W_kh=1
         be.mm(MMOp(dy, Co), MMOp(Wg, 3 * Ci, trans=True, ptr_off=Ci), dx, S * Lout, Ci, Co, 2 * Ci, c_off=Ci if pad == 0 else 0, c_rows_per_seq=Lout,
-              c_seq_stride=Lin * Ci, tag=tag)
+              c_seq_stride=Lin * Ci, tag=tag, **ex)
         return
     raise A2FError(f"mm_conv_dgrad: unsupported kernel/stride/pad {KH}/{stride}/{pad}")

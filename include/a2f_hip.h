@@ -298,10 +298,12 @@ int a2f_stream_triad(float* dst, const float* a, const float* b, int64_t n, a2f_
  * are lines with ld < K, zero padding and sequence ends are the bounds test.  `bytes` = addressable span from p (< 4 GiB):
  * anything beyond reads as zero.  All of p, ld, off, seq_stride and the contiguous extent must be multiples of 4 elements
  * (16-byte vector loads).
- * Epilogue, per element: v = alpha*acc; if bias: v += bias[n]; C2 (optional) = v;  act: 0 none, 1 ReLU, 3 GELU (erf form);
+ * Epilogue, per element: v = alpha*acc; if bias: v += bias[n]; C2 (optional) = v;  act: 0 none, 1 ReLU, 3 GELU (erf form), 4 GELU with
+ * C2 = gelu'(v) instead of v (the derivative the backward multiplies by: no erf / exp pass there);
  * keep_bits (optional, batch == 1): v = bit (m, n) of the keep mask ? v * keep_scale : 0 (train-mode dropout of the layer's output,
  * a2f_keep_bits layout with keep_wpr words per row);
- * aux_mode 1: v += aux[m*ldaux+n]; 2: v *= gelu'(aux); 3: v *= (aux > 0); accumulate: v += C_old.  Row m of C (and C2) is
+ * aux_mode 1: v += aux[m*ldaux+n]; 2: v *= gelu'(aux); 3: v *= (aux > 0); 4: v *= aux at C's own index (aux laid out like C, row map
+ * included: a saved derivative); accumulate: v += C_old.  Row m of C (and C2) is
  * stored at C + (m / c_rows_per_seq)*c_seq_stride + (m % c_rows_per_seq)*ldc + n  (c_rows_per_seq = 0: C + m*ldc + n).
  * split_k > 1: the contraction is cut into split_k slabs stored in `ws` (>= batch*split_k*M*N floats) and folded in fixed
  * order by a second kernel that applies the epilogue (deterministic; how weight gradients with K = 10^4 rows fill the chip).

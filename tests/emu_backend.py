@@ -175,16 +175,24 @@ class EmuBackend:
                 v = v + bias.reshape(-1)[bz * bias_bstride: bz * bias_bstride + N].double().view(1, -1)
             cidx = c_off + bz * c_bstride + crow + torch.arange(N).view(1, -1)
             assert int(cidx.max()) < cflat.numel(), "mm emu: C write outside its buffer"
-            if c2flat is not None:
-                c2flat[cidx] = v.float()
-            if act == 1:
-                v = v.clamp_min(0)
-            elif act == 3:
-                v = 0.5 * v * (1 + torch.erf(v / math.sqrt(2.0)))
+            if act == 4:                                   # GELU, C2 = gelu'(v)
+                cdf = 0.5 * (1 + torch.erf(v / math.sqrt(2.0)))
+                if c2flat is not None:
+                    c2flat[cidx] = (cdf + v * torch.exp(-0.5 * v * v) / math.sqrt(2 * math.pi)).float()
+                v = v * cdf
+            else:
+                if c2flat is not None:
+                    c2flat[cidx] = v.float()
+                if act == 1:
+                    v = v.clamp_min(0)
+                elif act == 3:
+                    v = 0.5 * v * (1 + torch.erf(v / math.sqrt(2.0)))
             if keep is not None:
                 assert batch == 1
                 v = torch.where(unpack_keep_bits(keep[0], N)[:M], v * float(keep[1]), torch.zeros_like(v))
-            if aux_mode:
+            if aux_mode == 4:                              # aux laid out like C (c_off and the row map included)
+                v = v * aux.reshape(-1)[cidx].double()
+            elif aux_mode:
                 ax = aux.reshape(-1)[bz * aux_bstride + m * ldaux + torch.arange(N).view(1, -1)].double()
                 if aux_mode == 1:
                     v = v + ax

@@ -116,3 +116,36 @@ def test_mm_rejects_bad_arguments():
     x = torch.zeros(8, 6, device=DEV)
     with pytest.raises(a2f_amd.A2FError):
         be.mm(MMOp(x, 6), MMOp(x, 6), torch.zeros(8, 8, device=DEV), 8, 8, 6, 8)       # K = 6 is not a multiple of 4
+
+
+def test_mm_saved_gelu_derivative_epilogues():
+    """act 4 (GELU with C2 = gelu'(v)) and aux_mode 4 (multiply by aux at C's own index, row map and c_off included): a forward
+    Linear + GELU that saves its derivative, and a strided-convolution data gradient (two launches writing disjoint positions)
+    multiplied by the derivative saved by the layer below, against the float64 emulator."""
+    from a2f_amd.ops import MM_ACT_GELU_SAVE_GRAD, mm_conv_dgrad
+    M, N, K = 300, 260, 96
+    x, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3)
+
+    def fwd(be, dev):
+        y, gp = torch.zeros(M, N, device=dev), torch.zeros(M, N, device=dev)
+        be.mm(MMOp(x.to(dev), K), MMOp(W.to(dev), K), y, M, N, K, N, bias=b.to(dev), act=MM_ACT_GELU_SAVE_GRAD, C2=gp)
+        return [y, gp]
+    a, e = both(fwd)
+    assert rel_l2(a[0], e[0]) < 3e-5 and rel_l2(a[1], e[1]) < 3e-5
+    z = (x.double() @ W.double().t() + b.double())
+    zt = z.clone().requires_grad_(True)
+    torch.nn.functional.gelu(zt).sum().backward()
+    assert rel_l2(a[1], zt.grad) < 3e-5                        # C2 really is d gelu / d pre-activation
+    S, Lin, Ci, Co, KH, stride = 2, 37, 8, 12, 3, 2
+    Lout = (Lin - KH) // stride + 1
+    dy, wg, mul = rnd(S, Lout, Co, seed=4), rnd(Co, KH * Ci, seed=5, scale=0.3), rnd(S, Lin, Ci, seed=6)
+
+    def dgrad(be, dev):
+        dx = torch.zeros(S, Lin, Ci, device=dev)
+        mm_conv_dgrad(be, dy.to(dev), wg.to(dev), dx, S, Lin, Lout, Ci, Co, KH, stride, mul=mul.to(dev))
+        plain = torch.zeros(S, Lin, Ci, device=dev)
+        mm_conv_dgrad(be, dy.to(dev), wg.to(dev), plain, S, Lin, Lout, Ci, Co, KH, stride)
+        return [dx, plain]
+    a, e = both(dgrad)
+    assert rel_l2(a[0], e[0]) < 3e-5
+    assert rel_l2(a[0], a[1] * mul) < 1e-6

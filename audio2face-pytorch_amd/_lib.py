@@ -57,6 +57,7 @@ class MMDesc(C.Structure):
         ("alpha", f32), ("reserved", i32),
         ("keep_bits", c_f32p), ("keep_wpr", i64),
         ("keep_scale", f32), ("reserved2", i32),
+        ("a_rowsum", c_f32p),
     ]
 
 

@@ -58,6 +58,7 @@ struct Args {
   int M, N, K;
   int act, aux_mode, accumulate, split_k, batch;
   float alpha;
+  float* a_rowsum;               // optional (A trans, plain operands, batch 1): a_rowsum[m] = sum_k A(m, k) - the bias gradient of a weight-gradient product
   const unsigned* keep;          // dropout keep bits of C (csrc/dropout.hip: word (m, n >> 5), bit n & 31), applied after the activation
   long long keep_wpr;
   float keep_scale;
@@ -436,7 +437,21 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, Cfg<CFG>::WPS) void gemm_mfma_kernel(
   u32x4_t ra0[SA::NL], rb0[SB::NL], ra1[SA::NL], rb1[SB::NL];
   fetch(kbeg, ra0, rb0);
   fetch(kbeg + BK, ra1, rb1);                                  // out of range (zeros) when there is no second tile
-  sa.template commit<PREC>(smem, ra0);
+  // Row sums of A beside the product (weight-gradient layout: A = dY^T, so sum_k A(m, k) is the bias gradient): every unit of a thread
+  // covers the same four m, so one float4 per thread collects them as the tiles pass through the registers on their way to LDS.
+  constexpr bool CAN_ROWSUM = AT && BT;                        // masked / out-of-range loads arrive as zeros on both addressing paths
+  const bool do_rowsum = CAN_ROWSUM && a.a_rowsum != nullptr;  // wave-uniform
+  f32x4 rsum = {0.f, 0.f, 0.f, 0.f};
+  auto commit_a = [&](char* img, const u32x4_t (&q)[SA::NL]) {
+    if constexpr (CAN_ROWSUM) {
+      if (do_rowsum) {
+#pragma unroll
+        for (int i = 0; i < SA::NL; ++i) rsum += __builtin_bit_cast(f32x4, q[i]);
+      }
+    }
+    sa.template commit<PREC>(img, q);
+  };
+  commit_a(smem, ra0);
   sb.template commit<PREC>(smem + A_BYTES, rb0);
   __syncthreads();
 
@@ -482,7 +497,7 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, Cfg<CFG>::WPS) void gemm_mfma_kernel(
 #pragma unroll
     for (int i = 0; i < SB::NL; ++i) asm volatile("" ::"v"(cb[i]));
 #else
-    sa.template commit<PREC>(nst, ca);
+    commit_a(nst, ca);
     sb.template commit<PREC>(nst + A_BYTES, cb);
 #endif
     compute(smem + (kt & 1) * STAGE);
@@ -498,6 +513,23 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, Cfg<CFG>::WPS) void gemm_mfma_kernel(
     ++kt;
   }
   if (nkt > 0) compute(smem + ((nkt - 1) & 1) * STAGE);
+
+  if constexpr (CAN_ROWSUM) {
+    if (do_rowsum && n0 == 0) {                                // one column of workgroups owns the sums (block-uniform)
+      constexpr int PER_ROW = BM / 4, GROUPS = TH / PER_ROW;   // threads t, t + PER_ROW, ... hold partial sums of the same four rows
+      __syncthreads();                                         // every wave is done with the operand images
+      float* red = reinterpret_cast<float*>(smem);
+      *reinterpret_cast<f32x4*>(red + (t / PER_ROW) * BM + (t % PER_ROW) * 4) = rsum;
+      __syncthreads();
+      if (t < BM && m0 + t < a.M) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) v += red[g * BM + t];
+        if (a.split_k > 1) a.ws[(long long)a.batch * a.split_k * a.M * a.N + (long long)sk * a.M + m0 + t] = v;     // slabs behind the C slabs
+        else a.a_rowsum[m0 + t] = v;
+      }
+    }
+  }
 
   // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   const int h = lane >> 5;
@@ -570,6 +602,14 @@ __global__ __launch_bounds__(256) void gemm_mfma_fold_kernel(const Args a) {
     float v = 0.f;
     for (int s = 0; s < a.split_k; ++s) v += a.ws[((long long)(bz * a.split_k + s)) * mn + r];
     epilogue_store(a, bz, m, n, c_row_offset(a, m), v);
+  }
+  if (a.a_rowsum) {                                            // the row-sum slabs of the split product, same fixed order
+    const float* rs = a.ws + (long long)a.batch * a.split_k * mn;
+    for (long long m = blockIdx.x * 256ll + threadIdx.x; m < a.M; m += (long long)gridDim.x * 256) {
+      float v = 0.f;
+      for (int s = 0; s < a.split_k; ++s) v += rs[(long long)s * a.M + m];
+      a.a_rowsum[m] = v;
+    }
   }
 }
 
@@ -675,6 +715,8 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   a.batch = batch;
   a.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   A2F_CHECK_ARG(d->keep_bits == nullptr || (batch == 1 && d->keep_wpr * 32 >= d->N), "a2f_mm: keep_bits need batch == 1 and keep_wpr * 32 >= N");
+  a.a_rowsum = d->a_rowsum;
+  A2F_CHECK_ARG(d->a_rowsum == nullptr || (batch == 1 && d->A.trans && d->B.trans), "a2f_mm: a_rowsum needs the weight-gradient layout (both operands trans), batch 1");
   a.keep = d->keep_bits;
   a.keep_wpr = d->keep_wpr;
   a.keep_scale = d->keep_scale;

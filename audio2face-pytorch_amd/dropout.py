@@ -141,6 +141,10 @@ def draw_encoder_masks(be, S: int, T: int, n_layers: int, heads: int, hidden: in
     TW = attn_keep_words(T)
     for l in range(n_layers):
         d = {}
+        m.layer_skip.append(bool(rng.rand() < cfg.layerdrop))              # HF Wav2Vec2Encoder: skip when the draw is below layerdrop
+        if m.layer_skip[-1]:
+            m.layers.append(d)                                             # a dropped layer needs no masks
+            continue
         if cfg.attention_dropout > 0.0:
             q = torch.empty(S * heads * T, TW, dtype=torch.int32, device=device)
             k = torch.empty(S * heads, TW, 32 * TW, dtype=torch.int32, device=device)
@@ -151,7 +155,6 @@ def draw_encoder_masks(be, S: int, T: int, n_layers: int, heads: int, hidden: in
             if s_ is not None:
                 d[name] = s_
         m.layers.append(d)
-        m.layer_skip.append(bool(rng.rand() < cfg.layerdrop))              # HF Wav2Vec2Encoder: skip when the draw is below layerdrop
     if cfg.apply_spec_augment and cfg.mask_time_prob > 0.0 and T > cfg.mask_time_length:
         m.spec = torch.from_numpy(compute_mask_indices((S, T), cfg.mask_time_prob, cfg.mask_time_length, min_masks=2, rng=rng)).to(device)
     return m

@@ -84,8 +84,7 @@ class LinearMMFn(torch.autograd.Function):
             dx = _new(xc, M, K)
             ops.mm_linear_dgrad(be, dy, Wc, dx, M, N, K)
         dW, db = _new(xc, N, K), _new(xc, N)
-        ops.mm_linear_wgrad(be, dy, xc, dW, M, N, K)
-        be.colsum(dy, M, N, N, db)
+        ops.mm_linear_wgrad(be, dy, xc, dW, M, N, K, db=db)        # bias gradient collected inside the weight-gradient kernel
         return dx, dW, db, None
 
 
@@ -154,12 +153,11 @@ class EncoderLayerFn(torch.autograd.Function):
             be.layernorm_bwd(dh2, a2, m2, r2, g2, M, d, da2, dg2, db2, None)
             dy2 = new(M, d)
             be.dropout_apply(da2, mk["hid2"][0], M, d, d, mk["hid2"][1], dy2)
-            be.colsum(dy2, M, d, d, dc2)
         else:
             be.layernorm_bwd(dh2, a2, m2, r2, g2, M, d, da2, dg2, db2, dc2)
             dy2 = da2
         dW2 = new(d, F)
-        ops.mm_linear_wgrad(be, dy2, g, dW2, M, d, F)
+        ops.mm_linear_wgrad(be, dy2, g, dW2, M, d, F, db=dc2 if "hid2" in mk else None)
         dz = new(M, F)
         # through GELU: the forward epilogue saved gelu'(pre-activation), so this epilogue only multiplies (evaluating erf / exp here
         # per element dropped the K = 768 product from 245 to 122 TFLOP/s; a separate streaming GELU' pass cost 3 % of the step)
@@ -169,9 +167,9 @@ class EncoderLayerFn(torch.autograd.Function):
             be.mm(MMOp(dy2, d), MMOp(W2, F, trans=True), dz, M, F, d, F, keep=mk.get("act"))
             be.gelu_bwd(dz, z, dz)
         dc1 = new(F)
-        be.colsum(dz, M, F, F, dc1)
         dW1 = new(F, d)
-        ops.mm_linear_wgrad(be, dz, h1, dW1, M, F, d)
+        ops.mm_linear_wgrad(be, dz, h1, dW1, M, F, d, db=dc1)      # bias gradients ride along in the weight-gradient kernels
+
         dh1 = new(M, d)
         ops.mm_linear_dgrad(be, dz, W1, dh1, M, F, d, aux=da2, aux_mode=MM_AUX_ADD)           # + residual branch
         # layer_norm after attention; colsum of its input gradient = out_proj's bias gradient
@@ -180,12 +178,11 @@ class EncoderLayerFn(torch.autograd.Function):
             be.layernorm_bwd(dh1, a1, m1, r1, g1, M, d, da1, dg1, db1, None)
             dy1 = new(M, d)
             be.dropout_apply(da1, mk["hid1"][0], M, d, d, mk["hid1"][1], dy1)
-            be.colsum(dy1, M, d, d, dbo)
         else:
             be.layernorm_bwd(dh1, a1, m1, r1, g1, M, d, da1, dg1, db1, dbo)
             dy1 = da1
         dWo = new(d, d)
-        ops.mm_linear_wgrad(be, dy1, att, dWo, M, d, d)
+        ops.mm_linear_wgrad(be, dy1, att, dWo, M, d, d, db=dbo if "hid1" in mk else None)
         datt = new(M, d)
         ops.mm_linear_dgrad(be, dy1, Wo, datt, M, d, d)
         dqkv = new(M, 3 * d)
@@ -194,11 +191,10 @@ class EncoderLayerFn(torch.autograd.Function):
         else:
             be.attn_bwd(qkv, att, datt, lse, S, T, heads, 3 * d, d, scale, dqkv)
         dbqkv = new(3 * d)
-        be.colsum(dqkv, M, 3 * d, 3 * d, dbqkv)
         dWs = []
         for i in range(3):
             dW = new(d, d)
-            be.mm(MMOp(dqkv, 3 * d, trans=True, ptr_off=i * d), MMOp(xc, d, trans=True), dW, d, d, M, d, split_k=0)
+            be.mm(MMOp(dqkv, 3 * d, trans=True, ptr_off=i * d), MMOp(xc, d, trans=True), dW, d, d, M, d, split_k=0, a_rowsum=dbqkv[i * d:(i + 1) * d])
             dWs.append(dW)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -367,7 +363,12 @@ class ConvStackFn(torch.autograd.Function):
             dws[i] = dw
             if i == 0 and not ctx.needs_input_grad[0]:
                 break
-            dxi = torch.zeros(S, Lin, Ci, device=xc.device, dtype=torch.float32)
+            # the gather-form data gradient writes positions [0, covered); only the tail no window reaches needs zeros (a full fill of
+            # the layer-1 gradient is 2 GB per half-batch)
+            covered = Lout * KH if KH == stride else 2 * Lout + 1
+            dxi = torch.empty(S, Lin, Ci, device=xc.device, dtype=torch.float32)
+            if covered < Lin:
+                dxi[:, covered:].zero_()
             ops.mm_conv_dgrad(be, dz, wg, dxi, S, Lin, Lout, Ci, Co, KH, stride, mul=saved[3 * (i - 1) + 2] if i > 0 else None)
             if i > 0:
                 dz = dxi                                           # already layer (i - 1)'s pre-activation gradient

@@ -152,6 +152,11 @@ def fit(config: ExpConfig, train_batches: Callable[[int], Iterable[Dict[str, tor
     if extractor is not None:
         extractor.to(device)
     step = TrainStep(model, loss_fn, lr=config.lr, use_graph=use_graph)
+    if step.opt.world() > 1:
+        # identical initial weights on every rank (same seed before the model was built); from here on every rank draws its own
+        # stochastic-regulariser masks (FaceFormer train mode), as DDP ranks do in the reference
+        import torch.distributed as dist
+        torch.manual_seed(torch.initial_seed() + 7919 * (dist.get_rank() + 1))
     ckpt_cb = ModelCheckpoint(os.path.join(log_dir, "checkpoints"))
     stop_cb = EarlyStopping(patience=patience)
     history = []

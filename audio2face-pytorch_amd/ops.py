@@ -9,6 +9,7 @@ CPU test-suite can check their index arithmetic with an emulator injected throug
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -55,6 +56,9 @@ def _chk(*ts):
             raise A2FError(f"a2f ops compute in fp32; got {t.dtype}")
         if not t.is_contiguous():
             raise A2FError("a2f ops need contiguous tensors")
+
+
+_NO_FUSED_ROWSUM = os.environ.get("A2F_MM_ROWSUM", "1") == "0"
 
 
 def _chk_bits(*ts):
@@ -129,7 +133,7 @@ class HipBackend:
 
     def mm(self, A: "MMOp", B: "MMOp", Cout, M, N, K, ldc, *, c_off=0, c_rows_per_seq=0, c_seq_stride=0, C2=None, bias=None, aux=None,
            ldaux=0, act=MM_ACT_NONE, aux_mode=MM_AUX_NONE, precision=None, split_k=1, batch=1, a_bstride=0, b_bstride=0, c_bstride=0,
-           bias_bstride=0, aux_bstride=0, accumulate=False, alpha=1.0, tag="gemm_mfma", keep=None):
+           bias_bstride=0, aux_bstride=0, accumulate=False, alpha=1.0, tag="gemm_mfma", keep=None, a_rowsum=None):
         """C[m,n] = epi(alpha * sum_k A(m,k) B(k,n)) on the bf16 matrix pipe (contract: include/a2f_hip.h, a2f_mm).
         keep = (bits int32 (M, wpr), scale): train-mode dropout of C in the epilogue."""
         _chk(A.t, B.t, Cout, C2, bias, aux)
@@ -149,8 +153,14 @@ class HipBackend:
         d.split_k = split_k
         ws = None
         if split_k > 1:
-            ws = torch.empty(batch * split_k * M * N, device=Cout.device, dtype=torch.float32)
+            ws = torch.empty(batch * split_k * M * N + (split_k * M if a_rowsum is not None else 0), device=Cout.device, dtype=torch.float32)
             d.ws = _ptr(ws)
+        if a_rowsum is not None:
+            _chk(a_rowsum)
+            if _NO_FUSED_ROWSUM:                                # A-B hook: the bias gradient as its own pass over dY
+                self.colsum(A.t, K, M, A.ld, a_rowsum, x_off=A.ptr_off)
+            else:
+                d.a_rowsum = _ptr(a_rowsum)
         d.batch, d.accumulate = batch, int(accumulate)
         d.a_bstride, d.b_bstride, d.c_bstride, d.bias_bstride, d.aux_bstride = a_bstride, b_bstride, c_bstride, bias_bstride, aux_bstride
         d.alpha = alpha
@@ -572,9 +582,10 @@ def mm_linear_dgrad(be, dy, W, dx, M, N, K, *, aux=None, aux_mode=MM_AUX_NONE, t
     be.mm(MMOp(dy, N), MMOp(W, K, trans=True), dx, M, K, N, K, aux=aux, ldaux=K, aux_mode=aux_mode, tag=tag)
 
 
-def mm_linear_wgrad(be, dy, x, dW, M, N, K, *, tag="gemm_mfma"):
-    """dW[N,K] = dy[M,N]^T x[M,K]: the contraction runs over the M rows of the batch (split-K slabs, fixed-order fold)."""
-    be.mm(MMOp(dy, N, trans=True), MMOp(x, K, trans=True), dW, N, K, M, K, split_k=0, tag=tag)
+def mm_linear_wgrad(be, dy, x, dW, M, N, K, *, tag="gemm_mfma", db=None):
+    """dW[N,K] = dy[M,N]^T x[M,K]: the contraction runs over the M rows of the batch (split-K slabs, fixed-order fold).  db (N), optional:
+    the bias gradient = column sums of dy, collected inside the same kernel."""
+    be.mm(MMOp(dy, N, trans=True), MMOp(x, K, trans=True), dW, N, K, M, K, split_k=0, tag=tag, a_rowsum=db)
 
 
 def mm_conv_fwd(be, x, Wg, y, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, bias=None, act=MM_ACT_NONE, pre=None, tag="gemm_mfma"):

@@ -408,6 +408,7 @@ def main():
         if args.encoder_precision == "bf16":
             model.encoder_autocast = torch.bfloat16
         model.train()                                            # Lightning's fit puts the reference's module in train mode
+        torch.manual_seed(4321 + 7919 * rank)                    # same initial weights on every rank (seed above), different dropout masks per rank
         if args.ff_deterministic:                                # A/B: the deterministic (eval-mode) function under the same step
             model.audio_encoder.train_regularisers = model.decoder_regularisers = False
         step = TrainStep(model, a2f_amd.FaceFormerLoss(), lr=1e-4)

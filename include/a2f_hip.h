@@ -305,6 +305,9 @@ int a2f_stream_triad(float* dst, const float* a, const float* b, int64_t n, a2f_
  * aux_mode 1: v += aux[m*ldaux+n]; 2: v *= gelu'(aux); 3: v *= (aux > 0); 4: v *= aux at C's own index (aux laid out like C, row map
  * included: a saved derivative); accumulate: v += C_old.  Row m of C (and C2) is
  * stored at C + (m / c_rows_per_seq)*c_seq_stride + (m % c_rows_per_seq)*ldc + n  (c_rows_per_seq = 0: C + m*ldc + n).
+ * a_rowsum (optional; both operands `trans`, batch 1): a_rowsum[m] = sum_k A(m,k), collected from the A tiles as
+ * they pass through the registers - with A = dY^T (weight gradient of a Linear) this is the bias gradient, at no extra pass over dY; with
+ * split_k > 1 `ws` needs split_k*M more floats.
  * split_k > 1: the contraction is cut into split_k slabs stored in `ws` (>= batch*split_k*M*N floats) and folded in fixed
  * order by a second kernel that applies the epilogue (deterministic; how weight gradients with K = 10^4 rows fill the chip).
  * batch > 1: independent problems at p + b*{a,b,c,bias}_bstride, aux + b*aux_bstride (the 16 groups of the positional
@@ -332,6 +335,7 @@ typedef struct a2f_mm_desc {
   float alpha; int32_t reserved;
   const uint32_t* keep_bits; int64_t keep_wpr;     /* optional dropout of C: see a2f_keep_bits */
   float keep_scale; int32_t reserved2;
+  float* a_rowsum;                                 /* optional: a_rowsum[m] = sum_k A(m,k), see below */
 } a2f_mm_desc;
 
 int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream);

@@ -158,7 +158,7 @@ class EmuBackend:
 
     def mm(self, A, B, Cout, M, N, K, ldc, *, c_off=0, c_rows_per_seq=0, c_seq_stride=0, C2=None, bias=None, aux=None, ldaux=0, act=0,
            aux_mode=0, precision=None, split_k=1, batch=1, a_bstride=0, b_bstride=0, c_bstride=0, bias_bstride=0, aux_bstride=0,
-           accumulate=False, alpha=1.0, tag=None, keep=None):
+           accumulate=False, alpha=1.0, tag=None, keep=None, a_rowsum=None):
         import copy
         self.calls.append(("mm", M, N, K, batch))
         cflat = Cout.reshape(-1)
@@ -171,6 +171,9 @@ class EmuBackend:
             Am = self._mm_matrix(Ab, K, M).t() if A.trans else self._mm_matrix(Ab, M, K)
             Bm = self._mm_matrix(Bb, K, N) if B.trans else self._mm_matrix(Bb, N, K).t()
             v = alpha * (Am @ Bm)
+            if a_rowsum is not None:
+                assert batch == 1 and A.trans and B.trans
+                a_rowsum.copy_(Am.sum(dim=1).float())
             if bias is not None:
                 v = v + bias.reshape(-1)[bz * bias_bstride: bz * bias_bstride + N].double().view(1, -1)
             cidx = c_off + bz * c_bstride + crow + torch.arange(N).view(1, -1)

@@ -149,3 +149,20 @@ def test_mm_saved_gelu_derivative_epilogues():
     a, e = both(dgrad)
     assert rel_l2(a[0], e[0]) < 3e-5
     assert rel_l2(a[0], a[1] * mul) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K,split", [(768, 768, 19200, 0), (3072, 768, 9600, 0), (132, 260, 777, 1), (768, 200, 4100, 5), (64, 48, 96, 1)])
+@pytest.mark.parametrize("precision", [1, 0])
+def test_mm_weight_gradient_with_fused_bias_gradient(M, N, K, split, precision):
+    """a_rowsum: dW = dY^T X and db = column sums of dY out of ONE kernel (plain path: K a multiple of 32; masked path otherwise;
+    with and without split-K slabs), against the float64 emulator; the sums are fp32 additions of the fp32 operand, so db holds the
+    tighter bound of a plain reduction in both precisions."""
+    dy, x = rnd(K, M, seed=1), rnd(K, N, seed=2)
+
+    def run(be, dev):
+        dW, db = torch.zeros(M, N, device=dev), torch.full((M,), 7.0, device=dev)
+        be.mm(MMOp(dy.to(dev), M, trans=True), MMOp(x.to(dev), N, trans=True), dW, M, N, K, N, split_k=split, precision=precision, a_rowsum=db)
+        return [dW, db]
+    a, e = both(run)
+    assert rel_l2(a[0], e[0]) < TOL[precision]
+    assert rel_l2(a[1], e[1]) < 1e-5

@@ -17,6 +17,7 @@ from .ops import MM_ACT_GELU, MM_ACT_GELU_SAVE_GRAD, MM_ACT_NONE, MM_AUX_ADD, MM
 LN_EPS = 1e-5
 import os as _os
 GELU_SAVED = _os.environ.get("A2F_GELU_SAVED", "1") != "0"       # A-B hook: 0 = pre-activation saved + streaming GELU' pass in the backward
+FUSED_QKV = _os.environ.get("A2F_FUSED_QKV", "1") != "0"         # A-B hook: 0 = three launches per projection group instead of one
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -111,9 +112,14 @@ class EncoderLayerFn(torch.autograd.Function):
         M, d = xc.shape
         F = W1.shape[0]
         keep = any(ctx.needs_input_grad)
+        # q | k | v as ONE product against the stacked (3d, d) weight (a 7 MB copy per call): one launch and one tile tail instead of three
+        Wqkv, bqkv = torch.cat((Wq, Wk, Wv), 0), torch.cat((bq, bk, bv), 0)
         qkv = _new(xc, M, 3 * d)
-        for i, (W, b) in enumerate(((Wq, bq), (Wk, bk), (Wv, bv))):
-            be.mm(MMOp(xc, d), MMOp(W, d), qkv, M, d, d, 3 * d, c_off=i * d, bias=b)
+        if FUSED_QKV:
+            be.mm(MMOp(xc, d), MMOp(Wqkv, d), qkv, M, 3 * d, d, 3 * d, bias=bqkv)
+        else:
+            for i in range(3):
+                be.mm(MMOp(xc, d), MMOp(Wqkv, d, ptr_off=i * d * d), qkv, M, d, d, 3 * d, c_off=i * d, bias=bqkv[i * d:(i + 1) * d])
         att, lse = _new(xc, M, d), _new(xc, S, heads, T)
         scale = float((d // heads) ** -0.5)
         if "attn" in mk:
@@ -132,7 +138,7 @@ class EncoderLayerFn(torch.autograd.Function):
         h2, m2, r2 = _new(xc, M, d), _new(xc, M), _new(xc, M)
         be.layernorm_fwd(a2, M, d, g2, b2, LN_EPS, h2, m2, r2)
         if keep:
-            ctx.save_for_backward(xc, qkv, att, lse, a1, m1, r1, h1, z, g, a2, m2, r2, Wq, Wk, Wv, Wo, g1, W1, W2, g2)
+            ctx.save_for_backward(xc, qkv, att, lse, a1, m1, r1, h1, z, g, a2, m2, r2, Wqkv, Wo, g1, W1, W2, g2)
             ctx.dims = (S, T, heads, scale)
             ctx.masks = mk
         return h2
@@ -140,7 +146,7 @@ class EncoderLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh2):
         be = ops.backend()
-        xc, qkv, att, lse, a1, m1, r1, h1, z, g, a2, m2, r2, Wq, Wk, Wv, Wo, g1, W1, W2, g2 = ctx.saved_tensors
+        xc, qkv, att, lse, a1, m1, r1, h1, z, g, a2, m2, r2, Wqkv, Wo, g1, W1, W2, g2 = ctx.saved_tensors
         S, T, heads, scale = ctx.dims
         mk = ctx.masks
         M, d = xc.shape
@@ -190,19 +196,23 @@ class EncoderLayerFn(torch.autograd.Function):
             be.attn_bwd_drop(qkv, att, datt, lse, S, T, heads, 3 * d, d, scale, dqkv, mk["attn"][0], mk["attn"][1], mk["attn"][2])
         else:
             be.attn_bwd(qkv, att, datt, lse, S, T, heads, 3 * d, d, scale, dqkv)
-        dbqkv = new(3 * d)
-        dWs = []
-        for i in range(3):
-            dW = new(d, d)
-            be.mm(MMOp(dqkv, 3 * d, trans=True, ptr_off=i * d), MMOp(xc, d, trans=True), dW, d, d, M, d, split_k=0, a_rowsum=dbqkv[i * d:(i + 1) * d])
-            dWs.append(dW)
+        dbqkv, dWqkv = new(3 * d), new(3 * d, d)
+        if FUSED_QKV:
+            ops.mm_linear_wgrad(be, dqkv, xc, dWqkv, M, 3 * d, d, db=dbqkv)     # the three projections' gradients in one product
+        else:
+            for i in range(3):
+                be.mm(MMOp(dqkv, 3 * d, trans=True, ptr_off=i * d), MMOp(xc, d, trans=True), dWqkv[i * d:(i + 1) * d], d, d, M, d, split_k=0,
+                      a_rowsum=dbqkv[i * d:(i + 1) * d])
         dx = None
         if ctx.needs_input_grad[0]:
             dx = new(M, d)
-            be.mm(MMOp(dqkv, 3 * d), MMOp(Wq, d, trans=True), dx, M, d, d, d, aux=da1, ldaux=d, aux_mode=MM_AUX_ADD)   # + residual branch
-            be.mm(MMOp(dqkv, 3 * d, ptr_off=d), MMOp(Wk, d, trans=True), dx, M, d, d, d, accumulate=True)
-            be.mm(MMOp(dqkv, 3 * d, ptr_off=2 * d), MMOp(Wv, d, trans=True), dx, M, d, d, d, accumulate=True)
-        return (dx, None, None, None, None, dWs[0], dbqkv[0:d], dWs[1], dbqkv[d:2 * d], dWs[2], dbqkv[2 * d:], dWo, dbo, dg1, db1,
+            if FUSED_QKV:
+                ops.mm_linear_dgrad(be, dqkv, Wqkv, dx, M, 3 * d, d, aux=da1, aux_mode=MM_AUX_ADD)   # K = 3d in one pass, + residual branch
+            else:
+                for i in range(3):
+                    be.mm(MMOp(dqkv, 3 * d, ptr_off=i * d), MMOp(Wqkv, d, trans=True, ptr_off=i * d * d), dx, M, d, d, d, accumulate=i > 0,
+                          **(dict(aux=da1, ldaux=d, aux_mode=MM_AUX_ADD) if i == 0 else {}))
+        return (dx, None, None, None, None, dWqkv[0:d], dbqkv[0:d], dWqkv[d:2 * d], dbqkv[d:2 * d], dWqkv[2 * d:], dbqkv[2 * d:], dWo, dbo, dg1, db1,
                 dW1, dc1, dW2, dc2, dg2, db2)
 
 

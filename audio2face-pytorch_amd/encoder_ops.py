@@ -20,6 +20,42 @@ GELU_SAVED = _os.environ.get("A2F_GELU_SAVED", "1") != "0"       # A-B hook: 0 =
 FUSED_QKV = _os.environ.get("A2F_FUSED_QKV", "1") != "0"         # A-B hook: 0 = three launches per projection group instead of one
 
 
+WGRAD_STREAM = _os.environ.get("A2F_WGRAD_STREAM", "1") != "0"   # A-B hook: 0 = weight gradients in line on the launch stream
+_wgrad_streams = {}
+
+
+class _WeightGradLane:
+    """Inside a backward: run the weight-gradient products on a second HIP stream beside the data-gradient chain.  A weight gradient and
+    the data gradient of the same layer both only read the incoming gradient, so they are independent; issued back to back on one stream
+    each of them ends in a tail of partly filled CUs (and a split-K fold launch) before the next may start - side by side the two kernels'
+    workgroups interleave and fill each other's tails.  `run(fn)` issues fn() on the lane after everything launched so far; `join(*outs)`
+    makes the launch stream wait for the lane and marks the tensors the lane allocated as used on the launch stream (caching-allocator
+    hygiene).  Inputs of fn must stay alive and unmodified until join()."""
+
+    def __init__(self, ref: torch.Tensor):
+        self.on = WGRAD_STREAM and ref.is_cuda
+        if self.on:
+            self.cur = torch.cuda.current_stream(ref.device)
+            key = (ref.device, self.cur.cuda_stream)
+            if key not in _wgrad_streams:
+                _wgrad_streams[key] = torch.cuda.Stream(device=ref.device)
+            self.lane = _wgrad_streams[key]
+
+    def run(self, fn):
+        if not self.on:
+            return fn()
+        self.lane.wait_event(self.cur.record_event())
+        with torch.cuda.stream(self.lane):
+            return fn()
+
+    def join(self, *outs):
+        if self.on:
+            self.cur.wait_stream(self.lane)
+            for t in outs:
+                if t is not None:
+                    t.record_stream(self.cur)
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
@@ -162,8 +198,9 @@ class EncoderLayerFn(torch.autograd.Function):
         else:
             be.layernorm_bwd(dh2, a2, m2, r2, g2, M, d, da2, dg2, db2, dc2)
             dy2 = da2
+        lane = _WeightGradLane(xc)
         dW2 = new(d, F)
-        ops.mm_linear_wgrad(be, dy2, g, dW2, M, d, F, db=dc2 if "hid2" in mk else None)
+        lane.run(lambda: ops.mm_linear_wgrad(be, dy2, g, dW2, M, d, F, db=dc2 if "hid2" in mk else None))
         dz = new(M, F)
         # through GELU: the forward epilogue saved gelu'(pre-activation), so this epilogue only multiplies (evaluating erf / exp here
         # per element dropped the K = 768 product from 245 to 122 TFLOP/s; a separate streaming GELU' pass cost 3 % of the step)
@@ -174,7 +211,7 @@ class EncoderLayerFn(torch.autograd.Function):
             be.gelu_bwd(dz, z, dz)
         dc1 = new(F)
         dW1 = new(F, d)
-        ops.mm_linear_wgrad(be, dz, h1, dW1, M, F, d, db=dc1)      # bias gradients ride along in the weight-gradient kernels
+        lane.run(lambda: ops.mm_linear_wgrad(be, dz, h1, dW1, M, F, d, db=dc1))      # bias gradients ride along in the weight-gradient kernels
 
         dh1 = new(M, d)
         ops.mm_linear_dgrad(be, dz, W1, dh1, M, F, d, aux=da2, aux_mode=MM_AUX_ADD)           # + residual branch
@@ -188,7 +225,7 @@ class EncoderLayerFn(torch.autograd.Function):
             be.layernorm_bwd(dh1, a1, m1, r1, g1, M, d, da1, dg1, db1, dbo)
             dy1 = da1
         dWo = new(d, d)
-        ops.mm_linear_wgrad(be, dy1, att, dWo, M, d, d, db=dbo if "hid1" in mk else None)
+        lane.run(lambda: ops.mm_linear_wgrad(be, dy1, att, dWo, M, d, d, db=dbo if "hid1" in mk else None))
         datt = new(M, d)
         ops.mm_linear_dgrad(be, dy1, Wo, datt, M, d, d)
         dqkv = new(M, 3 * d)
@@ -198,7 +235,7 @@ class EncoderLayerFn(torch.autograd.Function):
             be.attn_bwd(qkv, att, datt, lse, S, T, heads, 3 * d, d, scale, dqkv)
         dbqkv, dWqkv = new(3 * d), new(3 * d, d)
         if FUSED_QKV:
-            ops.mm_linear_wgrad(be, dqkv, xc, dWqkv, M, 3 * d, d, db=dbqkv)     # the three projections' gradients in one product
+            lane.run(lambda: ops.mm_linear_wgrad(be, dqkv, xc, dWqkv, M, 3 * d, d, db=dbqkv))     # the three projections' gradients in one product
         else:
             for i in range(3):
                 be.mm(MMOp(dqkv, 3 * d, trans=True, ptr_off=i * d), MMOp(xc, d, trans=True), dWqkv[i * d:(i + 1) * d], d, d, M, d, split_k=0,
@@ -212,6 +249,7 @@ class EncoderLayerFn(torch.autograd.Function):
                 for i in range(3):
                     be.mm(MMOp(dqkv, 3 * d, ptr_off=i * d), MMOp(Wqkv, d, trans=True, ptr_off=i * d * d), dx, M, d, d, d, accumulate=i > 0,
                           **(dict(aux=da1, ldaux=d, aux_mode=MM_AUX_ADD) if i == 0 else {}))
+        lane.join()                                  # outputs were allocated on the launch stream; the lane only wrote them
         return (dx, None, None, None, None, dWqkv[0:d], dbqkv[0:d], dWqkv[d:2 * d], dbqkv[d:2 * d], dWqkv[2 * d:], dbqkv[2 * d:], dWo, dbo, dg1, db1,
                 dW1, dc1, dW2, dc2, dg2, db2)
 
@@ -363,13 +401,17 @@ class ConvStackFn(torch.autograd.Function):
         dz = _f32c(dy) * saved[3 * (n - 1) + 2]                   # top layer: dy o gelu'
         dws = [None] * n
         dx = None
+        lane, held = _WeightGradLane(dz), []
         for i in range(n - 1, -1, -1):
             xc, wg, _gp = saved[3 * i: 3 * i + 3]
             S, Lin, Lout, Ci, Co, KH, stride = dims[i]
-            dwg = _new(xc, Co, KH * Ci)
-            ops.mm_conv_wgrad(be, xc, dz, dwg, S, Lin, Lout, Ci, Co, KH, stride)
-            dw = _new(xc, Co, Ci, KH)
-            be.conv_weight_pack(dwg, dw, Co, Ci, KH, 1)
+            dwg, dw = _new(xc, Co, KH * Ci), _new(xc, Co, Ci, KH)
+
+            def wgrad(xc=xc, dz=dz, dwg=dwg, dw=dw, dm=(S, Lin, Lout, Ci, Co, KH, stride)):
+                ops.mm_conv_wgrad(be, xc, dz, dwg, *dm)
+                be.conv_weight_pack(dwg, dw, dm[4], dm[3], dm[5], 1)
+            lane.run(wgrad)
+            held.append((dz, dwg))                                 # read / written by the lane: alive until join()
             dws[i] = dw
             if i == 0 and not ctx.needs_input_grad[0]:
                 break
@@ -384,6 +426,7 @@ class ConvStackFn(torch.autograd.Function):
                 dz = dxi                                           # already layer (i - 1)'s pre-activation gradient
             else:
                 dx = dxi
+        lane.join()
         return (dx, None, *dws)
 
 

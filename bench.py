@@ -434,10 +434,16 @@ def main():
                     "traffic": None, "note": "whole step, algorithmic fp32 flops (857 MFLOP/frame) / step time, against the exact-fp32 matrix peak; "
                                              "split-bf16 kernels execute 3 bf16 MFMA flops per algorithmic flop: bf16_pipe_frac = 3 x achieved / 2500"}
             roof["bf16_pipe_frac"] = round(3 * ach / MFMA_BF16_PEAK_TF, 4)
+            # per-launch HIP events are only meaningful when nothing else shares the GPU: this pass runs the same kernels with the
+            # two-stream half-batch pipeline and the weight-gradient lane switched off (one stream, launches back to back)
+            from a2f_amd import encoder_ops
+            old_lane, old_pipe = encoder_ops.WGRAD_STREAM, step.pipeline
+            encoder_ops.WGRAD_STREAM, step.pipeline = False, False
             be.prof, be.prof_flops = {}, {}
             for _ in range(2):
                 step(audio, one_hot, gt, templ)
             torch.cuda.synchronize()
+            encoder_ops.WGRAD_STREAM, step.pipeline = old_lane, old_pipe
             tf, nl, ms = gemm_prof_summary(be)
             if tf is not None:
                 roof["kernel"] = {"name": "gemm_mfma_kernel (all encoder / decoder-side GEMM launches of 2 steps)", "launches_timed": nl,
@@ -446,7 +452,7 @@ def main():
             hev = be.prof.get("head_fused", [])
             if hev:
                 hms = sum(a.elapsed_time(b) for a, b in hev) / len(hev)
-                hb = ALGO_BYTES_PER_FRAME["head_fused_ff"] * (2 * S * T / len(hev))          # frames per launch over the 2 profiled steps
+                hb = ALGO_BYTES_PER_FRAME["head_fused_ff"] * (2 * S * T / len(hev))          # frames per launch over the 2 profiled steps (single stream)
                 roof["head_hbm"] = {"kernel": "head_x3_kernel<64> + fold", "achieved": round(hb / (hms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(hb / (hms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(hms, 4), "launches_timed": len(hev)}
             be.prof = None

@@ -37,8 +37,8 @@ class GemmDesc(C.Structure):
 
 class MMOperand(C.Structure):
     """Mirror of ``a2f_mm_operand`` (include/a2f_hip.h)."""
-    _fields_ = [("p", c_f32p), ("bytes", i64), ("ld", i64), ("trans", i32), ("reserved", i32),
-                ("lines_per_seq", i64), ("seq_stride", i64), ("off", i64), ("seq_elems", i64)]
+    _fields_ = [("p", c_f32p), ("bytes", i64), ("ld", i64), ("trans", i32), ("format", i32),
+                ("lines_per_seq", i64), ("seq_stride", i64), ("off", i64), ("seq_elems", i64), ("p_lo", c_f32p)]
 
 
 class MMDesc(C.Structure):
@@ -100,6 +100,7 @@ SIGNATURES = {
     "a2f_ff_decoder_bwd_drop": (C.c_int, [c_f32p, c_f32p, i64, i64, i32, C.c_void_p, sz, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, f32, C.c_void_p]),
     "a2f_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, f32, f32, f32, f32, f32, f32, i32, C.c_void_p]),
     "a2f_mm": (C.c_int, [C.POINTER(MMDesc), C.c_void_p]),
+    "a2f_split_bf16": (C.c_int, [c_f32p, i64, c_f32p, c_f32p, C.c_void_p]),
     "a2f_layernorm_fwd": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, f32, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "a2f_layernorm_bwd_ws_bytes": (sz, [i64, i64]),
     "a2f_layernorm_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),

@@ -39,6 +39,7 @@ constexpr int THREADS = 256;           // CFG 0 / 1; CFG 2 runs 512 threads (see
 
 struct Op {
   const float* p;
+  const void* p_lo;      // bf16 image operands (format 1): p = hi image, p_lo = lo image, `bytes` = size of ONE image, ld in bf16 elements
   unsigned bytes;
   int ld, lps, off, seq_elems;
   int lps_shift;         // log2(lps) when lps is a power of two, else -1 (short sequences: division -> shift)
@@ -135,6 +136,69 @@ __device__ __forceinline__ f32x16 mfma(u32x4_t a, u32x4_t b, f32x16 c) {
 #else
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 #endif
+}
+
+// ---- epilogue of one workgroup tile: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+template <int TM, int TN>
+__device__ __forceinline__ void tile_epilogue(const Args& a, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, int bz) {
+  const int h = lane >> 5;
+  int ncol[TN];
+  float bv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    ncol[j] = n0 + (wn * TN + j) * 32 + (lane & 31);
+    bv[j] = (a.bias && a.split_k <= 1 && ncol[j] < a.N) ? a.bias[bz * a.bias_bstride + ncol[j]] : 0.f;
+  }
+  const bool generic = a.C2 || a.act || a.aux_mode || a.accumulate || a.keep;     // wave-uniform
+  if (a.split_k > 1) {
+    float* wsz = a.ws + (long long)blockIdx.z * a.M * a.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          if (m < a.M && ncol[j] < a.N) wsz[(long long)m * a.N + ncol[j]] = acc[i][j][r];
+      }
+  } else {
+    float* Cz = a.C + bz * a.c_bstride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= a.M) continue;
+        const long long crow = c_row_offset(a, m);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (ncol[j] >= a.N) continue;
+          float v = acc[i][j][r] * a.alpha + bv[j];
+          if (generic) {
+            if (a.act == 4) {
+              const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+              if (a.C2) a.C2[bz * a.c_bstride + crow + ncol[j]] = cdf + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+              v *= cdf;
+            } else {
+              if (a.C2) a.C2[bz * a.c_bstride + crow + ncol[j]] = v;
+              if (a.act == 1) v = fmaxf(v, 0.f);
+              else if (a.act == 3) v = gelu_f(v);
+            }
+            if (a.keep) v = ((a.keep[(long long)m * a.keep_wpr + (ncol[j] >> 5)] >> (ncol[j] & 31)) & 1u) ? v * a.keep_scale : 0.f;
+            if (a.aux_mode == 4) {
+              v *= a.aux[bz * a.c_bstride + crow + ncol[j]];
+            } else if (a.aux_mode) {
+              const float x = a.aux[bz * a.aux_bstride + (long long)m * a.ldaux + ncol[j]];
+              if (a.aux_mode == 1) v += x;
+              else if (a.aux_mode == 2) v *= gelu_grad_f(x);
+              else v *= (x > 0.f ? 1.f : 0.f);
+            }
+            if (a.accumulate) v += Cz[crow + ncol[j]];
+          }
+          Cz[crow + ncol[j]] = v;
+        }
+      }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -531,65 +595,204 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, Cfg<CFG>::WPS) void gemm_mfma_kernel(
     }
   }
 
-  // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-  const int h = lane >> 5;
-  int ncol[TN];
-  float bv[TN];
+  tile_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, lane, bz);
+}
+
+// =====================================================================================================================
+// Operands that ARRIVE as bf16 hi / lo images (a2f_mm_operand.format 1; produced by a2f_split_bf16 or by a producing kernel's
+// epilogue): nothing is converted here and nothing passes through registers - the k-tile is copied global -> LDS by the LDS-DMA
+// form of the buffer load (buffer_load_dwordx4 ... lds: a wave instruction fills 1 KB of LDS, lane l at + 16 l), which removes
+// the 40 conversion instructions, the eight ds_writes and the 16 staging registers per thread and k-tile of the fp32 path
+// (its measured price: 30-45 % of the kernel).  An LDS-DMA cannot scatter, so the swizzles live on the SOURCE side:
+//   R image (k contiguous), tile [X lines][32 k] in 64-byte rows: LDS slot (line, s) holds source chunk s ^ ((line >> 2) & 3) - the
+//     layout the fp32 path writes, read back by the same one-ds_read_b128 fragment;
+//   T image (lines contiguous), tile [32 k][X lines] with UNPADDED rows of 2 X bytes (a padded row would put lanes into the pad): the
+//     64-byte blocks of row k are XORed with (k & 3), so the four k-rows a transposing read touches per lane group land in four
+//     different bank quarters (conflict-free, checked exhaustively off line like the other layouts).
+// Plain operands only (no windows), K a multiple of 32; one barrier per k-tile: wait for the own DMA of tile t, barrier (everybody's
+// tile t is in LDS and everybody is done reading tile t - 1), issue the DMA of tile t + 1 into the other stage, multiply tile t.
+// =====================================================================================================================
+template <bool T, int X, int TH>
+struct StageImg {
+  static constexpr int IMG = X * 64;                          // bytes of one bf16 image tile (R: X x 64 B; T: 32 x 2 X B)
+  static constexpr int NI = IMG / (TH * 16);                  // DMA instructions per thread and image
+  static constexpr int PITCH = T ? 2 * X : 64;
+  static_assert(NI >= 1 && IMG % (TH * 16) == 0, "image tile must be a whole number of 1-KB wave pieces per wave");
+  unsigned voff[NI];                                          // byte offset of this lane's 16-byte chunk from the k-tile's base
+  int piece[NI];                                              // wave-uniform byte offset of the 1-KB piece inside the image
+
+  __device__ __forceinline__ void init(const Op& op, int x0, int xcount, int t) {
+    const int wave = t >> 6, p = t & 63;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    ncol[j] = n0 + (wn * TN + j) * 32 + (lane & 31);
-    bv[j] = (a.bias && a.split_k <= 1 && ncol[j] < a.N) ? a.bias[bz * a.bias_bstride + ncol[j]] : 0.f;
+    for (int i = 0; i < NI; ++i) {
+      const int pc = wave + (TH / 64) * i;
+      piece[i] = __builtin_amdgcn_readfirstlane(pc * 1024);
+      if constexpr (!T) {
+        const int line = pc * 16 + (p >> 2), slot = p & 3;
+        const int c = slot ^ ((line >> 2) & 3);
+        const int gl = x0 + line;
+        voff[i] = gl < xcount ? ((unsigned)gl * (unsigned)op.ld + (unsigned)(c * 8)) * 2u : 0xFFFFFFFFu;
+      } else {
+        constexpr int CPR = 2 * X / 16;                       // 16-byte chunks per k-row
+        const int krow = pc * (64 / CPR) + p / CPR, slot = p % CPR;
+        const int c16 = ((((slot >> 2) ^ (krow & 3)) << 2) | (slot & 3));
+        const int col = x0 + c16 * 8;
+        voff[i] = col < xcount ? ((unsigned)krow * (unsigned)op.ld + (unsigned)col) * 2u : 0xFFFFFFFFu;
+      }
+    }
   }
-  const bool generic = a.C2 || a.act || a.aux_mode || a.accumulate || a.keep;     // wave-uniform
+  // buffer resources of the hi / lo images for the k-tile starting at k0 (size 0 past the k-range: such a tile reads as zeros)
+  __device__ __forceinline__ static rsrc_t tile_rsrc(const void* img, const Op& op, int k0, int kend) {
+    const long long adv = (T ? (long long)k0 * op.ld : (long long)k0) * 2;             // bytes; wave-uniform
+    const unsigned left = k0 < kend ? op.bytes - (unsigned)adv : 0u;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(img) + adv), 0, (int)left, 0x00020000);
+  }
+  template <int PREC>
+  __device__ __forceinline__ void issue(const Op& op, int k0, int kend, char* stage) const {
+#if defined(__HIP_DEVICE_COMPILE__)          // the LDS address-space cast only parses in the device pass
+    const rsrc_t rh = tile_rsrc(op.p, op, k0, kend);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (__attribute__((address_space(3))) void*)(stage + piece[i]), 16, voff[i], 0, 0, 0);
+    if constexpr (PREC == 1) {
+      const rsrc_t rl = tile_rsrc(op.p_lo, op, k0, kend);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (__attribute__((address_space(3))) void*)(stage + IMG + piece[i]), 16, voff[i], 0, 0, 0);
+    }
+#endif
+  }
+  __device__ __forceinline__ static u32x4_t frag(const char* img, int rb, int ks, int lane) {
+    if constexpr (!T) {
+      const int line = rb + (lane & 31);
+      const int chunk = ks * 2 + (lane >> 5);
+      return *reinterpret_cast<const u32x4_t*>(img + line * 64 + ((chunk ^ ((line >> 2) & 3)) << 4));
+    } else {
+      const int g = lane >> 4, i = lane & 15;
+      const int krow = ks * 16 + 8 * (g >> 1) + (i >> 2);
+      const int byte = (rb + 16 * (g & 1) + 4 * (i & 3)) * 2;
+      const char* p = img + krow * PITCH + ((((byte >> 6) ^ (krow & 3)) << 6) | (byte & 63));
+      const u32x2_t r0 = tr_read(p);
+      const u32x2_t r1 = tr_read(p + 4 * PITCH);              // (krow + 4) & 3 == krow & 3: same block permutation
+      return u32x4_t{r0.x, r0.y, r1.x, r1.y};
+    }
+  }
+};
+
+// 128 x 128 tile; W4 = false: 8 waves of 32 x 64 (the CFG 3 geometry, four waves per SIMD); W4 = true: 4 waves of 64 x 64 (two waves per SIMD,
+// twice the MFMAs per fragment read and per barrier)
+template <bool AT, bool BT, int PREC, bool W4>
+__global__ __launch_bounds__(W4 ? 256 : 512, W4 ? 2 : 4) void gemm_img_kernel(const Args a) {
+  constexpr int BM = 128, BN = 128, TH = W4 ? 256 : 512, WGN = 2, TM = W4 ? 2 : 1, TN = 2;
+  constexpr int NIMG = PREC == 1 ? 2 : 1;
+  using SA = StageImg<AT, BM, TH>;
+  using SB = StageImg<BT, BN, TH>;
+  constexpr int A_BYTES = NIMG * SA::IMG, B_BYTES = NIMG * SB::IMG, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int tiles_n = (a.N + BN - 1) / BN;
+  int m0, n0;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    const int tm = wgid / tiles_n;
+    m0 = tm * BM;
+    n0 = (wgid - tm * tiles_n) * BN;
+  }
+  const int bz = 0;
+  const int sk = __builtin_amdgcn_readfirstlane((int)blockIdx.z);
+  int kbeg = 0, kend = a.K;
   if (a.split_k > 1) {
-    float* wsz = a.ws + (long long)blockIdx.z * a.M * a.N;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          if (m < a.M && ncol[j] < a.N) wsz[(long long)m * a.N + ncol[j]] = acc[i][j][r];
-      }
-  } else {
-    float* Cz = a.C + bz * a.c_bstride;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= a.M) continue;
-        const long long crow = c_row_offset(a, m);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if (ncol[j] >= a.N) continue;
-          float v = acc[i][j][r] * a.alpha + bv[j];
-          if (generic) {
-            if (a.act == 4) {
-              const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
-              if (a.C2) a.C2[bz * a.c_bstride + crow + ncol[j]] = cdf + v * 0.3989422804014327f * __expf(-0.5f * v * v);
-              v *= cdf;
-            } else {
-              if (a.C2) a.C2[bz * a.c_bstride + crow + ncol[j]] = v;
-              if (a.act == 1) v = fmaxf(v, 0.f);
-              else if (a.act == 3) v = gelu_f(v);
-            }
-            if (a.keep) v = ((a.keep[(long long)m * a.keep_wpr + (ncol[j] >> 5)] >> (ncol[j] & 31)) & 1u) ? v * a.keep_scale : 0.f;
-            if (a.aux_mode == 4) {
-              v *= a.aux[bz * a.c_bstride + crow + ncol[j]];
-            } else if (a.aux_mode) {
-              const float x = a.aux[bz * a.aux_bstride + (long long)m * a.ldaux + ncol[j]];
-              if (a.aux_mode == 1) v += x;
-              else if (a.aux_mode == 2) v *= gelu_grad_f(x);
-              else v *= (x > 0.f ? 1.f : 0.f);
-            }
-            if (a.accumulate) v += Cz[crow + ncol[j]];
-          }
-          Cz[crow + ncol[j]] = v;
-        }
-      }
+    const int ktiles = (a.K + BK - 1) / BK;
+    const int per = (ktiles + a.split_k - 1) / a.split_k;
+    kbeg = sk * per * BK;
+    kend = min(a.K, kbeg + per * BK);
   }
+  const int nkt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  SA sa;
+  SB sb;
+  sa.init(a.A, m0, a.M, t);
+  sb.init(a.B, n0, a.N, t);
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  sa.template issue<PREC>(a.A, kbeg, kend, smem);
+  sb.template issue<PREC>(a.B, kbeg, kend, smem + A_BYTES);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();                                            // the compiler drains the DMA (vmcnt 0) in front of the barrier
+    if (kt + 1 < nkt) {
+      char* nst = smem + ((kt + 1) & 1) * STAGE;
+      sa.template issue<PREC>(a.A, kbeg + (kt + 1) * BK, kend, nst);
+      sb.template issue<PREC>(a.B, kbeg + (kt + 1) * BK, kend, nst + A_BYTES);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const char* cur = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4_t fa[NIMG][TM], fb[NIMG][TN];
+#pragma unroll
+      for (int q = 0; q < NIMG; ++q) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[q][i] = SA::frag(cur + q * SA::IMG, (wm * TM + i) * 32, ks, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[q][j] = SB::frag(cur + A_BYTES + q * SB::IMG, (wn * TN + j) * 32, ks, lane);
+      }
+      if constexpr (PREC == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma(fa[1][i], fb[0][j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma(fa[0][i], fb[1][j], acc[i][j]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma(fa[0][i], fb[0][j], acc[i][j]);
+    }
+  }
+  tile_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, lane, bz);
+}
+
+template <bool AT, bool BT, int PREC, bool W4>
+static int launch_img(const Args& a, hipStream_t st) {
+  constexpr int NIMG = PREC == 1 ? 2 : 1;
+  constexpr int TH = W4 ? 256 : 512;
+  constexpr int smem = 2 * NIMG * (StageImg<AT, 128, TH>::IMG + StageImg<BT, 128, TH>::IMG);
+  auto kern = gemm_img_kernel<AT, BT, PREC, W4>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return set_err(A2F_ELAUNCH, "a2f_mm: cannot reserve %d bytes of LDS", smem);
+    attr_done = true;
+  }
+  dim3 grid((unsigned)(cdiv(a.N, 128) * cdiv(a.M, 128)), 1, (unsigned)a.split_k);
+  hipLaunchKernelGGL(kern, grid, dim3(TH), smem, st, a);
+  return A2F_OK;
+}
+
+template <int PREC>
+static int dispatch_img(const Args& a, bool at, bool bt, hipStream_t st) {
+  static const bool w4 = [] { const char* e = getenv("A2F_MM_IMG_W4"); return e && e[0] == '1'; }();          // A-B hook
+  if (w4) {
+    if (!at && !bt) return launch_img<false, false, PREC, true>(a, st);
+    if (!at && bt) return launch_img<false, true, PREC, true>(a, st);
+    if (at && bt) return launch_img<true, true, PREC, true>(a, st);
+    return launch_img<true, false, PREC, true>(a, st);
+  }
+  if (!at && !bt) return launch_img<false, false, PREC, false>(a, st);
+  if (!at && bt) return launch_img<false, true, PREC, false>(a, st);
+  if (at && bt) return launch_img<true, true, PREC, false>(a, st);
+  return launch_img<true, false, PREC, false>(a, st);
 }
 
 __global__ __launch_bounds__(256) void gemm_mfma_fold_kernel(const Args a) {
@@ -649,6 +852,16 @@ static int dispatch_layout(const Args& a, bool at, bool bt, bool plain, hipStrea
 
 static int fill_op(const a2f_mm_operand& o, int64_t bstride, int64_t contiguous_extent, Op& k, const char* name) {
   A2F_CHECK_ARG(o.p != nullptr, "a2f_mm: operand %s is null", name);
+  k.p_lo = o.p_lo;
+  if (o.format == 1) {          // bf16 hi / lo images: plain matrices only
+    A2F_CHECK_ARG(o.lines_per_seq == 0 && bstride == 0, "a2f_mm: image operand %s must be a plain matrix (no windows, no batch)", name);
+    A2F_CHECK_ARG(((uintptr_t)o.p & 15) == 0 && ((uintptr_t)o.p_lo & 15) == 0 && o.ld % 8 == 0 && contiguous_extent % 8 == 0,
+                  "a2f_mm: image operand %s: 16-byte aligned images, ld and the contiguous extent multiples of 8 elements", name);
+    A2F_CHECK_ARG(o.bytes > 0 && o.bytes < (int64_t)0xFFFFFFF0ll, "a2f_mm: image operand %s spans %lld bytes per image (must be < 4 GiB)", name, (long long)o.bytes);
+    k.p = o.p; k.bytes = (unsigned)o.bytes; k.ld = (int)o.ld; k.lps = 0; k.lps_shift = -1; k.off = 0; k.seq_elems = 0x7FFFFFF0; k.seq_stride = 0; k.bstride = 0;
+    return A2F_OK;
+  }
+  A2F_CHECK_ARG(o.format == 0, "a2f_mm: operand %s: format %d", name, o.format);
   A2F_CHECK_ARG(((uintptr_t)o.p & 15) == 0, "a2f_mm: operand %s must be 16-byte aligned", name);
   A2F_CHECK_ARG(o.bytes > 0 && o.bytes < (int64_t)0xFFFFFFF0ll, "a2f_mm: operand %s spans %lld bytes (must be < 4 GiB)", name, (long long)o.bytes);
   A2F_CHECK_ARG(o.ld % 4 == 0 && o.off % 4 == 0 && o.seq_stride % 4 == 0 && bstride % 4 == 0 && contiguous_extent % 4 == 0,
@@ -731,6 +944,22 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
     if (force && force[0] >= '0' && force[0] <= '3' && !(force[0] == '1' && d->N > 64)) cfg = force[0] - '0';
   }
   hipStream_t st = (hipStream_t)stream;
+  A2F_CHECK_ARG(d->A.format == d->B.format, "a2f_mm: both operands fp32 or both bf16 hi / lo images");
+  if (d->A.format == 1) {
+    A2F_CHECK_ARG(batch == 1 && d->K % BK == 0 && d->a_rowsum == nullptr, "a2f_mm: image operands need batch 1, K a multiple of %d, no a_rowsum", BK);
+    A2F_CHECK_ARG(d->precision == 0 || (d->A.p_lo && d->B.p_lo), "a2f_mm: image operands: precision 1 needs the lo images");
+    rc = d->precision == 1 ? dispatch_img<1>(a, at, bt, st) : dispatch_img<0>(a, at, bt, st);
+    if (rc) return rc;
+    A2F_CHECK_LAUNCH("a2f_mm (images)");
+    if (split > 1) {
+      const long long total = (long long)a.M * a.N;
+      long long blocks = (total + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(gemm_mfma_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+      A2F_CHECK_LAUNCH("a2f_mm fold");
+    }
+    return A2F_OK;
+  }
   static const bool no_plain = [] { const char* e = getenv("A2F_MM_PLAIN"); return e && e[0] == '0'; }();     // A-B hook
   const bool plain = !no_plain && a.A.lps == 0 && a.B.lps == 0 && (d->K % BK) == 0;
   if (d->precision == 1)

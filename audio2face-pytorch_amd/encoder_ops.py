@@ -205,9 +205,9 @@ class EncoderLayerFn(torch.autograd.Function):
         # through GELU: the forward epilogue saved gelu'(pre-activation), so this epilogue only multiplies (evaluating erf / exp here
         # per element dropped the K = 768 product from 245 to 122 TFLOP/s; a separate streaming GELU' pass cost 3 % of the step)
         if GELU_SAVED:
-            be.mm(MMOp(dy2, d), MMOp(W2, F, trans=True), dz, M, F, d, F, keep=mk.get("act"), aux=z, aux_mode=MM_AUX_MUL_LIKE_C)
+            ops.mm_linear_dgrad(be, dy2, W2, dz, M, d, F, keep=mk.get("act"), aux=z, aux_mode=MM_AUX_MUL_LIKE_C)
         else:
-            be.mm(MMOp(dy2, d), MMOp(W2, F, trans=True), dz, M, F, d, F, keep=mk.get("act"))
+            ops.mm_linear_dgrad(be, dy2, W2, dz, M, d, F, keep=mk.get("act"))
             be.gelu_bwd(dz, z, dz)
         dc1 = new(F)
         dW1 = new(F, d)

@@ -40,6 +40,23 @@ class MMOp:
         o.lines_per_seq, o.seq_stride, o.off, o.seq_elems = self.lines_per_seq, self.seq_stride, self.off, self.seq_elems
 
 
+class MMImg(MMOp):
+    """An a2f_mm operand that arrives as bf16 hi / lo images (a2f_mm_operand.format 1): ``img`` = (hi, lo) bfloat16 tensors of the matrix's
+    shape (``HipBackend.split_bf16`` or a producing kernel), ``ld`` in elements; plain matrices only."""
+
+    def __init__(self, img, ld: int, *, trans: bool = False):
+        self.hi, self.lo = img
+        super().__init__(self.hi, ld, trans=trans)
+
+    def fill(self, o: MMOperand):
+        for t in (self.hi, self.lo):
+            if t.device.type != "cuda" or t.dtype != torch.bfloat16 or not t.is_contiguous():
+                raise A2FError("image operands are contiguous bfloat16 HIP tensors")
+        o.p, o.p_lo = self.hi.data_ptr(), self.lo.data_ptr()
+        o.bytes = 2 * self.hi.numel()
+        o.ld, o.trans, o.format = self.ld, int(self.trans), 1
+
+
 def _ptr(t: Optional[torch.Tensor], off: int = 0) -> Optional[int]:
     if t is None:
         return None
@@ -136,7 +153,7 @@ class HipBackend:
            bias_bstride=0, aux_bstride=0, accumulate=False, alpha=1.0, tag="gemm_mfma", keep=None, a_rowsum=None):
         """C[m,n] = epi(alpha * sum_k A(m,k) B(k,n)) on the bf16 matrix pipe (contract: include/a2f_hip.h, a2f_mm).
         keep = (bits int32 (M, wpr), scale): train-mode dropout of C in the epilogue."""
-        _chk(A.t, B.t, Cout, C2, bias, aux)
+        _chk(*(t for t in (A.t, B.t) if t.dtype != torch.bfloat16), Cout, C2, bias, aux)
         d = MMDesc()
         A.fill(d.A)
         B.fill(d.B)
@@ -247,6 +264,13 @@ class HipBackend:
                                               self.mm_precision if precision is None else precision, _ptr(dqkv), _ptr(ws), keep_q.data_ptr(),
                                               keep_k.data_ptr(), float(keep_scale), self._stream(qkv)), "a2f_attn_bwd_drop")
         self._prof_end("attn", ev)
+
+    def split_bf16(self, x):
+        """fp32 tensor -> (hi, lo) bfloat16 images of the same shape (a2f_split_bf16): the format-1 operand form of a2f_mm."""
+        _chk(x)
+        hi, lo = torch.empty_like(x, dtype=torch.bfloat16), torch.empty_like(x, dtype=torch.bfloat16)
+        _lib.check(self.lib.a2f_split_bf16(_ptr(x), x.numel(), hi.data_ptr(), lo.data_ptr(), self._stream(x)), "a2f_split_bf16")
+        return hi, lo
 
     # ---- dropout keep masks (csrc/dropout.hip) ---------------------------------------------------
     def attn_keep_words(self, T):
@@ -577,9 +601,17 @@ def mm_linear_fwd(be, x, W, bias, out, M, N, K, *, act=MM_ACT_NONE, pre=None, au
     be.mm(MMOp(x, K), MMOp(W, K), out, M, N, K, N, bias=bias, act=act, C2=pre, aux=aux, ldaux=N, aux_mode=aux_mode, tag=tag)
 
 
-def mm_linear_dgrad(be, dy, W, dx, M, N, K, *, aux=None, aux_mode=MM_AUX_NONE, tag="gemm_mfma"):
-    """dx[M,K] = dy[M,N] W[N,K], optionally times an activation derivative evaluated on aux[M,K]."""
-    be.mm(MMOp(dy, N), MMOp(W, K, trans=True), dx, M, K, N, K, aux=aux, ldaux=K, aux_mode=aux_mode, tag=tag)
+DGRAD_TRANSPOSED_W = os.environ.get("A2F_DGRAD_WT", "1") != "0"     # A-B hook
+
+
+def mm_linear_dgrad(be, dy, W, dx, M, N, K, *, aux=None, aux_mode=MM_AUX_NONE, tag="gemm_mfma", keep=None):
+    """dx[M,K] = dy[M,N] W[N,K], optionally times an activation derivative evaluated on aux[M,K].  The weight is read through a
+    transposed copy (K, N) so that BOTH operands are k-contiguous: the row-image staging path (one ds_read_b128 per fragment) is
+    12-15 % faster than the transposing one, and the copy is 1/M of the product's traffic."""
+    if DGRAD_TRANSPOSED_W and W.is_cuda and M >= 1024:
+        be.mm(MMOp(dy, N), MMOp(W.t().contiguous(), N), dx, M, K, N, K, aux=aux, ldaux=K, aux_mode=aux_mode, tag=tag, keep=keep)
+        return
+    be.mm(MMOp(dy, N), MMOp(W, K, trans=True), dx, M, K, N, K, aux=aux, ldaux=K, aux_mode=aux_mode, tag=tag, keep=keep)
 
 
 def mm_linear_wgrad(be, dy, x, dW, M, N, K, *, tag="gemm_mfma", db=None):

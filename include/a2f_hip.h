@@ -298,6 +298,10 @@ int a2f_stream_triad(float* dst, const float* a, const float* b, int64_t n, a2f_
  * are lines with ld < K, zero padding and sequence ends are the bounds test.  `bytes` = addressable span from p (< 4 GiB):
  * anything beyond reads as zero.  All of p, ld, off, seq_stride and the contiguous extent must be multiples of 4 elements
  * (16-byte vector loads).
+ * format 1 operands (both or neither): the matrix arrives as two row-major bf16 images hi = RNE_bf16(x), lo = RNE_bf16(x - hi) (a2f_split_bf16
+ * or a producing kernel): p = hi image, p_lo = lo image, `bytes` = size of ONE image, ld in bf16 elements (a multiple of 8); plain matrices only,
+ * K a multiple of 32.  The kernel copies k-tiles global -> LDS with LDS-DMA loads and multiplies the same three products: identical arithmetic to
+ * format 0 without the on-chip conversion (precision 0 reads the hi image only).
  * Epilogue, per element: v = alpha*acc; if bias: v += bias[n]; C2 (optional) = v;  act: 0 none, 1 ReLU, 3 GELU (erf form), 4 GELU with
  * C2 = gelu'(v) instead of v (the derivative the backward multiplies by: no erf / exp pass there);
  * keep_bits (optional, batch == 1): v = bit (m, n) of the keep mask ? v * keep_scale : 0 (train-mode dropout of the layer's output,
@@ -317,8 +321,9 @@ typedef struct a2f_mm_operand {
   const float* p;
   int64_t bytes;
   int64_t ld;
-  int32_t trans, reserved;
+  int32_t trans, format;          /* format 0: fp32 (everything above); 1: bf16 hi / lo images, see below */
   int64_t lines_per_seq, seq_stride, off, seq_elems;
+  const void* p_lo;               /* format 1: the lo image */
 } a2f_mm_operand;
 
 typedef struct a2f_mm_desc {
@@ -339,6 +344,9 @@ typedef struct a2f_mm_desc {
 } a2f_mm_desc;
 
 int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream);
+/* x (n fp32, n % 4 == 0, 16-byte aligned) -> hi[i] = RNE_bf16(x[i]), lo[i] = RNE_bf16(x[i] - hi[i]) (bf16 bit patterns, n each): the image form of
+ * an a2f_mm operand (format 1). */
+int a2f_split_bf16(const float* x, int64_t n, uint16_t* hi, uint16_t* lo, a2f_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row-wise kernels of the wav2vec2 encoder path (csrc/rowops.hip; HF Wav2Vec2Model as wrapped by

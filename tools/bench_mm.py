@@ -43,6 +43,15 @@ def shape(M, N, K, name):
         res[f"fwd_{tag}_TF"] = round(fl / (timeit(lambda: be.mm(MMOp(x, K), MMOp(W, K), y, M, N, K, N, precision=prec)) * 1e-3), 1)
         res[f"dgrad_{tag}_TF"] = round(fl / (timeit(lambda: be.mm(MMOp(dy, N), MMOp(W, K, trans=True), dx, M, K, N, K, precision=prec)) * 1e-3), 1)
         res[f"wgrad_{tag}_TF"] = round(fl / (timeit(lambda: be.mm(MMOp(dy, N, trans=True), MMOp(x, K, trans=True), dW, N, K, M, K, split_k=0, precision=prec)) * 1e-3), 1)
+    # the same products with the operands as ready-made bf16 hi / lo images (format 1: LDS-DMA staging, no conversion on chip)
+    from a2f_amd.ops import MMImg
+    ix, iW, idy = be.split_bf16(x), be.split_bf16(W), be.split_bf16(dy)
+    for prec, tag in ((1, "x3"), (0, "bf16")):
+        res[f"fwd_img_{tag}_TF"] = round(fl / (timeit(lambda: be.mm(MMImg(ix, K), MMImg(iW, K), y, M, N, K, N, precision=prec)) * 1e-3), 1)
+        res[f"dgrad_img_{tag}_TF"] = round(fl / (timeit(lambda: be.mm(MMImg(idy, N), MMImg(iW, K, trans=True), dx, M, K, N, K, precision=prec)) * 1e-3), 1)
+        res[f"wgrad_img_{tag}_TF"] = round(fl / (timeit(lambda: be.mm(MMImg(idy, N, trans=True), MMImg(ix, K, trans=True), dW, N, K, M, K, split_k=0,
+                                                                        precision=prec)) * 1e-3), 1)
+    res["split_ms_x"] = round(timeit(lambda: be.split_bf16(x)), 4)
     res["torch_f32_fwd_TF"] = round(fl / (timeit(lambda: torch.matmul(x, W.t())) * 1e-3), 1)
     res["torch_f32_wgrad_TF"] = round(fl / (timeit(lambda: torch.matmul(dy.t(), x)) * 1e-3), 1)
     res["torch_bf16_fwd_TF"] = round(fl / (timeit(lambda: torch.matmul(xb, Wb.t())) * 1e-3), 1)

@@ -681,8 +681,10 @@ struct StageImg {
 
 // 128 x 128 tile; W4 = false: 8 waves of 32 x 64 (the CFG 3 geometry, four waves per SIMD); W4 = true: 4 waves of 64 x 64 (two waves per SIMD,
 // twice the MFMAs per fragment read and per barrier)
-template <bool AT, bool BT, int PREC, bool W4>
-__global__ __launch_bounds__(W4 ? 256 : 512, W4 ? 2 : 4) void gemm_img_kernel(const Args a) {
+template <bool AT, bool BT, int PREC, int MODE>
+__global__ __launch_bounds__(MODE == 1 ? 256 : 512, MODE == 0 ? 4 : 2) void gemm_img_kernel(const Args a) {
+  constexpr bool W4 = MODE == 1;
+  constexpr bool ST3 = MODE == 2;        // three LDS stages, one workgroup per CU: the DMA of tile t + 2 is in flight across the barrier of tile t + 1
   constexpr int BM = 128, BN = 128, TH = W4 ? 256 : 512, WGN = 2, TM = W4 ? 2 : 1, TN = 2;
   constexpr int NIMG = PREC == 1 ? 2 : 1;
   using SA = StageImg<AT, BM, TH>;
@@ -725,15 +727,36 @@ __global__ __launch_bounds__(W4 ? 256 : 512, W4 ? 2 : 4) void gemm_img_kernel(co
 
   sa.template issue<PREC>(a.A, kbeg, kend, smem);
   sb.template issue<PREC>(a.B, kbeg, kend, smem + A_BYTES);
+  if constexpr (ST3) {                                          // second tile in flight before the loop (zeros / no traffic past the k-range)
+    sa.template issue<PREC>(a.A, kbeg + BK, kend, smem + STAGE);
+    sb.template issue<PREC>(a.B, kbeg + BK, kend, smem + STAGE + A_BYTES);
+  }
+  int st_cur = 0;                                               // ST3: stage of tile kt
   for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();                                            // the compiler drains the DMA (vmcnt 0) in front of the barrier
-    if (kt + 1 < nkt) {
-      char* nst = smem + ((kt + 1) & 1) * STAGE;
-      sa.template issue<PREC>(a.A, kbeg + (kt + 1) * BK, kend, nst);
-      sb.template issue<PREC>(a.B, kbeg + (kt + 1) * BK, kend, nst + A_BYTES);
+    const char* cur;
+    if constexpr (ST3) {
+      // tile kt has landed when at most the instructions of tile kt + 1 are outstanding (counted wait: never 0 inside the loop);
+      // the raw barrier then publishes it - and says everybody is done reading tile kt - 1, whose stage the next DMA overwrites
+      constexpr int PER_TILE = (SA::NI + SB::NI) * NIMG;
+      if constexpr (PER_TILE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if constexpr (PER_TILE == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      int st_nxt = st_cur + 2; st_nxt = st_nxt >= 3 ? st_nxt - 3 : st_nxt;
+      sa.template issue<PREC>(a.A, kbeg + (kt + 2) * BK, kend, smem + st_nxt * STAGE);
+      sb.template issue<PREC>(a.B, kbeg + (kt + 2) * BK, kend, smem + st_nxt * STAGE + A_BYTES);
+      cur = smem + st_cur * STAGE;
+      st_cur = st_cur == 2 ? 0 : st_cur + 1;
+    } else {
+      __syncthreads();                                          // the compiler drains the DMA (vmcnt 0) in front of the barrier
+      if (kt + 1 < nkt) {
+        char* nst = smem + ((kt + 1) & 1) * STAGE;
+        sa.template issue<PREC>(a.A, kbeg + (kt + 1) * BK, kend, nst);
+        sb.template issue<PREC>(a.B, kbeg + (kt + 1) * BK, kend, nst + A_BYTES);
+      }
+      cur = smem + (kt & 1) * STAGE;
     }
     __builtin_amdgcn_sched_barrier(0);
-    const char* cur = smem + (kt & 1) * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       u32x4_t fa[NIMG][TM], fb[NIMG][TN];
@@ -763,12 +786,12 @@ __global__ __launch_bounds__(W4 ? 256 : 512, W4 ? 2 : 4) void gemm_img_kernel(co
   tile_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, lane, bz);
 }
 
-template <bool AT, bool BT, int PREC, bool W4>
+template <bool AT, bool BT, int PREC, int MODE>
 static int launch_img(const Args& a, hipStream_t st) {
   constexpr int NIMG = PREC == 1 ? 2 : 1;
-  constexpr int TH = W4 ? 256 : 512;
-  constexpr int smem = 2 * NIMG * (StageImg<AT, 128, TH>::IMG + StageImg<BT, 128, TH>::IMG);
-  auto kern = gemm_img_kernel<AT, BT, PREC, W4>;
+  constexpr int TH = MODE == 1 ? 256 : 512;
+  constexpr int smem = (MODE == 2 ? 3 : 2) * NIMG * (StageImg<AT, 128, TH>::IMG + StageImg<BT, 128, TH>::IMG);
+  auto kern = gemm_img_kernel<AT, BT, PREC, MODE>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -782,17 +805,23 @@ static int launch_img(const Args& a, hipStream_t st) {
 
 template <int PREC>
 static int dispatch_img(const Args& a, bool at, bool bt, hipStream_t st) {
-  static const bool w4 = [] { const char* e = getenv("A2F_MM_IMG_W4"); return e && e[0] == '1'; }();          // A-B hook
-  if (w4) {
-    if (!at && !bt) return launch_img<false, false, PREC, true>(a, st);
-    if (!at && bt) return launch_img<false, true, PREC, true>(a, st);
-    if (at && bt) return launch_img<true, true, PREC, true>(a, st);
-    return launch_img<true, false, PREC, true>(a, st);
+  static const int mode = [] { const char* e = getenv("A2F_MM_IMG_MODE"); return e ? e[0] - '0' : 0; }();    // A-B hook: 0 | 1 | 2
+  if (mode == 1) {
+    if (!at && !bt) return launch_img<false, false, PREC, 1>(a, st);
+    if (!at && bt) return launch_img<false, true, PREC, 1>(a, st);
+    if (at && bt) return launch_img<true, true, PREC, 1>(a, st);
+    return launch_img<true, false, PREC, 1>(a, st);
   }
-  if (!at && !bt) return launch_img<false, false, PREC, false>(a, st);
-  if (!at && bt) return launch_img<false, true, PREC, false>(a, st);
-  if (at && bt) return launch_img<true, true, PREC, false>(a, st);
-  return launch_img<true, false, PREC, false>(a, st);
+  if (mode == 2) {
+    if (!at && !bt) return launch_img<false, false, PREC, 2>(a, st);
+    if (!at && bt) return launch_img<false, true, PREC, 2>(a, st);
+    if (at && bt) return launch_img<true, true, PREC, 2>(a, st);
+    return launch_img<true, false, PREC, 2>(a, st);
+  }
+  if (!at && !bt) return launch_img<false, false, PREC, 0>(a, st);
+  if (!at && bt) return launch_img<false, true, PREC, 0>(a, st);
+  if (at && bt) return launch_img<true, true, PREC, 0>(a, st);
+  return launch_img<true, false, PREC, 0>(a, st);
 }
 
 __global__ __launch_bounds__(256) void gemm_mfma_fold_kernel(const Args a) {

@@ -864,3 +864,22 @@ def test_faceformer_decoder_drawn_masks_on_gpu():
     m.eval()
     d = m.decode_hidden(enc, oh).detach()
     assert m.last_decoder_masks is None and rel_l2(a.cpu(), d.cpu()) > 1e-3
+
+
+def test_mfcc_extractor_hip_products_vs_torch_ops():
+    """MFCCExtractor on HIP tensors (STFT as a windowed-DFT matrix product, mel filter bank and DCT on a2f_gemm_f32, exact fp32 MFMA)
+    against its torch-ops form (torch.stft: rocFFT on the device, and the CPU): same features to fp32 rounding.  PARITY UNPINNED
+    against torchaudio (absent here) - this pins the two evaluations of the restated definition against each other."""
+    from a2f_amd.extractor import MFCCExtractor
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn(8, 11440, generator=gen) * 0.1
+    x[3] *= 1e-3
+    t = torch.arange(11440) / 22000.0
+    x[5] = 0.3 * torch.sin(2 * 3.14159265 * 440.0 * t) + 1e-4 * x[5]          # a tone 70 dB above its noise floor: wide dynamic range
+    ex = MFCCExtractor(22000, 32, 52, 440, None, 1024).to(DEV)
+    hip = ex(x.to(DEV))
+    ex.use_hip = False
+    fft_gpu = ex(x.to(DEV))
+    cpu = MFCCExtractor(22000, 32, 52, 440, None, 1024)(x)
+    assert hip.shape == (8, 52, 32)
+    assert rel_l2(hip.cpu(), cpu) < 1e-4 and rel_l2(hip.cpu(), fft_gpu.cpu()) < 1e-4

@@ -150,3 +150,30 @@ def test_wav2vec_extractor_matches_hf_golden_g12():
             y = ex(x)
         assert tuple(y.shape) == (B, out_dim, n_feature)
         assert packed_error(g, f"{name}::features", y) < 2e-5
+
+
+def test_mfcc_matrix_product_form_equals_stft_form():
+    """The HIP evaluation of the MFCC front end (windowed DFT basis x frames, mel filter bank and DCT as three products of the library's
+    GEMM) composed over the float64 emulator of the C ABI against the torch.stft form of the same definition: mel spectrogram and
+    MFCC agree to fp32 rounding (both forms stay PARITY-UNPINNED against torchaudio, which is not in this image)."""
+    import torch
+    from a2f_amd import ops
+    from a2f_amd.extractor import MFCCExtractor
+    from emu_backend import EmuBackend
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 11440, generator=gen) * 0.1
+    x[1] *= 1e-3                                                             # one quiet clip: the batch-wide top_db floor becomes active
+    ex = MFCCExtractor(22000, 32, 52, 440, None, 1024)
+    ref_mel, ref = ex.mel_spectrogram(x), ex(x)
+    old = ops.set_backend(EmuBackend())
+    try:
+        mel = ex.mel_spectrogram_hip(x)
+        assert mel.shape == ref_mel.shape and float((mel - ref_mel).norm() / ref_mel.norm()) < 1e-6
+
+        class _AsHip(torch.Tensor):                                          # route forward() through the HIP branch on a CPU tensor
+            is_cuda = True
+        got = ex(x.as_subclass(_AsHip))
+    finally:
+        ops.set_backend(old)
+    assert got.shape == ref.shape == (3, 52, 32)
+    assert float((torch.as_tensor(got) - ref).norm() / ref.norm()) < 1e-5

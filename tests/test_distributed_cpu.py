@@ -106,3 +106,71 @@ def test_flat_adam_aliases_parameters_and_matches_torch_adam():
             assert a.data_ptr() >= opt.flat_p.data_ptr() and torch.allclose(a, b, atol=1e-6)
     finally:
         ops.set_backend(old)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# FaceFormer: sequences shard over ranks (the reference trains batch = 1 per sequence; S sequences per step here)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _run_ff(rank, world, port, out_path):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import types
+    import a2f_amd
+    from a2f_amd import ops
+    from a2f_amd.trainer import TrainStep
+    from emu_backend import EmuBackend
+    if world > 1:
+        torch.set_num_threads(1)
+    ops.set_backend(EmuBackend())
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    S, T, nv = 4, 6, 33
+
+    class _Enc(torch.nn.Module):                     # pinned "encoder": a learnable map of the audio so gradients reach it
+        def __init__(self):
+            super().__init__()
+            self.proj = torch.nn.Linear(8, 768)
+
+        def forward(self, wave, dataset, frame_num=None):
+            f = wave[:, : frame_num * 8].reshape(wave.shape[0], frame_num, 8)
+            return types.SimpleNamespace(last_hidden_state=self.proj(f))
+
+    torch.manual_seed(21)
+    model = a2f_amd.Faceformer(n_verts=nv, n_onehot=12, audio_encoder=_Enc())
+    with torch.no_grad():
+        model.vertice_map_r.weight.normal_(0, 0.1); model.vertice_map.weight.normal_(0, 0.01)
+    model.train()
+    model.decoder_regularisers = False               # the two runs must compute the same function
+    step = TrainStep(model, a2f_amd.FaceFormerLoss(), lr=1e-3)
+    g = torch.Generator().manual_seed(9)
+    audio = torch.randn(S, T * 16000 // 60 + 8, generator=g)
+    oh = torch.zeros(S, 12); oh[torch.arange(S), torch.arange(S) % 8] = 1
+    templ = torch.randn(S, nv // 3, 3, generator=g)
+    gt = templ.view(S, 1, nv // 3, 3) * 0.01 + 0.003 * torch.randn(S, T, nv // 3, 3, generator=g)
+    per = S // world
+    sl = slice(rank * per, (rank + 1) * per)
+    for _ in range(2):
+        out = step(*TrainStep.unpack_batch({"audio": audio[sl], "one_hot": oh[sl], "verts": gt[sl], "template_vert": templ[sl]}))
+    if rank == 0:
+        torch.save({"flat": step.opt.flat_p.clone(), "loss": float(out["loss"].detach())}, out_path)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_faceformer_dp2_gloo_matches_single_process():
+    """Two ranks, two sequences each, against one process with all four: the mean over equal shards of per-sequence means is the
+    mean over all sequences, so after two steps (all-reduce of the flat gradient buffer incl. the encoder stand-in's parameters,
+    fused Adam with the 1/world factor) both land on the same parameters."""
+    with tempfile.TemporaryDirectory() as d:
+        p1, p2 = os.path.join(d, "f1.pt"), os.path.join(d, "f2.pt")
+        _run_ff(0, 1, 0, p1)
+        from a2f_amd import ops
+        ops.set_backend(None)
+        mp.spawn(_run_ff, args=(2, _free_port(), p2), nprocs=2, join=True)
+        a, b = torch.load(p1), torch.load(p2)
+        rel = float((a["flat"] - b["flat"]).norm() / a["flat"].norm())
+        assert rel < 1e-5, rel

@@ -80,9 +80,27 @@ __device__ __forceinline__ u32x2_t tr_read(const char* lds_addr) {
 __device__ __forceinline__ f32x16 mfma(u32x4_t a, u32x4_t b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
+// PREC 2 (forward only): fp8 e4m3 operands on v_mfma_f32_32x32x16_fp8_fp8 - BASELINE configs[4] names "fp8 MFMA attention".  The
+// LDS images stay bf16 (as PREC 0); a fragment is narrowed to eight e4m3 bytes in registers (elements .x/.y of the first vector)
+// right before the product.  Probabilities are multiplied by 2^8 before narrowing (1 / T is below e4m3's normal range) and the
+// factor is taken out again with the normaliser.  Measured accuracy: tests/test_gpu_encoder_kernels.py, DESIGN 7.
+constexpr float FP8_P_SCALE = 256.f;
+__device__ __forceinline__ u32x4_t bf16x8_to_fp8(const u32x4_t v) {
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_bit_cast(float, v.x << 16), __builtin_bit_cast(float, v.x & 0xFFFF0000u), lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_bit_cast(float, v.y << 16), __builtin_bit_cast(float, v.y & 0xFFFF0000u), lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_bit_cast(float, v.z << 16), __builtin_bit_cast(float, v.z & 0xFFFF0000u), hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_bit_cast(float, v.w << 16), __builtin_bit_cast(float, v.w & 0xFFFF0000u), hi, true);
+  return u32x4_t{(unsigned)lo, (unsigned)hi, 0u, 0u};
+}
+__device__ __forceinline__ f32x16 mfma8(const u32x4_t a, const u32x4_t b, f32x16 c) {
+  const long la = (long)(((unsigned long long)a.y << 32) | a.x), lb = (long)(((unsigned long long)b.y << 32) | b.x);
+  return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(la, lb, c, 0, 0, 0);
+}
 // c += (ah + al)(bh + bl) without lo*lo; small terms first
 template <int PREC>
 __device__ __forceinline__ f32x16 mac(const u32x4_t (&a)[2], const u32x4_t (&b)[2], f32x16 c) {
+  if constexpr (PREC == 2) return mfma8(a[0], b[0], c);
   if constexpr (PREC == 1) {
     c = mfma(a[1], b[0], c);
     c = mfma(a[0], b[1], c);
@@ -143,6 +161,7 @@ __device__ __forceinline__ void frag_rows(const char* img, int rb, int ks, int l
   const int off = img_off(row, 2 * ks + (lane >> 5));
   f[0] = *reinterpret_cast<const u32x4_t*>(img + off);
   if constexpr (PREC == 1) f[1] = *reinterpret_cast<const u32x4_t*>(img + IMG + off);
+  if constexpr (PREC == 2) f[0] = bf16x8_to_fp8(f[0]);
 }
 // MFMA A operand along the tile's row index (k = row), rows taken in the PERMUTED order of an accumulator tile used as the
 // other operand: element j of lane half h <-> row rb + 16 s + 8 (j >> 2) + 4 h + (j & 3); lane r <-> column cb + r
@@ -159,10 +178,20 @@ __device__ __forceinline__ void frag_cols(const char* img, int rb, int s, int cb
     const u32x2_t b0 = tr_read(img + IMG + o0), b1 = tr_read(img + IMG + o1);
     f[1] = u32x4_t{b0.x, b0.y, b1.x, b1.y};
   }
+  if constexpr (PREC == 2) f[0] = bf16x8_to_fp8(f[0]);
 }
 // registers 8 s .. 8 s + 7 of an accumulator tile as the bf16 operand of k-step s (permuted-k order, see frag_cols)
 template <int PREC>
 __device__ __forceinline__ void acc_operand(const f32x16& x, int s, u32x4_t (&f)[2]) {
+  if constexpr (PREC == 2) {                  // probabilities: scaled into e4m3's normal range, narrowed straight from fp32
+    int lo8 = 0, hi8 = 0;
+    lo8 = __builtin_amdgcn_cvt_pk_fp8_f32(x[8 * s + 0] * FP8_P_SCALE, x[8 * s + 1] * FP8_P_SCALE, lo8, false);
+    lo8 = __builtin_amdgcn_cvt_pk_fp8_f32(x[8 * s + 2] * FP8_P_SCALE, x[8 * s + 3] * FP8_P_SCALE, lo8, true);
+    hi8 = __builtin_amdgcn_cvt_pk_fp8_f32(x[8 * s + 4] * FP8_P_SCALE, x[8 * s + 5] * FP8_P_SCALE, hi8, false);
+    hi8 = __builtin_amdgcn_cvt_pk_fp8_f32(x[8 * s + 6] * FP8_P_SCALE, x[8 * s + 7] * FP8_P_SCALE, hi8, true);
+    f[0] = u32x4_t{(unsigned)lo8, (unsigned)hi8, 0u, 0u};
+    return;
+  }
   unsigned hi[4], lo[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -194,6 +223,7 @@ __device__ __forceinline__ void reg_operand(rsrc_t rs, int row, int ld, int col0
       hi[3] = cvt2(b.z * mul, b.w * mul);
     }
     f[ks][0] = u32x4_t{hi[0], hi[1], hi[2], hi[3]};
+    if constexpr (PREC == 2) f[ks][0] = bf16x8_to_fp8(f[ks][0]);
   }
 }
 
@@ -316,7 +346,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
 
   // ---- epilogue: O = O^T / l, rows = this lane's query, 4 consecutive d per register quad
   const float lt = l + __shfl_xor(l, 32, 64);
-  const float inv = (DROP ? a.keep_scale : 1.f) / lt;
+  const float inv = (DROP ? a.keep_scale : 1.f) / (PREC == 2 ? lt * FP8_P_SCALE : lt);
   if (q < T) {
     float* orow = a.out_ctx + ((long long)seq * T + q) * a.ldo + hc;
 #pragma unroll
@@ -587,7 +617,7 @@ static int check_common(const float* qkv, int64_t S, int64_t T, int64_t H, int64
                 (long long)T, (long long)H, (long long)ld, (long long)ldo);
   A2F_CHECK_ARG(ld % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)qkv & 15) == 0, "attention: strides must be multiples of 4 floats, buffers 16-byte aligned");
   A2F_CHECK_ARG(T * ld * 4 < (1ll << 31) && H * 64 <= 1024, "attention: one sequence of the q|k|v buffer must span < 2 GiB");
-  A2F_CHECK_ARG(precision == 0 || precision == 1, "attention: precision %d", precision);
+  A2F_CHECK_ARG(precision == 0 || precision == 1 || precision == 2, "attention: precision %d", precision);
   return A2F_OK;
 }
 
@@ -608,7 +638,7 @@ static int attn_fwd_impl(const float* qkv, int64_t S, int64_t T, int64_t H, int6
   a.keep_q = keep_q; a.TW = (int)a2f_attn_keep_words(T); a.keep_scale = keep_scale;
   const dim3 grid((unsigned)cdiv(T, 128), (unsigned)H, (unsigned)S);
   hipStream_t st = (hipStream_t)stream;
-  static bool done[4] = {false, false, false, false};
+  static bool done[6] = {false, false, false, false, false, false};
   const int lds = precision == 1 ? 2 * 4 * IMG : 2 * 2 * IMG;
 #define A2F_ATTN_FWD(P, D)                                                        \
   do {                                                                            \
@@ -616,6 +646,7 @@ static int attn_fwd_impl(const float* qkv, int64_t S, int64_t T, int64_t H, int6
     hipLaunchKernelGGL((attn_fwd_kernel<P, D>), grid, dim3(THREADS), lds, st, a); \
   } while (0)
   if (precision == 1) { if (keep_q) A2F_ATTN_FWD(1, true); else A2F_ATTN_FWD(1, false); }
+  else if (precision == 2) { if (keep_q) A2F_ATTN_FWD(2, true); else A2F_ATTN_FWD(2, false); }
   else { if (keep_q) A2F_ATTN_FWD(0, true); else A2F_ATTN_FWD(0, false); }
 #undef A2F_ATTN_FWD
   A2F_CHECK_LAUNCH("attn_fwd");
@@ -637,6 +668,7 @@ static int attn_bwd_impl(const float* qkv, const float* ctx, const float* dctx, 
   a.ld = (int)ld; a.ldo = (int)ldo; a.koff = (int)(H * 64); a.voff = (int)(2 * H * 64);
   a.S = (int)S; a.T = (int)T; a.H = (int)H; a.scale = scale;
   a.keep_q = keep_q; a.keep_k = keep_k; a.TW = (int)a2f_attn_keep_words(T); a.keep_scale = keep_scale;
+  if (precision == 2) precision = 0;          // fp8 is a forward mode: gradients would need dynamic scaling; the backward runs its bf16 kernels
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(S * T, THREADS / 64)), dim3(THREADS), 0, st, a);
   A2F_CHECK_LAUNCH("attn_bwd delta");

@@ -147,6 +147,7 @@ class HipBackend:
 
     # ---- a2f_mm (bf16-MFMA GEMM family) ---------------------------------------------------------
     mm_precision = 1          # 1 = bf16x3 split products (fp32-class, the parity setting); 0 = plain bf16 operands (16-mixed)
+    attn_precision = None     # None: the attention kernels follow mm_precision; 2 = fp8 (e4m3) forward products (BASELINE configs[4]), bf16 backward
 
     def mm(self, A: "MMOp", B: "MMOp", Cout, M, N, K, ldc, *, c_off=0, c_rows_per_seq=0, c_seq_stride=0, C2=None, bias=None, aux=None,
            ldaux=0, act=MM_ACT_NONE, aux_mode=MM_AUX_NONE, precision=None, split_k=1, batch=1, a_bstride=0, b_bstride=0, c_bstride=0,
@@ -232,10 +233,15 @@ class HipBackend:
                                              _ptr(dbeta), _ptr(dy), _ptr(ws), nb, self._stream(wave)), "a2f_featenc0_bwd")
 
     # ---- MFMA flash attention (csrc/attention.hip) -----------------------------------------------
+    def _attn_prec(self, precision):
+        if precision is not None:
+            return precision
+        return self.mm_precision if self.attn_precision is None else self.attn_precision
+
     def attn_fwd(self, qkv, S, T, H, ld, scale, ctx, ldo, lse, precision=None):
         _chk(qkv, ctx, lse)
         ev = self._prof_begin("attn")
-        _lib.check(self.lib.a2f_attn_fwd(_ptr(qkv), S, T, H, ld, scale, self.mm_precision if precision is None else precision, _ptr(ctx), ldo,
+        _lib.check(self.lib.a2f_attn_fwd(_ptr(qkv), S, T, H, ld, scale, self._attn_prec(precision), _ptr(ctx), ldo,
                                          _ptr(lse), self._stream(qkv)), "a2f_attn_fwd")
         self._prof_end("attn", ev)
 
@@ -244,14 +250,14 @@ class HipBackend:
         ws = torch.empty(S * H * T, dtype=torch.float32, device=qkv.device)
         ev = self._prof_begin("attn")
         _lib.check(self.lib.a2f_attn_bwd(_ptr(qkv), _ptr(ctx), _ptr(dctx), _ptr(lse), S, T, H, ld, ldo, scale,
-                                         self.mm_precision if precision is None else precision, _ptr(dqkv), _ptr(ws), self._stream(qkv)), "a2f_attn_bwd")
+                                         self._attn_prec(precision), _ptr(dqkv), _ptr(ws), self._stream(qkv)), "a2f_attn_bwd")
         self._prof_end("attn", ev)
 
     def attn_fwd_drop(self, qkv, S, T, H, ld, scale, ctx, ldo, lse, keep_q, keep_scale, precision=None):
         _chk(qkv, ctx, lse)
         _chk_bits(keep_q)
         ev = self._prof_begin("attn")
-        _lib.check(self.lib.a2f_attn_fwd_drop(_ptr(qkv), S, T, H, ld, scale, self.mm_precision if precision is None else precision, _ptr(ctx), ldo,
+        _lib.check(self.lib.a2f_attn_fwd_drop(_ptr(qkv), S, T, H, ld, scale, self._attn_prec(precision), _ptr(ctx), ldo,
                                               _ptr(lse), keep_q.data_ptr(), float(keep_scale), self._stream(qkv)), "a2f_attn_fwd_drop")
         self._prof_end("attn", ev)
 
@@ -261,7 +267,7 @@ class HipBackend:
         ws = torch.empty(S * H * T, dtype=torch.float32, device=qkv.device)
         ev = self._prof_begin("attn")
         _lib.check(self.lib.a2f_attn_bwd_drop(_ptr(qkv), _ptr(ctx), _ptr(dctx), _ptr(lse), S, T, H, ld, ldo, scale,
-                                              self.mm_precision if precision is None else precision, _ptr(dqkv), _ptr(ws), keep_q.data_ptr(),
+                                              self._attn_prec(precision), _ptr(dqkv), _ptr(ws), keep_q.data_ptr(),
                                               keep_k.data_ptr(), float(keep_scale), self._stream(qkv)), "a2f_attn_bwd_drop")
         self._prof_end("attn", ev)
 

@@ -393,7 +393,8 @@ int a2f_dropout_apply(const float* x, const uint32_t* bits, int64_t R, int64_t C
  *   q|k|v projection; q NOT yet scaled: `scale` = head_dim^-0.5 is applied on chip).
  *   fwd: ctx (S*T, ldo) = softmax(scale q k^T) v per head; lse (S, H, T) = log-sum-exp of the scaled scores (saved for bwd).
  *   bwd: dqkv (S*T, ld) from dctx (S*T, ldo), recomputing the probabilities from q, k and lse; delta_ws: S*H*T floats scratch.
- *   precision 1 = bf16x3 split products (fp32-class), 0 = bf16 operands; fp32 softmax and accumulation in both.
+ *   precision 1 = bf16x3 split products (fp32-class), 0 = bf16 operands, 2 = fp8 e4m3 operands on v_mfma_f32_32x32x16_fp8_fp8 for the
+ *   FORWARD products (probabilities pre-scaled by 2^8; the backward of this mode runs the bf16 kernels); fp32 softmax and accumulation always.
  * Deterministic (no atomics).  T*ld*4 must be < 2 GiB.
  */
 int a2f_attn_fwd(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx, int64_t ldo,

@@ -18,6 +18,7 @@ LN_EPS = 1e-5
 import os as _os
 GELU_SAVED = _os.environ.get("A2F_GELU_SAVED", "1") != "0"       # A-B hook: 0 = pre-activation saved + streaming GELU' pass in the backward
 FUSED_QKV = _os.environ.get("A2F_FUSED_QKV", "1") != "0"         # A-B hook: 0 = three launches per projection group instead of one
+POSCONV_WGRAD_T = _os.environ.get("A2F_POSCONV_WGRAD_T", "1") != "0"   # A-B hook: 0 = positional-conv weight gradient with the 48 channels on the m axis
 
 
 WGRAD_STREAM = _os.environ.get("A2F_WGRAD_STREAM", "1") != "0"   # A-B hook: 0 = weight gradients in line on the launch stream
@@ -472,11 +473,17 @@ class PosConvFn(torch.autograd.Function):
         db = _new(dy, C)
         be.colsum(dz, S * T, C, C, db)
         # weight gradient: dwg[g][co][kk*Cg+ci] = sum_rows dz[row, g*Cg+co] * window(hg[g])[row, kk*Cg+ci]
-        dwg = _new(dy, G, Cg, K * Cg)
-        B = MMOp(hg, Cg, trans=True, lines_per_seq=T, seq_stride=T * Cg, off=-pad * Cg, seq_elems=T * Cg)
-        be.mm(MMOp(dz, C, trans=True), B, dwg, Cg, K * Cg, S * T, K * Cg, batch=G, a_bstride=Cg, b_bstride=S * T * Cg, c_bstride=Cg * K * Cg,
-              split_k=0)
-        dw = dwg.view(G, Cg, K, Cg).permute(0, 1, 3, 2).reshape(C, Cg, K)
+        # computed TRANSPOSED, (K*Cg) x Cg per group: with the 48 output channels on the n axis the 128 x 64 tile wastes a quarter of its
+        # MFMAs; with them on the m axis (48 of a 128- or 256-row tile) 60-80 % were wasted (this product was 6.5 ms of the 64 x 600 step)
+        A = MMOp(hg, Cg, trans=True, lines_per_seq=T, seq_stride=T * Cg, off=-pad * Cg, seq_elems=T * Cg)
+        if POSCONV_WGRAD_T:
+            dwgT = _new(dy, G, K * Cg, Cg)
+            be.mm(A, MMOp(dz, C, trans=True), dwgT, K * Cg, Cg, S * T, Cg, batch=G, a_bstride=S * T * Cg, b_bstride=Cg, c_bstride=K * Cg * Cg, split_k=0)
+            dw = dwgT.view(G, K, Cg, Cg).permute(0, 3, 2, 1).reshape(C, Cg, K)          # [g][kk][ci][co] -> (g*Cg + co, ci, kk)
+        else:
+            dwg = _new(dy, G, Cg, K * Cg)
+            be.mm(MMOp(dz, C, trans=True), A, dwg, Cg, K * Cg, S * T, K * Cg, batch=G, a_bstride=Cg, b_bstride=S * T * Cg, c_bstride=Cg * K * Cg, split_k=0)
+            dw = dwg.view(G, Cg, K, Cg).permute(0, 1, 3, 2).reshape(C, Cg, K)
         dh = None
         if ctx.needs_input_grad[0]:
             # data gradient: dh[s,t',g,ci] = sum_{kk',co} dz[s, t'-(K/2-1)+kk', g, co] * w[g*Cg+co, ci, K-1-kk']  (+ the residual branch)

@@ -646,8 +646,11 @@ def mm_conv_dgrad(be, dy, Wg, dx, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, ta
     (Lin >= 2 Lout + 1) or pad = 1 (Lin = 2 Lout).  mul (S,Lin,Ci), optional: every written element is multiplied by it in the
     epilogue (the saved activation derivative of the layer below: dx then IS that layer's pre-activation gradient)."""
     ex = dict(aux=mul, aux_mode=MM_AUX_MUL_LIKE_C) if mul is not None else {}
+    # plain products read the packed weight through a transposed copy (KH*Ci, Co): both operands k-contiguous (see mm_linear_dgrad)
+    WgT = Wg.t().contiguous() if (DGRAD_TRANSPOSED_W and Wg.is_cuda and S * Lout >= 1024) else None
     if KH == stride and pad == 0:
-        be.mm(MMOp(dy, Co), MMOp(Wg, KH * Ci, trans=True), dx, S * Lout, KH * Ci, Co, KH * Ci, c_rows_per_seq=Lout, c_seq_stride=Lin * Ci, tag=tag, **ex)
+        Bop = MMOp(WgT, Co) if WgT is not None else MMOp(Wg, KH * Ci, trans=True)
+        be.mm(MMOp(dy, Co), Bop, dx, S * Lout, KH * Ci, Co, KH * Ci, c_rows_per_seq=Lout, c_seq_stride=Lin * Ci, tag=tag, **ex)
         return
     if KH == 3 and stride == 2 and pad in (0, 1):
         # positions touched by two taps (pad 0: even j = 2q from dy[q-1] (kh=2), dy[q] (kh=0); pad 1: odd j = 2q+1 from dy[q] (kh=2),
@@ -658,7 +661,8 @@ def mm_conv_dgrad(be, dy, Wg, dx, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, ta
         B = MMOp(Wg, 3 * Ci, trans=True, lines_per_seq=Co, seq_stride=-2 * Ci, off=2 * Ci, seq_elems=_BIG)
         be.mm(A, B, dx, S * rows, Ci, 2 * Co, 2 * Ci, c_off=0 if pad == 0 else Ci, c_rows_per_seq=rows, c_seq_stride=Lin * Ci, tag=tag, **ex)
         # positions touched by the middle tap only: dy[q] against W_kh=1
-        be.mm(MMOp(dy, Co), MMOp(Wg, 3 * Ci, trans=True, ptr_off=Ci), dx, S * Lout, Ci, Co, 2 * Ci, c_off=Ci if pad == 0 else 0, c_rows_per_seq=Lout,
+        Bmid = MMOp(WgT, Co, ptr_off=Ci * Co) if WgT is not None else MMOp(Wg, 3 * Ci, trans=True, ptr_off=Ci)
+        be.mm(MMOp(dy, Co), Bmid, dx, S * Lout, Ci, Co, 2 * Ci, c_off=Ci if pad == 0 else 0, c_rows_per_seq=Lout,
               c_seq_stride=Lin * Ci, tag=tag, **ex)
         return
     raise A2FError(f"mm_conv_dgrad: unsupported kernel/stride/pad {KH}/{stride}/{pad}")

@@ -30,7 +30,11 @@ constexpr int FH = 4;                  // heads
 constexpr int FHD = 16;                // head dim
 constexpr int FFF = 128;               // feed-forward width
 constexpr int FF_THREADS = 256;
-constexpr int FF_FWD_THREADS = 512;    // forward: waves 4..7 only help with the self-attention sweep (two waves per head, every other trip of keys each)
+constexpr int FF_FWD_THREADS = 512;
+constexpr int FF_BWD2_THREADS = 512;   // backward (record form): waves 4..7 help with the attention sweep
+constexpr int FB2_U = 4;               // key slots per trip and wave in that form
+// gradient record of one frame (floats): what the weight-gradient products need beside the saved activations
+constexpr int GR_QKV = 0, GR_SA = 192, GR_HP = 256, GR_F = 384, GR_EMB = 448, GR_Y2 = 512, GR_Y = 576, FF_GREC = 640;    // forward: waves 4..7 only help with the self-attention sweep (two waves per head, every other trip of keys each)
 #ifndef FA_U_SET
 #define FA_U_SET 4
 #endif
@@ -578,6 +582,271 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
   }
 }
 
+template <bool DROP>
+__global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(const float* __restrict__ P, const float* __restrict__ dy, int T,
+                                                                              int period, float* __restrict__ save, float* __restrict__ grec,
+                                                                              float* __restrict__ dcross, float* __restrict__ dstyle, const FFDrop dm) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __builtin_amdgcn_s_setprio(3);          // a latency-bound chain: when it shares a CU with GEMM waves of another stream (the pipelined step), its waves issue first
+  float* Wqkv = lds;                        // [192][64] row-major: lane = input index for the transposed products
+  float* Wo = Wqkv + 192 * FD;              // [64][64]
+  float* Am = Wo + FD * FD;                 // [64][64]
+  float* xs = Am + FD * FD;                 // [64]  x_i
+  float* cs = xs + FD;                      // [64]  ctx_i
+  float* hs = cs + FD;                      // [128] h_i (post-ReLU)
+  float* y2s = hs + FFF;                    // [64]
+  float* ys = y2s + FD;                     // [64]  y_i (decoder output row)
+  float* dfs = ys + FD;                     // [64]
+  float* dhps = dfs + FD;                   // [128]
+  float* pbuf = dhps + FFF;                 // [4][64] / [2][128] partial sums
+  float* dsas = pbuf + 4 * FD;              // [64]
+  float* dcs = dsas + FD;                   // [64]
+  float* dqkvs = dcs + FD;                  // [192]
+  float* dembs = dqkvs + 192;               // [64] gradient w.r.t. emb_{i+1} from the previous (later-time) iteration
+  float* qs = dembs + FD;                   // [64]
+  float* mrg = qs + FD;                     // [64] dq partial of the heads' second waves
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int head = wave & 3, apart = wave >> 2;     // attention sweep: head and which half of the key trips
+  const int64_t s = blockIdx.x;
+  float* svbase = save + s * (int64_t)T * SV_STRIDE;
+
+  for (int e = t; e < 192 * FD; e += FF_BWD2_THREADS) Wqkv[e] = P[A2F_FF_WQKV + e];
+  for (int e = t; e < FD * FD; e += FF_BWD2_THREADS) { Wo[e] = P[A2F_FF_WO + e]; Am[e] = P[A2F_FF_A + e]; }
+  if (t < FD) dembs[t] = 0.f;
+  // zero this sequence's dK / dV accumulators
+  for (int64_t e = t; e < (int64_t)T * 128; e += FF_BWD2_THREADS) svbase[(e >> 7) * SV_STRIDE + SV_DK + (e & 127)] = 0.f;
+
+  // weight columns for the transposed FFN products, in registers
+  //   W1^T dhp : output k = t & 63, rows [32*(t>>6), +32)          -> w1c[r] = W1[32*(t>>6)+r][k]
+  //   W2^T df  : output u = t & 127, rows [32*(t>>7), +32)         -> w2c[r] = W2[32*(t>>7)+r][u]
+  float w1c[32], w2c[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    w1c[r] = t < FF_THREADS ? P[A2F_FF_W1 + ((t >> 6) * 32 + r) * FD + (t & 63)] : 0.f;
+    w2c[r] = t < FF_THREADS ? P[A2F_FF_W2 + ((t >> 7) * 32 + r) * FFF + (t & 127)] : 0.f;
+  }
+  // The weight gradients are NOT accumulated here: every step leaves its factors (dqkv, dsa, dhp, df, demb, y2) in the gradient record
+  // `grec` (FF_GREC floats per frame) and the host entry forms dW = sum_frames g (x) activation as a2f_mm products afterwards - that
+  // frees ~230 registers per thread, which is what lets a second wave per head join the attention sweep.  LayerNorm gains / biases
+  // and the style gradient are per-lane scalars and stay in registers.
+  float gg1 = 0.f, gb1n = 0.f, gg2 = 0.f, gb2n = 0.f, gg3 = 0.f, gb3n = 0.f, gsty = 0.f;   // wave 0 lanes
+  float* gbase = grec + s * (int64_t)T * FF_GREC;
+
+  const float ln_g1 = P[A2F_FF_LN + 0 * FD + lane], ln_b1 = P[A2F_FF_LN + 1 * FD + lane];
+  const float ln_g2 = P[A2F_FF_LN + 2 * FD + lane], ln_b2 = P[A2F_FF_LN + 3 * FD + lane];
+  const float ln_g3 = P[A2F_FF_LN + 4 * FD + lane], ln_b3 = P[A2F_FF_LN + 5 * FD + lane];
+  const float slope = exp2f(-2.f * (float)(head + 1));
+  const int js = lane >> 2, dq = lane & 3;
+  float carry = 0.f;                                   // wave 0: (A^T demb_{i+1})[lane]
+  __syncthreads();
+
+  for (int i = T - 1; i >= 0; --i) {
+    float* sv = svbase + (int64_t)i * SV_STRIDE;
+    float* gr = gbase + (int64_t)i * FF_GREC;
+    float dy2 = 0.f, xh2 = 0.f, xh1 = 0.f;
+    const unsigned* rowbits = DROP ? dm.row + (s * T + i) * FF_ROW_WORDS : nullptr;
+    // ---- S1: stage saved vectors; wave 0: LayerNorm-3 backward ----
+    if (wave == 0) {
+      const float xh3 = sv[SV_XH3 + lane];
+      const float rstd3 = sv[SV_ST + 2];
+      const float dy3 = dy[(s * T + i) * FD + lane] + carry;
+      gg3 += dy3 * xh3;
+      gb3n += dy3;
+      const float du3 = wave_layernorm_bwd(dy3 * ln_g3, xh3, rstd3);
+      dy2 = du3;                                       // residual branch of norm3(y2 + ffn)
+      float df = du3;                                  // the feed-forward branch sees it through dropout3
+      if constexpr (DROP) df = ((rowbits[8 + (lane >> 5)] >> (lane & 31)) & 1u) ? du3 * dm.scale : 0.f;
+      dfs[lane] = df;
+      gr[GR_F + lane] = df;
+      const float yv = xh3 * ln_g3 + ln_b3;
+      ys[lane] = yv;
+      gr[GR_Y + lane] = yv;
+      xh2 = sv[SV_XH2 + lane];
+      const float y2v = xh2 * ln_g2 + ln_b2;
+      y2s[lane] = y2v;
+      gr[GR_Y2 + lane] = y2v;
+    } else if (wave == 1) {
+      hs[lane] = sv[SV_H + lane];
+      hs[64 + lane] = sv[SV_H + 64 + lane];
+    } else if (wave == 2) {
+      xs[lane] = sv[SV_X + lane];
+      cs[lane] = sv[SV_CTX + lane];
+    } else if (wave == 3) {
+      qs[lane] = sv[SV_Q + lane];
+    }
+    __syncthreads();
+    // ---- S2: dW2 += df (x) h ; dh = W2^T df (partials) ; dA += demb_{i+1} (x) y_i ; dc += demb_{i+1} ----
+    if (t < FF_THREADS) {
+      float acc = 0.f;
+      const int half = t >> 7;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) acc += w2c[r] * dfs[half * 32 + r];
+      pbuf[half * FFF + (t & 127)] = acc;
+    }
+    __syncthreads();
+    // ---- S3: ReLU backward ; dW1 += dhp (x) y2 ----
+    if (t < FFF) {
+      const float dh = pbuf[t] + pbuf[FFF + t];
+      // hs is the activation AFTER its dropout: a dropped unit is 0 there, a kept one relu * scale - so (hs > 0) is both masks at once
+      const float dhp = hs[t] > 0.f ? (DROP ? dh * dm.scale : dh) : 0.f;
+      dhps[t] = dhp;
+      gr[GR_HP + t] = dhp;
+    }
+    __syncthreads();
+    // ---- S4: W1^T dhp (4 partial sums per output) ----
+    {
+      float acc = 0.f;
+      if (wave < 4) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) acc += w1c[r] * dhps[wave * 32 + r];
+      }
+      __syncthreads();                                 // pbuf readers of S3 are done
+      if (wave < 4) pbuf[wave * FD + lane] = acc;
+    }
+    __syncthreads();
+    // ---- S5: wave 0: LayerNorm-2 and LayerNorm-1 backward ----
+    float dx = 0.f;
+    if (wave == 0) {
+      dy2 += pbuf[lane] + pbuf[FD + lane] + pbuf[2 * FD + lane] + pbuf[3 * FD + lane];
+      const float rstd2 = sv[SV_ST + 1], rstd1 = sv[SV_ST + 0];
+      gg2 += dy2 * xh2;
+      gb2n += dy2;
+      const float du2 = wave_layernorm_bwd(dy2 * ln_g2, xh2, rstd2);
+      dcross[(s * T + i) * FD + lane] = du2;           // u2 = y1 + cross_i
+      xh1 = sv[SV_XH1 + lane];
+      gg1 += du2 * xh1;
+      gb1n += du2;
+      const float du1 = wave_layernorm_bwd(du2 * ln_g1, xh1, rstd1);
+      dx = du1;                                        // u1 = x + dropout1(self_attn(x))
+      float dsa = du1;
+      if constexpr (DROP) dsa = ((rowbits[2 + (lane >> 5)] >> (lane & 31)) & 1u) ? du1 * dm.scale : 0.f;
+      dsas[lane] = dsa;
+      gr[GR_SA + lane] = dsa;
+    }
+    __syncthreads();
+    // ---- S6: out-projection: dWo += dsa (x) ctx (wave 3) ; dctx = Wo^T dsa (wave 0) ----
+    if (wave == 0) {
+      float acc = 0.f;
+#pragma unroll 16
+      for (int r = 0; r < FD; ++r) acc += Wo[r * FD + lane] * dsas[r];
+      dcs[lane] = acc;
+    }
+    __syncthreads();
+    // ---- S7: attention backward for head = wave ----
+    {
+      const float4 qv = *reinterpret_cast<const float4*>(qs + head * FHD + dq * 4);
+      const float4 dcv = *reinterpret_cast<const float4*>(dcs + head * FHD + dq * 4);
+      const float m = sv[SV_ST + 4 + head];
+      const float invl = 1.f / sv[SV_ST + 8 + head];
+      float* kbase = svbase + SV_K + head * FHD + dq * 4;
+      float* vbase = svbase + SV_V + head * FHD + dq * 4;
+      float* dkbase = svbase + SV_DK + head * FHD + dq * 4;
+      float* dvbase = svbase + SV_DV + head * FHD + dq * 4;
+      // sum_j a_j da_j = dctx . ctx (ctx = sum_j a_j v_j is saved), so ONE pass over the keys does everything: a, da, ds,
+      // dq, dK += ds q, dV += a dctx.  FB_U key slots per trip, all loads issued before use (L2 latency bound);
+      // a slot past i re-reads row i and neither accumulates nor stores.
+      float rowsum = dot4(dcv, *reinterpret_cast<const float4*>(cs + head * FHD + dq * 4));
+      rowsum += __shfl_xor(rowsum, 1, 64);
+      rowsum += __shfl_xor(rowsum, 2, 64);
+      float4 dqa = make_float4(0.f, 0.f, 0.f, 0.f);
+      const unsigned* abits = DROP ? dm.attn + ((s * FH + head) * T + i) * dm.TW : nullptr;
+      constexpr int FB_U = FB2_U;                          // two waves per head: half the slots per trip, alternate trips
+      for (int j0 = js + apart * 16 * FB_U; j0 <= i; j0 += 2 * 16 * FB_U) {
+        float4 kk[FB_U], vv[FB_U], dk[FB_U], dv[FB_U];
+        unsigned kw[FB_U];
+#pragma unroll
+        for (int u = 0; u < FB_U; ++u) {
+          const int jj = min(j0 + 16 * u, i);
+          const int64_t off = (int64_t)jj * SV_STRIDE;
+          kk[u] = *reinterpret_cast<const float4*>(kbase + off);
+          vv[u] = *reinterpret_cast<const float4*>(vbase + off);
+          dk[u] = *reinterpret_cast<const float4*>(dkbase + off);
+          dv[u] = *reinterpret_cast<const float4*>(dvbase + off);
+          if constexpr (DROP) kw[u] = abits[jj >> 5];
+        }
+#pragma unroll
+        for (int u = 0; u < FB_U; ++u) {
+          const int j = j0 + 16 * u;
+          const bool valid = j <= i;
+          float p = dot4(qv, kk[u]);
+          p += __shfl_xor(p, 1, 64);
+          p += __shfl_xor(p, 2, 64);
+          float da = dot4(dcv, vv[u]);
+          da += __shfl_xor(da, 1, 64);
+          da += __shfl_xor(da, 2, 64);
+          const float a = valid ? expf(p - slope * (float)((i - min(j, i)) / period) - m) * invl : 0.f;
+          float ad = a;                                // ctx = sum_j a_j D_j v_j: dV sees a D, da_j = D_j (dctx . v_j); sum_j a_j da_j = dctx . ctx still
+          if constexpr (DROP) {
+            const float dj = ((kw[u] >> (min(j, i) & 31)) & 1u) ? dm.scale : 0.f;
+            ad = a * dj;
+            da *= dj;
+          }
+          const float ds = a * (da - rowsum);
+          dqa.x += ds * kk[u].x; dqa.y += ds * kk[u].y; dqa.z += ds * kk[u].z; dqa.w += ds * kk[u].w;
+          if (valid) {
+            const int64_t off = (int64_t)j * SV_STRIDE;
+            *reinterpret_cast<float4*>(dkbase + off) = make_float4(dk[u].x + ds * qv.x, dk[u].y + ds * qv.y, dk[u].z + ds * qv.z, dk[u].w + ds * qv.w);
+            *reinterpret_cast<float4*>(dvbase + off) = make_float4(dv[u].x + ad * dcv.x, dv[u].y + ad * dcv.y, dv[u].z + ad * dcv.z, dv[u].w + ad * dcv.w);
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 4; off < 64; off <<= 1) {
+        dqa.x += __shfl_xor(dqa.x, off, 64); dqa.y += __shfl_xor(dqa.y, off, 64);
+        dqa.z += __shfl_xor(dqa.z, off, 64); dqa.w += __shfl_xor(dqa.w, off, 64);
+      }
+      if (js == 0 && apart == 1) *reinterpret_cast<float4*>(mrg + head * FHD + dq * 4) = dqa;
+      __syncthreads();                                 // dK / dV row i complete (includes this step's j = i term); second-wave dq partials visible
+      if (js == 0 && apart == 0) {                     // q was stored pre-scaled: d(q_raw) = 0.25 d(q_scaled)
+        const float4 o = *reinterpret_cast<const float4*>(mrg + head * FHD + dq * 4);
+        const float4 r = make_float4(0.25f * (dqa.x + o.x), 0.25f * (dqa.y + o.y), 0.25f * (dqa.z + o.z), 0.25f * (dqa.w + o.w));
+        *reinterpret_cast<float4*>(dqkvs + head * FHD + dq * 4) = r;
+        *reinterpret_cast<float4*>(gr + GR_QKV + head * FHD + dq * 4) = r;
+      }
+    }
+    if (t >= 64 && t < 192) { const float g = sv[SV_DK + (t - 64)]; dqkvs[t] = g; gr[GR_QKV + t] = g; }     // SV_DV follows SV_DK: columns 64..127 are dV
+    __syncthreads();
+    // ---- S9: dWqkv += dqkv (x) x ; dx += Wqkv^T dqkv (4 partial sums per output) ----
+    if (wave < 4) {
+      float acc = 0.f;
+#pragma unroll 16
+      for (int r = 0; r < 48; ++r) acc += Wqkv[(wave * 48 + r) * FD + lane] * dqkvs[wave * 48 + r];
+      pbuf[wave * FD + lane] = acc;
+    }
+    __syncthreads();
+    // ---- S10: wave 0: gradient w.r.t. emb_i; carry A^T demb to step i-1 ----
+    if (wave == 0) {
+      float demb = dx + pbuf[lane] + pbuf[FD + lane] + pbuf[2 * FD + lane] + pbuf[3 * FD + lane];
+      if constexpr (DROP) demb = ((rowbits[lane >> 5] >> (lane & 31)) & 1u) ? demb * dm.scale : 0.f;      // through the PPE dropout
+      gsty += demb;                                    // style enters every emb (emb_0 = style, emb_i = A y + c + style)
+      dembs[lane] = demb;
+      gr[GR_EMB + lane] = demb;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      float acc = 0.f;
+#pragma unroll 16
+      for (int r = 0; r < FD; ++r) acc += Am[r * FD + lane] * dembs[r];
+      carry = acc;
+    }
+    // dembs stays valid for the dA / dc accumulation of the next (earlier-time) iteration
+  }
+  // demb_0 belongs to emb_0 = style only: it must not reach dA / dc (no feedback produced emb_0) - nothing to do.
+
+  // ---- the per-lane scalars of this sequence: LayerNorm gains / biases into its slab (folded in sequence order), style gradient
+  float* dP = save + (int64_t)gridDim.x * T * SV_STRIDE + s * (int64_t)A2F_FF_PARAM_FLOATS;
+  if (wave == 0) {
+    dP[A2F_FF_LN + 0 * FD + lane] = gg1;
+    dP[A2F_FF_LN + 1 * FD + lane] = gb1n;
+    dP[A2F_FF_LN + 2 * FD + lane] = gg2;
+    dP[A2F_FF_LN + 3 * FD + lane] = gb2n;
+    dP[A2F_FF_LN + 4 * FD + lane] = gg3;
+    dP[A2F_FF_LN + 5 * FD + lane] = gb3n;
+    dstyle[s * FD + lane] = gsty;
+  }
+}
+
 // dparams[i] = sum over sequences (fixed order) of the per-sequence slabs the backward kernel left behind `save`
 __global__ __launch_bounds__(256) void ff_decoder_fold_kernel(const float* __restrict__ slabs, int S, float* __restrict__ dP) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -588,14 +857,27 @@ __global__ __launch_bounds__(256) void ff_decoder_fold_kernel(const float* __res
 }
 
 constexpr size_t FF_FWD_LDS = (size_t)(FD * 192 + 2 * FD * FD + 4 * FD + FFF + 4 * FD + FD + 2 * FD + 2 * FH * 2) * sizeof(float);
+__global__ __launch_bounds__(256) void ff_decoder_fold_range_kernel(const float* __restrict__ slabs, int S, float* __restrict__ dP, int off, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += slabs[(int64_t)s * A2F_FF_PARAM_FLOATS + off + i];
+  dP[off + i] = acc;
+}
+
+constexpr int FF_GEMM_SPLIT_MAX = 64;
+constexpr size_t FF_GEMM_WS_FLOATS = (size_t)FF_GEMM_SPLIT_MAX * (192 * 64 + 192);
+
 constexpr size_t FF_BWD_LDS = (size_t)(192 * FD + 2 * FD * FD + 2 * FD + FFF + 3 * FD + FFF + 4 * FD + 2 * FD + 192 + 2 * FD) * sizeof(float);
 
 }  // namespace a2f
 
 extern "C" size_t a2f_ff_save_bytes(int64_t S, int64_t T) {
   if (S <= 0 || T <= 0) return 16;
-  // per-step save rows + one gradient slab per sequence (written by the backward kernel, folded in sequence order)
-  return ((size_t)S * (size_t)T * a2f::SV_STRIDE + (size_t)S * A2F_FF_PARAM_FLOATS) * sizeof(float);
+  // per-step save rows + one gradient slab per sequence (written by the backward kernel, folded in sequence order) + the backward's
+  // per-frame gradient records and the split-K workspace of its weight-gradient products
+  return ((size_t)S * (size_t)T * a2f::SV_STRIDE + (size_t)S * A2F_FF_PARAM_FLOATS + (size_t)S * (size_t)T * a2f::FF_GREC + a2f::FF_GEMM_WS_FLOATS) *
+         sizeof(float);
 }
 
 static int ff_check_drop(const uint32_t* row_bits, const uint32_t* attn_bits, float keep_scale, const char* who) {
@@ -630,6 +912,58 @@ static int ff_fwd_impl(const float* params, const float* pe, const float* cross,
   return A2F_OK;
 }
 
+// Record form of the backward: the recurrence kernel (8 waves) leaves per-frame gradient factors in `grec`; the weight gradients are five
+// a2f_mm products over all S*T frames (bias gradients ride along as row sums), LayerNorm gradients are folded from the per-sequence slabs.
+static int ff_bwd2_run(const float* params, const float* dy, int64_t S, int64_t T, int32_t period, float* save, float* dparams, float* dcross,
+                       float* dstyle, const a2f::FFDrop& dm, bool drop, hipStream_t st) {
+  using namespace a2f;
+  constexpr size_t LDS = FF_BWD_LDS + 64 * sizeof(float);
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[drop]) {
+    const void* k = drop ? reinterpret_cast<const void*>(&ff_decoder_bwd2_kernel<true>) : reinterpret_cast<const void*>(&ff_decoder_bwd2_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    if (e != hipSuccess) return set_err(A2F_ELAUNCH, "ff_decoder_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set[drop] = true;
+  }
+  float* slabs = save + (size_t)S * T * SV_STRIDE;
+  float* grec = slabs + (size_t)S * A2F_FF_PARAM_FLOATS;
+  float* ws = grec + (size_t)S * T * FF_GREC;
+  if (drop)
+    hipLaunchKernelGGL(ff_decoder_bwd2_kernel<true>, dim3((unsigned)S), dim3(FF_BWD2_THREADS), LDS, st, params, dy, (int)T, (int)period, save, grec, dcross, dstyle, dm);
+  else
+    hipLaunchKernelGGL(ff_decoder_bwd2_kernel<false>, dim3((unsigned)S), dim3(FF_BWD2_THREADS), LDS, st, params, dy, (int)T, (int)period, save, grec, dcross, dstyle, dm);
+  A2F_CHECK_LAUNCH("ff_decoder_bwd (recurrence)");
+  hipLaunchKernelGGL(ff_decoder_fold_range_kernel, dim3(2), dim3(256), 0, st, (const float*)slabs, (int)S, dparams, (int)A2F_FF_LN, 6 * FD);
+  A2F_CHECK_LAUNCH("ff_decoder_bwd (LayerNorm fold)");
+  const int64_t R = S * T;
+  auto product = [&](const float* Abase, int64_t a_ld, int64_t a_rows, const float* Bbase, int64_t b_ld, int64_t b_rows, int64_t M, int64_t N, int64_t K,
+                     int64_t lps, int64_t a_off, int64_t b_off, float* Cdst, float* rowsum) -> int {
+    a2f_mm_desc d{};
+    d.A.p = Abase; d.A.bytes = a_rows * a_ld * 4; d.A.ld = a_ld; d.A.trans = 1;
+    d.B.p = Bbase; d.B.bytes = b_rows * b_ld * 4; d.B.ld = b_ld; d.B.trans = 1;
+    if (lps > 0) {                               // rows q + 1 of A against rows q of B inside every sequence (the feedback pairs demb_{i+1}, y_i)
+      d.A.lines_per_seq = lps; d.A.seq_stride = T * a_ld; d.A.off = a_off; d.A.seq_elems = T * a_ld;
+      d.B.lines_per_seq = lps; d.B.seq_stride = T * b_ld; d.B.off = b_off; d.B.seq_elems = T * b_ld;
+    }
+    d.C = Cdst; d.ldc = N; d.M = M; d.N = N; d.K = K; d.precision = 1; d.batch = 1; d.alpha = 1.f;
+    int64_t split = K / 512; split = split < 1 ? 1 : split > FF_GEMM_SPLIT_MAX ? FF_GEMM_SPLIT_MAX : split;
+    d.split_k = (int32_t)split; d.ws = ws; d.a_rowsum = rowsum;
+    return a2f_mm(&d, (a2f_stream_t)st);
+  };
+  int rc;
+  // plain operands address element (row, column) at base + row * ld + column: pass base + column offset, rows = R
+  if ((rc = product(grec + GR_QKV, FF_GREC, R, save + SV_X, SV_STRIDE, R, 192, 64, R, 0, 0, 0, dparams + A2F_FF_WQKV, dparams + A2F_FF_BQKV))) return rc;
+  if ((rc = product(grec + GR_SA, FF_GREC, R, save + SV_CTX, SV_STRIDE, R, 64, 64, R, 0, 0, 0, dparams + A2F_FF_WO, dparams + A2F_FF_BO))) return rc;
+  if ((rc = product(grec + GR_HP, FF_GREC, R, grec + GR_Y2, FF_GREC, R, 128, 64, R, 0, 0, 0, dparams + A2F_FF_W1, dparams + A2F_FF_B1))) return rc;
+  if ((rc = product(grec + GR_F, FF_GREC, R, save + SV_H, SV_STRIDE, R, 64, 128, R, 0, 0, 0, dparams + A2F_FF_W2, dparams + A2F_FF_B2))) return rc;
+  if (T > 1) {
+    if ((rc = product(grec, FF_GREC, R, grec, FF_GREC, R, 64, 64, S * (T - 1), T - 1, GR_EMB + FF_GREC, GR_Y, dparams + A2F_FF_A, dparams + A2F_FF_C))) return rc;
+  } else {
+    if (hipMemsetAsync(dparams + A2F_FF_A, 0, (64 * 64 + 64) * sizeof(float), st) != hipSuccess) return set_err(A2F_ELAUNCH, "ff_decoder_bwd: memset");
+  }
+  return A2F_OK;
+}
+
 static int ff_bwd_impl(const float* params, const float* dy, int64_t S, int64_t T, int32_t period, void* save, size_t save_bytes, float* dparams,
                        float* dcross, float* dstyle, const uint32_t* row_bits, const uint32_t* attn_bits, float keep_scale, a2f_stream_t stream) {
   using namespace a2f;
@@ -646,6 +980,8 @@ static int ff_bwd_impl(const float* params, const float* dy, int64_t S, int64_t 
     attr_set[drop] = true;
   }
   const FFDrop dm{row_bits, attn_bits, (int)a2f_attn_keep_words(T), keep_scale};
+  static const bool legacy = [] { const char* e = getenv("A2F_FF_BWD"); return e && e[0] == '1'; }();      // A-B hook: 1 = register-accumulator form
+  if (!legacy && (uint64_t)S * T * SV_STRIDE * 4ull < 0xFFFFFFF0ull) return ff_bwd2_run(params, dy, S, T, period, (float*)save, dparams, dcross, dstyle, dm, drop, (hipStream_t)stream);
   if (drop)
     hipLaunchKernelGGL(ff_decoder_bwd_kernel<true>, dim3((unsigned)S), dim3(FF_THREADS), FF_BWD_LDS, (hipStream_t)stream, params, dy, (int)T, (int)period,
                        (float*)save, dcross, dstyle, dm);

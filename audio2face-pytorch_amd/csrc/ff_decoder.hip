@@ -980,7 +980,8 @@ static int ff_bwd_impl(const float* params, const float* dy, int64_t S, int64_t 
     attr_set[drop] = true;
   }
   const FFDrop dm{row_bits, attn_bits, (int)a2f_attn_keep_words(T), keep_scale};
-  static const bool legacy = [] { const char* e = getenv("A2F_FF_BWD"); return e && e[0] == '1'; }();      // A-B hook: 1 = register-accumulator form
+  const char* form = getenv("A2F_FF_BWD");                                   // A-B hook, read per call: 1 = register-accumulator form
+  const bool legacy = form && form[0] == '1';
   if (!legacy && (uint64_t)S * T * SV_STRIDE * 4ull < 0xFFFFFFF0ull) return ff_bwd2_run(params, dy, S, T, period, (float*)save, dparams, dcross, dstyle, dm, drop, (hipStream_t)stream);
   if (drop)
     hipLaunchKernelGGL(ff_decoder_bwd_kernel<true>, dim3((unsigned)S), dim3(FF_THREADS), FF_BWD_LDS, (hipStream_t)stream, params, dy, (int)T, (int)period,

@@ -117,6 +117,26 @@ __device__ __forceinline__ void split4(const u32x4_t raw, u32x2_t& hi, u32x2_t& 
   lo.x = __builtin_bit_cast(unsigned, __builtin_convertvector(r0, bf16x2_t));
   lo.y = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
 }
+// x = hi + mid + lo (three bf16 pieces = 24 significand bits: every fp32 value is represented exactly unless it underflows)
+__device__ __forceinline__ void split4x3(const u32x4_t raw, u32x2_t& hi, u32x2_t& mid, u32x2_t& lo) {
+  const f32x4 f = __builtin_bit_cast(f32x4, raw);
+  const f32x2_t v0 = {f.x, f.y};
+  const f32x2_t v1 = {f.z, f.w};
+  const bf16x2_t h0 = __builtin_convertvector(v0, bf16x2_t);
+  const bf16x2_t h1 = __builtin_convertvector(v1, bf16x2_t);
+  const f32x2_t r0 = v0 - __builtin_convertvector(h0, f32x2_t);
+  const f32x2_t r1 = v1 - __builtin_convertvector(h1, f32x2_t);
+  const bf16x2_t m0 = __builtin_convertvector(r0, bf16x2_t);
+  const bf16x2_t m1 = __builtin_convertvector(r1, bf16x2_t);
+  const f32x2_t q0 = r0 - __builtin_convertvector(m0, f32x2_t);
+  const f32x2_t q1 = r1 - __builtin_convertvector(m1, f32x2_t);
+  hi.x = __builtin_bit_cast(unsigned, h0);
+  hi.y = __builtin_bit_cast(unsigned, h1);
+  mid.x = __builtin_bit_cast(unsigned, m0);
+  mid.y = __builtin_bit_cast(unsigned, m1);
+  lo.x = __builtin_bit_cast(unsigned, __builtin_convertvector(q0, bf16x2_t));
+  lo.y = __builtin_bit_cast(unsigned, __builtin_convertvector(q1, bf16x2_t));
+}
 __device__ __forceinline__ u32x2_t cvt4(const u32x4_t raw) {
   const f32x4 f = __builtin_bit_cast(f32x4, raw);
   const f32x2_t v0 = {f.x, f.y};
@@ -375,6 +395,12 @@ struct Stage {
         split4(reg[i], hi, lo);
         *reinterpret_cast<u32x2_t*>(img + lds_w[i]) = hi;
         *reinterpret_cast<u32x2_t*>(img + IMG + lds_w[i]) = lo;
+      } else if constexpr (PREC == 2) {
+        u32x2_t hi, mid, lo;
+        split4x3(reg[i], hi, mid, lo);
+        *reinterpret_cast<u32x2_t*>(img + lds_w[i]) = hi;
+        *reinterpret_cast<u32x2_t*>(img + IMG + lds_w[i]) = mid;
+        *reinterpret_cast<u32x2_t*>(img + 2 * IMG + lds_w[i]) = lo;
       } else {
         *reinterpret_cast<u32x2_t*>(img + lds_w[i]) = cvt4(reg[i]);
       }
@@ -413,11 +439,11 @@ struct Cfg {
 };
 
 template <bool AT, bool BT, int PREC, int CFG, bool PLAIN>
-__global__ __launch_bounds__(Cfg<CFG>::TH, Cfg<CFG>::WPS) void gemm_mfma_kernel(const Args a) {
+__global__ __launch_bounds__(Cfg<CFG>::TH, PREC == 2 ? (CFG == 3 ? 2 : 1) : Cfg<CFG>::WPS) void gemm_mfma_kernel(const Args a) {   // bf16x6: three images per operand, one workgroup per CU
   constexpr int BM = Cfg<CFG>::BM, BN = Cfg<CFG>::BN, TH = Cfg<CFG>::TH;
   constexpr int WGN = Cfg<CFG>::WGN;
   constexpr int TM = Cfg<CFG>::TM, TN = Cfg<CFG>::TN;
-  constexpr int NIMG = PREC == 1 ? 2 : 1;
+  constexpr int NIMG = PREC == 2 ? 3 : PREC == 1 ? 2 : 1;
   using SA = Stage<AT, BM, TH>;
   using SB = Stage<BT, BN, TH>;
   constexpr int A_BYTES = NIMG * SA::IMG, B_BYTES = NIMG * SB::IMG;
@@ -529,6 +555,15 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, Cfg<CFG>::WPS) void gemm_mfma_kernel(
         for (int i = 0; i < TM; ++i) fa[q][i] = SA::frag(cur + q * SA::IMG, (wm * TM + i) * 32, ks, lane);
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[q][j] = SB::frag(cur + A_BYTES + q * SB::IMG, (wn * TN + j) * 32, ks, lane);
+      }
+      if constexpr (PREC == 2) {           // bf16x6: the six products of order <= 2^-16, smallest first
+        constexpr int PA[5] = {2, 0, 1, 1, 0}, PB[5] = {0, 2, 1, 0, 1};
+#pragma unroll
+        for (int p = 0; p < 5; ++p)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma(fa[PA[p]][i], fb[PB[p]][j], acc[i][j]);
       }
       if constexpr (PREC == 1) {           // small terms first; consecutive MFMAs hit different accumulators
 #pragma unroll
@@ -848,7 +883,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_fold_kernel(const Args a) {
 template <bool AT, bool BT, int PREC, int CFG, bool PLAIN>
 static int launch(const Args& a, hipStream_t st) {
   constexpr int BM = Cfg<CFG>::BM, BN = Cfg<CFG>::BN, TH = Cfg<CFG>::TH;
-  constexpr int NIMG = PREC == 1 ? 2 : 1;
+  constexpr int NIMG = PREC == 2 ? 3 : PREC == 1 ? 2 : 1;
   constexpr int smem = 2 * NIMG * (Stage<AT, BM, TH>::IMG + Stage<BT, BN, TH>::IMG);
   auto kern = gemm_mfma_kernel<AT, BT, PREC, CFG, PLAIN>;
   static bool attr_done = false;                        // set-once per instantiation (idempotent; safe to repeat)
@@ -923,7 +958,7 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   A2F_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0 && d->M < (1ll << 31) && d->N < (1ll << 31) && d->K < (1ll << 31),
                 "a2f_mm: M=%lld N=%lld K=%lld", (long long)d->M, (long long)d->N, (long long)d->K);
   A2F_CHECK_ARG(d->C != nullptr, "a2f_mm: C is null");
-  A2F_CHECK_ARG(d->precision == 0 || d->precision == 1, "a2f_mm: precision %d (0 = bf16, 1 = bf16x3)", d->precision);
+  A2F_CHECK_ARG(d->precision >= 0 && d->precision <= 2, "a2f_mm: precision %d (0 = bf16, 1 = bf16x3, 2 = bf16x6)", d->precision);
   A2F_CHECK_ARG(d->act == 0 || d->act == 1 || d->act == 3 || d->act == 4, "a2f_mm: act %d", d->act);
   A2F_CHECK_ARG(d->aux_mode >= 0 && d->aux_mode <= 4 && (d->aux_mode == 0 || d->aux != nullptr), "a2f_mm: aux_mode %d / aux", d->aux_mode);
   const int batch = d->batch > 0 ? d->batch : 1;
@@ -967,7 +1002,9 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   // LDS per 128 x 128 workgroup, so only one 8-wave workgroup would fit) -> 256 x 128 on 8 waves when there are enough tiles, else
   // 128 x 128 on 4 waves; everything else -> 128 x 128 on 8 waves, two workgroups per CU = four waves per SIMD (+10-25 % over 4 waves)
   int cfg = d->N <= 64 ? 1 : 3;
-  if (cfg == 3 && at && bt) cfg = (cdiv(d->M, 256) * cdiv(d->N, 128) * batch * split >= 200) ? 2 : 0;
+  // (bf16x6: three images per operand = one workgroup per CU whatever the tile, so the 8-wave 128 x 128 form wins there too: 8.4 vs 10.6 ms
+  // for the Audio2Mesh step)
+  if (cfg == 3 && at && bt && d->precision != 2) cfg = (cdiv(d->M, 256) * cdiv(d->N, 128) * batch * split >= 200) ? 2 : 0;
   {
     const char* force = getenv("A2F_MM_CFG");                 // tuning / A-B hook: 0 | 1 | 2
     if (force && force[0] >= '0' && force[0] <= '3' && !(force[0] == '1' && d->N > 64)) cfg = force[0] - '0';
@@ -975,7 +1012,7 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   A2F_CHECK_ARG(d->A.format == d->B.format, "a2f_mm: both operands fp32 or both bf16 hi / lo images");
   if (d->A.format == 1) {
-    A2F_CHECK_ARG(batch == 1 && d->K % BK == 0 && d->a_rowsum == nullptr, "a2f_mm: image operands need batch 1, K a multiple of %d, no a_rowsum", BK);
+    A2F_CHECK_ARG(batch == 1 && d->K % BK == 0 && d->a_rowsum == nullptr && d->precision != 2, "a2f_mm: image operands need batch 1, K a multiple of %d, no a_rowsum, precision 0 | 1", BK);
     A2F_CHECK_ARG(d->precision == 0 || (d->A.p_lo && d->B.p_lo), "a2f_mm: image operands: precision 1 needs the lo images");
     rc = d->precision == 1 ? dispatch_img<1>(a, at, bt, st) : dispatch_img<0>(a, at, bt, st);
     if (rc) return rc;
@@ -991,7 +1028,10 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   }
   static const bool no_plain = [] { const char* e = getenv("A2F_MM_PLAIN"); return e && e[0] == '0'; }();     // A-B hook
   const bool plain = !no_plain && a.A.lps == 0 && a.B.lps == 0 && (d->K % BK) == 0;
-  if (d->precision == 1)
+  if (d->precision == 2) {                 // three images per operand: the 256 x 128 tile does not fit
+    if (cfg == 2) cfg = 3;
+    rc = cfg == 0 ? dispatch_layout<2, 0>(a, at, bt, plain, st) : cfg == 1 ? dispatch_layout<2, 1>(a, at, bt, plain, st) : dispatch_layout<2, 3>(a, at, bt, plain, st);
+  } else if (d->precision == 1)
     rc = cfg == 0 ? dispatch_layout<1, 0>(a, at, bt, plain, st) : cfg == 1 ? dispatch_layout<1, 1>(a, at, bt, plain, st)
        : cfg == 2 ? dispatch_layout<1, 2>(a, at, bt, plain, st) : dispatch_layout<1, 3>(a, at, bt, plain, st);
   else

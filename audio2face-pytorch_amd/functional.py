@@ -458,12 +458,32 @@ def _unpack_conv_w(dwg, Co, Ci, KH, Cip):
     return dwg.view(-1, KH, Cip)[:Co, :, :Ci].permute(0, 2, 1).contiguous()
 
 
+# a2f_mm_desc.precision of the trunk on a2f_mm: 2 = bf16x6 (default: holds the G2 fixture's weight gradients like the legacy path),
+# 1 = bf16x3 (faster; the batch-statistics BatchNorm backward amplifies its 2^-16 product error beyond the parity bar at B = 4)
+A2M_MM_PRECISION = int(os.environ.get("A2F_A2M_MM_PRECISION", "2"))
+
+
+@contextlib.contextmanager
+def _mm_precision(be, prec):
+    old = be.mm_precision
+    be.mm_precision = prec
+    try:
+        yield
+    finally:
+        be.mm_precision = old
+
+
 class A2MTrunkMMFn(torch.autograd.Function):
     """Same signature / outputs as A2MTrunkFn (x, one_hot, training, 20 BN buffers, 46 parameters -> h3 (B,50))."""
 
     @staticmethod
     def forward(ctx, x, one_hot, training, *rest):
         be = ops.backend()
+        with _mm_precision(be, A2M_MM_PRECISION):
+            return A2MTrunkMMFn._forward(ctx, be, x, one_hot, training, *rest)
+
+    @staticmethod
+    def _forward(ctx, be, x, one_hot, training, *rest):
         bufs, params = rest[:20], rest[20:]
         convs = [(_f32c(params[2 * i]), _f32c(params[2 * i + 1])) for i in range(10)]
         bns = [(_f32c(params[20 + 2 * i]), _f32c(params[21 + 2 * i])) for i in range(10)]
@@ -545,6 +565,11 @@ class A2MTrunkMMFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh3):
         be = ops.backend()
+        with _mm_precision(be, A2M_MM_PRECISION):
+            return A2MTrunkMMFn._backward(ctx, be, dh3)
+
+    @staticmethod
+    def _backward(ctx, be, dh3):
         sv = ctx.sv
         B, no, H0, Hlast, KH9, training, cat, z8, z1, z2, fw = ctx.misc
         dev = cat.device
@@ -566,10 +591,6 @@ class A2MTrunkMMFn(torch.autograd.Function):
         d = new(B, 256)                                       # grad w.r.t. conv-9 pre-activation (ReLU mask of cat fused)
         ops.linear_bwd_input(be, dz1, fw[0], d, B, 72, ncat, n_cols=256, aux=cat, ldaux=ncat, aux_mode=AUX_RELU_BWD)
 
-        def bias_grad(dout, R, Cp, C):
-            dbv = new(Cp)
-            be.colsum(dout, R, Cp, Cp, dbv)
-            return dbv[:C]
 
         def bn_bwd(i, dy, R, C, Cp, relu):
             mu, istd = sv["stats"][i]
@@ -579,9 +600,9 @@ class A2MTrunkMMFn(torch.autograd.Function):
             return dx
 
         # conv 9: (KH9,1)/s KH9, no pad: a plain GEMM over the (B, KH9*256) rows of zb
-        dwg = new(256, KH9 * 256)
-        ops.mm_linear_wgrad(be, d, sv["conv_in"][9], dwg, B, 256, KH9 * 256)
-        g_conv[18], g_conv[19] = _unpack_conv_w(dwg, 256, 256, KH9, 256).view(256, 256, KH9, 1), bias_grad(d, B, 256, 256)
+        dwg, dbv = new(256, KH9 * 256), new(256)
+        ops.mm_linear_wgrad(be, d, sv["conv_in"][9], dwg, B, 256, KH9 * 256, db=dbv)      # bias gradients: row sums inside the weight-gradient product
+        g_conv[18], g_conv[19] = _unpack_conv_w(dwg, 256, 256, KH9, 256).view(256, 256, KH9, 1), dbv
         dzb = new(B, KH9 * 256)
         ops.mm_linear_dgrad(be, d, sv["wg"][9], dzb, B, 256, KH9 * 256)
         dz = bn_bwd(9, dzb, B * Hlast, 256, 256, False)
@@ -589,9 +610,9 @@ class A2MTrunkMMFn(torch.autograd.Function):
         Hd = 2 * Hlast
 
         def conv_bwd(i, dout, S, Lin, Lout, ci, co, cip, cop, shape, need_dx=True):
-            dwg = new(cop, 3 * cip)
-            ops.mm_conv_wgrad(be, sv["conv_in"][i], dout, dwg, S, Lin, Lout, cip, cop, 3, 2, pad=1)
-            g_conv[2 * i], g_conv[2 * i + 1] = _unpack_conv_w(dwg, co, ci, 3, cip).view(*shape), bias_grad(dout, S * Lout, cop, co)
+            dwg, dbv = new(cop, 3 * cip), new(cop)
+            ops.mm_conv_wgrad(be, sv["conv_in"][i], dout, dwg, S, Lin, Lout, cip, cop, 3, 2, pad=1, db=dbv)
+            g_conv[2 * i], g_conv[2 * i + 1] = _unpack_conv_w(dwg, co, ci, 3, cip).view(*shape), dbv[:co]
             if not need_dx:
                 return None
             din = new(S * Lin, cip)                           # every position is written (Lin = 2 Lout, pad = 1)
@@ -621,11 +642,12 @@ class A2MTrunkMMFn(torch.autograd.Function):
         return (None, None, None) + (None,) * 20 + tuple(g_conv) + tuple(g_bn) + tuple(g_fc)
 
 
-# Which trunk Audio2Mesh uses.  Default "legacy" = A2MTrunkFn (bf16x6 split products on the generic GEMM: the setting that holds the
-# G2 fixture's weight gradients at 1.7e-5).  "mm" = A2MTrunkMMFn on a2f_mm with bf16x3 products: 1.28x faster per step (B = 1024:
-# 8.9 vs 11.4 ms) and the same predictions (9e-6), but the batch-statistics BatchNorm backward amplifies the 2^-16 product error
-# into 1e-2 on the deepest weight gradients of the B = 4 fixture - outside the parity bar, so it is opt-in.
-A2M_USE_MM = os.environ.get("A2F_A2M_GEMM", "legacy") == "mm"
+# Which trunk Audio2Mesh uses.  Default "mm" = A2MTrunkMMFn on a2f_mm with bf16x6 products (A2M_MM_PRECISION = 2): the G2 fixture's weight
+# gradients at 1e-5 like the legacy path, bias gradients as row sums inside the weight-gradient products; B = 1024 step 8.4 ms.
+# "legacy" = A2MTrunkFn (bf16x6 on the generic GEMM of round 1, 11.4 ms) stays selectable for A/B.  A2F_A2M_MM_PRECISION=1 (bf16x3,
+# 7.6 ms) gives the same predictions (9e-6) but the batch-statistics BatchNorm backward amplifies its 2^-16 product error into 1e-2 on
+# the deepest weight gradients of the B = 4 fixture - outside the parity bar, so it is opt-in.
+A2M_USE_MM = os.environ.get("A2F_A2M_GEMM", "mm") == "mm"
 
 
 # =================================================================================================

@@ -633,11 +633,12 @@ def mm_conv_fwd(be, x, Wg, y, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, bias=N
     be.mm(A, MMOp(Wg, KH * Ci), y, S * Lout, Co, KH * Ci, Co, bias=bias, act=act, C2=pre, tag=tag)
 
 
-def mm_conv_wgrad(be, x, dy, dWg, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, tag="gemm_mfma"):
-    """dWg[Co, KH*Ci] = sum over (sequence, position) of dy[row, co] * window(x)[row, :]."""
+def mm_conv_wgrad(be, x, dy, dWg, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, tag="gemm_mfma", db=None):
+    """dWg[Co, KH*Ci] = sum over (sequence, position) of dy[row, co] * window(x)[row, :].  db (Co), optional: the bias gradient =
+    column sums of dy, collected inside the same kernel."""
     A = MMOp(dy, Co, trans=True)
     B = MMOp(x, stride * Ci, trans=True, lines_per_seq=Lout, seq_stride=Lin * Ci, off=-pad * Ci, seq_elems=Lin * Ci)
-    be.mm(A, B, dWg, Co, KH * Ci, S * Lout, KH * Ci, split_k=0, tag=tag)
+    be.mm(A, B, dWg, Co, KH * Ci, S * Lout, KH * Ci, split_k=0, tag=tag, a_rowsum=db)
 
 
 def mm_conv_dgrad(be, dy, Wg, dx, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, tag="gemm_mfma", mul=None):

@@ -1,7 +1,8 @@
 """GPU: a2f_mm (bf16-MFMA GEMM family, csrc/gemm_mfma.hip) against the float64 emulator of its contract (include/a2f_hip.h).
 
 precision 1 (bf16x3 split products, the parity setting): <= 2^-16 relative error per product -> 3e-5 relative L2 on the
-result; precision 0 (plain bf16 operands, `percision: 16-mixed`): 2^-9 per operand -> 1e-2.  All calls go through the C ABI.
+result; precision 0 (plain bf16 operands, `percision: 16-mixed`): 2^-9 per operand -> 1e-2; precision 2 (bf16x6: three pieces per operand,
+the six products down to 2^-16 of the leading one, fp32 accumulate): fp32-GEMM class -> 2e-6.  All calls go through the C ABI.
 """
 import pytest
 import torch
@@ -14,7 +15,7 @@ from golden_util import rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-TOL = {1: 3e-5, 0: 1e-2}
+TOL = {1: 3e-5, 0: 1e-2, 2: 2e-6}
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -34,7 +35,7 @@ def both(fn):
 
 @pytest.mark.parametrize("M,N,K", [(600, 768, 768), (130, 64, 768), (257, 48, 100), (1, 4, 4), (1200, 3072, 768), (96, 132, 36), (333, 200, 4)])
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
-@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("precision", [1, 0, 2])
 def test_mm_layouts_epilogues(M, N, K, layout, precision):
     at, bt = layout[0] == "t", layout[1] == "n"
     if at and M % 4:
@@ -152,7 +153,7 @@ def test_mm_saved_gelu_derivative_epilogues():
 
 
 @pytest.mark.parametrize("M,N,K,split", [(768, 768, 19200, 0), (3072, 768, 9600, 0), (132, 260, 777, 1), (768, 200, 4100, 5), (64, 48, 96, 1)])
-@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("precision", [1, 0, 2])
 def test_mm_weight_gradient_with_fused_bias_gradient(M, N, K, split, precision):
     """a_rowsum: dW = dY^T X and db = column sums of dY out of ONE kernel (plain path: K a multiple of 32; masked path otherwise;
     with and without split-K slabs), against the float64 emulator; the sums are fp32 additions of the fp32 operand, so db holds the

@@ -288,7 +288,9 @@ int a2f_stream_triad(float* dst, const float* a, const float* b, int64_t n, a2f_
  * Storage is fp32; operands are converted to bf16 while they are staged into LDS and multiplied with
  * v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  precision 1 (bf16x3): x = hi + lo, lo*hi' + hi*lo' + hi*hi', <= 2^-16
  * relative error per product - the setting the 1e-4 parity bar is met with; precision 0: plain bf16 operands (the
- * reference's `percision: 16-mixed`).
+ * reference's `percision: 16-mixed`); precision 2 (bf16x6): x = hi + mid + lo, the six products down to 2^-16 of the leading
+ * one - fp32-GEMM class (2e-6 on the result), three LDS images per operand, fp32 operands (format 0) only: the Audio2Mesh
+ * trunk, whose batch-statistics BatchNorm backward amplifies the bf16x3 error beyond the parity bar.
  * Operands (a2f_mm_operand): `trans` = 0: a line is a row of A (column of B) and k is the contiguous axis; `trans` = 1: a
  * line is one k and the m (n) index is contiguous.  Line i of an operand with lines_per_seq > 0 belongs to sequence
  * s = i / lines_per_seq, position q = i % lines_per_seq; element j of the line sits at element offset

@@ -232,10 +232,12 @@ size_t a2f_ff_save_bytes(int64_t S, int64_t T);
  * reference builds it. */
 int a2f_ff_decoder_fwd(const float* params, const float* pe, const float* cross, const float* style, int64_t S, int64_t T,
                        int32_t period, float* y, void* save, size_t save_bytes, a2f_stream_t stream);
-/* dy (S,T,64) -> dparams (A2F_FF_PARAM_FLOATS, OVERWRITTEN: every sequence leaves its gradient block in a slab behind the
- * per-step rows of `save`, a fold kernel sums the slabs in sequence order - deterministic, no atomics), dcross (S,T,64),
- * dstyle (S,64).  `save` is the forward's buffer (a2f_ff_save_bytes covers the slabs); its dK/dV accumulator columns are
- * scratch for this call. */
+/* dy (S,T,64) -> dparams (A2F_FF_PARAM_FLOATS, OVERWRITTEN), dcross (S,T,64), dstyle (S,64).  Deterministic, no atomics: the
+ * reverse-time recurrence kernel leaves 640 gradient factors per frame and per-sequence LayerNorm-gradient slabs behind the
+ * per-step rows of `save`; weight and bias gradients are then five bf16x3 products over all S*T frames launched on the same
+ * stream by this call (split-K slabs folded in fixed order), the slabs are summed in sequence order.  `save` is the forward's
+ * buffer (a2f_ff_save_bytes covers records, slabs and the products' workspace); its dK/dV accumulator columns are scratch
+ * for this call.  Environment A2F_FF_BWD=1 (A-B hook, read per call): the single-kernel form with register accumulators. */
 int a2f_ff_decoder_bwd(const float* params, const float* dy, int64_t S, int64_t T, int32_t period, void* save,
                        size_t save_bytes, float* dparams, float* dcross, float* dstyle, a2f_stream_t stream);
 /* Train-mode variants: dropout 0.1 of the PPE output (faceformer.py:73,88) and of nn.TransformerDecoderLayer's self-attention

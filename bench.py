@@ -291,7 +291,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="voca", choices=["voca", "faceformer", "audio2mesh"])
+    ap.add_argument("--workload", default="voca", choices=["voca", "faceformer", "audio2mesh", "faceformer_long"])
+    ap.add_argument("--ff-long-seqs", type=int, default=12)
+    ap.add_argument("--ff-long-frames", type=int, default=3000)
     ap.add_argument("--seqs", type=int, default=32)
     ap.add_argument("--frames", type=int, default=600)
     ap.add_argument("--ff-seqs", type=int, default=64)
@@ -398,9 +400,12 @@ def main():
         return res
 
     # ------------------------------------------------------------------ FaceFormer (BASELINE configs[2])
-    def run_faceformer(steps, warmup):
+    def run_faceformer(steps, warmup, S=None, T=None, fp8_attention=False, config_name="BASELINE configs[2]", cpu=True):
         torch.manual_seed(1234)
-        S, T = args.ff_seqs, args.ff_frames
+        S, T = S or args.ff_seqs, T or args.ff_frames
+        old_attn = be.attn_precision
+        if fp8_attention:                                        # configs[4]: fp8 (e4m3) QK^T / PV products in the encoder's attention forward
+            be.attn_precision = 2
         model = a2f_amd.Faceformer(n_verts=NV3, n_onehot=12).to(device)
         with torch.no_grad():                                    # the reference zero-initialises both vertice maps (faceformer.py:132-135):
             model.vertice_map_r.weight.normal_(0, 0.1)           # non-zero values so the recurrence and its backward do real work
@@ -419,9 +424,10 @@ def main():
         res = {
             "value": round(fps, 1), "unit": "mesh-frames/s", "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 3),
             "dtype": "f32 storage; " + ("encoder products as bf16 MFMA (16-mixed), fp32 accumulate / softmax / LayerNorm" if args.encoder_precision == "bf16"
-                                        else getattr(model.audio_encoder, "dtype_note", "encoder in fp32 torch ops")),
+                                        else getattr(model.audio_encoder, "dtype_note", "encoder in fp32 torch ops"))
+                     + ("; encoder attention forward QK^T / PV as fp8 e4m3 MFMA (backward bf16)" if fp8_attention else ""),
             "config": {"workload": f"FaceFormer train step (wav2vec2-base encoder + incremental decoder + fused head/FaceFormerLoss, bwd, Adam over 96.4 M "
-                                   f"parameters), {S} independent batch-1 sequences x {T} frames per GPU per step, BASELINE configs[2]",
+                                   f"parameters), {S} independent batch-1 sequences x {T} frames per GPU per step, {config_name}",
                        "frames_per_gpu_step": S * T, "parallelism": f"dp{world}", "final_loss": round(loss_val, 6), "encoder": enc_path,
                        "train_mode": ("deterministic function (regularisers off, --ff-deterministic)" if args.ff_deterministic else
                                       "reference train mode: wav2vec2 dropout x6 kinds of sites / LayerDrop 0.1 / SpecAugment, decoder + PPE dropout 0.1 "
@@ -457,8 +463,9 @@ def main():
                                     "frac": round(hb / (hms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(hms, 4), "launches_timed": len(hev)}
             be.prof = None
             res["roofline"] = roof
-        if want_cpu:
+        if want_cpu and cpu:
             res["cpu_baseline"] = cpu_baseline_faceformer()
+        be.attn_precision = old_attn
         del step, model
         return res
 
@@ -486,7 +493,11 @@ def main():
         del step, model
         return res
 
-    runners = {"voca": run_voca, "faceformer": run_faceformer, "audio2mesh": run_audio2mesh}
+    def run_faceformer_long(steps, warmup):                      # BASELINE configs[4]: 3000-frame sequences, fp8 MFMA attention
+        return run_faceformer(min(steps, 3), 2, S=args.ff_long_seqs, T=args.ff_long_frames, fp8_attention=True,
+                              config_name="BASELINE configs[4] (long context, fp8 attention; per GPU)", cpu=False)
+
+    runners = {"voca": run_voca, "faceformer": run_faceformer, "audio2mesh": run_audio2mesh, "faceformer_long": run_faceformer_long}
     main_res = runners[args.workload](args.steps, args.warmup)
     result = {"metric": "mesh-frames/sec training (VOCASET 5023-vert)", "value": main_res.pop("value"), "unit": main_res.pop("unit"),
               "n_gpus": world, "steps": main_res.pop("steps"), "warmup": args.warmup, "ms_per_step": main_res.pop("ms_per_step"),
@@ -494,7 +505,7 @@ def main():
     result.update(main_res)
     if not args.no_secondary:
         sec = []
-        for name in ("faceformer", "audio2mesh", "voca"):
+        for name in ("faceformer", "audio2mesh", "faceformer_long", "voca"):
             if name == args.workload:
                 continue
             if name == "voca":

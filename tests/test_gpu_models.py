@@ -607,21 +607,23 @@ def test_bench_self_launches_two_ranks():
 
 
 def test_bench_secondary_lines_small():
-    """The driver-run bench line carries FaceFormer and Audio2Mesh as `secondary` entries, each with its own roofline
-    (small shapes here; the default run uses 16 x 600 frames and B = 1024)."""
+    """The driver-run bench line carries FaceFormer (configs[2]), Audio2Mesh and the long-context FaceFormer (configs[4]) as `secondary`
+    entries, each with its own roofline (small shapes here; the default run uses 64 x 600 frames, B = 1024 and 12 x 3000 frames)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "3", "--seqs", "4", "--frames", "64",
-                        "--ff-seqs", "2", "--ff-frames", "60", "--a2m-batch", "64", "--secondary-steps", "3", "--no-cpu-baseline"],
+                        "--ff-seqs", "2", "--ff-frames", "60", "--ff-long-seqs", "1", "--ff-long-frames", "120", "--a2m-batch", "64",
+                        "--secondary-steps", "3", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["roofline"]["kernel"] == "head_x3_kernel" and out["roofline"]["measured_stream_GBs"]["copy"] > 1000
     sec = {e["model"]: e for e in out["secondary"]}
-    assert set(sec) == {"faceformer", "audio2mesh"}
+    assert set(sec) == {"faceformer", "audio2mesh", "faceformer_long"}                   # configs[2], Audio2Mesh, configs[4] (fp8 attention)
+    assert "fp8" in sec["faceformer_long"]["dtype"] and "fp8" not in sec["faceformer"]["dtype"]
     for e in sec.values():
         assert e["value"] > 0 and e["roofline"]["bound"] == "mfma" and 0 < e["roofline"]["frac"] < 1
 

@@ -34,7 +34,10 @@ constexpr int FF_FWD_THREADS = 512;
 constexpr int FF_BWD2_THREADS = 512;   // backward (record form): waves 4..7 help with the attention sweep
 constexpr int FB2_U = 4;               // key slots per trip and wave in that form
 // gradient record of one frame (floats): what the weight-gradient products need beside the saved activations
-constexpr int GR_QKV = 0, GR_SA = 192, GR_HP = 256, GR_F = 384, GR_EMB = 448, GR_Y2 = 512, GR_Y = 576, FF_GREC = 640;    // forward: waves 4..7 only help with the self-attention sweep (two waves per head, every other trip of keys each)
+constexpr int GR_QKV = 0, GR_SA = 192, GR_HP = 256, GR_F = 384, GR_EMB = 448, GR_Y2 = 512, GR_Y = 576, GR_DC = 640, GR_RS = 704, FF_GREC = 720;
+// blocked form of the backward (sequences of FF_BLK_MIN frames and more): the recurrence runs in blocks of FF_BLK steps, attention terms that cross a block
+// boundary are batched over the whole chip (ff_bwd_prep_kernel / ff_bwd_rect_kernel below).  FF_NREC floats per frame: Nt[h][a'][b], then n[h][b]
+constexpr int FF_BLK = 128, FF_BLK_MIN = 256, FF_NREC = 4 * 272, NR_N = 1024;    // forward: waves 4..7 only help with the self-attention sweep (two waves per head, every other trip of keys each)
 #ifndef FA_U_SET
 #define FA_U_SET 4
 #endif
@@ -585,7 +588,11 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
 template <bool DROP>
 __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(const float* __restrict__ P, const float* __restrict__ dy, int T,
                                                                               int period, float* __restrict__ save, float* __restrict__ grec,
-                                                                              float* __restrict__ dcross, float* __restrict__ dstyle, const FFDrop dm) {
+                                                                              float* __restrict__ dcross, float* __restrict__ dstyle, const FFDrop dm,
+                                                                              const float* __restrict__ nrec, int i_lo, int i_hi) {
+  // steps i_hi-1 .. i_lo of the reverse-time recurrence (the whole sequence: i_lo = 0, i_hi = T).  Blocked form: the attention sweep covers the keys
+  // j >= i_lo only; the keys of earlier blocks enter dq through the precomputed Nt / n (nrec) and receive their dK / dV from ff_bwd_rect_kernel; the
+  // state carried from launch to launch (feedback carry, LayerNorm / style sums) lives in this sequence's slab.
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __builtin_amdgcn_s_setprio(3);          // a latency-bound chain: when it shares a CU with GEMM waves of another stream (the pipelined step), its waves issue first
   float* Wqkv = lds;                        // [192][64] row-major: lane = input index for the transposed products
@@ -614,8 +621,9 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
   for (int e = t; e < 192 * FD; e += FF_BWD2_THREADS) Wqkv[e] = P[A2F_FF_WQKV + e];
   for (int e = t; e < FD * FD; e += FF_BWD2_THREADS) { Wo[e] = P[A2F_FF_WO + e]; Am[e] = P[A2F_FF_A + e]; }
   if (t < FD) dembs[t] = 0.f;
-  // zero this sequence's dK / dV accumulators
-  for (int64_t e = t; e < (int64_t)T * 128; e += FF_BWD2_THREADS) svbase[(e >> 7) * SV_STRIDE + SV_DK + (e & 127)] = 0.f;
+  // zero this sequence's dK / dV accumulators (first launch of the sequence)
+  if (i_hi == T)
+    for (int64_t e = t; e < (int64_t)T * 128; e += FF_BWD2_THREADS) svbase[(e >> 7) * SV_STRIDE + SV_DK + (e & 127)] = 0.f;
 
   // weight columns for the transposed FFN products, in registers
   //   W1^T dhp : output k = t & 63, rows [32*(t>>6), +32)          -> w1c[r] = W1[32*(t>>6)+r][k]
@@ -639,9 +647,17 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
   const float slope = exp2f(-2.f * (float)(head + 1));
   const int js = lane >> 2, dq = lane & 3;
   float carry = 0.f;                                   // wave 0: (A^T demb_{i+1})[lane]
+  float* dP = save + (int64_t)gridDim.x * T * SV_STRIDE + s * (int64_t)A2F_FF_PARAM_FLOATS;      // this sequence's slab
+  if (i_hi < T && wave == 0) {                         // resume: state left by the launch of the later block
+    gg1 = dP[A2F_FF_LN + 0 * FD + lane]; gb1n = dP[A2F_FF_LN + 1 * FD + lane];
+    gg2 = dP[A2F_FF_LN + 2 * FD + lane]; gb2n = dP[A2F_FF_LN + 3 * FD + lane];
+    gg3 = dP[A2F_FF_LN + 4 * FD + lane]; gb3n = dP[A2F_FF_LN + 5 * FD + lane];
+    carry = dP[A2F_FF_A + lane];
+    gsty = dP[A2F_FF_A + FD + lane];
+  }
   __syncthreads();
 
-  for (int i = T - 1; i >= 0; --i) {
+  for (int i = i_hi - 1; i >= i_lo; --i) {
     float* sv = svbase + (int64_t)i * SV_STRIDE;
     float* gr = gbase + (int64_t)i * FF_GREC;
     float dy2 = 0.f, xh2 = 0.f, xh1 = 0.f;
@@ -731,6 +747,7 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
 #pragma unroll 16
       for (int r = 0; r < FD; ++r) acc += Wo[r * FD + lane] * dsas[r];
       dcs[lane] = acc;
+      gr[GR_DC + lane] = acc;
     }
     __syncthreads();
     // ---- S7: attention backward for head = wave ----
@@ -750,9 +767,20 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
       rowsum += __shfl_xor(rowsum, 1, 64);
       rowsum += __shfl_xor(rowsum, 2, 64);
       float4 dqa = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane == 0 && apart == 0) gr[GR_RS + head] = rowsum;
+      if (i_lo > 0 && apart == 0) {                        // keys of the earlier blocks: dq += Nt^T dctx - rowsum n  (lane: a' = js, b = 4 dq ..)
+        const float* nr = nrec + (s * T + i) * FF_NREC;
+        const float4 nt = *reinterpret_cast<const float4*>(nr + head * 256 + js * 16 + dq * 4);
+        const float dca = dcs[head * FHD + js];
+        dqa = make_float4(nt.x * dca, nt.y * dca, nt.z * dca, nt.w * dca);
+        if (js == 0) {
+          const float4 nn = *reinterpret_cast<const float4*>(nr + NR_N + head * FHD + dq * 4);
+          dqa.x -= rowsum * nn.x; dqa.y -= rowsum * nn.y; dqa.z -= rowsum * nn.z; dqa.w -= rowsum * nn.w;
+        }
+      }
       const unsigned* abits = DROP ? dm.attn + ((s * FH + head) * T + i) * dm.TW : nullptr;
       constexpr int FB_U = FB2_U;                          // two waves per head: half the slots per trip, alternate trips
-      for (int j0 = js + apart * 16 * FB_U; j0 <= i; j0 += 2 * 16 * FB_U) {
+      for (int j0 = i_lo + js + apart * 16 * FB_U; j0 <= i; j0 += 2 * 16 * FB_U) {
         float4 kk[FB_U], vv[FB_U], dk[FB_U], dv[FB_U];
         unsigned kw[FB_U];
 #pragma unroll
@@ -835,16 +863,114 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
   // demb_0 belongs to emb_0 = style only: it must not reach dA / dc (no feedback produced emb_0) - nothing to do.
 
   // ---- the per-lane scalars of this sequence: LayerNorm gains / biases into its slab (folded in sequence order), style gradient
-  float* dP = save + (int64_t)gridDim.x * T * SV_STRIDE + s * (int64_t)A2F_FF_PARAM_FLOATS;
   if (wave == 0) {
+    dP[A2F_FF_A + lane] = carry;                       // (state for the launch of the earlier block; the A / c gradients themselves come from the products)
+    dP[A2F_FF_A + FD + lane] = gsty;
     dP[A2F_FF_LN + 0 * FD + lane] = gg1;
     dP[A2F_FF_LN + 1 * FD + lane] = gb1n;
     dP[A2F_FF_LN + 2 * FD + lane] = gg2;
     dP[A2F_FF_LN + 3 * FD + lane] = gb2n;
     dP[A2F_FF_LN + 4 * FD + lane] = gg3;
     dP[A2F_FF_LN + 5 * FD + lane] = gb3n;
-    dstyle[s * FD + lane] = gsty;
+    if (i_lo == 0) dstyle[s * FD + lane] = gsty;
   }
+}
+
+// Blocked backward, attention terms across block boundaries (a_ij = exp(q_i . k_j - bias - m_i) / l_i is known from the forward):
+//   ff_bwd_prep_kernel : for every step i of a block that starts at i0 > 0:  Nt_i[a'][b] = sum_{j < i0} a_ij D_ij v_j[a'] k_j[b],  n_i[b] = sum_{j < i0} a_ij k_j[b]
+//                        so that the recurrence gets  sum_{j < i0} ds_ij k_j = Nt_i^T dctx_i - (dctx_i . ctx_i) n_i  without touching those keys;
+//   ff_bwd_rect_kernel : after the recurrence of block [i0, i1) has left dctx_i and dctx_i . ctx_i in the records: for every key j < i0
+//                        dK_j += sum_i ds_ij q_i,  dV_j += sum_i a_ij D_ij dctx_i  (one thread per (key, head): plain read-add-write, fixed order).
+// Both run over the whole chip; what stays in the one-workgroup-per-sequence recurrence is the sweep over the <= FF_BLK keys of the own block.
+template <bool DROP>
+__global__ __launch_bounds__(256) void ff_bwd_prep_kernel(const float* __restrict__ save, float* __restrict__ nrec, int T, int period, const FFDrop dm) {
+  const int quarter = threadIdx.x >> 6, lane = threadIdx.x & 63;       // wave = which four b of k_j[b]
+  const int head = blockIdx.y;
+  const int64_t s = blockIdx.z;
+  const int i_base = FF_BLK + blockIdx.x * 64;                          // 64 consecutive steps: one block of the recurrence (FF_BLK is a multiple of 64)
+  const int i0 = (i_base / FF_BLK) * FF_BLK;
+  const int i = i_base + lane, ii = min(i, T - 1);
+  const float* svbase = save + s * (int64_t)T * SV_STRIDE;
+  const float* svi = svbase + (int64_t)ii * SV_STRIDE;
+  float q[FHD];
+#pragma unroll
+  for (int c = 0; c < FHD; ++c) q[c] = svi[SV_Q + head * FHD + c];
+  const float m = svi[SV_ST + 4 + head], invl = 1.f / svi[SV_ST + 8 + head];
+  const float slope = exp2f(-2.f * (float)(head + 1));
+  const unsigned* abits = DROP ? dm.attn + ((s * FH + head) * T + ii) * dm.TW : nullptr;
+  float acc[FHD][4], nacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < FHD; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
+  int qd = ii / period, r = ii - qd * period;                           // (i - j) / period and % period at j = 0
+  unsigned word = 0;
+  for (int j = 0; j < i0; ++j) {
+    const float* svj = svbase + (int64_t)j * SV_STRIDE;                 // wave-uniform row
+    float p = 0.f;
+#pragma unroll
+    for (int c = 0; c < FHD; ++c) p += q[c] * svj[SV_K + head * FHD + c];
+    const float a = expf(p - slope * (float)qd - m) * invl;
+    float ad = a;
+    if constexpr (DROP) {
+      if ((j & 31) == 0) word = abits[j >> 5];
+      ad = ((word >> (j & 31)) & 1u) ? a * dm.scale : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float kb = svj[SV_K + head * FHD + quarter * 4 + c];
+      nacc[c] += a * kb;
+      const float w = ad * kb;
+#pragma unroll
+      for (int a2 = 0; a2 < FHD; ++a2) acc[a2][c] += w * svj[SV_V + head * FHD + a2];
+    }
+    if (--r < 0) { r = period - 1; --qd; }
+  }
+  if (i < T) {
+    float* nr = nrec + (s * T + i) * FF_NREC;
+#pragma unroll
+    for (int a2 = 0; a2 < FHD; ++a2)
+      *reinterpret_cast<float4*>(nr + head * 256 + a2 * 16 + quarter * 4) = make_float4(acc[a2][0], acc[a2][1], acc[a2][2], acc[a2][3]);
+    *reinterpret_cast<float4*>(nr + NR_N + head * FHD + quarter * 4) = make_float4(nacc[0], nacc[1], nacc[2], nacc[3]);
+  }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(256) void ff_bwd_rect_kernel(float* __restrict__ save, const float* __restrict__ grec, int T, int period, int i_lo, int i_hi,
+                                                          const FFDrop dm) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= i_lo) return;                                                // no barriers below
+  const int head = blockIdx.y;
+  const int64_t s = blockIdx.z;
+  float* svbase = save + s * (int64_t)T * SV_STRIDE;
+  const float* gbase = grec + s * (int64_t)T * FF_GREC;
+  float* svj = svbase + (int64_t)j * SV_STRIDE;
+  float k[FHD], v[FHD], dk[FHD], dv[FHD];
+#pragma unroll
+  for (int c = 0; c < FHD; ++c) { k[c] = svj[SV_K + head * FHD + c]; v[c] = svj[SV_V + head * FHD + c]; dk[c] = 0.f; dv[c] = 0.f; }
+  const float slope = exp2f(-2.f * (float)(head + 1));
+  int qd = (i_lo - j) / period, r = (i_lo - j) - qd * period;
+  const unsigned* abits = DROP ? dm.attn + ((s * FH + head) * T) * dm.TW + (j >> 5) : nullptr;
+  for (int i = i_lo; i < i_hi; ++i) {
+    const float* svi = svbase + (int64_t)i * SV_STRIDE;                 // wave-uniform rows
+    const float* gr = gbase + (int64_t)i * FF_GREC;
+    float p = 0.f, da = 0.f;
+#pragma unroll
+    for (int c = 0; c < FHD; ++c) { p += svi[SV_Q + head * FHD + c] * k[c]; da += gr[GR_DC + head * FHD + c] * v[c]; }
+    const float a = expf(p - slope * (float)qd - svi[SV_ST + 4 + head]) / svi[SV_ST + 8 + head];
+    float ad = a;
+    if constexpr (DROP) {
+      const float dj = ((abits[(int64_t)i * dm.TW] >> (j & 31)) & 1u) ? dm.scale : 0.f;
+      ad = a * dj;
+      da *= dj;
+    }
+    const float ds = a * (da - gr[GR_RS + head]);
+#pragma unroll
+    for (int c = 0; c < FHD; ++c) { dk[c] += ds * svi[SV_Q + head * FHD + c]; dv[c] += ad * gr[GR_DC + head * FHD + c]; }
+    if (++r == period) { r = 0; ++qd; }
+  }
+#pragma unroll
+  for (int c = 0; c < FHD; ++c) { svj[SV_DK + head * FHD + c] += dk[c]; svj[SV_DV + head * FHD + c] += dv[c]; }
 }
 
 // dparams[i] = sum over sequences (fixed order) of the per-sequence slabs the backward kernel left behind `save`
@@ -876,8 +1002,8 @@ extern "C" size_t a2f_ff_save_bytes(int64_t S, int64_t T) {
   if (S <= 0 || T <= 0) return 16;
   // per-step save rows + one gradient slab per sequence (written by the backward kernel, folded in sequence order) + the backward's
   // per-frame gradient records and the split-K workspace of its weight-gradient products
-  return ((size_t)S * (size_t)T * a2f::SV_STRIDE + (size_t)S * A2F_FF_PARAM_FLOATS + (size_t)S * (size_t)T * a2f::FF_GREC + a2f::FF_GEMM_WS_FLOATS) *
-         sizeof(float);
+  return ((size_t)S * (size_t)T * a2f::SV_STRIDE + (size_t)S * A2F_FF_PARAM_FLOATS + (size_t)S * (size_t)T * a2f::FF_GREC + a2f::FF_GEMM_WS_FLOATS +
+          (T >= a2f::FF_BLK_MIN ? (size_t)S * (size_t)T * a2f::FF_NREC : 0)) * sizeof(float);
 }
 
 static int ff_check_drop(const uint32_t* row_bits, const uint32_t* attn_bits, float keep_scale, const char* who) {
@@ -915,7 +1041,7 @@ static int ff_fwd_impl(const float* params, const float* pe, const float* cross,
 // Record form of the backward: the recurrence kernel (8 waves) leaves per-frame gradient factors in `grec`; the weight gradients are five
 // a2f_mm products over all S*T frames (bias gradients ride along as row sums), LayerNorm gradients are folded from the per-sequence slabs.
 static int ff_bwd2_run(const float* params, const float* dy, int64_t S, int64_t T, int32_t period, float* save, float* dparams, float* dcross,
-                       float* dstyle, const a2f::FFDrop& dm, bool drop, hipStream_t st) {
+                       float* dstyle, const a2f::FFDrop& dm, bool drop, bool blocked, hipStream_t st) {
   using namespace a2f;
   constexpr size_t LDS = FF_BWD_LDS + 64 * sizeof(float);
   static bool attr_set[2] = {false, false};
@@ -928,10 +1054,33 @@ static int ff_bwd2_run(const float* params, const float* dy, int64_t S, int64_t 
   float* slabs = save + (size_t)S * T * SV_STRIDE;
   float* grec = slabs + (size_t)S * A2F_FF_PARAM_FLOATS;
   float* ws = grec + (size_t)S * T * FF_GREC;
-  if (drop)
-    hipLaunchKernelGGL(ff_decoder_bwd2_kernel<true>, dim3((unsigned)S), dim3(FF_BWD2_THREADS), LDS, st, params, dy, (int)T, (int)period, save, grec, dcross, dstyle, dm);
-  else
-    hipLaunchKernelGGL(ff_decoder_bwd2_kernel<false>, dim3((unsigned)S), dim3(FF_BWD2_THREADS), LDS, st, params, dy, (int)T, (int)period, save, grec, dcross, dstyle, dm);
+  float* nrec = ws + FF_GEMM_WS_FLOATS;
+  auto recurrence = [&](int lo, int hi) {
+    if (drop)
+      hipLaunchKernelGGL(ff_decoder_bwd2_kernel<true>, dim3((unsigned)S), dim3(FF_BWD2_THREADS), LDS, st, params, dy, (int)T, (int)period, save, grec, dcross, dstyle, dm,
+                         (const float*)nrec, lo, hi);
+    else
+      hipLaunchKernelGGL(ff_decoder_bwd2_kernel<false>, dim3((unsigned)S), dim3(FF_BWD2_THREADS), LDS, st, params, dy, (int)T, (int)period, save, grec, dcross, dstyle, dm,
+                         (const float*)nrec, lo, hi);
+  };
+  if (!blocked || T < FF_BLK_MIN) {
+    recurrence(0, (int)T);
+  } else {
+    const dim3 pg((unsigned)((T - FF_BLK + 63) / 64), FH, (unsigned)S);
+    if (drop) hipLaunchKernelGGL(ff_bwd_prep_kernel<true>, pg, dim3(256), 0, st, (const float*)save, nrec, (int)T, (int)period, dm);
+    else hipLaunchKernelGGL(ff_bwd_prep_kernel<false>, pg, dim3(256), 0, st, (const float*)save, nrec, (int)T, (int)period, dm);
+    A2F_CHECK_LAUNCH("ff_decoder_bwd (cross-block dq terms)");
+    for (int hi = (int)T; hi > 0;) {
+      const int lo = ((hi - 1) / FF_BLK) * FF_BLK;
+      recurrence(lo, hi);
+      if (lo > 0) {
+        const dim3 rg((unsigned)((lo + 255) / 256), FH, (unsigned)S);
+        if (drop) hipLaunchKernelGGL(ff_bwd_rect_kernel<true>, rg, dim3(256), 0, st, save, (const float*)grec, (int)T, (int)period, lo, hi, dm);
+        else hipLaunchKernelGGL(ff_bwd_rect_kernel<false>, rg, dim3(256), 0, st, save, (const float*)grec, (int)T, (int)period, lo, hi, dm);
+      }
+      hi = lo;
+    }
+  }
   A2F_CHECK_LAUNCH("ff_decoder_bwd (recurrence)");
   hipLaunchKernelGGL(ff_decoder_fold_range_kernel, dim3(2), dim3(256), 0, st, (const float*)slabs, (int)S, dparams, (int)A2F_FF_LN, 6 * FD);
   A2F_CHECK_LAUNCH("ff_decoder_bwd (LayerNorm fold)");
@@ -982,7 +1131,8 @@ static int ff_bwd_impl(const float* params, const float* dy, int64_t S, int64_t 
   const FFDrop dm{row_bits, attn_bits, (int)a2f_attn_keep_words(T), keep_scale};
   const char* form = getenv("A2F_FF_BWD");                                   // A-B hook, read per call: 1 = register-accumulator form
   const bool legacy = form && form[0] == '1';
-  if (!legacy && (uint64_t)S * T * SV_STRIDE * 4ull < 0xFFFFFFF0ull) return ff_bwd2_run(params, dy, S, T, period, (float*)save, dparams, dcross, dstyle, dm, drop, (hipStream_t)stream);
+  if (!legacy && (uint64_t)S * T * SV_STRIDE * 4ull < 0xFFFFFFF0ull)            // 2 = record form in one launch (no blocks)
+    return ff_bwd2_run(params, dy, S, T, period, (float*)save, dparams, dcross, dstyle, dm, drop, !(form && form[0] == '2'), (hipStream_t)stream);
   if (drop)
     hipLaunchKernelGGL(ff_decoder_bwd_kernel<true>, dim3((unsigned)S), dim3(FF_THREADS), FF_BWD_LDS, (hipStream_t)stream, params, dy, (int)T, (int)period,
                        (float*)save, dcross, dstyle, dm);

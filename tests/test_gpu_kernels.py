@@ -338,11 +338,13 @@ def test_batchnorm_fwd_bwd(R, C, training, relu):
         assert rel_l2(a, b) < 2e-5, name
 
 
-@pytest.mark.parametrize("form", ["0", "1"])
-@pytest.mark.parametrize("S,T,period", [(1, 5, 60), (3, 70, 60), (2, 33, 7), (2, 1, 7)])
+@pytest.mark.parametrize("form", ["0", "1", "2"])
+@pytest.mark.parametrize("S,T,period", [(1, 5, 60), (3, 70, 60), (2, 33, 7), (2, 1, 7), (2, 300, 60), (1, 257, 7)])
 def test_ff_decoder_kernels_vs_spec(S, T, period, form, monkeypatch):
     """Recurrence forward + reverse-time backward against autograd on the float64 statement of the same recurrence.  form 0 = record
-    form of the backward (recurrence kernel + weight-gradient products over all frames), 1 = register-accumulator kernel."""
+    form of the backward (recurrence kernel + weight-gradient products over all frames; from 256 frames on in blocks of 128 steps with the
+    cross-block attention terms batched over the chip: T = 300 / 257 run three blocks), 1 = register-accumulator kernel, 2 = record form
+    in one launch."""
     monkeypatch.setenv("A2F_FF_BWD", form)
     from a2f_amd._lib import load as _load
     nP = 192 * 64 + 192 + 64 * 64 + 64 + 128 * 64 + 128 + 64 * 128 + 64 + 6 * 64 + 64 * 64 + 64
@@ -380,8 +382,8 @@ def test_ff_decoder_kernels_vs_spec(S, T, period, form, monkeypatch):
         o += sz_
 
 
-@pytest.mark.parametrize("form", ["0", "1"])
-@pytest.mark.parametrize("S,T,period", [(1, 5, 60), (3, 70, 60), (2, 133, 7)])
+@pytest.mark.parametrize("form", ["0", "1", "2"])
+@pytest.mark.parametrize("S,T,period", [(1, 5, 60), (3, 70, 60), (2, 133, 7), (2, 290, 60)])
 def test_ff_decoder_dropout_kernels_vs_spec(S, T, period, form, monkeypatch):
     """a2f_ff_decoder_fwd_drop / bwd_drop (one keep mask per frame row at the PPE output, the self-attention probabilities, dropout1, the
     feed-forward activation and dropout3) against autograd on the float64 statement of the same masked recurrence; masks come from

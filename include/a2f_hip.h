@@ -237,7 +237,9 @@ int a2f_ff_decoder_fwd(const float* params, const float* pe, const float* cross,
  * per-step rows of `save`; weight and bias gradients are then five bf16x3 products over all S*T frames launched on the same
  * stream by this call (split-K slabs folded in fixed order), the slabs are summed in sequence order.  `save` is the forward's
  * buffer (a2f_ff_save_bytes covers records, slabs and the products' workspace); its dK/dV accumulator columns are scratch
- * for this call.  Environment A2F_FF_BWD=1 (A-B hook, read per call): the single-kernel form with register accumulators. */
+ * for this call.  From 256 frames on the recurrence is launched in blocks of 128 steps; attention terms across block
+ * boundaries are computed by two chip-wide kernels (see ff_decoder.hip).  Environment A2F_FF_BWD (A-B hook, read per call):
+ * 1 = the single-kernel form with register accumulators, 2 = record form in one launch. */
 int a2f_ff_decoder_bwd(const float* params, const float* dy, int64_t S, int64_t T, int32_t period, void* save,
                        size_t save_bytes, float* dparams, float* dcross, float* dstyle, a2f_stream_t stream);
 /* Train-mode variants: dropout 0.1 of the PPE output (faceformer.py:73,88) and of nn.TransformerDecoderLayer's self-attention

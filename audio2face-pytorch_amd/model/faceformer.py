@@ -209,8 +209,9 @@ class Faceformer(nn.Module):
         ~17 ms (forward + backward at T = 600) whatever S is; run back to back with the encoder it leaves >= 75 % of the CUs idle
         for that time.  Here the step is cut into two half-batches A, B and issued on two HIP streams:
 
-            main stream : encoder fwd A | encoder fwd B |     encoder bwd A      | encoder bwd B
-            side stream :               | decoder fwd + head + decoder bwd of A  | ... of B |
+            main stream   : encoder fwd A | encoder fwd B |     encoder bwd A      | encoder bwd B
+            side stream A :               | decoder fwd + head + decoder bwd of A  |
+            side stream B :                               | decoder fwd + head of B, then (after A's) its backward |
 
         so A's recurrence runs beside B's encoder forward and B's beside A's encoder backward.  To issue a half's decoder backward
         BEFORE the other half's encoder launches (the host issues ~2 500 launches per step; what is issued late starts late) the
@@ -222,9 +223,11 @@ class Faceformer(nn.Module):
         assert S >= 2 and audio.is_cuda
         frame_num = audio.shape[1] * 60 // 16000
         cur = torch.cuda.current_stream()
-        if Faceformer._pipe_stream is None or Faceformer._pipe_stream.device != audio.device:
-            Faceformer._pipe_stream = torch.cuda.Stream(device=audio.device, priority=-1)     # the short dependent chain goes first in dispatch
-        side = Faceformer._pipe_stream
+        if Faceformer._pipe_stream is None or Faceformer._pipe_stream[0].device != audio.device:
+            # one side stream per half: the recurrence takes the same time whatever the number of sequences, so at long T (3000 frames: 89 ms) the
+            # second half's recurrence has to start while the first half's is still running, not queue behind it
+            Faceformer._pipe_stream = [torch.cuda.Stream(device=audio.device, priority=-1) for _ in range(2)]     # short dependent chains go first in dispatch
+        sides = Faceformer._pipe_stream
         cuts = (0, (S + 1) // 2, S)                             # equal halves measured best (7/16 .. 5/16 for the first half: +0.4 .. +1.4 %)
         enc_params = {id(p) for p in self.audio_encoder.parameters()}
         dec_params = [p for p in self.parameters() if p.requires_grad and id(p) not in enc_params]
@@ -233,6 +236,7 @@ class Faceformer(nn.Module):
             lo, hi = cuts[g], cuts[g + 1]
             enc = self.encode(audio[lo:hi], frame_num)                          # main stream
             ready = cur.record_event()
+            side = sides[g]
             with torch.cuda.stream(side):
                 side.wait_event(ready)
                 enc.record_stream(side)
@@ -240,6 +244,8 @@ class Faceformer(nn.Module):
                 y = self.decode_hidden(enc_d, one_hot[lo:hi])
                 _pred, out3 = self._head_loss_batch(y, template[lo:hi], gt[lo:hi], k_rec, k_vel)
                 w = (hi - lo) / S
+                if halves:
+                    side.wait_event(halves[-1][2])                              # the halves add into the same decoder-side .grad tensors: in half order
                 torch.autograd.backward(out3[0] * w, inputs=[enc_d] + dec_params)
                 outs.append(out3.detach() * w)
                 halves.append((enc, enc_d.grad, side.record_event()))
@@ -249,7 +255,8 @@ class Faceformer(nn.Module):
             d_enc.record_stream(cur)
             enc.backward(d_enc)                                                 # main stream: encoder backward of this half
         halves.clear()
-        cur.wait_stream(side)
+        for side in sides:
+            cur.wait_stream(side)
         for o in outs:
             o.record_stream(cur)
         tot = outs[0] + outs[1]

@@ -228,6 +228,10 @@ class Faceformer(nn.Module):
             # second half's recurrence has to start while the first half's is still running, not queue behind it
             Faceformer._pipe_stream = [torch.cuda.Stream(device=audio.device, priority=-1) for _ in range(2)]     # short dependent chains go first in dispatch
         sides = Faceformer._pipe_stream
+        if frame_num < 1200:
+            # at 600 frames a half's recurrence (11 ms) is over long before the other half's starts: one side stream does - and a further stream
+            # can land on a hardware queue another stream of the process already uses (measured inside the full bench run: 182 vs 157 ms)
+            sides = [sides[0], sides[0]]
         cuts = (0, (S + 1) // 2, S)                             # equal halves measured best (7/16 .. 5/16 for the first half: +0.4 .. +1.4 %)
         enc_params = {id(p) for p in self.audio_encoder.parameters()}
         dec_params = [p for p in self.parameters() if p.requires_grad and id(p) not in enc_params]
@@ -255,7 +259,7 @@ class Faceformer(nn.Module):
             d_enc.record_stream(cur)
             enc.backward(d_enc)                                                 # main stream: encoder backward of this half
         halves.clear()
-        for side in sides:
+        for side in sides[:1] if sides[0] is sides[1] else sides:
             cur.wait_stream(side)
         for o in outs:
             o.record_stream(cur)

@@ -123,10 +123,13 @@ class TrainStep:
         self.overlap = bool(overlap) and self._head_off is not None
         # FaceFormer with several sequences per step: two half-batches on two streams (Faceformer.train_step_pipelined); A2F_FF_PIPELINE=0
         # keeps the single-stream order
-        # (measured on MI355X, T = 600: 64 sequences 179.5 -> 171.5 ms; 32 sequences 101.5 -> 102.2 ms - a 16-sequence half's encoder
-        # forward is shorter than the other half's recurrence, so it pays from ~48 sequences per step up)
+        # (measured on MI355X with the round-1 recurrence, 17 ms per half at T = 600: 64 sequences 179.5 -> 171.5 ms.  With the 8-wave forward and the
+        # blocked record-form backward the recurrence is 11 ms at T = 600 and the halves' doubled per-launch tails cost as much as hiding it gains:
+        # 64 x 600 155.9 ms single-stream vs 158-161 ms pipelined inside the full bench run; at 3000 frames (89 ms per half) it pays: 12 x 3000
+        # 251 -> 238 ms.  So: from 1200 frames per sequence and 48 x 600 frames per step up.)
         self.pipeline = os.environ.get("A2F_FF_PIPELINE", "1") != "0"
         self.pipeline_min_seqs = int(os.environ.get("A2F_FF_PIPELINE_MIN_SEQS", "48"))    # in sequences of 600 frames: the test is on frames per step
+        self.pipeline_min_frames = int(os.environ.get("A2F_FF_PIPELINE_MIN_FRAMES", "1200"))
         self._graph2 = None
 
     def _direct(self, ins, phase):
@@ -228,8 +231,9 @@ class TrainStep:
             lf = getattr(self.loss_fn, "loss", self.loss_fn)          # FaceFormerLoss wraps a VocaLoss
             if hasattr(self.model, "forward_with_loss_batch") and x.dim() == 2 and x.shape[0] > 1:
                 # S independent batch-1 FaceFormer problems per step (train.py:33 fixes batch = 1)
-                if (self.pipeline and x.is_cuda and x.shape[0] >= 2 and x.shape[0] * (x.shape[1] * 60 // 16000) >= self.pipeline_min_seqs * 600
-                        and hasattr(self.model, "train_step_pipelined")):
+                frames = x.shape[1] * 60 // 16000
+                if (self.pipeline and x.is_cuda and x.shape[0] >= 2 and frames >= self.pipeline_min_frames
+                        and x.shape[0] * frames >= self.pipeline_min_seqs * 600 and hasattr(self.model, "train_step_pipelined")):
                     # two half-batches on two streams: each half's decoder recurrence runs under the other half's encoder work
                     loss = self.model.train_step_pipelined(x, one_hot, template, gt, lf.k_rec, lf.k_vel)
                     loss["err"] = loss["rec_loss"] / 3.0

@@ -925,9 +925,8 @@ def test_faceformer_full_size_pipelined_step_is_bitwise_reproducible(S, T):
             m.vertice_map_r.weight.normal_(0, 0.1); m.vertice_map.weight.normal_(0, 0.001)
         m.train()
         step = TrainStep(m, a2f_amd.FaceFormerLoss(), lr=1e-4)
-        assert step.pipeline and S * T >= step.pipeline_min_seqs * 600 or T == 3000
-        if T == 3000:
-            step.pipeline_min_seqs = 1                          # 18 000 frames per step: below the default threshold, forced here
+        assert step.pipeline
+        step.pipeline_min_seqs, step.pipeline_min_frames = 1, 1   # force the two-stream form (default: from 1200 frames per sequence, 28 800 per step)
         torch.manual_seed(99)
         for _ in range(2):
             out = step(audio, one_hot, gt, templ)

@@ -555,8 +555,11 @@ class A2MTrunkMMFn(torch.autograd.Function):
         be.mm(ops.MMOp(zb, KH9 * 256), ops.MMOp(wg, KH9 * 256), cat, B, 256, KH9 * 256, ncat, bias=b, act=ops.MM_ACT_RELU)
         sv["wg"][9], sv["conv_in"][9] = wg, zb
         z1, z2, h3 = new(B, 72), new(B, 128), new(B, 50)
-        ops.linear_fwd(be, cat, fcs[0][0], fcs[0][1], z1, B, 72, ncat)
-        ops.linear_fwd(be, z1, fcs[1][0], fcs[1][1], z2, B, 128, 72, act=ACT_TANH)
+        # output_net.0 / .1 on a2f_mm as well (1024 x 72 x 268 takes 80 us on the exact-fp32 generic GEMM, a few us here); the 50-wide
+        # layer keeps the generic GEMM: its K = 50 rows are not 16-byte aligned
+        ops.mm_linear_fwd(be, cat, fcs[0][0], fcs[0][1], z1, B, 72, ncat)
+        ops.mm_linear_fwd(be, z1, fcs[1][0], fcs[1][1], z2, B, 128, 72)
+        torch.tanh_(z2)
         ops.linear_fwd(be, z2, fcs[2][0], fcs[2][1], h3, B, 50, 128)
         ctx.sv = sv
         ctx.misc = (B, no, H0, Hd, KH9, training, cat, z8, z1, z2, [f[0] for f in fcs])
@@ -583,13 +586,13 @@ class A2MTrunkMMFn(torch.autograd.Function):
         dz2 = new(B, 128)
         ops.linear_bwd_input(be, dh3, fw[2], dz2, B, 50, 128, aux=z2, ldaux=128, aux_mode=AUX_TANH_BWD)
         dW, db = new(128, 72), new(128)
-        ops.linear_bwd_weight(be, dz2, z1, dW, db, B, 128, 72); g_fc[2], g_fc[3] = dW, db
+        ops.mm_linear_wgrad(be, dz2, z1, dW, B, 128, 72, db=db); g_fc[2], g_fc[3] = dW, db
         dz1 = new(B, 72)
-        ops.linear_bwd_input(be, dz2, fw[1], dz1, B, 128, 72)
+        be.mm(ops.MMOp(dz2, 128), ops.MMOp(fw[1], 72, trans=True), dz1, B, 72, 128, 72)
         dW, db = new(72, ncat), new(72)
-        ops.linear_bwd_weight(be, dz1, cat, dW, db, B, 72, ncat); g_fc[0], g_fc[1] = dW, db
-        d = new(B, 256)                                       # grad w.r.t. conv-9 pre-activation (ReLU mask of cat fused)
-        ops.linear_bwd_input(be, dz1, fw[0], d, B, 72, ncat, n_cols=256, aux=cat, ldaux=ncat, aux_mode=AUX_RELU_BWD)
+        ops.mm_linear_wgrad(be, dz1, cat, dW, B, 72, ncat, db=db); g_fc[0], g_fc[1] = dW, db
+        d = new(B, 256)                                       # grad w.r.t. conv-9 pre-activation (ReLU mask of cat fused): the first 256 input columns of output_net.0
+        be.mm(ops.MMOp(dz1, 72), ops.MMOp(fw[0], ncat, trans=True), d, B, 256, 72, 256, aux=cat, ldaux=ncat, aux_mode=ops.MM_AUX_RELU_BWD)
 
 
         def bn_bwd(i, dy, R, C, Cp, relu):

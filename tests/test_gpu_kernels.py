@@ -318,7 +318,7 @@ def test_head_fused_rejects_bad_arguments():
         be.head_fused(z(4, 50), z(30, 50), z(30), z(4, 30), 4, z(4, 30), 4, 3, 30, 50, 1.0, 10.0, z(4, 30), z(3), z(4, 50), z(30, 50), z(30))
 
 
-@pytest.mark.parametrize("R,C", [(7, 3), (1000, 72), (4096, 108), (333, 162), (2049, 243), (512, 256), (5, 1000)])
+@pytest.mark.parametrize("R,C", [(7, 3), (1000, 72), (4096, 108), (333, 162), (2049, 243), (512, 256), (5, 1000), (333, 164), (2049, 244), (70001, 72), (3, 8)])
 @pytest.mark.parametrize("training,relu", [(True, True), (True, False), (False, True)])
 def test_batchnorm_fwd_bwd(R, C, training, relu):
     hip, emu = ops.HipBackend(), EmuBackend()

@@ -597,13 +597,17 @@ def test_bench_self_launches_two_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(A2F_BENCH_BACKEND="gloo", A2F_BENCH_SHARE_GPU="1")
+    # the secondary entries run too (small shapes): every rank must issue the same collectives in every leg, the rank-0-only roofline passes included
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "3", "--seqs", "4",
-                        "--frames", "64", "--no-secondary"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+                        "--frames", "64", "--ff-seqs", "2", "--ff-frames", "60", "--ff-long-seqs", "2", "--ff-long-frames", "120", "--a2m-batch", "64",
+                        "--secondary-steps", "3"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["value"] > 0
+    assert {e["model"] for e in out["secondary"]} == {"faceformer", "audio2mesh", "faceformer_long"}
+    assert all(e["config"]["parallelism"] == "dp2" and e["value"] > 0 for e in out["secondary"])
 
 
 def test_bench_secondary_lines_small():

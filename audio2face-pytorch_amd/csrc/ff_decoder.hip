@@ -7,8 +7,12 @@
 // K/V cache: O(T^2) work, gradients identical (SURVEY §3.3 identities 1-5; tests/ pin both against the reference).
 //
 // Mapping: ONE workgroup per sequence (forward: 8 waves, the upper four only help with the attention sweep - two waves per head, alternate
-// trips of keys, partial softmaxes merged through LDS: 5.9 -> 5.2 ms at T = 600, 74 -> 54 ms at T = 3000; backward: 4 waves, its 480-500
-// registers of weight-gradient accumulators allow one wave per SIMD); sequences are independent, so a batch of S sequences fills S CUs.
+// trips of keys, partial softmaxes merged through LDS: 5.9 -> 5.2 ms at T = 600, 74 -> 54 ms at T = 3000; backward, default = RECORD FORM:
+// ff_decoder_bwd2_kernel, 8 waves, leaves per-frame gradient factors and the host entry turns them into the weight gradients with five a2f_mm
+// products over all frames; from 256 frames on it runs in blocks of 128 steps and the attention terms that cross a block boundary are computed
+// on the whole chip by ff_bwd_prep_kernel / ff_bwd_rect_kernel: 10.6 -> 5.5 ms at T = 600, 176 -> 30 ms at T = 3000.  ff_decoder_bwd_kernel is
+// the round-1 form, kept selectable: 4 waves, 480-500 registers of weight-gradient accumulators, one wave per SIMD); sequences are independent,
+// so a batch of S sequences fills S CUs.
 // The step is latency-bound (a chain of 64-wide mat-vecs, LayerNorms and a softmax), so everything a step touches
 // stays on chip:
 //   * LDS: the self-attention / feedback weight matrices in the orientation that makes lane = output index
@@ -30,14 +34,14 @@ constexpr int FH = 4;                  // heads
 constexpr int FHD = 16;                // head dim
 constexpr int FFF = 128;               // feed-forward width
 constexpr int FF_THREADS = 256;
-constexpr int FF_FWD_THREADS = 512;
+constexpr int FF_FWD_THREADS = 512;   // forward: waves 4..7 only help with the self-attention sweep (two waves per head, every other trip of keys each)
 constexpr int FF_BWD2_THREADS = 512;   // backward (record form): waves 4..7 help with the attention sweep
 constexpr int FB2_U = 4;               // key slots per trip and wave in that form
 // gradient record of one frame (floats): what the weight-gradient products need beside the saved activations
 constexpr int GR_QKV = 0, GR_SA = 192, GR_HP = 256, GR_F = 384, GR_EMB = 448, GR_Y2 = 512, GR_Y = 576, GR_DC = 640, GR_RS = 704, FF_GREC = 720;
 // blocked form of the backward (sequences of FF_BLK_MIN frames and more): the recurrence runs in blocks of FF_BLK steps, attention terms that cross a block
 // boundary are batched over the whole chip (ff_bwd_prep_kernel / ff_bwd_rect_kernel below).  FF_NREC floats per frame: Nt[h][a'][b], then n[h][b]
-constexpr int FF_BLK = 128, FF_BLK_MIN = 256, FF_NREC = 4 * 272, NR_N = 1024;    // forward: waves 4..7 only help with the self-attention sweep (two waves per head, every other trip of keys each)
+constexpr int FF_BLK = 128, FF_BLK_MIN = 256, FF_NREC = 4 * 272, NR_N = 1024;
 #ifndef FA_U_SET
 #define FA_U_SET 4
 #endif

@@ -1007,7 +1007,7 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   if (cfg == 3 && at && bt && d->precision != 2) cfg = (cdiv(d->M, 256) * cdiv(d->N, 128) * batch * split >= 200) ? 2 : 0;
   {
     const char* force = getenv("A2F_MM_CFG");                 // tuning / A-B hook: 0 | 1 | 2
-    if (force && force[0] >= '0' && force[0] <= '3' && !(force[0] == '1' && d->N > 64)) cfg = force[0] - '0';
+    if (force && force[0] >= '0' && force[0] <= '3') cfg = force[0] - '0';
   }
   hipStream_t st = (hipStream_t)stream;
   A2F_CHECK_ARG(d->A.format == d->B.format, "a2f_mm: both operands fp32 or both bf16 hi / lo images");

@@ -141,17 +141,29 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
   const int js = lane >> 2, dq = lane & 3;                      // attention lanes: 16 key slots x 4 quarter-heads
   float emb = sty;                                              // wave 0: embedding fed to the next step
   float y2 = 0.f;
+  // Inputs of a step that do not depend on the recurrence (positional-encoding row, cross-attention row, keep words) are fetched one step
+  // ahead into registers: issued where they are used, each of these L2 round trips (~1 us) would sit on the critical path of the step.
+  float pe_nx = wave == 0 ? pe[lane] : 0.f;                    // wave 0: pe row of the coming step
+  int ph = 0;                                                   // i % period
   __syncthreads();
 
   for (int i = 0; i < T; ++i) {
     float* sv = svbase + (int64_t)i * SV_STRIDE;
     const unsigned* rowbits = DROP ? dm.row + (s * T + i) * FF_ROW_WORDS : nullptr;
+    float cross_i = 0.f;
+    unsigned kw_x = 0, kw_d1 = 0, kw_d3 = 0, kw_act = 0;
     if (wave == 0) {
-      float x = emb + pe[(i % period) * FD + lane];             // periodic positional encoding
-      if constexpr (DROP) x = ((rowbits[lane >> 5] >> (lane & 31)) & 1u) ? x * dm.scale : 0.f;
+      const float pe_i = pe_nx;
+      cross_i = cross[(s * T + i) * FD + lane];                 // used after the self-attention: in flight across the projections and the sweep
+      if constexpr (DROP) { kw_x = rowbits[lane >> 5]; kw_d1 = rowbits[2 + (lane >> 5)]; kw_d3 = rowbits[8 + (lane >> 5)]; }
+      if (++ph == period) ph = 0;
+      pe_nx = pe[ph * FD + lane];                               // next step's row (the table has `period` rows: always in range)
+      float x = emb + pe_i;                                     // periodic positional encoding
+      if constexpr (DROP) x = ((kw_x >> (lane & 31)) & 1u) ? x * dm.scale : 0.f;
       xs[lane] = x;
       sv[SV_X + lane] = x;
     }
+    if constexpr (DROP) { if (t < FFF) kw_act = rowbits[4 + (t >> 5)]; }
     __syncthreads();
     if (t < 192) {                                              // q | k | v projections
       float acc = bqkv;
@@ -238,13 +250,13 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
       float sa = bo;
 #pragma unroll 16
       for (int k = 0; k < FD; ++k) sa += WoT[k * FD + lane] * cs[k];
-      if constexpr (DROP) sa = ((rowbits[2 + (lane >> 5)] >> (lane & 31)) & 1u) ? sa * dm.scale : 0.f;     // dropout1
+      if constexpr (DROP) sa = ((kw_d1 >> (lane & 31)) & 1u) ? sa * dm.scale : 0.f;     // dropout1
       float rstd;
       float xh = wave_layernorm(xs[lane] + sa, rstd);                       // norm1(x + self_attn)
       sv[SV_XH1 + lane] = xh;
       if (lane == 0) sv[SV_ST + 0] = rstd;
       const float y1 = xh * g1 + be1;
-      xh = wave_layernorm(y1 + cross[(s * T + i) * FD + lane], rstd);       // norm2(y1 + cross-attention row)
+      xh = wave_layernorm(y1 + cross_i, rstd);                              // norm2(y1 + cross-attention row)
       sv[SV_XH2 + lane] = xh;
       if (lane == 0) sv[SV_ST + 1] = rstd;
       y2 = xh * g2 + be2;
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
 #pragma unroll
       for (int k = 0; k < FD; ++k) acc += w1r[k] * y2s[k];
       acc = fmaxf(acc, 0.f);
-      if constexpr (DROP) acc = ((rowbits[4 + (t >> 5)] >> (t & 31)) & 1u) ? acc * dm.scale : 0.f;          // dropout after the activation
+      if constexpr (DROP) acc = ((kw_act >> (t & 31)) & 1u) ? acc * dm.scale : 0.f;          // dropout after the activation
       hs[t] = acc;
       sv[SV_H + t] = acc;
     }
@@ -270,7 +282,7 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
     __syncthreads();
     if (wave == 0) {
       float f = b2 + part[lane] + part[FD + lane] + part[2 * FD + lane] + part[3 * FD + lane];
-      if constexpr (DROP) f = ((rowbits[8 + (lane >> 5)] >> (lane & 31)) & 1u) ? f * dm.scale : 0.f;         // dropout3
+      if constexpr (DROP) f = ((kw_d3 >> (lane & 31)) & 1u) ? f * dm.scale : 0.f;         // dropout3
       float rstd;
       const float xh = wave_layernorm(y2 + f, rstd);                        // norm3(y2 + ffn)
       sv[SV_XH3 + lane] = xh;

@@ -92,6 +92,13 @@ constexpr int FF_ROW_WORDS = 10;
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
+// -DFF_STAMPS: timing build only - thread 0 of sequence 0 leaves s_memtime stamps of step FF_STAMP_STEP after every barrier in the (then unused)
+// A / c block of its gradient slab (tools/ff_stamps.py)
+#ifdef FF_STAMPS
+#define FF_STAMP(n) do { if (t == 0 && s == 0 && i == FF_STAMP_STEP) stamp_out[n] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FF_STAMP(n) do { } while (0)
+#endif
 template <bool DROP>
 __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const float* __restrict__ P, const float* __restrict__ pe,
                                                                         const float* __restrict__ cross, const float* __restrict__ style,
@@ -116,6 +123,9 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
   const int head = wave & 3, apart = wave >> 2;     // self-attention: head and which half of the key trips this wave sweeps
   const int64_t s = blockIdx.x;
   float* svbase = save + s * (int64_t)T * SV_STRIDE;
+#ifdef FF_STAMPS
+  long long* stamp_out = reinterpret_cast<long long*>(save + (int64_t)gridDim.x * T * SV_STRIDE + A2F_FF_A);
+#endif
 
   for (int e = t; e < 192 * FD; e += FF_FWD_THREADS) { const int o = e / FD, k = e - o * FD; WqkvT[k * 192 + o] = P[A2F_FF_WQKV + e]; }
   for (int e = t; e < FD * FD; e += FF_FWD_THREADS) {
@@ -148,6 +158,7 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
   __syncthreads();
 
   for (int i = 0; i < T; ++i) {
+    FF_STAMP(0);
     float* sv = svbase + (int64_t)i * SV_STRIDE;
     const unsigned* rowbits = DROP ? dm.row + (s * T + i) * FF_ROW_WORDS : nullptr;
     float cross_i = 0.f;
@@ -165,15 +176,24 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
     }
     if constexpr (DROP) { if (t < FFF) kw_act = rowbits[4 + (t >> 5)]; }
     __syncthreads();
+    FF_STAMP(1);
     if (t < 192) {                                              // q | k | v projections
-      float acc = bqkv;
-#pragma unroll 16
-      for (int k = 0; k < FD; ++k) acc += WqkvT[k * 192 + t] * xs[k];
+      // four independent partial sums, the broadcast operand read as float4: the 64-long dependent multiply-add chain and its 128 LDS reads were
+      // the phase's latency (s_memtime stamps: 2 700 clk for this product)
+      float a0 = bqkv, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int k = 0; k < FD; k += 4) {
+        const float4 xv = *reinterpret_cast<const float4*>(xs + k);
+        a0 += WqkvT[k * 192 + t] * xv.x; a1 += WqkvT[(k + 1) * 192 + t] * xv.y;
+        a2 += WqkvT[(k + 2) * 192 + t] * xv.z; a3 += WqkvT[(k + 3) * 192 + t] * xv.w;
+      }
+      float acc = (a0 + a1) + (a2 + a3);
       if (t < 64) { acc *= 0.25f; qs[t] = acc; sv[SV_Q + t] = acc; }
       else if (t < 128) sv[SV_K + (t - 64)] = acc;
       else sv[SV_V + (t - 128)] = acc;
     }
-    __syncthreads();                                            // K/V row i visible to the whole workgroup
+    __syncthreads();
+    FF_STAMP(2);                                            // K/V row i visible to the whole workgroup
     {
       // ---- self-attention for `head` over keys j <= i; the head's two waves take alternate trips of 16 FA_U keys ----
       const float4 qv = *reinterpret_cast<const float4*>(qs + head * FHD + dq * 4);
@@ -232,6 +252,7 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
       if (lane == 0) { mrg_s[(apart * FH + head) * 2] = m; mrg_s[(apart * FH + head) * 2 + 1] = lsum; }
     }
     __syncthreads();
+    FF_STAMP(3);
     if (wave < FH && js == 0) {                                  // merge the two partial softmaxes of head = wave (a wave that saw no key has m = -inf, l = 0)
       const float m0 = mrg_s[wave * 2], l0 = mrg_s[wave * 2 + 1], m1 = mrg_s[(FH + wave) * 2], l1 = mrg_s[(FH + wave) * 2 + 1];
       const float mm = fmaxf(m0, m1);
@@ -246,6 +267,7 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
       if (lane == 0) { sv[SV_ST + 4 + wave] = mm; sv[SV_ST + 8 + wave] = lt; }
     }
     __syncthreads();
+    FF_STAMP(4);
     if (wave == 0) {
       float sa = bo;
 #pragma unroll 16
@@ -263,6 +285,7 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
       y2s[lane] = y2;
     }
     __syncthreads();
+    FF_STAMP(5);
     if (t < FFF) {                                                          // linear1 + ReLU
       float acc = b1;
 #pragma unroll
@@ -273,6 +296,7 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
       sv[SV_H + t] = acc;
     }
     __syncthreads();
+    FF_STAMP(6);
     if (wave < 4) {                                                         // linear2, 4 partial sums per output
       float acc = 0.f;
 #pragma unroll
@@ -280,6 +304,7 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
       part[wave * FD + lane] = acc;
     }
     __syncthreads();
+    FF_STAMP(7);
     if (wave == 0) {
       float f = b2 + part[lane] + part[FD + lane] + part[2 * FD + lane] + part[3 * FD + lane];
       if constexpr (DROP) f = ((kw_d3 >> (lane & 31)) & 1u) ? f * dm.scale : 0.f;         // dropout3
@@ -292,6 +317,7 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
       ys[lane] = y3;
     }
     __syncthreads();
+    FF_STAMP(8);
     if (wave == 0) {                                                        // feedback: emb = A y + c + style
       float acc = cfb + sty;
 #pragma unroll 16

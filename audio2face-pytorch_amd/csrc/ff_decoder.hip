@@ -148,6 +148,7 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
   const float g3 = P[A2F_FF_LN + 4 * FD + lane], be3 = P[A2F_FF_LN + 5 * FD + lane];
   const float sty = style[s * FD + lane];
   const float slope = exp2f(-2.f * (float)(head + 1));
+  const float inv_period = 1.f / (float)period;
   const int js = lane >> 2, dq = lane & 3;                      // attention lanes: 16 key slots x 4 quarter-heads
   float emb = sty;                                              // wave 0: embedding fed to the next step
   float y2 = 0.f;
@@ -200,7 +201,8 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
       const float* kbase = svbase + SV_K + head * FHD + dq * 4;
       const float* vbase = svbase + SV_V + head * FHD + dq * 4;
       // ONE pass over the keys with a running maximum (online softmax), FA_U key slots per trip: the K/V rows come from
-      // L2 and the loop is bound by that latency, so the eight loads of a trip are issued before any of them is used.
+      // L2, so the eight loads of a trip are issued before any of them is used; a head's two waves share a SIMD, one reduces while the
+      // other waits - the sweep is bound by the instructions per key (s_memtime stamps: ~1 400 clk per trip and wave), not by the round trips.
       // A slot past i re-reads row i (always valid memory) and is masked out.
       float mrun = -INFINITY, lsum = 0.f;
       float4 cacc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -216,24 +218,33 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
           vv[u] = *reinterpret_cast<const float4*>(vbase + off);
           if constexpr (DROP) kw[u] = abits[jj >> 5];
         }
+        // scores of the trip first, ONE rescale of the running sums per trip (trip maximum), one exponential per key; the periodic bias
+        // floor((i - j) / period) through a float reciprocal ((d + 0.5) / period is never within 0.5 / period of an integer: exact for T < 2^21)
+        float pu[FA_U];
+        float mt = mrun;
 #pragma unroll
         for (int u = 0; u < FA_U; ++u) {
           const int j = j0 + 16 * u;
           float p = dot4(qv, kk[u]);
           p += __shfl_xor(p, 1, 64);
           p += __shfl_xor(p, 2, 64);
-          const bool valid = j <= i;
-          p = valid ? p - slope * (float)((i - j) / period) : -INFINITY;
-          const float mnew = fmaxf(mrun, p);
-          const float sc = mnew == -INFINITY ? 1.f : expf(mrun - mnew);
-          const float e = valid ? expf(p - mnew) : 0.f;
-          lsum = lsum * sc + e;                                    // the normaliser keeps every key; only the value sum is thinned
+          p = j <= i ? p - slope * floorf(((float)(i - j) + 0.5f) * inv_period) : -INFINITY;
+          pu[u] = p;
+          mt = fmaxf(mt, p);
+        }
+        const float sc = mt == -INFINITY ? 1.f : expf(mrun - mt);
+        lsum *= sc;
+        cacc.x *= sc; cacc.y *= sc; cacc.z *= sc; cacc.w *= sc;
+#pragma unroll
+        for (int u = 0; u < FA_U; ++u) {
+          const int j = j0 + 16 * u;
+          const float e = pu[u] == -INFINITY ? 0.f : expf(pu[u] - mt);
+          lsum += e;                                               // the normaliser keeps every key; only the value sum is thinned
           float ev = e;
           if constexpr (DROP) ev = ((kw[u] >> (j & 31)) & 1u) ? e * dm.scale : 0.f;
-          cacc.x = cacc.x * sc + ev * vv[u].x; cacc.y = cacc.y * sc + ev * vv[u].y;
-          cacc.z = cacc.z * sc + ev * vv[u].z; cacc.w = cacc.w * sc + ev * vv[u].w;
-          mrun = mnew;
+          cacc.x += ev * vv[u].x; cacc.y += ev * vv[u].y; cacc.z += ev * vv[u].z; cacc.w += ev * vv[u].w;
         }
+        mrun = mt;
       }
       const float m = wave_max(mrun);
       {

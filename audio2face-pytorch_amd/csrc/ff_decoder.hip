@@ -698,6 +698,7 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
   const float ln_g2 = P[A2F_FF_LN + 2 * FD + lane], ln_b2 = P[A2F_FF_LN + 3 * FD + lane];
   const float ln_g3 = P[A2F_FF_LN + 4 * FD + lane], ln_b3 = P[A2F_FF_LN + 5 * FD + lane];
   const float slope = exp2f(-2.f * (float)(head + 1));
+  const float inv_period = 1.f / (float)period;
   const int js = lane >> 2, dq = lane & 3;
   float carry = 0.f;                                   // wave 0: (A^T demb_{i+1})[lane]
   float* dP = save + (int64_t)gridDim.x * T * SV_STRIDE + s * (int64_t)A2F_FF_PARAM_FLOATS;      // this sequence's slab
@@ -856,7 +857,7 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
           float da = dot4(dcv, vv[u]);
           da += __shfl_xor(da, 1, 64);
           da += __shfl_xor(da, 2, 64);
-          const float a = valid ? expf(p - slope * (float)((i - min(j, i)) / period) - m) * invl : 0.f;
+          const float a = valid ? expf(p - slope * floorf(((float)(i - min(j, i)) + 0.5f) * inv_period) - m) * invl : 0.f;   // exact floor for T < 2^21
           float ad = a;                                // ctx = sum_j a_j D_j v_j: dV sees a D, da_j = D_j (dctx . v_j); sum_j a_j da_j = dctx . ctx still
           if constexpr (DROP) {
             const float dj = ((kw[u] >> (min(j, i) & 31)) & 1u) ? dm.scale : 0.f;
@@ -890,10 +891,14 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
     __syncthreads();
     // ---- S9: dWqkv += dqkv (x) x ; dx += Wqkv^T dqkv (4 partial sums per output) ----
     if (wave < 4) {
-      float acc = 0.f;
-#pragma unroll 16
-      for (int r = 0; r < 48; ++r) acc += Wqkv[(wave * 48 + r) * FD + lane] * dqkvs[wave * 48 + r];
-      pbuf[wave * FD + lane] = acc;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;        // four partial sums, the broadcast operand as float4 (as in the forward's projection)
+#pragma unroll
+      for (int r = 0; r < 48; r += 4) {
+        const float4 gv = *reinterpret_cast<const float4*>(dqkvs + wave * 48 + r);
+        a0 += Wqkv[(wave * 48 + r) * FD + lane] * gv.x; a1 += Wqkv[(wave * 48 + r + 1) * FD + lane] * gv.y;
+        a2 += Wqkv[(wave * 48 + r + 2) * FD + lane] * gv.z; a3 += Wqkv[(wave * 48 + r + 3) * FD + lane] * gv.w;
+      }
+      pbuf[wave * FD + lane] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
     // ---- S10: wave 0: gradient w.r.t. emb_i; carry A^T demb to step i-1 ----
@@ -991,35 +996,59 @@ __global__ __launch_bounds__(256) void ff_bwd_prep_kernel(const float* __restric
 template <bool DROP>
 __global__ __launch_bounds__(256) void ff_bwd_rect_kernel(float* __restrict__ save, const float* __restrict__ grec, int T, int period, int i_lo, int i_hi,
                                                           const FFDrop dm) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= i_lo) return;                                                // no barriers below
+  // the block's per-step vectors (q_i, dctx_i of this head, softmax statistics, dctx_i . ctx_i) staged in LDS once: read from global inside the
+  // step loop, every iteration waited for an L2 round trip (223 us per launch at T = 3000 where the arithmetic needs 10)
+  __shared__ __attribute__((aligned(16))) float qs[FF_BLK][FHD], ds_[FF_BLK][FHD];
+  __shared__ float ms[FF_BLK], ils[FF_BLK], rss[FF_BLK];
+  const int t = threadIdx.x;
+  const int j = blockIdx.x * 256 + t;
   const int head = blockIdx.y;
   const int64_t s = blockIdx.z;
   float* svbase = save + s * (int64_t)T * SV_STRIDE;
   const float* gbase = grec + s * (int64_t)T * FF_GREC;
+  const int ni = i_hi - i_lo;                                           // <= FF_BLK
+  for (int e = t; e < ni * FHD; e += 256) {
+    const int ii = e >> 4, c = e & 15;
+    qs[ii][c] = svbase[(int64_t)(i_lo + ii) * SV_STRIDE + SV_Q + head * FHD + c];
+    ds_[ii][c] = gbase[(int64_t)(i_lo + ii) * FF_GREC + GR_DC + head * FHD + c];
+  }
+  if (t < ni) {
+    const float* svi = svbase + (int64_t)(i_lo + t) * SV_STRIDE;
+    ms[t] = svi[SV_ST + 4 + head];
+    ils[t] = 1.f / svi[SV_ST + 8 + head];
+    rss[t] = gbase[(int64_t)(i_lo + t) * FF_GREC + GR_RS + head];
+  }
+  __syncthreads();
+  if (j >= i_lo) return;
   float* svj = svbase + (int64_t)j * SV_STRIDE;
   float k[FHD], v[FHD], dk[FHD], dv[FHD];
 #pragma unroll
   for (int c = 0; c < FHD; ++c) { k[c] = svj[SV_K + head * FHD + c]; v[c] = svj[SV_V + head * FHD + c]; dk[c] = 0.f; dv[c] = 0.f; }
   const float slope = exp2f(-2.f * (float)(head + 1));
   int qd = (i_lo - j) / period, r = (i_lo - j) - qd * period;
-  const unsigned* abits = DROP ? dm.attn + ((s * FH + head) * T) * dm.TW + (j >> 5) : nullptr;
-  for (int i = i_lo; i < i_hi; ++i) {
-    const float* svi = svbase + (int64_t)i * SV_STRIDE;                 // wave-uniform rows
-    const float* gr = gbase + (int64_t)i * FF_GREC;
+  const unsigned* abits = DROP ? dm.attn + ((s * FH + head) * T + i_lo) * dm.TW + (j >> 5) : nullptr;
+  for (int ii = 0; ii < ni; ++ii) {
+    float q[FHD], dc[FHD];
+#pragma unroll
+    for (int c = 0; c < FHD; c += 4) {
+      const float4 a4 = *reinterpret_cast<const float4*>(&qs[ii][c]);
+      const float4 b4 = *reinterpret_cast<const float4*>(&ds_[ii][c]);
+      q[c] = a4.x; q[c + 1] = a4.y; q[c + 2] = a4.z; q[c + 3] = a4.w;
+      dc[c] = b4.x; dc[c + 1] = b4.y; dc[c + 2] = b4.z; dc[c + 3] = b4.w;
+    }
     float p = 0.f, da = 0.f;
 #pragma unroll
-    for (int c = 0; c < FHD; ++c) { p += svi[SV_Q + head * FHD + c] * k[c]; da += gr[GR_DC + head * FHD + c] * v[c]; }
-    const float a = expf(p - slope * (float)qd - svi[SV_ST + 4 + head]) / svi[SV_ST + 8 + head];
+    for (int c = 0; c < FHD; ++c) { p += q[c] * k[c]; da += dc[c] * v[c]; }
+    const float a = expf(p - slope * (float)qd - ms[ii]) * ils[ii];
     float ad = a;
     if constexpr (DROP) {
-      const float dj = ((abits[(int64_t)i * dm.TW] >> (j & 31)) & 1u) ? dm.scale : 0.f;
+      const float dj = ((abits[(int64_t)ii * dm.TW] >> (j & 31)) & 1u) ? dm.scale : 0.f;
       ad = a * dj;
       da *= dj;
     }
-    const float ds = a * (da - gr[GR_RS + head]);
+    const float ds = a * (da - rss[ii]);
 #pragma unroll
-    for (int c = 0; c < FHD; ++c) { dk[c] += ds * svi[SV_Q + head * FHD + c]; dv[c] += ad * gr[GR_DC + head * FHD + c]; }
+    for (int c = 0; c < FHD; ++c) { dk[c] += ds * q[c]; dv[c] += ad * dc[c]; }
     if (++r == period) { r = 0; ++qd; }
   }
 #pragma unroll

@@ -942,15 +942,11 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
 // Both run over the whole chip; what stays in the one-workgroup-per-sequence recurrence is the sweep over the <= FF_BLK keys of the own block.
 template <bool DROP>
 __global__ __launch_bounds__(256) void ff_bwd_prep_kernel(const float* __restrict__ save, float* __restrict__ nrec, int T, int period, const FFDrop dm) {
-  // keys in chunks of PREP_JC rows staged in LDS (K | V of this head: 32 floats per key) and shared by the four waves (= the four quarters of b)
-  constexpr int PREP_JC = 64;
-  __shared__ __attribute__((aligned(16))) float kv[PREP_JC][2 * FHD];
-  const int t = threadIdx.x;
-  const int quarter = t >> 6, lane = t & 63;                           // wave = which four b of k_j[b]
+  const int quarter = threadIdx.x >> 6, lane = threadIdx.x & 63;       // wave = which four b of k_j[b]
   const int head = blockIdx.y;
   const int64_t s = blockIdx.z;
   const int i_base = FF_BLK + blockIdx.x * 64;                          // 64 consecutive steps: one block of the recurrence (FF_BLK is a multiple of 64)
-  const int i0 = (i_base / FF_BLK) * FF_BLK;                            // a multiple of PREP_JC
+  const int i0 = (i_base / FF_BLK) * FF_BLK;
   const int i = i_base + lane, ii = min(i, T - 1);
   const float* svbase = save + s * (int64_t)T * SV_STRIDE;
   const float* svi = svbase + (int64_t)ii * SV_STRIDE;
@@ -967,45 +963,26 @@ __global__ __launch_bounds__(256) void ff_bwd_prep_kernel(const float* __restric
     for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
   int qd = ii / period, r = ii - qd * period;                           // (i - j) / period and % period at j = 0
   unsigned word = 0;
-  for (int j0 = 0; j0 < i0; j0 += PREP_JC) {
-    __syncthreads();                                                    // the previous chunk is consumed
-    for (int e = t; e < PREP_JC * 8; e += 256) {                        // 8 float4 per key: K (4), V (4)
-      const int row = e >> 3, part = e & 7;
-      const float* src = svbase + (int64_t)(j0 + row) * SV_STRIDE + (part < 4 ? SV_K + head * FHD + part * 4 : SV_V + head * FHD + (part - 4) * 4);
-      *reinterpret_cast<float4*>(&kv[row][part * 4]) = *reinterpret_cast<const float4*>(src);
+  for (int j = 0; j < i0; ++j) {
+    const float* svj = svbase + (int64_t)j * SV_STRIDE;                 // wave-uniform row
+    float p = 0.f;
+#pragma unroll
+    for (int c = 0; c < FHD; ++c) p += q[c] * svj[SV_K + head * FHD + c];
+    const float a = expf(p - slope * (float)qd - m) * invl;
+    float ad = a;
+    if constexpr (DROP) {
+      if ((j & 31) == 0) word = abits[j >> 5];
+      ad = ((word >> (j & 31)) & 1u) ? a * dm.scale : 0.f;
     }
-    __syncthreads();
-    for (int jj = 0; jj < PREP_JC; ++jj) {
-      const int j = j0 + jj;
-      float kr[FHD], vr[FHD];
 #pragma unroll
-      for (int c = 0; c < FHD; c += 4) {
-        const float4 a4 = *reinterpret_cast<const float4*>(&kv[jj][c]);
-        const float4 b4 = *reinterpret_cast<const float4*>(&kv[jj][FHD + c]);
-        kr[c] = a4.x; kr[c + 1] = a4.y; kr[c + 2] = a4.z; kr[c + 3] = a4.w;
-        vr[c] = b4.x; vr[c + 1] = b4.y; vr[c + 2] = b4.z; vr[c + 3] = b4.w;
-      }
-      float p = 0.f;
+    for (int c = 0; c < 4; ++c) {
+      const float kb = svj[SV_K + head * FHD + quarter * 4 + c];
+      nacc[c] += a * kb;
+      const float w = ad * kb;
 #pragma unroll
-      for (int c = 0; c < FHD; ++c) p += q[c] * kr[c];
-      const float a = expf(p - slope * (float)qd - m) * invl;
-      float ad = a;
-      if constexpr (DROP) {
-        if ((j & 31) == 0) word = abits[j >> 5];
-        ad = ((word >> (j & 31)) & 1u) ? a * dm.scale : 0.f;
-      }
-      const float4 kq4 = *reinterpret_cast<const float4*>(&kv[jj][quarter * 4]);       // this wave's four b (wave-uniform address)
-      const float kq[4] = {kq4.x, kq4.y, kq4.z, kq4.w};
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float kb = kq[c];
-        nacc[c] += a * kb;
-        const float w = ad * kb;
-#pragma unroll
-        for (int a2 = 0; a2 < FHD; ++a2) acc[a2][c] += w * vr[a2];
-      }
-      if (--r < 0) { r = period - 1; --qd; }
+      for (int a2 = 0; a2 < FHD; ++a2) acc[a2][c] += w * svj[SV_V + head * FHD + a2];
     }
+    if (--r < 0) { r = period - 1; --qd; }
   }
   if (i < T) {
     float* nr = nrec + (s * T + i) * FF_NREC;

@@ -1,0 +1,29 @@
+import os, sys
+sys.path.insert(0, '/root/repo')
+import torch
+from a2f_amd import ops
+S, T, period = 24, 600, 60
+dev = torch.device("cuda"); be = ops.backend()
+nP = 192*64+192+64*64+64+128*64+128+64*128+64+6*64+64*64+64
+g = torch.Generator().manual_seed(0)
+P = (torch.randn(nP, generator=g)*0.1).to(dev); pe = torch.randn(period,64,generator=g).to(dev)
+cross, style, dy = torch.randn(S,T,64,generator=g).to(dev), torch.randn(S,64,generator=g).to(dev), torch.randn(S,T,64,generator=g).to(dev)
+row = torch.empty(S*T, 10, dtype=torch.int32, device=dev); attn = torch.empty(S*4*T, be.attn_keep_words(T), dtype=torch.int32, device=dev)
+be.keep_bits(4242, 1000, S*T, 320, 0.1, row); be.keep_bits(4242, 1001, S*4*T, T, 0.1, attn)
+drop = (row, attn, 1/0.9)
+outs = []
+side = torch.cuda.Stream()
+big = torch.randn(8192, 8192, device=dev)
+for rep in range(6):
+    y = torch.empty(S,T,64,device=dev); save = torch.full((be.ff_save_floats(S,T),), float("nan") if rep >= 2 else 0.0, device=dev)
+    dP, dc, ds = torch.empty(nP,device=dev), torch.empty(S,T,64,device=dev), torch.empty(S,64,device=dev)
+    if rep % 2:                                   # competing work on another stream
+        with torch.cuda.stream(side):
+            for _ in range(20): big @ big
+    be.ff_decoder_fwd(P, pe, cross, style, S, T, period, y, save, drop=drop)
+    be.ff_decoder_bwd(P, dy, S, T, period, save, dP, dc, ds, drop=drop)
+    torch.cuda.synchronize()
+    off = S*T*896 + S*nP + S*T*720 + 64*(192*64+192)
+    outs.append((dP.clone(), dc.clone(), ds.clone(), save[off:off+S*T*1088].clone()))
+for i in range(1, 6):
+    print(i, [bool(torch.equal(a, b)) for a, b in zip(outs[0], outs[i])], [bool(torch.isnan(a).any()) for a in outs[i][:3]])

@@ -439,6 +439,43 @@ def test_ff_decoder_dropout_kernels_vs_spec(S, T, period, form, monkeypatch):
         o += sz_
 
 
+def test_ff_decoder_bitwise_stable_under_contention():
+    """Forward + blocked backward (five blocks: cross-block dq kernel, per-block recurrence and dK / dV kernels, weight-gradient products) on a
+    high-priority stream while the library's GEMM kernels keep the chip busy on another stream, against the same call on an idle chip: every output
+    bitwise equal, the save buffer filled with a different constant each time.  (A variant of the cross-block dq kernel that staged keys through
+    LDS passed every other test and failed exactly this: its results changed when other kernels competed for the CUs.)"""
+    from a2f_amd.ops import MMOp
+    S, T, period = 24, 600, 60
+    be = ops.HipBackend()
+    nP = 192 * 64 + 192 + 64 * 64 + 64 + 128 * 64 + 128 + 64 * 128 + 64 + 6 * 64 + 64 * 64 + 64
+    P = rnd(nP, seed=70, scale=0.1).to(DEV)
+    pe = rnd(period, 64, seed=71).to(DEV)
+    cross, style, dy = rnd(S, T, 64, seed=72).to(DEV), rnd(S, 64, seed=73).to(DEV), rnd(S, T, 64, seed=74).to(DEV)
+    row = torch.empty(S * T, 10, dtype=torch.int32, device=DEV)
+    attn = torch.empty(S * 4 * T, be.attn_keep_words(T), dtype=torch.int32, device=DEV)
+    be.keep_bits(4242, 1000, S * T, 320, 0.1, row)
+    be.keep_bits(4242, 1001, S * 4 * T, T, 0.1, attn)
+    drop = (row, attn, 1 / 0.9)
+    side = torch.cuda.Stream(priority=-1)
+    a, w, o = rnd(9600, 768, seed=1).to(DEV), rnd(3072, 768, seed=2).to(DEV), torch.empty(9600, 3072, device=DEV)
+    outs = []
+    for rep in range(4):
+        y = torch.empty(S, T, 64, device=DEV)
+        save = torch.full((be.ff_save_floats(S, T),), float(rep), device=DEV)
+        dP, dc, ds = torch.empty(nP, device=DEV), torch.empty(S, T, 64, device=DEV), torch.empty(S, 64, device=DEV)
+        torch.cuda.synchronize()
+        if rep % 2:
+            for _ in range(300):
+                be.mm(MMOp(a, 768), MMOp(w, 768), o, 9600, 3072, 768, 3072)
+        with torch.cuda.stream(side):
+            be.ff_decoder_fwd(P, pe, cross, style, S, T, period, y, save, drop=drop)
+            be.ff_decoder_bwd(P, dy, S, T, period, save, dP, dc, ds, drop=drop)
+        torch.cuda.synchronize()
+        outs.append((y, dP, dc, ds))
+    for rep in range(1, 4):
+        assert all(torch.equal(u, v) for u, v in zip(outs[0], outs[rep])), rep
+
+
 @pytest.mark.parametrize("prec", [0, 1])
 @pytest.mark.parametrize("M,N,K", [(32, 111, 5000), (32, 96, 777), (64, 96, 3001), (64, 192, 1200), (72, 72, 640), (128, 72, 19), (50, 128, 2048), (1, 1, 3)])
 def test_wgrad_kernel_vs_contract(M, N, K, prec):

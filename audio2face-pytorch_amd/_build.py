@@ -47,20 +47,35 @@ def needs_build() -> bool:
 
 
 def _compile_one(src: str, obj: str, verbose: bool):
-    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj + ".tmp"]
+    tmp = f"{obj}.tmp.{os.getpid()}"                       # unique per process: a concurrent builder never writes the same file
+    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", tmp]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {os.path.basename(src)}:\n" + r.stdout + r.stderr)
-    os.replace(obj + ".tmp", obj)
+    os.replace(tmp, obj)
     return r.stderr
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Incremental build under an exclusive file lock: under torchrun every rank that finds a stale library would otherwise compile the
+    same objects at once; the ranks that waited for the lock find the library fresh and return."""
     if not force and not needs_build():
         return LIB_PATH
+    import fcntl
     os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(os.path.join(OBJ_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():            # another process built it while this one waited
+                return LIB_PATH
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     hdr_t = max(os.path.getmtime(h) for h in _headers())
     jobs, objs = [], []
     for s in _sources():
@@ -74,13 +89,14 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         for warn in ex.map(lambda so: _compile_one(so[0], so[1], verbose), jobs):
             if verbose and warn:
                 print(warn, file=sys.stderr)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + ".tmp"] + objs
+    tmp_lib = f"{LIB_PATH}.tmp.{os.getpid()}"
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    os.replace(tmp_lib, LIB_PATH)
     return LIB_PATH
 
 

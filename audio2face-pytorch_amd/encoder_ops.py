@@ -57,6 +57,31 @@ class _WeightGradLane:
                     t.record_stream(self.cur)
 
 
+# ---- precision travels with the autograd node -----------------------------------------------------------------------------------
+# `ops.backend().mm_precision` / `.attn_precision` select the product form (bf16x3 split = the parity setting, plain bf16 = 16-mixed, fp8
+# attention forward).  A node's backward runs long after its forward, when the caller may have restored another setting (Faceformer.encode
+# switches to bf16 around the encoder forward only): every forward records the setting it ran under and every backward re-instates it, so
+# that e.g. the attention backward recomputes P = exp(q k^T - lse) with the product form the saved lse came from.
+def _save_prec(ctx):
+    be = ops.backend()
+    ctx.prec = (be.mm_precision, be.attn_precision)
+
+
+def _restores_precision(backward):
+    import functools
+
+    @functools.wraps(backward)
+    def wrapped(ctx, *grads):
+        be = ops.backend()
+        old = (be.mm_precision, be.attn_precision)
+        be.mm_precision, be.attn_precision = ctx.prec
+        try:
+            return backward(ctx, *grads)
+        finally:
+            be.mm_precision, be.attn_precision = old
+    return wrapped
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
@@ -97,6 +122,7 @@ class LinearMMFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, keep=None):
         be = ops.backend()
+        _save_prec(ctx)
         xc, Wc, bc = _f32c(x), _f32c(W), _f32c(b)
         M, K = xc.shape
         N = Wc.shape[0]
@@ -107,6 +133,7 @@ class LinearMMFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_restores_precision
     def backward(ctx, dy):
         be = ops.backend()
         xc, Wc = ctx.saved_tensors
@@ -142,6 +169,7 @@ class EncoderLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, S, T, heads, masks, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2):
         be = ops.backend()
+        _save_prec(ctx)
         xc = _f32c(x)
         P = [_f32c(p) for p in (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2)]
         Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2 = P
@@ -181,6 +209,7 @@ class EncoderLayerFn(torch.autograd.Function):
         return h2
 
     @staticmethod
+    @_restores_precision
     def backward(ctx, dh2):
         be = ops.backend()
         xc, qkv, att, lse, a1, m1, r1, h1, z, g, a2, m2, r2, Wqkv, Wo, g1, W1, W2, g2 = ctx.saved_tensors
@@ -287,6 +316,7 @@ class FeatEnc0Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, wave, w, gamma, beta):
         be = ops.backend()
+        _save_prec(ctx)
         xc, wc, g, b = _f32c(wave), _f32c(w), _f32c(gamma), _f32c(beta)
         S, N = xc.shape
         C = wc.shape[0]
@@ -297,6 +327,7 @@ class FeatEnc0Fn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_restores_precision
     def backward(ctx, dout):
         be = ops.backend()
         xc, wc, g, b, stats = ctx.saved_tensors
@@ -331,6 +362,7 @@ class ConvGeluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, stride):
         be = ops.backend()
+        _save_prec(ctx)
         xc, wc = _f32c(x), _f32c(w)
         S, Lin, Ci = xc.shape
         Co, _, KH = wc.shape
@@ -347,6 +379,7 @@ class ConvGeluFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_restores_precision
     def backward(ctx, dy):
         be = ops.backend()
         xc, wg, z = ctx.saved_tensors
@@ -373,6 +406,7 @@ class ConvStackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, strides, *weights):
         be = ops.backend()
+        _save_prec(ctx)
         cur = _f32c(x)
         keep = any(ctx.needs_input_grad)
         saved, dims = [], []
@@ -395,6 +429,7 @@ class ConvStackFn(torch.autograd.Function):
         return cur
 
     @staticmethod
+    @_restores_precision
     def backward(ctx, dy):
         be = ops.backend()
         saved, dims = ctx.saved_tensors, ctx.dims
@@ -443,6 +478,7 @@ class PosConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, w, bias, groups):
         be = ops.backend()
+        _save_prec(ctx)
         hc, wc, bc = _f32c(h), _f32c(w), _f32c(bias)
         S, T, C = hc.shape
         Cg, K = wc.shape[1], wc.shape[2]
@@ -462,6 +498,7 @@ class PosConvFn(torch.autograd.Function):
         return y.view(S, T, C)
 
     @staticmethod
+    @_restores_precision
     def backward(ctx, dy):
         be = ops.backend()
         hg, wc, z = ctx.saved_tensors

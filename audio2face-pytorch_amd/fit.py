@@ -64,19 +64,23 @@ class ModelCheckpoint:
         self.best = float("inf")
         self.best_path: Optional[str] = None
 
-    def update(self, value: float, epoch: int, global_step: int, save_fn: Callable[[str], None]) -> bool:
+    def update(self, value: float, epoch: int, global_step: int, save_fn: Callable[[str], None], writer: bool = True) -> bool:
+        """``value`` must be the same number on every rank (fit all-reduces val/err), so every rank takes the same decision and tracks the
+        same ``best_path``; only the ``writer`` rank (rank 0, as Lightning does) touches the file system."""
         if not value < self.best:
             return False
-        os.makedirs(self.dirpath, exist_ok=True)
         path = os.path.join(self.dirpath, f"epoch={epoch}-step={global_step}.ckpt")
-        save_fn(path)
-        if self.best_path and self.best_path != path and os.path.exists(self.best_path):
-            os.remove(self.best_path)
+        if writer:
+            os.makedirs(self.dirpath, exist_ok=True)
+            save_fn(path)
+            if self.best_path and self.best_path != path and os.path.exists(self.best_path):
+                os.remove(self.best_path)
         self.best, self.best_path = value, path
         return True
 
 
-def save_checkpoint(path: str, model: torch.nn.Module, step: Optional[TrainStep], config: ExpConfig, epoch: int, global_step: int):
+def save_checkpoint(path: str, model: torch.nn.Module, step: Optional[TrainStep], config: ExpConfig, epoch: int, global_step: int,
+                    extractor: Optional[torch.nn.Module] = None):
     ckpt = {
         "epoch": epoch, "global_step": global_step, "pytorch-lightning_version": LIGHTNING_VERSION_TAG,
         "state_dict": {"model." + k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
@@ -86,15 +90,23 @@ def save_checkpoint(path: str, model: torch.nn.Module, step: Optional[TrainStep]
         o = step.opt
         ckpt["optimizer_states"] = [{"kind": "a2f_amd.FlatAdam", "step_count": o.step_count, "lr": o.lr, "weight_decay": o.wd, "betas": o.betas,
                                      "eps": o.eps, "m": o.m.detach().cpu().clone(), "v": o.v.detach().cpu().clone()}]
-    torch.save(ckpt, path)
+    if extractor is not None:                      # Lightning's state_dict covers Audio2FaceModel.feature_extractor too (lightning_model.py:101-107)
+        ckpt["state_dict"].update({"feature_extractor." + k: v.detach().cpu().clone() for k, v in extractor.state_dict().items()})
+    tmp = f"{path}.tmp.{os.getpid()}"              # write-then-rename: a reader never sees a half-written file
+    torch.save(ckpt, tmp)
+    os.replace(tmp, path)
 
 
-def load_checkpoint(path: str, model: torch.nn.Module, step: Optional[TrainStep] = None) -> Dict:
-    """Restores the network (keys with the ``model.`` prefix; ``feature_extractor.*`` keys of a Lightning checkpoint are skipped)
-    and, when given, the optimizer state of ``step``.  Returns the checkpoint dictionary."""
+def load_checkpoint(path: str, model: torch.nn.Module, step: Optional[TrainStep] = None, extractor: Optional[torch.nn.Module] = None) -> Dict:
+    """Restores the network (keys with the ``model.`` prefix), the ``feature_extractor.*`` keys into ``extractor`` when one is given
+    (otherwise they are skipped) and, when given, the optimizer state of ``step``.  Returns the checkpoint dictionary."""
     ckpt = torch.load(path, map_location="cpu", weights_only=False)
     sd = {k[len("model."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("model.")}
     model.load_state_dict(sd)
+    if extractor is not None:
+        esd = {k[len("feature_extractor."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("feature_extractor.")}
+        if esd:
+            extractor.load_state_dict(esd)
     if step is not None and ckpt.get("optimizer_states"):
         st = ckpt["optimizer_states"][0]
         if st.get("kind") == "a2f_amd.FlatAdam":
@@ -103,8 +115,19 @@ def load_checkpoint(path: str, model: torch.nn.Module, step: Optional[TrainStep]
     return ckpt
 
 
+def next_version_dir(log_dir: str) -> str:
+    """TensorBoardLogger's layout (train.py:36-40): every run writes to a fresh ``version_N`` below the experiment directory, so the
+    largest-``step=`` rule of train.py:62-63 only ever sees this run's checkpoints."""
+    n = 0
+    if os.path.isdir(log_dir):
+        for f in os.listdir(log_dir):
+            if f.startswith("version_") and f[len("version_"):].isdigit():
+                n = max(n, int(f[len("version_"):]) + 1)
+    return os.path.join(log_dir, f"version_{n}")
+
+
 def best_checkpoint(dirpath: str) -> str:
-    """train.py:62-63: the checkpoint whose file name carries the largest ``step=``."""
+    """train.py:62-63: the checkpoint whose file name carries the largest ``step=`` (inside ONE run's checkpoint directory)."""
     ckpts = [f for f in os.listdir(dirpath) if f.endswith(".ckpt")]
     return os.path.join(dirpath, sorted(ckpts, key=lambda x: int(x.split("=")[-1].split(".")[0]))[-1])
 
@@ -118,7 +141,10 @@ def mse_error(pred: torch.Tensor, gt: torch.Tensor, width: int = 5023 * 3) -> to
 def validate(model: torch.nn.Module, loss_fn, batches: Iterable[Dict[str, torch.Tensor]], extractor=None) -> Dict[str, float]:
     """validation_step + on_validation_epoch_end (lightning_model.py:135-143,163-173): eval mode, no gradients."""
     was_training = model.training
+    ex_training = extractor.training if isinstance(extractor, torch.nn.Module) else None
     model.eval()
+    if ex_training is not None:
+        extractor.eval()                                  # Lightning's eval() covers Audio2FaceModel.feature_extractor as well
     errs: List[float] = []
     last = {}
     with torch.no_grad():
@@ -130,15 +156,25 @@ def validate(model: torch.nn.Module, loss_fn, batches: Iterable[Dict[str, torch.
             last = {k: float(v) for k, v in loss_fn(pred, gt).items()}
             errs.append(float(mse_error(pred, gt, width=pred.shape[-2] * pred.shape[-1])))
     model.train(was_training)
+    if ex_training is not None:
+        extractor.train(ex_training)
     return {"val/err": sum(errs) / max(len(errs), 1), **{"val/" + k: v for k, v in last.items()}}
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
 
 
 def fit(config: ExpConfig, train_batches: Callable[[int], Iterable[Dict[str, torch.Tensor]]],
         val_batches: Callable[[int], Iterable[Dict[str, torch.Tensor]]], device, log_dir: str, max_epochs: int = 50, patience: int = 5,
-        log: Callable[[str], None] = print, model: Optional[torch.nn.Module] = None, use_graph: bool = False):
+        log: Callable[[str], None] = print, model: Optional[torch.nn.Module] = None, use_graph: bool = False, extractor="auto"):
     """trainer.fit + the reload of train.py:62-67.  ``train_batches(epoch)`` / ``val_batches(epoch)`` yield the batch dictionaries
     of the reference's data module (``audio``, ``one_hot``, ``verts``, ``template_vert``; un-scaled: the x100 happens here).
-    Returns (model with the best checkpoint loaded, history)."""
+    ``extractor``: "auto" builds the configured feature extractor; pass a module (e.g. one with pretrained weights loaded) or None.
+    Under torchrun every rank runs this function: val/err is averaged over the ranks so that checkpoint / early-stop decisions agree,
+    rank 0 alone writes and removes checkpoint files (as Lightning does), and all ranks meet at a barrier before the best one is
+    reloaded.  Returns (model with the best checkpoint loaded, history); ``fit.last_extractor`` is the extractor it used."""
     config = apply_model_overrides(config)
     loss_fn = None
     if model is None:
@@ -146,18 +182,26 @@ def fit(config: ExpConfig, train_batches: Callable[[int], Iterable[Dict[str, tor
     if loss_fn is None:
         from .registry import get_loss_fn
         loss_fn = get_loss_fn(config.modelname)
-    from .registry import build_extractor
-    extractor = build_extractor(config)
+    if isinstance(extractor, str) and extractor == "auto":
+        from .registry import build_extractor
+        extractor = build_extractor(config)
+    fit.last_extractor = extractor
     model.to(device)
     if extractor is not None:
         extractor.to(device)
     step = TrainStep(model, loss_fn, lr=config.lr, use_graph=use_graph)
-    if step.opt.world() > 1:
+    dist = _dist()
+    rank = dist.get_rank() if dist else 0
+    world = dist.get_world_size() if dist else 1
+    if world > 1:
         # identical initial weights on every rank (same seed before the model was built); from here on every rank draws its own
         # stochastic-regulariser masks (FaceFormer train mode), as DDP ranks do in the reference
-        import torch.distributed as dist
-        torch.manual_seed(torch.initial_seed() + 7919 * (dist.get_rank() + 1))
-    ckpt_cb = ModelCheckpoint(os.path.join(log_dir, "checkpoints"))
+        torch.manual_seed(torch.initial_seed() + 7919 * (rank + 1))
+    # one fresh version_N directory per run (TensorBoardLogger's layout); rank 0 picks it, the others learn it
+    run_dir = [next_version_dir(log_dir) if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(run_dir, src=0)
+    ckpt_cb = ModelCheckpoint(os.path.join(run_dir[0], "checkpoints"))
     stop_cb = EarlyStopping(patience=patience)
     history = []
     global_step = 0
@@ -173,13 +217,26 @@ def fit(config: ExpConfig, train_batches: Callable[[int], Iterable[Dict[str, tor
             global_step += 1
         rec = {"epoch": epoch, "global_step": global_step, "train/err": sum(errs) / max(len(errs), 1)}
         rec.update(validate(model, loss_fn, val_batches(epoch), extractor))
+        if world > 1:                                            # sync_dist: the monitored value is the mean over the ranks, identical everywhere
+            t = torch.tensor([rec["val/err"], rec["train/err"]], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t)
+            rec["val/err"], rec["train/err"] = float(t[0]) / world, float(t[1]) / world
         rec["saved"] = ckpt_cb.update(rec["val/err"], epoch, global_step,
-                                      lambda p: save_checkpoint(p, model, step, config, epoch, global_step))
+                                      lambda p: save_checkpoint(p, model, step, config, epoch, global_step, extractor if isinstance(extractor, torch.nn.Module) else None),
+                                      writer=rank == 0)
         history.append(rec)
         log(f"Epoch {epoch} train err: {rec['train/err']:.6f}  val error: {rec['val/err']:.6f}" + ("  (checkpoint)" if rec["saved"] else ""))
         if stop_cb.update(rec["val/err"], epoch):
             log(f"early stop at epoch {epoch}: val/err has not improved for {patience} epochs (best {stop_cb.best:.6f})")
             break
     if ckpt_cb.best_path:
-        load_checkpoint(best_checkpoint(ckpt_cb.dirpath), model)
+        if world > 1:
+            dist.barrier()                                       # rank 0 has finished writing (os.replace) before anyone reads
+        # this run's directory holds exactly one checkpoint - the best: train.py:62-63's largest-step rule and best_path agree
+        load_checkpoint(ckpt_cb.best_path, model, extractor=extractor if isinstance(extractor, torch.nn.Module) else None)
+    fit.last_run_dir = run_dir[0]
     return model, history
+
+
+fit.last_extractor = None
+fit.last_run_dir = None

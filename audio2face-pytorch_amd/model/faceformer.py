@@ -83,17 +83,17 @@ class Faceformer(nn.Module):
                  L.norm1.weight, L.norm1.bias, L.norm2.weight, L.norm2.bias, L.norm3.weight, L.norm3.bias, A, c]
         return torch.cat([p.reshape(-1) for p in parts])
 
-    # Mixed precision of the reference's trainer (`percision: "16-mixed"`, config.yaml:6 -> Lightning autocast) applies to
-    # the torch-op wav2vec2 encoder only: set to torch.bfloat16 / torch.float16 (registry.build_from_config does it from
-    # the config key); the HIP decoder / head / loss always compute in fp32 on the fp32 view of the encoder states.
+    # Mixed precision of the reference's trainer (`percision: "16-mixed"`, config.yaml:6 -> Lightning autocast) applies to the wav2vec2
+    # encoder only: set to torch.bfloat16 / torch.float16 (registry.build_from_config does it from the config key).  On the hand-written
+    # encoder it means plain bf16 operands on the matrix pipe (fp32 accumulate / softmax / LayerNorm) instead of the bf16x3 split
+    # products - forward AND backward: every encoder autograd node records the precision it ran under (encoder_ops._save_prec).  The HIP
+    # decoder / head / loss always compute in fp32 on the fp32 encoder states.
     encoder_autocast = None
 
     def encode(self, audio, frame_num):
         wave = normalize_waveform(audio)                                     # audio_preprocessor, faceformer.py:142-144
-        if self.encoder_autocast is not None and wave.is_cuda:
-            if getattr(self.audio_encoder, "use_hip", False):
-                # hand-written encoder: mixed precision = plain bf16 operands on the matrix pipe (fp32 accumulate / softmax /
-                # LayerNorm) instead of the bf16x3 split products
+        if self.encoder_autocast is not None:
+            if isinstance(self.audio_encoder, Wav2Vec2Model):
                 from .. import ops
                 be = ops.backend()
                 old, be.mm_precision = be.mm_precision, 0
@@ -101,7 +101,7 @@ class Faceformer(nn.Module):
                     return self.audio_encoder(wave, self.dataset, frame_num=frame_num).last_hidden_state
                 finally:
                     be.mm_precision = old
-            with torch.autocast("cuda", dtype=self.encoder_autocast):
+            with torch.autocast(wave.device.type, dtype=self.encoder_autocast):      # a caller-supplied torch-ops encoder module
                 h = self.audio_encoder(wave, self.dataset, frame_num=frame_num).last_hidden_state
             return h.float()
         return self.audio_encoder(wave, self.dataset, frame_num=frame_num).last_hidden_state

@@ -2,10 +2,11 @@
 subclasses HF ``transformers.Wav2Vec2Model``; this is a self-contained module with HF-compatible state-dict keys, so
 ``facebook/wav2vec2-base-960h`` weights load with ``load_state_dict``).
 
-Arithmetic: third-party (HF) architecture.  On HIP tensors ``forward`` runs the hand-written path (``encoder_ops``: every
+Arithmetic: third-party (HF) architecture.  ``forward`` runs the hand-written path and nothing else (``encoder_ops``: every
 contraction on the bf16-MFMA GEMM family ``a2f_mm`` - feature-encoder convolutions 1..6 as implicit GEMMs, feature projection,
 grouped positional convolution, the 12 Transformer layers - MFMA flash attention, HIP LayerNorm / GELU' / bias-gradient
-kernels, forward and backward).  The torch-ops restatement below it is what host-side (CPU) tests of this module run.  ``forward(input_values, dataset, frame_num=...)`` keeps the reference wrapper's signature and
+kernels, forward and backward).  There is no torch-ops forward in the product: off-device tensors fail in ``ops._chk``; the torch-ops
+restatement the CPU suite compares against lives in ``tests/torch_ops_encoder.py``.  ``forward(input_values, dataset, frame_num=...)`` keeps the reference wrapper's signature and
 returns an object with ``.last_hidden_state`` (1,T,768); the vocaset branch interpolates the 49 Hz conv features to
 ``frame_num`` frames with align_corners=True (wav2vec.py:76-84,125-128).
 
@@ -21,7 +22,6 @@ import types
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 CONV_KERNEL = (10, 3, 3, 3, 3, 2, 2)
 CONV_STRIDE = (5, 2, 2, 2, 2, 2, 2)
@@ -39,15 +39,6 @@ class _FeatureExtractor(nn.Module):
     def __init__(self, dim=512):
         super().__init__()
         self.conv_layers = nn.ModuleList(_ConvLayer(1 if i == 0 else dim, dim, k, i == 0) for i, k in enumerate(CONV_KERNEL))
-
-    def forward(self, wave):
-        z = wave[:, None, :]
-        for i, layer in enumerate(self.conv_layers):
-            z = F.conv1d(z, layer.conv.weight, None, stride=CONV_STRIDE[i])
-            if i == 0:
-                z = F.group_norm(z, z.shape[1], layer.layer_norm.weight, layer.layer_norm.bias, 1e-5)
-            z = F.gelu(z)
-        return z
 
 
 class _FeatureProjection(nn.Module):
@@ -90,25 +81,6 @@ class _EncoderLayer(nn.Module):
         self.final_layer_norm = nn.LayerNorm(hidden, eps=1e-5)
         self.heads = heads
 
-    def forward(self, h, masks=None):
-        B, T, d = h.shape
-        hd = d // self.heads
-        a = self.attention
-        q = a.q_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
-        k = a.k_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
-        v = a.v_proj(h).view(B, T, self.heads, hd).transpose(1, 2)
-        mk = masks or {}
-        drop = lambda x, key: x * (_unpack(mk[key][0], x.shape[-1]).view(x.shape) * mk[key][1]).to(x.dtype) if key in mk else x
-        if "attn" in mk:                                                    # HF eager attention: softmax -> dropout -> @ v
-            pr = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * hd ** -0.5, dim=-1)
-            pr = pr * (_unpack(mk["attn"][0], T).view(B, self.heads, T, T) * mk["attn"][2]).to(pr.dtype)
-            ctx = torch.matmul(pr, v)
-        else:
-            ctx = F.scaled_dot_product_attention(q, k, v)                   # softmax(q k^T / sqrt(hd)) v
-        h = self.layer_norm(h + drop(a.out_proj(ctx.transpose(1, 2).reshape(B, T, d)), "hid1"))
-        f = self.feed_forward
-        return self.final_layer_norm(h + drop(f.output_dense(drop(F.gelu(f.intermediate_dense(h)), "act")), "hid2"))
-
 
 class _Encoder(nn.Module):
     def __init__(self, hidden=768, layers=12, ffn=3072, heads=12):
@@ -117,33 +89,11 @@ class _Encoder(nn.Module):
         self.layer_norm = nn.LayerNorm(hidden, eps=1e-5)
         self.layers = nn.ModuleList(_EncoderLayer(hidden, ffn, heads) for _ in range(layers))
 
-    def forward(self, h, masks=None):
-        pc = self.pos_conv_embed
-        z = pc.conv(h.transpose(1, 2))
-        z = z[:, :, :-1] if pc.k % 2 == 0 else z
-        h = self.layer_norm(h + F.gelu(z).transpose(1, 2))
-        if masks is not None and masks.enc is not None:
-            h = h * (_unpack(masks.enc[0], h.shape[-1]).view(h.shape) * masks.enc[1]).to(h.dtype)
-        for l, layer in enumerate(self.layers):
-            if masks is not None and masks.layer_skip[l]:
-                continue                                                     # LayerDrop
-            h = layer(h, masks.layers[l] if masks is not None else None)
-        return h
-
-
-def _unpack(bits, C):
-    from ..dropout import unpack_keep_bits
-    return unpack_keep_bits(bits, C)
-
 
 def linear_interpolation(features, output_len):
-    """(B,L,C) -> (B,output_len,C), align_corners=True   (wav2vec.py:76-84)."""
-    # HIP tensors: csrc/interp.hip (gather-form backward, no atomics; 7 ms less per 16-sequence FaceFormer step than the
-    # torch op on the transposed view).  Off-device tensors only occur in host-side tests of this torch-ops module.
-    if features.is_cuda and features.shape[-1] % 4 == 0:
-        from ..functional import LinearInterpFn
-        return LinearInterpFn.apply(features.float(), int(output_len)).to(features.dtype)
-    return F.interpolate(features.transpose(1, 2), size=output_len, align_corners=True, mode="linear").transpose(1, 2)
+    """(B,L,C) -> (B,output_len,C), align_corners=True   (wav2vec.py:76-84): csrc/interp.hip, gather-form backward, no atomics."""
+    from ..functional import LinearInterpFn
+    return LinearInterpFn.apply(features.float(), int(output_len)).to(features.dtype)
 
 
 def normalize_waveform(audio):
@@ -161,15 +111,15 @@ class Wav2Vec2Model(nn.Module):
         self.feature_extractor = _FeatureExtractor(conv_dim)
         self.feature_projection = _FeatureProjection(conv_dim, hidden)
         self.encoder = _Encoder(hidden, layers, ffn, heads)
-        self.conv_autotune = True
         self.heads = heads
-        self.use_hip = True          # HIP tensors -> hand-written path; False keeps the torch-ops restatement (A/B timing, debugging)
         # the train-mode probabilities of facebook/wav2vec2-base-960h's configuration (what the reference's from_pretrained loads)
         self.config = types.SimpleNamespace(feat_proj_dropout=0.1, hidden_dropout=0.1, attention_dropout=0.1, activation_dropout=0.1,
                                             layerdrop=0.1, apply_spec_augment=True, mask_time_prob=0.05, mask_time_length=10)
         self.train_regularisers = True
         self.injected_masks = None   # an EncoderMasks to use instead of drawing (parity tests: masks recorded from the reference)
         self.last_masks = None
+        self.layers_run = 0          # Transformer layers executed / forwards since the counters were reset (LayerDrop skips layers: bench.py
+        self.forwards_run = 0        # subtracts them from the step's flop count)
 
     compute_path = "hand-written HIP (a2f_mm bf16-MFMA GEMMs, MFMA flash attention, HIP LayerNorm / GELU / GroupNorm kernels)"
 
@@ -235,9 +185,11 @@ class Wav2Vec2Model(nn.Module):
         h = LayerNormFn.apply(h, enc.layer_norm.weight, enc.layer_norm.bias)
         if masks is not None and masks.enc is not None:
             h = DropoutFn.apply(h, masks.enc[0], masks.enc[1])
+        self.forwards_run += 1
         for l, layer in enumerate(enc.layers):
             if masks is not None and masks.layer_skip[l]:
                 continue                                                     # LayerDrop (HF Wav2Vec2Encoder.forward)
+            self.layers_run += 1
             a, f = layer.attention, layer.feed_forward
             h = EncoderLayerFn.apply(h, S, T, self.heads, masks.layers[l] if masks is not None else None,
                                      a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias, a.v_proj.weight,
@@ -253,22 +205,4 @@ class Wav2Vec2Model(nn.Module):
             frame_num = None                                   # plain HF Wav2Vec2Model.forward: 49 Hz frames, no interpolation
         if attention_mask is not None:
             raise NotImplementedError("attention_mask is never passed by the reference FaceFormer (faceformer.py:149-151)")
-        if input_values.is_cuda and self.use_hip:
-            return types.SimpleNamespace(last_hidden_state=self._forward_hip(input_values, frame_num))
-        # conv_autotune: let MIOpen pick its fastest algorithm for the feature-encoder / positional convolutions of this
-        # shape (find mode, first call only): 124 -> 114 ms per 16 x 600 FaceFormer step; its default choice is an im2col path
-        old_benchmark = torch.backends.cudnn.benchmark
-        torch.backends.cudnn.benchmark = old_benchmark or (bool(self.conv_autotune) and input_values.is_cuda)
-        try:
-            z = self.feature_extractor(input_values).transpose(1, 2)
-            if frame_num is not None:
-                z = linear_interpolation(z, frame_num)
-            fp = self.feature_projection
-            h = fp.projection(fp.layer_norm(z))
-            masks = self.last_masks = self._step_masks(h.shape[0], h.shape[1], h.device)
-            if masks is not None and masks.featproj is not None:
-                h = h * (_unpack(masks.featproj[0], h.shape[-1]).view(h.shape) * masks.featproj[1]).to(h.dtype)
-            h = self._spec_augment(h, masks)
-            return types.SimpleNamespace(last_hidden_state=self.encoder(h, masks))
-        finally:
-            torch.backends.cudnn.benchmark = old_benchmark
+        return types.SimpleNamespace(last_hidden_state=self._forward_hip(input_values, frame_num))

@@ -193,6 +193,12 @@ class HipBackend:
             pf = getattr(self, "prof_flops", None)
             if pf is not None:
                 pf[tag] = pf.get(tag, 0.0) + 2.0 * M * N * K * batch
+            ps = getattr(self, "prof_shapes", None)
+            if ps is not None and ev is not None:                # per launch variant: layout / shape / precision -> events, flops per launch
+                key = (("T" if A.trans else "N") + ("T" if not B.trans else "N"), M, N, K, batch, bool(A.lines_per_seq or B.lines_per_seq),
+                       d.precision, getattr(A, "hi", None) is not None)
+                ent = ps.setdefault(key, {"events": [], "flops": 2.0 * M * N * K * batch})
+                ent["events"].append(ev)
 
     # ---- row-wise encoder kernels (csrc/rowops.hip) ----------------------------------------------
     def layernorm_fwd(self, x, R, Cc, gamma, beta, eps, y, mean, rstd):

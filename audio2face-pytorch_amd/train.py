@@ -77,10 +77,11 @@ def main(argv=None):
     from .trainer import TrainStep
     x, one_hot, gt, template = TrainStep.unpack_batch(batch)
     model.eval()
+    ex = fit.last_extractor                                     # the extractor fit trained with (not a freshly initialised one), in eval mode
+    if isinstance(ex, torch.nn.Module):
+        ex.eval()
     with torch.no_grad():
-        from .registry import build_extractor
-        ex = build_extractor(cfg)
-        pred = model.predict(ex.to(device)(x) if ex is not None else x, one_hot, template) / 100            # predict_step: back to metres
+        pred = model.predict(ex(x) if ex is not None else x, one_hot, template) / 100            # predict_step: back to metres
     log(f"predicted {tuple(pred.shape)} vertices (metres), best val/err {min(h['val/err'] for h in history):.6f} after {len(history)} epochs")
     if world > 1:
         dist.destroy_process_group()

@@ -49,6 +49,8 @@ MFMA_F32_PEAK_TF = 157.3          # exact-fp32 matrix peak (v_mfma_f32_32x32x2_f
 MFMA_BF16_PEAK_TF = 2500.0        # dense bf16 matrix peak
 FF_MFLOP_PER_FRAME = 857.0        # 3 x 2 x (141.9 M encoder + 1.0 M decoder/head) MAC at T = 600
 A2M_MFLOP_PER_FRAME = 393.0       # 3 x 2 x 65 509 514 MAC
+FF_LAYER_MFLOP_PER_FRAME = 6.0 * (7.078 + 0.92) # one of the 12 Transformer layers: 3 x 2 x (7.08 M MAC of projections / FFN + 0.92 M MAC of attention at T = 600)
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"   # this round's PMC measurement of the dominant kernels (tools/pmc_head.sh, tools/pmc_gemm.sh)
 
 
 # ------------------------------------------------------------------------------------------------ self launch (N > 1)
@@ -257,25 +259,43 @@ def measured_stream_rates(device):
 
 
 # ------------------------------------------------------------------------------------------------ timed regions
-def timed(step_fn, steps, warmup, barrier, world, device):
+def timed(step_fn, steps, warmup, barrier, world, device, budget_s=8.0, max_blocks=9):
+    """W untimed warm-up steps, then BLOCKS of exactly ``steps`` steps, each bracketed by barrier + synchronize on both sides and reduced
+    with MAX over the ranks.  The reported time is the MEDIAN block (>= 50 timed steps, median): the number of blocks is the
+    smallest that reaches 50 timed steps (at least 3, at most ``max_blocks``), cut so that the timed region stays within ``budget_s``
+    seconds (every rank takes the decision from the same max-reduced first block).  Returns (median block seconds, last loss, info)."""
     import torch
     import torch.distributed as dist
     out = None
     for _ in range(warmup):
         out = step_fn()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        out = step_fn()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+
+    def one_block():
+        nonlocal out
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step_fn()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            te = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        return el
+
+    blocks = [one_block()]
+    want = max(3, min(max_blocks, -(-50 // steps)))
+    want = max(1, min(want, int(budget_s / max(blocks[0], 1e-9))))
+    while len(blocks) < want:
+        blocks.append(one_block())
     loss_val = float(out["loss"])
     assert loss_val == loss_val, "loss is NaN"
-    return elapsed, loss_val
+    srt = sorted(blocks)
+    med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    info = {"blocks": len(blocks), "steps_per_block": steps, "statistic": "median block, max over ranks per block",
+            "ms_per_step_per_block": [round(1e3 * b / steps, 4) for b in blocks]}
+    return med, loss_val, info
 
 
 def gemm_prof_summary(be):
@@ -348,6 +368,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    dist_info = None
+    if world > 1 or force_dist:
+        # evidence for the scaling run that the collective library really saw N ranks on N devices: an all-reduce whose result every
+        # rank checks (sum of rank + 1 = N (N + 1) / 2) and the device each rank is bound to
+        chk = torch.tensor([float(rank + 1)], device=device)
+        dist.all_reduce(chk)
+        want_sum = world * (world + 1) / 2
+        assert float(chk.item()) == want_sum, f"all-reduce self-check failed on rank {rank}: {float(chk.item())} != {want_sum}"
+        prop = torch.cuda.get_device_properties(device)
+        mine = {"rank": rank, "local_rank": local_rank, "device": f"cuda:{local_rank}", "name": prop.name,
+                "uuid": str(getattr(prop, "uuid", "")), "pci_bus_id": getattr(prop, "pci_bus_id", None)}
+        devs = [None] * world
+        dist.all_gather_object(devs, mine)
+        dist_info = {"backend": dist.get_backend(), "collective_library": "RCCL" if backend == "nccl" else backend, "rccl_world": dist.get_world_size(),
+                     "allreduce_selfcheck": f"sum(rank + 1) = {float(chk.item()):.0f} on every rank (expected {want_sum:.0f})",
+                     "distinct_devices": len({(d["uuid"], d["pci_bus_id"], d["device"]) for d in devs}), "ranks": devs}
+
     be = ops.backend()
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     want_roof = rank == 0 and not args.no_roofline
@@ -360,10 +397,10 @@ def main():
         step = TrainStep(model, a2f_amd.VocaLoss(), lr=1e-4, use_graph=not args.no_graph)
         x, one_hot, gt, templ = make_voca_batch(args.seqs, args.frames, rank, device, features=args.input == "features")
         B = one_hot.shape[0]
-        elapsed, loss_val = timed(lambda: step(x, one_hot, gt, templ), steps, max(warmup, 3), barrier, world, device)   # >= 3: two eager warm-up steps + the capture step
+        elapsed, loss_val, tinfo = timed(lambda: step(x, one_hot, gt, templ), steps, max(warmup, 3), barrier, world, device)   # >= 3: two eager warm-up steps + the capture step
         res = {
             "value": round(world * B * steps / elapsed, 1), "unit": "mesh-frames/s", "steps": steps,
-            "ms_per_step": round(1e3 * elapsed / steps, 4),
+            "ms_per_step": round(1e3 * elapsed / steps, 4), "timing": tinfo,
             "dtype": "f32 (head matrix products: bf16x3 split operands, f32 accumulate)",
             "config": {"workload": f"VOCA train step (fwd+VocaLoss+bwd+Adam), {args.seqs} seq x {args.frames} frames = {B} windows "
                                    f"(29,16) per GPU per step{' built on chip from (S,T,29) features' if args.input == 'features' else ''}, 5023-vertex meshes, BASELINE configs[1]",
@@ -385,12 +422,16 @@ def main():
             dom = "head_x3_kernel" if os.environ.get("A2F_HEAD_CFG", "5") == "5" else "head_fused_kernel"   # library default: cfg 5
             bytes_per_launch = ALGO_BYTES_PER_FRAME["head_fused"] * B
             achieved = bytes_per_launch / (head_ms * 1e-3) / 1e9
-            traffic = None
-            tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            # HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes: tools/pmc_head.sh writes the
+            # file; a PMC pass cannot run inside this process).  Only a measurement of THIS round's kernel at THIS shape is reported.
+            traffic, traffic_src = None, None
+            tj = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
             if os.path.exists(tj):
-                traffic = json.load(open(tj)).get(dom)
+                ent = json.load(open(tj)).get(dom)
+                if isinstance(ent, dict) and ent.get("frames") == B:
+                    traffic, traffic_src = ent.get("hbm_bytes_per_launch"), f"profiles/{PMC_TRAFFIC_FILE} ({ent.get('how', 'rocprofv3 --pmc')})"
             res["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(head_ms, 4), "launches_timed": nl,
                                "measured_stream_GBs": stream_rates,
                                "whole_step_frac": round(B * steps / elapsed * 182732 / 1e9 / HBM_PEAK_GBS, 4)}
@@ -400,12 +441,13 @@ def main():
         return res
 
     # ------------------------------------------------------------------ FaceFormer (BASELINE configs[2])
-    def run_faceformer(steps, warmup, S=None, T=None, fp8_attention=False, config_name="BASELINE configs[2]", cpu=True):
-        torch.manual_seed(1234)
-        S, T = S or args.ff_seqs, T or args.ff_frames
-        old_attn = be.attn_precision
-        if fp8_attention:                                        # configs[4]: fp8 (e4m3) QK^T / PV products in the encoder's attention forward
-            be.attn_precision = 2
+    def ff_mflop_per_frame(T, layers_run=12.0):
+        """Algorithmic fp32 MFLOP per frame of a FaceFormer train step (3 x 2 x MAC; SURVEY 8(d): 857 at T = 600 with all 12 layers): conv
+        feature encoder 41.0 M MAC, positional conv 4.7, decoder + head 1.0, per Transformer layer 7.08 (projections + FFN) + 0.92 T / 600
+        (attention is quadratic in T); ``layers_run`` = the mean number of layers LayerDrop left in the timed steps."""
+        return 6.0 * (41.0 + 4.7 + 1.0 + 0.22 + layers_run * (7.078 + 0.92 * T / 600.0))
+
+    def ff_model():
         model = a2f_amd.Faceformer(n_verts=NV3, n_onehot=12).to(device)
         with torch.no_grad():                                    # the reference zero-initialises both vertice maps (faceformer.py:132-135):
             model.vertice_map_r.weight.normal_(0, 0.1)           # non-zero values so the recurrence and its backward do real work
@@ -413,60 +455,113 @@ def main():
         if args.encoder_precision == "bf16":
             model.encoder_autocast = torch.bfloat16
         model.train()                                            # Lightning's fit puts the reference's module in train mode
-        torch.manual_seed(4321 + 7919 * rank)                    # same initial weights on every rank (seed above), different dropout masks per rank
         if args.ff_deterministic:                                # A/B: the deterministic (eval-mode) function under the same step
             model.audio_encoder.train_regularisers = model.decoder_regularisers = False
+        return model
+
+    def run_faceformer(steps, warmup, S=None, T=None, config_name="BASELINE configs[2]", cpu=True, batch_points=(1, 16), long=False):
+        torch.manual_seed(1234)
+        S, T = S or args.ff_seqs, T or args.ff_frames
+        model = ff_model()
+        torch.manual_seed(4321 + 7919 * rank)                    # same initial weights on every rank (seed above), different dropout masks per rank
         step = TrainStep(model, a2f_amd.FaceFormerLoss(), lr=1e-4)
         audio, one_hot, gt, templ = make_ff_batch(S, T, rank, device)
-        elapsed, loss_val = timed(lambda: step(audio, one_hot, gt, templ), steps, max(warmup, 2), barrier, world, device)
+        enc = model.audio_encoder
+        enc.layers_run, enc.forwards_run = 0, 0
+        elapsed, loss_val, tinfo = timed(lambda: step(audio, one_hot, gt, templ), steps, max(warmup, 2), barrier, world, device,
+                                         budget_s=12.0 if not long else 4.0, max_blocks=5 if not long else 3)
+        layers_run = enc.layers_run / max(enc.forwards_run, 1) if getattr(enc, "forwards_run", 0) else 12.0
         fps = world * S * T * steps / elapsed
         enc_path = getattr(model.audio_encoder, "compute_path", "torch ops (rocBLAS / MIOpen / SDPA)")
+        split = args.encoder_precision != "bf16"
         res = {
-            "value": round(fps, 1), "unit": "mesh-frames/s", "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 3),
-            "dtype": "f32 storage; " + ("encoder products as bf16 MFMA (16-mixed), fp32 accumulate / softmax / LayerNorm" if args.encoder_precision == "bf16"
-                                        else getattr(model.audio_encoder, "dtype_note", "encoder in fp32 torch ops"))
-                     + ("; encoder attention forward QK^T / PV as fp8 e4m3 MFMA (backward bf16)" if fp8_attention else ""),
+            "value": round(fps, 1), "unit": "mesh-frames/s", "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 3), "timing": tinfo,
+            "dtype": "f32 storage; " + ("encoder products (GEMMs and attention, forward and backward) as plain bf16 MFMA (16-mixed), fp32 accumulate / softmax / LayerNorm"
+                                        if not split else "encoder products (GEMMs and attention, forward and backward) as bf16x3 split MFMA (fp32-class: the parity "
+                                        "setting, <= 1e-4 vs the oracle), fp32 accumulate / softmax / LayerNorm"),
             "config": {"workload": f"FaceFormer train step (wav2vec2-base encoder + incremental decoder + fused head/FaceFormerLoss, bwd, Adam over 96.4 M "
                                    f"parameters), {S} independent batch-1 sequences x {T} frames per GPU per step, {config_name}",
                        "frames_per_gpu_step": S * T, "parallelism": f"dp{world}", "final_loss": round(loss_val, 6), "encoder": enc_path,
                        "train_mode": ("deterministic function (regularisers off, --ff-deterministic)" if args.ff_deterministic else
-                                      "reference train mode: wav2vec2 dropout x6 kinds of sites / LayerDrop 0.1 / SpecAugment, decoder + PPE dropout 0.1 "
-                                      "(one mask per frame row), masks drawn on the device every step")},
+                                      "reference train mode: wav2vec2 dropout x6 kinds of sites / LayerDrop 0.1 / SpecAugment (exactly the reference's); decoder + PPE "
+                                      "dropout 0.1 with ONE mask per frame row - a deliberate deviation from the reference's per-loop-step redraw "
+                                      "(faceformer.py:154-185; DESIGN 3.6, fixture G14); masks drawn on the device every step"),
+                       "mean_transformer_layers_run": round(layers_run, 3)},
         }
         if want_roof:
-            # whole step against the matrix peak (857 MFLOP/frame algorithmic) + the tagged GEMM launches alone
-            ach = fps / world * FF_MFLOP_PER_FRAME * 1e6 / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
-                    "traffic": None, "note": "whole step, algorithmic fp32 flops (857 MFLOP/frame) / step time, against the exact-fp32 matrix peak; "
-                                             "split-bf16 kernels execute 3 bf16 MFMA flops per algorithmic flop: bf16_pipe_frac = 3 x achieved / 2500"}
-            roof["bf16_pipe_frac"] = round(3 * ach / MFMA_BF16_PEAK_TF, 4)
+            # whole step and the dominant GEMM variant against the pipe the kernels run on: the DENSE bf16 matrix peak.  A bf16x3 kernel
+            # executes three bf16 MFMA flops per algorithmic (fp32) flop: `achieved` = executed, `algorithmic` = 2 M N K / t
+            mult = 3.0 if split else 1.0
+            mf = ff_mflop_per_frame(T, layers_run)
+            alg = fps / world * mf * 1e6 / 1e12
+            roof = {"bound": "mfma", "achieved": round(mult * alg, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(mult * alg / MFMA_BF16_PEAK_TF, 4),
+                    "traffic": None, "algorithmic": round(alg, 2), "algorithmic_frac": round(alg / MFMA_BF16_PEAK_TF, 4), "executed_per_algorithmic": mult,
+                    "algorithmic_mflop_per_frame": round(mf, 1),
+                    "note": "whole step: algorithmic fp32 flops (3 x 2 x MAC per frame, LayerDrop-skipped layers subtracted) / step time; achieved = executed "
+                            "bf16 MFMA flops (x3 for split products) against the dense bf16 peak (2.5 PFLOP/s)"}
             # per-launch HIP events are only meaningful when nothing else shares the GPU: this pass runs the same kernels with the
             # two-stream half-batch pipeline and the weight-gradient lane switched off (one stream, launches back to back)
             from a2f_amd import encoder_ops
             old_lane, old_pipe = encoder_ops.WGRAD_STREAM, step.pipeline
             encoder_ops.WGRAD_STREAM, step.pipeline = False, False
-            be.prof, be.prof_flops = {}, {}
+            be.prof, be.prof_flops, be.prof_shapes = {}, {}, {}
             for _ in range(2):
                 step._fwd_bwd(audio, one_hot, gt, templ)         # forward + loss + backward only: rank 0 runs this leg alone, so no collective (no Adam either)
             torch.cuda.synchronize()
             encoder_ops.WGRAD_STREAM, step.pipeline = old_lane, old_pipe
             tf, nl, ms = gemm_prof_summary(be)
             if tf is not None:
-                roof["kernel"] = {"name": "gemm_mfma_kernel (all encoder / decoder-side GEMM launches of 2 steps)", "launches_timed": nl,
-                                  "total_ms": round(ms, 3), "achieved_TFLOPs": round(tf, 2), "frac_of_f32_matrix_peak": round(tf / MFMA_F32_PEAK_TF, 4),
-                                  "bf16_pipe_frac": round(3 * tf / MFMA_BF16_PEAK_TF, 4)}
+                roof["gemm_family"] = {"name": "gemm_mfma_kernel (all encoder / decoder-side GEMM launches of 2 steps, single stream)", "launches_timed": nl,
+                                       "total_ms": round(ms, 3), "algorithmic_TFLOPs": round(tf, 2), "achieved_TFLOPs": round(mult * tf, 2),
+                                       "frac": round(mult * tf / MFMA_BF16_PEAK_TF, 4)}
+            top = None
+            for key, ent in be.prof_shapes.items():
+                tms = sum(a.elapsed_time(b) for a, b in ent["events"])
+                if top is None or tms > top[1]:
+                    top = (key, tms, ent)
+            if top is not None:
+                (lay, M_, N_, K_, bt_, win, prec, img), tms, ent = top
+                n = len(ent["events"])
+                ktf = ent["flops"] * n / (tms * 1e-3) / 1e12
+                kmult = {0: 1.0, 1: 3.0, 2: 6.0}[prec]
+                traffic = None
+                tj = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
+                if os.path.exists(tj):
+                    e2 = json.load(open(tj)).get(f"gemm_mfma_kernel {lay} {M_}x{N_}x{K_}")
+                    if isinstance(e2, dict):
+                        traffic = e2.get("hbm_bytes_per_launch")
+                roof["kernel"] = {"name": f"gemm_mfma_kernel {lay} M={M_} N={N_} K={K_}" + (f" batch={bt_}" if bt_ > 1 else "") + (" windowed (conv)" if win else "")
+                                          + (" image operands" if img else "") + f" precision={prec}",
+                                  "launches_timed": n, "avg_launch_ms": round(tms / n, 4), "total_ms": round(tms, 3),
+                                  "algorithmic_TFLOPs": round(ktf, 2), "achieved": round(kmult * ktf, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                                  "frac": round(kmult * ktf / MFMA_BF16_PEAK_TF, 4), "traffic": traffic,
+                                  "note": "the launch variant (layout, shape) with the largest total time in the single-stream pass"}
             hev = be.prof.get("head_fused", [])
             if hev:
                 hms = sum(a.elapsed_time(b) for a, b in hev) / len(hev)
                 hb = ALGO_BYTES_PER_FRAME["head_fused_ff"] * (2 * S * T / len(hev))          # frames per launch over the 2 profiled steps (single stream)
                 roof["head_hbm"] = {"kernel": "head_x3_kernel<64> + fold", "achieved": round(hb / (hms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(hb / (hms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(hms, 4), "launches_timed": len(hev)}
-            be.prof = None
+            be.prof = be.prof_shapes = None
             res["roofline"] = roof
+        # the reference trains ONE sequence per optimizer step (train.py:33): the same step at S = 1 and S = 16 beside the S-sequence figure
+        pts = []
+        for s_pt in batch_points:
+            if s_pt >= S:
+                continue
+            a2, o2, g2, t2 = audio[:s_pt], one_hot[:s_pt], gt[:s_pt], templ[:s_pt]
+            el, _lv, _ti = timed(lambda: step(a2, o2, g2, t2), 3, 2, barrier, world, device, budget_s=2.0, max_blocks=3)
+            pts.append({"seqs_per_step": s_pt, "ms_per_step": round(1e3 * el / 3, 3), "value": round(world * s_pt * T * 3 / el, 1)})
+        if pts:
+            res["sequences_per_step_points"] = pts
         if want_cpu and cpu:
             res["cpu_baseline"] = cpu_baseline_faceformer()
-        be.attn_precision = old_attn
-        del step, model
+        del step
+        return res, model, (audio, one_hot, templ)
+
+    def run_faceformer_entry(steps, warmup):
+        res, model, _ = run_faceformer(steps, warmup)
+        del model
         return res
 
     # ------------------------------------------------------------------ Audio2Mesh
@@ -476,33 +571,74 @@ def main():
         model = a2f_amd.Audio2Mesh(n_verts=NV3, n_onehot=12).to(device).train()
         step = TrainStep(model, a2f_amd.VocaLoss(), lr=1e-4, use_graph=not args.no_graph)
         x, one_hot, gt, templ = make_a2m_batch(B, rank, device)
-        elapsed, loss_val = timed(lambda: step(x, one_hot, gt, templ), steps, max(warmup, 3), barrier, world, device)
+        elapsed, loss_val, tinfo = timed(lambda: step(x, one_hot, gt, templ), steps, max(warmup, 3), barrier, world, device)
         fps = world * B * steps / elapsed
         res = {
-            "value": round(fps, 1), "unit": "mesh-frames/s", "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 3),
-            "dtype": "f32 storage and accumulate; convolution products as split-bf16 MFMA (fp32-class)",
+            "value": round(fps, 1), "unit": "mesh-frames/s", "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 3), "timing": tinfo,
+            "dtype": "f32 storage and accumulate; convolution products as bf16x6 split MFMA (fp32-class)",
             "config": {"workload": f"Audio2Mesh train step (train-mode BatchNorm, fwd+VocaLoss+bwd+Adam), B = {B} windows (52,32) per GPU per step",
                        "frames_per_gpu_step": B, "parallelism": f"dp{world}", "final_loss": round(loss_val, 6)},
         }
         if want_roof:
-            ach = fps / world * A2M_MFLOP_PER_FRAME * 1e6 / 1e12
-            res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
-                               "traffic": None, "note": "whole step, algorithmic fp32 flops (393 MFLOP/frame) / step time, against the exact-fp32 matrix peak"}
+            alg = fps / world * A2M_MFLOP_PER_FRAME * 1e6 / 1e12
+            res["roofline"] = {"bound": "mfma", "achieved": round(6.0 * alg, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(6.0 * alg / MFMA_BF16_PEAK_TF, 4),
+                               "traffic": None, "algorithmic": round(alg, 2), "algorithmic_frac": round(alg / MFMA_BF16_PEAK_TF, 4), "executed_per_algorithmic": 6.0,
+                               "note": "whole step: algorithmic fp32 flops (393 MFLOP/frame) / step time; the convolutions run as bf16x6 split products (six bf16 "
+                                       "MFMA flops per algorithmic flop): achieved = executed flops against the dense bf16 peak (2.5 PFLOP/s)"}
         if want_cpu:
             res["cpu_baseline"] = cpu_baseline_a2m()
         del step, model
         return res
 
-    def run_faceformer_long(steps, warmup):                      # BASELINE configs[4]: 3000-frame sequences, fp8 MFMA attention
-        return run_faceformer(min(steps, 3), 2, S=args.ff_long_seqs, T=args.ff_long_frames, fp8_attention=True,
-                              config_name="BASELINE configs[4] (long context, fp8 attention; per GPU)", cpu=False)
+    def run_faceformer_long(steps, warmup):
+        """BASELINE configs[4]: 3000-frame sequences, per-vertex-L2 tolerance 1e-3.  The timed setting is the one that MEETS that tolerance
+        (bf16x3 split products in GEMMs and attention: <= 1e-4 vs the oracle at T = 3000, tests/test_gpu_models.py::
+        test_faceformer_config5_T3000_*).  The fp8 (e4m3) attention-forward modes are carried as labelled `variants`, each with its error
+        measured here (eval-mode vertex offsets of one sequence against the bf16x3 path on the same weights and input)."""
+        S, T = args.ff_long_seqs, args.ff_long_frames
+        res, model, (audio, one_hot, templ) = run_faceformer(min(steps, 3), 2, S=S, T=T, config_name="BASELINE configs[4] (long context; per GPU)", cpu=False,
+                                                             batch_points=(), long=True)
+        res["parity_setting"] = {"attention": "bf16x3 split MFMA (forward and backward)", "tolerance": 1e-3,
+                                 "pinned_by": "tests/test_gpu_models.py::test_faceformer_config5_T3000_encoder_vs_oracle (<= 1e-4 vs the CPU oracle)"}
+        variants = []
+        was_training = model.training
+        model.eval()
+        with torch.no_grad():
+            ref = model(audio[:1], one_hot[:1], templ[:1]).view(T, -1) - templ[:1].reshape(1, -1)
+        for name, ap, label in (("fp8x3_attention_forward", 3, "three-term e4m3 split operands on v_mfma_f32_32x32x16_fp8_fp8 (per-head power-of-two scales)"),
+                                ("fp8_attention_forward", 2, "single e4m3 operands on v_mfma_f32_32x32x16_fp8_fp8")):
+            if ap not in getattr(be, "attn_precisions", (0, 1, 2)):
+                continue
+            old_attn = be.attn_precision
+            be.attn_precision = ap
+            try:
+                model.eval()
+                with torch.no_grad():
+                    p2 = model(audio[:1], one_hot[:1], templ[:1]).view(T, -1) - templ[:1].reshape(1, -1)
+                err = float((p2 - ref).double().norm() / ref.double().norm())
+                model.train(was_training)
+                torch.manual_seed(4321 + 7919 * rank)
+                step = TrainStep(model, a2f_amd.FaceFormerLoss(), lr=1e-4)
+                audio_f, one_hot_f, gt_f, templ_f = make_ff_batch(S, T, rank, device)
+                el, _lv, _ti = timed(lambda: step(audio_f, one_hot_f, gt_f, templ_f), min(steps, 3), 2, barrier, world, device, budget_s=2.0, max_blocks=1)
+                variants.append({"variant": name, "attention_forward": label, "attention_backward": "bf16x3 split MFMA",
+                                 "vertex_offset_rel_l2_vs_parity_setting": float(f"{err:.3e}"), "meets_1e-3": bool(err <= 1e-3),
+                                 "ms_per_step": round(1e3 * el / min(steps, 3), 3), "value": round(world * S * T * min(steps, 3) / el, 1)})
+                del step, audio_f, one_hot_f, gt_f, templ_f
+            finally:
+                be.attn_precision = old_attn
+        res["variants"] = variants
+        del model
+        return res
 
-    runners = {"voca": run_voca, "faceformer": run_faceformer, "audio2mesh": run_audio2mesh, "faceformer_long": run_faceformer_long}
+    runners = {"voca": run_voca, "faceformer": run_faceformer_entry, "audio2mesh": run_audio2mesh, "faceformer_long": run_faceformer_long}
     main_res = runners[args.workload](args.steps, args.warmup)
     result = {"metric": "mesh-frames/sec training (VOCASET 5023-vert)", "value": main_res.pop("value"), "unit": main_res.pop("unit"),
               "n_gpus": world, "steps": main_res.pop("steps"), "warmup": args.warmup, "ms_per_step": main_res.pop("ms_per_step"),
               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": main_res.pop("dtype"), "data": "synthetic"}
     result.update(main_res)
+    if dist_info is not None:
+        result["distributed"] = dist_info
     if not args.no_secondary:
         sec = []
         for name in ("faceformer", "audio2mesh", "faceformer_long", "voca"):

@@ -87,8 +87,10 @@ def encoder_layer(P, pre: str, h: torch.Tensor) -> torch.Tensor:
     return x[None]
 
 
-def wav2vec2_forward(P: Dict[str, torch.Tensor], wave: torch.Tensor, frame_num: int, n_layers: int = N_LAYERS) -> torch.Tensor:
-    """Normalised waveform (1,N) -> last_hidden_state (1,frame_num,768).  wav2vec.py:116-189 (eval)."""
+def wav2vec2_forward(P: Dict[str, torch.Tensor], wave: torch.Tensor, frame_num: int, n_layers: int = N_LAYERS, checkpoint: bool = False) -> torch.Tensor:
+    """Normalised waveform (1,N) -> last_hidden_state (1,frame_num,768).  wav2vec.py:116-189 (eval).  ``checkpoint``: recompute each
+    Transformer layer in the backward instead of keeping its (12, T, T) attention matrices (same arithmetic; bounds the host memory of
+    the T = 3000 gradient tests)."""
     z = feature_encoder(P, wave).transpose(1, 2)                                   # (1,L,512)  :116-117
     z = linear_interpolation(z, frame_num)                                         # :125-128
     c = z.shape[-1]
@@ -98,5 +100,9 @@ def wav2vec2_forward(P: Dict[str, torch.Tensor], wave: torch.Tensor, frame_num: 
     d = h.shape[-1]
     h = F.layer_norm(h, (d,), P["encoder.layer_norm.weight"], P["encoder.layer_norm.bias"], EPS)
     for l in range(n_layers):
-        h = encoder_layer(P, f"encoder.layers.{l}.", h)
+        if checkpoint and torch.is_grad_enabled():
+            from torch.utils.checkpoint import checkpoint as _ckpt
+            h = _ckpt(lambda hh, pre=f"encoder.layers.{l}.": encoder_layer(P, pre, hh), h, use_reentrant=False)
+        else:
+            h = encoder_layer(P, f"encoder.layers.{l}.", h)
     return h

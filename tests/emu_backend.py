@@ -138,6 +138,7 @@ class EmuBackend:
 
     # ------------------------------------------------------------------ a2f_mm (bf16-MFMA GEMM family), float64 contract
     mm_precision = 1
+    attn_precision = None
 
     def split_bf16(self, x):
         hi = x.to(torch.bfloat16)
@@ -237,6 +238,17 @@ class EmuBackend:
         flat = x.reshape(-1)[x_off:].double()
         idx = torch.arange(R).view(-1, 1) * ld + torch.arange(Cc).view(1, -1)
         out.copy_(flat[idx].sum(0).float())
+
+    def interp_linear(self, x, N, L_in, C_, L_out, y, backward=False):
+        """a2f_interp_linear_fwd / _bwd: align_corners=True linear interpolation along the row axis of (N, L, C) and its adjoint."""
+        import torch.nn.functional as F
+        if not backward:
+            y.copy_(F.interpolate(x.reshape(N, L_in, C_).double().transpose(1, 2), size=L_out, align_corners=True, mode="linear").transpose(1, 2).float())
+            return
+        with torch.enable_grad():
+            z = torch.zeros(N, L_in, C_, dtype=torch.float64, requires_grad=True)
+            F.interpolate(z.transpose(1, 2), size=L_out, align_corners=True, mode="linear").transpose(1, 2).backward(x.reshape(N, L_out, C_).double())
+        y.copy_(z.grad.float())
 
     def gelu_bwd(self, dy, z, out):
         zd = z.double()

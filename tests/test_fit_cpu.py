@@ -122,8 +122,67 @@ def test_fit_loop_validates_checkpoints_and_reloads_best(emu, tmp_path):
                         patience=5, log=logs.append)
     assert len(hist) == 3 and all("val/err" in h and "train/err" in h for h in hist)
     best = min(range(3), key=lambda i: hist[i]["val/err"])
-    files = os.listdir(tmp_path / "checkpoints")
-    assert files == [f"epoch={best}-step={2 * (best + 1)}.ckpt"]
-    ck = torch.load(tmp_path / "checkpoints" / files[0], weights_only=False)
+    assert F.fit.last_run_dir == str(tmp_path / "version_0")                                              # TensorBoardLogger's layout: one fresh version_N per run
+    files = os.listdir(tmp_path / "version_0" / "checkpoints")
+    assert files == [f"epoch={best}-step={2 * (best + 1)}.ckpt"]                                          # written atomically: no .tmp left behind
+    ck = torch.load(tmp_path / "version_0" / "checkpoints" / files[0], weights_only=False)
     for k, p in model.state_dict().items():
         assert torch.equal(p.cpu(), ck["state_dict"]["model." + k]), k                                      # best checkpoint is what fit() returns
+
+
+def test_fit_second_run_never_reloads_a_stale_checkpoint(emu, tmp_path):
+    """A leftover checkpoint with a larger step= from an earlier run in the same experiment directory must not be what fit() reloads."""
+    cfg = _cfg(lr=1e-3)
+
+    def batch(seed):
+        g = torch.Generator().manual_seed(seed)
+        tv = torch.randn(4, 5023, 3, generator=g) * 0.05
+        oh = torch.zeros(4, 12); oh[torch.arange(4), torch.arange(4) % 8] = 1
+        return {"audio": torch.randn(4, 29, 16, generator=g), "one_hot": oh, "template_vert": tv, "verts": tv + torch.randn(4, 5023, 3, generator=g) * 0.005}
+    os.makedirs(tmp_path / "version_0" / "checkpoints")
+    (tmp_path / "version_0" / "checkpoints" / "epoch=9-step=999999.ckpt").write_bytes(b"not a checkpoint")
+    model, hist = F.fit(cfg, lambda e: (batch(100 + e),), lambda e: (batch(7),), "cpu", str(tmp_path), max_epochs=1, log=lambda *_: None)
+    assert F.fit.last_run_dir == str(tmp_path / "version_1") and len(os.listdir(tmp_path / "version_1" / "checkpoints")) == 1
+
+
+def _fit_rank(rank, world, port, tmp, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from emu_backend import EmuBackend
+    ops.set_backend(EmuBackend())
+    cfg = _cfg(lr=1e-3)
+
+    def batch(seed):
+        g = torch.Generator().manual_seed(seed)
+        tv = torch.randn(4, 5023, 3, generator=g) * 0.05
+        oh = torch.zeros(4, 12); oh[torch.arange(4), torch.arange(4) % 8] = 1
+        return {"audio": torch.randn(4, 29, 16, generator=g), "one_hot": oh, "template_vert": tv, "verts": tv + torch.randn(4, 5023, 3, generator=g) * 0.005}
+    torch.manual_seed(0)
+    # different validation data per rank: without the all-reduce of val/err the ranks would disagree on which epoch is best
+    model, hist = F.fit(cfg, lambda e: (batch(100 + 10 * e + rank),), lambda e: (batch(7 + 50 * rank + e),), "cpu", tmp, max_epochs=3, log=lambda *_: None)
+    q.put((rank, [h["val/err"] for h in hist], [h["saved"] for h in hist], F.fit.last_run_dir,
+           float(sum(p.double().sum() for p in model.parameters()))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fit_under_two_ranks_writes_once_and_agrees(tmp_path):
+    """torchrun-style launch (gloo, world 2): every rank runs fit(); val/err is rank-averaged so decisions agree, rank 0 alone writes
+    (one checkpoint file, no temp files), all ranks reload the same best checkpoint after the barrier."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_fit_rank, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, v0, s0, d0, w0), (_, v1, s1, d1, w1) = res
+    assert v0 == v1 and s0 == s1 and d0 == d1 and w0 == w1
+    files = os.listdir(os.path.join(d0, "checkpoints"))
+    assert len(files) == 1 and files[0].endswith(".ckpt")

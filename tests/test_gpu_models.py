@@ -182,7 +182,7 @@ def test_audio2mesh_golden_g2(mode, trunk, monkeypatch):
             wgrad = dict(m.named_parameters())[k.replace(".bias", ".weight")].grad
             assert float(p.grad.norm()) < 1e-3 * float(wgrad.norm()), k
             continue
-        assert packed_error(g, f"{mode}::grad::{k}", p.grad) < 5e-4, k
+        assert packed_error(g, f"{mode}::grad::{k}", p.grad) < TOL, k
     if mode == "train":
         for k, b in m.named_buffers():
             if b.is_floating_point():
@@ -211,7 +211,7 @@ def test_audio2mesh_fused_training_path_golden_g2():
             wgrad = dict(m.named_parameters())[k.replace(".bias", ".weight")].grad
             assert float(p.grad.norm()) < 1e-3 * float(wgrad.norm()), k
             continue
-        assert packed_error(g, f"train::grad::{k}", p.grad) < 5e-4, k
+        assert packed_error(g, f"train::grad::{k}", p.grad) < TOL, k
 
 
 def test_audio2mesh_audio_sample_windows_g7():
@@ -538,15 +538,92 @@ def test_faceformer_config2_full_size_vs_oracle():
     assert abs(float(loss["loss"].detach()) - float(ol["loss"])) <= 1e-4 * abs(float(ol["loss"]))
     loss["loss"].backward()
     assert rel_l2(a_gpu.grad, a_cpu.grad) < TOL
+    _assert_all_grads(m, E, P)
+
+
+# gradients that are identically zero in exact arithmetic (only rounding noise on both sides): k_proj.bias shifts every score of a
+# query by the same amount (softmax shift invariance); the cross-attention q / k projections see a one-key softmax (identity 3)
+_EXACT_ZERO_GRADS = ("attention.k_proj.bias",)
+
+
+def _assert_all_grads(m, E, P, tol=TOL):
+    """EVERY encoder and decoder-side parameter gradient of the HIP path against the oracle's autograd (E: encoder parameters in HF
+    names, P: decoder-side parameters in the reference's names)."""
+    worst = []
     enc_params = dict(m.audio_encoder.named_parameters())
-    for k in ("feature_extractor.conv_layers.0.conv.weight", "feature_extractor.conv_layers.3.conv.weight",
-              "feature_projection.projection.weight", "encoder.layers.0.attention.q_proj.weight",
-              "encoder.layers.11.feed_forward.output_dense.weight", "encoder.layers.5.final_layer_norm.weight",
-              "encoder.pos_conv_embed.conv.parametrizations.weight.original1"):
-        assert rel_l2(enc_params[k].grad, E[k].grad) < TOL, k
+    for k, v in E.items():
+        if v.grad is None or k.endswith(_EXACT_ZERO_GRADS):
+            continue
+        worst.append((rel_l2(enc_params[k].grad, v.grad), "audio_encoder." + k))
     dec_params = dict(m.named_parameters())
-    for k in ("audio_feature_map.weight", "vertice_map_r.weight", "transformer_decoder.layers.0.self_attn.in_proj_weight"):
-        assert rel_l2(dec_params[k].grad, P[k].grad) < TOL, k
+    for k, v in P.items():
+        if k not in dec_params or not (torch.is_tensor(v) and v.requires_grad) or v.grad is None or float(v.grad.abs().max()) == 0.0:
+            continue
+        worst.append((rel_l2(dec_params[k].grad, v.grad), k))
+    worst.sort(reverse=True)
+    print("gradients compared:", len(worst), "worst:", [(f"{e:.2e}", k) for e, k in worst[:5]])
+    assert len(worst) > 200 if E else len(worst) >= 10
+    bad = [(f"{e:.2e}", k) for e, k in worst if not e < tol]
+    assert not bad, bad
+
+
+def _ff_long_inputs(T, seed):
+    gen = torch.Generator().manual_seed(seed)
+    audio = torch.randn(1, T * 16000 // 60 + 8, generator=gen) * 0.1
+    oh = torch.zeros(1, 12); oh[0, 2] = 1
+    template = torch.randn(1, 5023, 3, generator=gen) * 5
+    gt = template.view(1, 1, 5023, 3) + torch.randn(1, T, 5023, 3, generator=gen) * 0.5
+    return audio, oh, template, gt
+
+
+def test_faceformer_config5_T3000_decoder_gradients_vs_oracle():
+    """BASELINE configs[4]'s length through the blocked backward: T = 3000 = 24 blocks of 128 steps (cross-block dK / dV kernels, prep
+    pass, per-block recurrence launches) with a pinned encoder output - EVERY decoder-side gradient and d loss / d encoder-output
+    against the oracle's autograd through the whole 3000-step recurrence (faceformer.py:154-185)."""
+    from oracle import faceformer as o_ff
+    T = 3000
+    m = _faceformer()
+    dsd = W.formula_state_dict(W.faceformer_decoder_shapes(NV, 12, 64), gains=FF_GAINS)
+    audio, oh, template, gt = _ff_long_inputs(T, 3001)
+    enc = W.formula_input("t3000.enc", (1, T, 768))
+    P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.startswith("PPE") else v) for k, v in dsd.items()}
+    e_cpu = enc.clone().requires_grad_(True)
+    ref = o_ff.decode_incremental(P, e_cpu, oh, template)
+    ol = o_loss.faceformer_loss(ref, gt)
+    ol["loss"].backward()
+    e_gpu = enc.to(DEV).requires_grad_(True)
+    pred, loss = m.forward_with_loss(audio.to(DEV), oh.to(DEV), template.to(DEV), gt.to(DEV), encoder_states=e_gpu)
+    assert rel_l2(pred.detach().cpu() - template.view(1, 1, 5023, 3), ref.detach() - template.view(1, 1, 5023, 3)) < TOL
+    assert abs(float(loss["loss"].detach()) - float(ol["loss"].detach())) <= 1e-4 * abs(float(ol["loss"].detach()))
+    loss["loss"].backward()
+    assert rel_l2(e_gpu.grad, e_cpu.grad) < TOL
+    _assert_all_grads(m, {}, P)
+
+
+def test_faceformer_config5_T3000_full_gradients_vs_oracle():
+    """configs[4] end to end with the real encoder: N = 800 008 samples -> 3000 frames, forward + backward through the decoder's 24
+    blocks, the flash-attention backward over 3000 keys and the whole encoder, in the configuration's parity setting (bf16x3): d loss /
+    d audio and every parameter gradient against the oracle's autograd at the configuration's 1e-3 (the fp32-class path is held to the
+    usual 1e-4)."""
+    from oracle import faceformer as o_ff, wav2vec2 as o_w2v
+    m, esd, dsd = _faceformer_full()
+    T = 3000
+    audio, oh, template, gt = _ff_long_inputs(T, 3002)
+    E = {k: v.clone().requires_grad_(True) for k, v in esd.items()}
+    P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.startswith("PPE") else v) for k, v in dsd.items()}
+    a_cpu = audio.clone().requires_grad_(True)
+    enc = o_w2v.wav2vec2_forward(E, o_w2v.normalize_waveform(a_cpu), T, checkpoint=True)
+    ref = o_ff.decode_incremental(P, enc, oh, template)
+    ol = o_loss.faceformer_loss(ref, gt)
+    ol["loss"].backward()
+    a_gpu = audio.to(DEV).requires_grad_(True)
+    pred, loss = m.forward_with_loss(a_gpu, oh.to(DEV), template.to(DEV), gt.to(DEV))
+    err = rel_l2(pred.detach().cpu() - template.view(1, 1, 5023, 3), ref.detach() - template.view(1, 1, 5023, 3))
+    print("T=3000 parity setting, vertex offsets vs oracle:", err)
+    assert err < TOL
+    loss["loss"].backward()
+    assert rel_l2(a_gpu.grad, a_cpu.grad) < TOL
+    _assert_all_grads(m, E, P)
 
 
 def test_faceformer_config5_T3000_encoder_vs_oracle():
@@ -569,12 +646,16 @@ def test_faceformer_config5_T3000_encoder_vs_oracle():
     assert pred.shape == (1, T, 5023, 3)
     ref_off = torch.nn.functional.linear(y_ref, dsd["vertice_map_r.weight"], dsd["vertice_map_r.bias"])
     assert rel_l2(pred.cpu().view(T, -1) - template.view(1, -1), ref_off) < TOL
-    # the configuration as BASELINE words it - fp8 MFMA attention (bf16 matrix products elsewhere, fp32 decoder / head): what the 3-bit
-    # mantissa costs end to end.  Asserted only as a sanity band; the numbers are recorded in DESIGN 7 (they are far outside 1e-3).
+    # bench.py's configs[4] entry is timed in the library's DEFAULT setting (bf16x3 GEMMs and attention) - the assert above, at 10x inside
+    # the configuration's 1e-3.  The other settings, measured the same way (bench.py carries the fp8 ones as labelled variants):
     from a2f_amd import ops
     be = ops.backend()
+    assert be.mm_precision == 1 and be.attn_precision is None          # what the timed bench entry runs
     errs = {}
-    for name, (mmp, ap) in {"bf16": (0, None), "fp8_attention": (0, 2)}.items():
+    settings = {"bf16_everywhere": (0, None), "bf16x3_gemms_fp8_attention": (1, 2)}
+    if 3 in getattr(be, "attn_precisions", ()):
+        settings["bf16x3_gemms_fp8x3_attention"] = (1, 3)
+    for name, (mmp, ap) in settings.items():
         old = be.mm_precision, be.attn_precision
         be.mm_precision, be.attn_precision = mmp, ap
         try:
@@ -584,7 +665,10 @@ def test_faceformer_config5_T3000_encoder_vs_oracle():
             be.mm_precision, be.attn_precision = old
         errs[name] = rel_l2(p2.cpu().view(T, -1) - template.view(1, -1), ref_off)
     print("T=3000 vertex-offset error vs oracle:", errs)
-    assert errs["bf16"] < 0.2 and errs["bf16"] < errs["fp8_attention"] < 1.0
+    if "bf16x3_gemms_fp8x3_attention" in errs:                       # the fp8 MFMA attention form that is allowed to carry configs[4]
+        assert errs["bf16x3_gemms_fp8x3_attention"] < 1e-3
+    # single-term e4m3 attention is NOT a configs[4] setting: if it ever met the tolerance this test (and bench.py's labelling) must change
+    assert errs["bf16x3_gemms_fp8_attention"] > 1e-3
 
 
 def test_bench_self_launches_two_ranks():
@@ -625,11 +709,66 @@ def test_bench_secondary_lines_small():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["roofline"]["kernel"] == "head_x3_kernel" and out["roofline"]["measured_stream_GBs"]["copy"] > 1000
+    assert out["timing"]["blocks"] >= 1 and len(out["timing"]["ms_per_step_per_block"]) == out["timing"]["blocks"]
     sec = {e["model"]: e for e in out["secondary"]}
-    assert set(sec) == {"faceformer", "audio2mesh", "faceformer_long"}                   # configs[2], Audio2Mesh, configs[4] (fp8 attention)
-    assert "fp8" in sec["faceformer_long"]["dtype"] and "fp8" not in sec["faceformer"]["dtype"]
+    assert set(sec) == {"faceformer", "audio2mesh", "faceformer_long"}                   # configs[2], Audio2Mesh, configs[4]
+    # configs[4] is timed in the setting that meets its tolerance (bf16x3); fp8 attention only appears as labelled variants with their error
+    assert "fp8" not in sec["faceformer_long"]["dtype"] and "fp8" not in sec["faceformer"]["dtype"]
+    assert sec["faceformer_long"]["parity_setting"]["tolerance"] == 1e-3
+    for v in sec["faceformer_long"]["variants"]:
+        assert "fp8" in v["variant"] and v["vertex_offset_rel_l2_vs_parity_setting"] > 0 and v["value"] > 0
+        assert v["meets_1e-3"] == (v["vertex_offset_rel_l2_vs_parity_setting"] <= 1e-3)
+    assert {p["seqs_per_step"] for p in sec["faceformer"]["sequences_per_step_points"]} == {1}       # S = 2 here: only the S = 1 point is below it
     for e in sec.values():
-        assert e["value"] > 0 and e["roofline"]["bound"] == "mfma" and 0 < e["roofline"]["frac"] < 1
+        r = e["roofline"]
+        assert e["value"] > 0 and r["bound"] == "mfma" and r["peak"] == 2500.0 and 0 < r["frac"] < 1
+        assert abs(r["achieved"] - r["executed_per_algorithmic"] * r["algorithmic"]) <= 0.02 * r["achieved"] + 0.02
+    k = sec["faceformer"]["roofline"]["kernel"]
+    assert k["name"].startswith("gemm_mfma_kernel") and k["launches_timed"] > 0 and 0 < k["frac"] < 1
+
+
+def test_bench_roofline_fractions_stay_below_one_at_the_default_shapes():
+    """The formula of the FaceFormer / Audio2Mesh roofline entries at the DEFAULT shapes' measured rates (round 2's driver line: 247.5 k
+    frames/s at 64 x 600, 126 k at B = 1024): executed flops against the bf16 peak, never above 1 (round 2 printed 1.35 against the fp32 peak)."""
+    for fps, mflop, mult in ((247548.8, 857.0, 3.0), (126000.0, 393.0, 6.0), (400000.0, 857.0, 3.0)):
+        alg = fps * mflop * 1e6 / 1e12
+        assert 0 < mult * alg / 2500.0 < 1
+
+
+def test_mixed_precision_backward_runs_in_the_forward_precision():
+    """`percision: 16-mixed` (encoder_autocast): the encoder's backward nodes run in the precision their forward ran in (plain bf16), although
+    Faceformer.encode restores the backend's setting right after the forward: gradients equal, bit for bit, those of a step whose whole
+    forward + backward ran under mm_precision = 0 - and differ from the bf16-forward / bf16x3-backward mixture round 2 computed."""
+    from a2f_amd import ops
+    be = ops.backend()
+    torch.manual_seed(0)
+    m = a2f_amd.Faceformer(n_verts=NV, n_onehot=12).to(DEV).eval()
+    with torch.no_grad():
+        m.vertice_map_r.weight.normal_(0, 0.1); m.vertice_map.weight.normal_(0, 0.001)
+    T = 40
+    audio = torch.randn(2, T * 16000 // 60 + 8, device=DEV) * 0.1
+
+    def grads(autocast, held):
+        m.zero_grad()
+        m.encoder_autocast = autocast
+        old = be.mm_precision
+        if held is not None:
+            be.mm_precision = held
+        try:
+            h = m.encode(audio, T)
+            if held is None:
+                assert be.mm_precision == old                      # encode restored the setting before the backward runs
+            (h * torch.linspace(-1, 1, h.numel(), device=DEV).view_as(h)).sum().backward()
+        finally:
+            be.mm_precision = old
+            m.encoder_autocast = None
+        return [p.grad.clone() for p in m.audio_encoder.parameters() if p.grad is not None]
+
+    g_auto = grads(torch.bfloat16, None)
+    g_held = grads(None, 0)
+    g_split = grads(None, None)
+    assert all(torch.equal(a, b) for a, b in zip(g_auto, g_held))
+    assert any(not torch.equal(a, b) for a, b in zip(g_auto, g_split))
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -680,9 +819,9 @@ def test_fit_loop_on_gpu_voca_and_faceformer(tmp_path):
         va = lambda e: (synthetic_batch(cfg, cfg.batch_size, DEV, 7, frames=30),)
         model, hist = F.fit(cfg, tr, va, DEV, str(tmp_path / name), max_epochs=epochs, log=lambda *_: None)
         assert len(hist) == epochs and all(h["val/err"] == h["val/err"] and h["val/err"] > 0 for h in hist)
-        files = os.listdir(tmp_path / name / "checkpoints")
+        files = os.listdir(tmp_path / name / "version_0" / "checkpoints")
         assert len(files) == 1 and files[0].startswith("epoch=")
-        ck = torch.load(tmp_path / name / "checkpoints" / files[0], weights_only=False)
+        ck = torch.load(tmp_path / name / "version_0" / "checkpoints" / files[0], weights_only=False)
         assert ck["hyper_parameters"]["config"].modelname == name and all(k.startswith("model.") for k in ck["state_dict"])
 
 

@@ -191,7 +191,9 @@ def test_faceformer_fused_loss_path_odd_T(emu):
 
 
 def test_wav2vec2_module_matches_hf_golden():
-    """The self-contained encoder (HF-compatible keys) reproduces HF Wav2Vec2Model outputs (G6); pure torch ops, CPU ok."""
+    """The self-contained encoder module (HF-compatible keys), evaluated by the test-side torch-ops restatement, reproduces HF
+    Wav2Vec2Model outputs (G6): pins the module's parameter layout and the restatement the emulator tests compare against."""
+    import torch_ops_encoder
     from a2f_amd.model.wav2vec import Wav2Vec2Model, normalize_waveform
     g = load("g6_wav2vec2")
     m = Wav2Vec2Model().eval()
@@ -199,8 +201,17 @@ def test_wav2vec2_module_matches_hf_golden():
     T = 60
     audio = W.formula_input(f"g6.audio{T}", (1, T * 16000 // 60 + 3), 0.1) + 0.01
     with torch.no_grad():
-        out = m(normalize_waveform(audio), "vocaset", frame_num=T).last_hidden_state
+        out = torch_ops_encoder.forward(m, normalize_waveform(audio), "vocaset", frame_num=T).last_hidden_state
     assert packed_error(g, f"T{T}::last_hidden_state", out) < 2e-5
+
+
+def test_wav2vec2_module_has_no_cpu_path():
+    """The product module has one forward - the HIP path: with the real backend, off-device tensors fail loudly."""
+    from a2f_amd.model.wav2vec import Wav2Vec2Model
+    m = Wav2Vec2Model(layers=1).eval()
+    with pytest.raises(Exception) as ei:
+        m(torch.zeros(1, 4000), "vocaset", frame_num=10)
+    assert "HIP" in str(ei.value) or "liba2f_hip" in str(ei.value) or "a2f" in str(ei.value).lower()
 
 
 def test_faceformer_end_to_end_golden_g8(emu):

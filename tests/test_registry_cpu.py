@@ -132,10 +132,13 @@ def test_mfcc_top_db_floor_is_batch_wide():
 def test_wav2vec_extractor_matches_hf_golden_g12():
     """N2: Wav2VecExtractor (extractor.py:63-96) after the resampler against fixture G12 = the installed HF processor + HF
     Wav2Vec2Model + the reference's resize, formula weights: the joint (batch, time) normalisation quirk, the plain 49 Hz
-    forward, transpose and bilinear resize."""
+    forward, transpose and bilinear resize.  The encoder inside runs the product's only path - the hand-written one - over the float64
+    emulator of the C ABI (the GPU run of the same fixture: tests/test_gpu_models.py::test_wav2vec_extractor_on_gpu_g12)."""
     import numpy as np
     import torch
+    from a2f_amd import ops
     from a2f_amd.extractor import Wav2VecExtractor, get_extractor
+    from emu_backend import EmuBackend
     from golden_util import load, packed_error
     from oracle import weights as W
     g = load("g12_wav2vec_extractor")
@@ -146,8 +149,12 @@ def test_wav2vec_extractor_matches_hf_golden_g12():
         ex.model.load_state_dict(W.formula_state_dict(W.wav2vec2_shapes(), gains={"original0": 40.0}))
         assert not any(p.requires_grad for p in ex.model.feature_extractor.parameters())          # freeze_feature_encoder
         x = W.formula_input(f"g12.audio.{name}", (B, n), 0.1) + 0.02 * torch.arange(B).view(B, 1)
-        with torch.no_grad():
-            y = ex(x)
+        old = ops.set_backend(EmuBackend())
+        try:
+            with torch.no_grad():
+                y = ex(x)
+        finally:
+            ops.set_backend(old)
         assert tuple(y.shape) == (B, out_dim, n_feature)
         assert packed_error(g, f"{name}::features", y) < 2e-5
 

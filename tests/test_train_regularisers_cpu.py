@@ -100,7 +100,8 @@ def test_philox_restatement_known_answers():
 def test_torch_ops_train_mode_matches_reference_g13():
     """The torch-ops restatement of the wrapper in train mode, fed the reference's recorded masks."""
     g, m, wave, S, T = g13_model_and_input()
-    hs = m(wave, "vocaset", frame_num=T).last_hidden_state
+    import torch_ops_encoder
+    hs = torch_ops_encoder.forward(m, wave, "vocaset", frame_num=T).last_hidden_state
     check_against_g13(g, m, hs, T, 2e-5, 1e-4)
 
 

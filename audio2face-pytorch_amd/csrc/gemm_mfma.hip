@@ -17,209 +17,10 @@
 //     per k-tile); a wave owns a 64 x 64 (32 x 64) block of C = 2 x 2 (1 x 2) accumulator tiles, so a 16-deep k-step is
 //     8 (6) fragment reads for 12 (6) MFMAs in bf16x3;
 //   * split-K slabs + fixed-order fold for weight gradients (K = rows of the batch), batch index for grouped convolutions.
-#include "a2f_common.h"
-#include <stdlib.h>
+#include "gemm_mfma.h"
 
 namespace a2f {
 namespace mm {
-
-using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
-using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
-using f32x2_t = __attribute__((ext_vector_type(2))) float;
-using u32x2_t = __attribute__((ext_vector_type(2))) unsigned;
-using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
-using i16x4_t = __attribute__((ext_vector_type(4))) short;
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-
-constexpr int BK = 32;
-#ifndef MM_TPAD
-#define MM_TPAD 64            // bytes of padding per row of a [k][lines] image (64: transposing reads conflict-free)
-#endif
-constexpr int THREADS = 256;           // CFG 0 / 1; CFG 2 runs 512 threads (see gemm_mfma_kernel)
-
-struct Op {
-  const float* p;
-  const void* p_lo;      // bf16 image operands (format 1): p = hi image, p_lo = lo image, `bytes` = size of ONE image, ld in bf16 elements
-  unsigned bytes;
-  int ld, lps, off, seq_elems;
-  int lps_shift;         // log2(lps) when lps is a power of two, else -1 (short sequences: division -> shift)
-  long long seq_stride;
-  long long bstride;
-};
-
-struct Args {
-  Op A, B;
-  float* C;
-  float* C2;
-  const float* bias;
-  const float* aux;
-  float* ws;
-  long long ldc, c_seq_stride, c_bstride, bias_bstride, ldaux, aux_bstride;
-  int c_rps;
-  int M, N, K;
-  int act, aux_mode, accumulate, split_k, batch;
-  float alpha;
-  float* a_rowsum;               // optional (A trans, plain operands, batch 1): a_rowsum[m] = sum_k A(m, k) - the bias gradient of a weight-gradient product
-  const unsigned* keep;          // dropout keep bits of C (csrc/dropout.hip: word (m, n >> 5), bit n & 31), applied after the activation
-  long long keep_wpr;
-  float keep_scale;
-};
-
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
-}
-
-// one output element through the epilogue (shared by the GEMM kernel and the split-K fold)
-__device__ __forceinline__ void epilogue_store(const Args& a, int bz, int m, int n, long long crow, float v) {
-  v *= a.alpha;
-  if (a.bias) v += a.bias[bz * a.bias_bstride + n];
-  const long long ci = bz * a.c_bstride + crow + n;
-  if (a.act == 4) {                        // GELU with its derivative saved for the backward (C2 = gelu'(v) instead of v)
-    const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
-    if (a.C2) a.C2[ci] = cdf + v * 0.3989422804014327f * __expf(-0.5f * v * v);
-    v *= cdf;
-  } else {
-    if (a.C2) a.C2[ci] = v;
-    if (a.act == 1) v = fmaxf(v, 0.f);
-    else if (a.act == 3) v = gelu_f(v);
-  }
-  if (a.keep) v = ((a.keep[(long long)m * a.keep_wpr + (n >> 5)] >> (n & 31)) & 1u) ? v * a.keep_scale : 0.f;
-  if (a.aux_mode == 4) {
-    v *= a.aux[ci];                        // aux laid out like C (same row map): a saved activation derivative
-  } else if (a.aux_mode) {
-    const float x = a.aux[bz * a.aux_bstride + (long long)m * a.ldaux + n];
-    if (a.aux_mode == 1) v += x;
-    else if (a.aux_mode == 2) v *= gelu_grad_f(x);
-    else v *= (x > 0.f ? 1.f : 0.f);
-  }
-  if (a.accumulate) v += a.C[ci];
-  a.C[ci] = v;
-}
-
-__device__ __forceinline__ long long c_row_offset(const Args& a, int m) {
-  if (a.c_rps <= 0) return (long long)m * a.ldc;
-  return (long long)(m / a.c_rps) * a.c_seq_stride + (long long)(m % a.c_rps) * a.ldc;
-}
-
-// NB: bit-cast the WHOLE vector first.  __builtin_bit_cast(float, raw.y) on a vector-element lvalue reads element 0 with
-// hipcc 7.2 (all four values came out as raw.x).
-__device__ __forceinline__ void split4(const u32x4_t raw, u32x2_t& hi, u32x2_t& lo) {
-  const f32x4 f = __builtin_bit_cast(f32x4, raw);
-  const f32x2_t v0 = {f.x, f.y};
-  const f32x2_t v1 = {f.z, f.w};
-  const bf16x2_t h0 = __builtin_convertvector(v0, bf16x2_t);
-  const bf16x2_t h1 = __builtin_convertvector(v1, bf16x2_t);
-  const f32x2_t r0 = v0 - __builtin_convertvector(h0, f32x2_t);
-  const f32x2_t r1 = v1 - __builtin_convertvector(h1, f32x2_t);
-  hi.x = __builtin_bit_cast(unsigned, h0);
-  hi.y = __builtin_bit_cast(unsigned, h1);
-  lo.x = __builtin_bit_cast(unsigned, __builtin_convertvector(r0, bf16x2_t));
-  lo.y = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
-}
-// x = hi + mid + lo (three bf16 pieces = 24 significand bits: every fp32 value is represented exactly unless it underflows)
-__device__ __forceinline__ void split4x3(const u32x4_t raw, u32x2_t& hi, u32x2_t& mid, u32x2_t& lo) {
-  const f32x4 f = __builtin_bit_cast(f32x4, raw);
-  const f32x2_t v0 = {f.x, f.y};
-  const f32x2_t v1 = {f.z, f.w};
-  const bf16x2_t h0 = __builtin_convertvector(v0, bf16x2_t);
-  const bf16x2_t h1 = __builtin_convertvector(v1, bf16x2_t);
-  const f32x2_t r0 = v0 - __builtin_convertvector(h0, f32x2_t);
-  const f32x2_t r1 = v1 - __builtin_convertvector(h1, f32x2_t);
-  const bf16x2_t m0 = __builtin_convertvector(r0, bf16x2_t);
-  const bf16x2_t m1 = __builtin_convertvector(r1, bf16x2_t);
-  const f32x2_t q0 = r0 - __builtin_convertvector(m0, f32x2_t);
-  const f32x2_t q1 = r1 - __builtin_convertvector(m1, f32x2_t);
-  hi.x = __builtin_bit_cast(unsigned, h0);
-  hi.y = __builtin_bit_cast(unsigned, h1);
-  mid.x = __builtin_bit_cast(unsigned, m0);
-  mid.y = __builtin_bit_cast(unsigned, m1);
-  lo.x = __builtin_bit_cast(unsigned, __builtin_convertvector(q0, bf16x2_t));
-  lo.y = __builtin_bit_cast(unsigned, __builtin_convertvector(q1, bf16x2_t));
-}
-__device__ __forceinline__ u32x2_t cvt4(const u32x4_t raw) {
-  const f32x4 f = __builtin_bit_cast(f32x4, raw);
-  const f32x2_t v0 = {f.x, f.y};
-  const f32x2_t v1 = {f.z, f.w};
-  u32x2_t r;
-  r.x = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, bf16x2_t));
-  r.y = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, bf16x2_t));
-  return r;
-}
-__device__ __forceinline__ u32x2_t tr_read(const char* lds_addr) {
-  return __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4_t*)(lds_addr)));
-}
-__device__ __forceinline__ f32x16 mfma(u32x4_t a, u32x4_t b, f32x16 c) {
-#ifdef MM_ABL_NOMFMA        // timing ablation only: operands stay live, no matrix instruction
-  asm volatile("" ::"v"(a), "v"(b));
-  return c;
-#else
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-#endif
-}
-
-// ---- epilogue of one workgroup tile: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-template <int TM, int TN>
-__device__ __forceinline__ void tile_epilogue(const Args& a, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int lane, int bz) {
-  const int h = lane >> 5;
-  int ncol[TN];
-  float bv[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    ncol[j] = n0 + (wn * TN + j) * 32 + (lane & 31);
-    bv[j] = (a.bias && a.split_k <= 1 && ncol[j] < a.N) ? a.bias[bz * a.bias_bstride + ncol[j]] : 0.f;
-  }
-  const bool generic = a.C2 || a.act || a.aux_mode || a.accumulate || a.keep;     // wave-uniform
-  if (a.split_k > 1) {
-    float* wsz = a.ws + (long long)blockIdx.z * a.M * a.N;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          if (m < a.M && ncol[j] < a.N) wsz[(long long)m * a.N + ncol[j]] = acc[i][j][r];
-      }
-  } else {
-    float* Cz = a.C + bz * a.c_bstride;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= a.M) continue;
-        const long long crow = c_row_offset(a, m);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if (ncol[j] >= a.N) continue;
-          float v = acc[i][j][r] * a.alpha + bv[j];
-          if (generic) {
-            if (a.act == 4) {
-              const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
-              if (a.C2) a.C2[bz * a.c_bstride + crow + ncol[j]] = cdf + v * 0.3989422804014327f * __expf(-0.5f * v * v);
-              v *= cdf;
-            } else {
-              if (a.C2) a.C2[bz * a.c_bstride + crow + ncol[j]] = v;
-              if (a.act == 1) v = fmaxf(v, 0.f);
-              else if (a.act == 3) v = gelu_f(v);
-            }
-            if (a.keep) v = ((a.keep[(long long)m * a.keep_wpr + (ncol[j] >> 5)] >> (ncol[j] & 31)) & 1u) ? v * a.keep_scale : 0.f;
-            if (a.aux_mode == 4) {
-              v *= a.aux[bz * a.c_bstride + crow + ncol[j]];
-            } else if (a.aux_mode) {
-              const float x = a.aux[bz * a.aux_bstride + (long long)m * a.ldaux + ncol[j]];
-              if (a.aux_mode == 1) v += x;
-              else if (a.aux_mode == 2) v *= gelu_grad_f(x);
-              else v *= (x > 0.f ? 1.f : 0.f);
-            }
-            if (a.accumulate) v += Cz[crow + ncol[j]];
-          }
-          Cz[crow + ncol[j]] = v;
-        }
-      }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // One operand's staging: X = number of lines (R) or contiguous extent (T) a tile spans (BM for A, BN for B).
@@ -633,232 +434,6 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, PREC == 2 ? (CFG == 3 ? 2 : 1) : Cfg<
   tile_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, lane, bz);
 }
 
-// =====================================================================================================================
-// Operands that ARRIVE as bf16 hi / lo images (a2f_mm_operand.format 1; produced by a2f_split_bf16 or by a producing kernel's
-// epilogue): nothing is converted here and nothing passes through registers - the k-tile is copied global -> LDS by the LDS-DMA
-// form of the buffer load (buffer_load_dwordx4 ... lds: a wave instruction fills 1 KB of LDS, lane l at + 16 l), which removes
-// the 40 conversion instructions, the eight ds_writes and the 16 staging registers per thread and k-tile of the fp32 path
-// (its measured price: 30-45 % of the kernel).  An LDS-DMA cannot scatter, so the swizzles live on the SOURCE side:
-//   R image (k contiguous), tile [X lines][32 k] in 64-byte rows: LDS slot (line, s) holds source chunk s ^ ((line >> 2) & 3) - the
-//     layout the fp32 path writes, read back by the same one-ds_read_b128 fragment;
-//   T image (lines contiguous), tile [32 k][X lines] with UNPADDED rows of 2 X bytes (a padded row would put lanes into the pad): the
-//     64-byte blocks of row k are XORed with (k & 3), so the four k-rows a transposing read touches per lane group land in four
-//     different bank quarters (conflict-free, checked exhaustively off line like the other layouts).
-// Plain operands only (no windows), K a multiple of 32; one barrier per k-tile: wait for the own DMA of tile t, barrier (everybody's
-// tile t is in LDS and everybody is done reading tile t - 1), issue the DMA of tile t + 1 into the other stage, multiply tile t.
-// =====================================================================================================================
-template <bool T, int X, int TH>
-struct StageImg {
-  static constexpr int IMG = X * 64;                          // bytes of one bf16 image tile (R: X x 64 B; T: 32 x 2 X B)
-  static constexpr int NI = IMG / (TH * 16);                  // DMA instructions per thread and image
-  static constexpr int PITCH = T ? 2 * X : 64;
-  static_assert(NI >= 1 && IMG % (TH * 16) == 0, "image tile must be a whole number of 1-KB wave pieces per wave");
-  unsigned voff[NI];                                          // byte offset of this lane's 16-byte chunk from the k-tile's base
-  int piece[NI];                                              // wave-uniform byte offset of the 1-KB piece inside the image
-
-  __device__ __forceinline__ void init(const Op& op, int x0, int xcount, int t) {
-    const int wave = t >> 6, p = t & 63;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int pc = wave + (TH / 64) * i;
-      piece[i] = __builtin_amdgcn_readfirstlane(pc * 1024);
-      if constexpr (!T) {
-        const int line = pc * 16 + (p >> 2), slot = p & 3;
-        const int c = slot ^ ((line >> 2) & 3);
-        const int gl = x0 + line;
-        voff[i] = gl < xcount ? ((unsigned)gl * (unsigned)op.ld + (unsigned)(c * 8)) * 2u : 0xFFFFFFFFu;
-      } else {
-        constexpr int CPR = 2 * X / 16;                       // 16-byte chunks per k-row
-        const int krow = pc * (64 / CPR) + p / CPR, slot = p % CPR;
-        const int c16 = ((((slot >> 2) ^ (krow & 3)) << 2) | (slot & 3));
-        const int col = x0 + c16 * 8;
-        voff[i] = col < xcount ? ((unsigned)krow * (unsigned)op.ld + (unsigned)col) * 2u : 0xFFFFFFFFu;
-      }
-    }
-  }
-  // buffer resources of the hi / lo images for the k-tile starting at k0 (size 0 past the k-range: such a tile reads as zeros)
-  __device__ __forceinline__ static rsrc_t tile_rsrc(const void* img, const Op& op, int k0, int kend) {
-    const long long adv = (T ? (long long)k0 * op.ld : (long long)k0) * 2;             // bytes; wave-uniform
-    const unsigned left = k0 < kend ? op.bytes - (unsigned)adv : 0u;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(img) + adv), 0, (int)left, 0x00020000);
-  }
-  template <int PREC>
-  __device__ __forceinline__ void issue(const Op& op, int k0, int kend, char* stage) const {
-#if defined(__HIP_DEVICE_COMPILE__)          // the LDS address-space cast only parses in the device pass
-    const rsrc_t rh = tile_rsrc(op.p, op, k0, kend);
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (__attribute__((address_space(3))) void*)(stage + piece[i]), 16, voff[i], 0, 0, 0);
-    if constexpr (PREC == 1) {
-      const rsrc_t rl = tile_rsrc(op.p_lo, op, k0, kend);
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (__attribute__((address_space(3))) void*)(stage + IMG + piece[i]), 16, voff[i], 0, 0, 0);
-    }
-#endif
-  }
-  __device__ __forceinline__ static u32x4_t frag(const char* img, int rb, int ks, int lane) {
-    if constexpr (!T) {
-      const int line = rb + (lane & 31);
-      const int chunk = ks * 2 + (lane >> 5);
-      return *reinterpret_cast<const u32x4_t*>(img + line * 64 + ((chunk ^ ((line >> 2) & 3)) << 4));
-    } else {
-      const int g = lane >> 4, i = lane & 15;
-      const int krow = ks * 16 + 8 * (g >> 1) + (i >> 2);
-      const int byte = (rb + 16 * (g & 1) + 4 * (i & 3)) * 2;
-      const char* p = img + krow * PITCH + ((((byte >> 6) ^ (krow & 3)) << 6) | (byte & 63));
-      const u32x2_t r0 = tr_read(p);
-      const u32x2_t r1 = tr_read(p + 4 * PITCH);              // (krow + 4) & 3 == krow & 3: same block permutation
-      return u32x4_t{r0.x, r0.y, r1.x, r1.y};
-    }
-  }
-};
-
-// 128 x 128 tile; W4 = false: 8 waves of 32 x 64 (the CFG 3 geometry, four waves per SIMD); W4 = true: 4 waves of 64 x 64 (two waves per SIMD,
-// twice the MFMAs per fragment read and per barrier)
-template <bool AT, bool BT, int PREC, int MODE>
-__global__ __launch_bounds__(MODE == 1 ? 256 : 512, MODE == 0 ? 4 : 2) void gemm_img_kernel(const Args a) {
-  constexpr bool W4 = MODE == 1;
-  constexpr bool ST3 = MODE == 2;        // three LDS stages, one workgroup per CU: the DMA of tile t + 2 is in flight across the barrier of tile t + 1
-  constexpr int BM = 128, BN = 128, TH = W4 ? 256 : 512, WGN = 2, TM = W4 ? 2 : 1, TN = 2;
-  constexpr int NIMG = PREC == 1 ? 2 : 1;
-  using SA = StageImg<AT, BM, TH>;
-  using SB = StageImg<BT, BN, TH>;
-  constexpr int A_BYTES = NIMG * SA::IMG, B_BYTES = NIMG * SB::IMG, STAGE = A_BYTES + B_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave / WGN, wn = wave % WGN;
-  const int tiles_n = (a.N + BN - 1) / BN;
-  int m0, n0;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
-    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-    const int tm = wgid / tiles_n;
-    m0 = tm * BM;
-    n0 = (wgid - tm * tiles_n) * BN;
-  }
-  const int bz = 0;
-  const int sk = __builtin_amdgcn_readfirstlane((int)blockIdx.z);
-  int kbeg = 0, kend = a.K;
-  if (a.split_k > 1) {
-    const int ktiles = (a.K + BK - 1) / BK;
-    const int per = (ktiles + a.split_k - 1) / a.split_k;
-    kbeg = sk * per * BK;
-    kend = min(a.K, kbeg + per * BK);
-  }
-  const int nkt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
-  SA sa;
-  SB sb;
-  sa.init(a.A, m0, a.M, t);
-  sb.init(a.B, n0, a.N, t);
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  sa.template issue<PREC>(a.A, kbeg, kend, smem);
-  sb.template issue<PREC>(a.B, kbeg, kend, smem + A_BYTES);
-  if constexpr (ST3) {                                          // second tile in flight before the loop (zeros / no traffic past the k-range)
-    sa.template issue<PREC>(a.A, kbeg + BK, kend, smem + STAGE);
-    sb.template issue<PREC>(a.B, kbeg + BK, kend, smem + STAGE + A_BYTES);
-  }
-  int st_cur = 0;                                               // ST3: stage of tile kt
-  for (int kt = 0; kt < nkt; ++kt) {
-    const char* cur;
-    if constexpr (ST3) {
-      // tile kt has landed when at most the instructions of tile kt + 1 are outstanding (counted wait: never 0 inside the loop);
-      // the raw barrier then publishes it - and says everybody is done reading tile kt - 1, whose stage the next DMA overwrites
-      constexpr int PER_TILE = (SA::NI + SB::NI) * NIMG;
-      if constexpr (PER_TILE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if constexpr (PER_TILE == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      int st_nxt = st_cur + 2; st_nxt = st_nxt >= 3 ? st_nxt - 3 : st_nxt;
-      sa.template issue<PREC>(a.A, kbeg + (kt + 2) * BK, kend, smem + st_nxt * STAGE);
-      sb.template issue<PREC>(a.B, kbeg + (kt + 2) * BK, kend, smem + st_nxt * STAGE + A_BYTES);
-      cur = smem + st_cur * STAGE;
-      st_cur = st_cur == 2 ? 0 : st_cur + 1;
-    } else {
-      __syncthreads();                                          // the compiler drains the DMA (vmcnt 0) in front of the barrier
-      if (kt + 1 < nkt) {
-        char* nst = smem + ((kt + 1) & 1) * STAGE;
-        sa.template issue<PREC>(a.A, kbeg + (kt + 1) * BK, kend, nst);
-        sb.template issue<PREC>(a.B, kbeg + (kt + 1) * BK, kend, nst + A_BYTES);
-      }
-      cur = smem + (kt & 1) * STAGE;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      u32x4_t fa[NIMG][TM], fb[NIMG][TN];
-#pragma unroll
-      for (int q = 0; q < NIMG; ++q) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[q][i] = SA::frag(cur + q * SA::IMG, (wm * TM + i) * 32, ks, lane);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[q][j] = SB::frag(cur + A_BYTES + q * SB::IMG, (wn * TN + j) * 32, ks, lane);
-      }
-      if constexpr (PREC == 1) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = mfma(fa[1][i], fb[0][j], acc[i][j]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = mfma(fa[0][i], fb[1][j], acc[i][j]);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma(fa[0][i], fb[0][j], acc[i][j]);
-    }
-  }
-  tile_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, lane, bz);
-}
-
-template <bool AT, bool BT, int PREC, int MODE>
-static int launch_img(const Args& a, hipStream_t st) {
-  constexpr int NIMG = PREC == 1 ? 2 : 1;
-  constexpr int TH = MODE == 1 ? 256 : 512;
-  constexpr int smem = (MODE == 2 ? 3 : 2) * NIMG * (StageImg<AT, 128, TH>::IMG + StageImg<BT, 128, TH>::IMG);
-  auto kern = gemm_img_kernel<AT, BT, PREC, MODE>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-      return set_err(A2F_ELAUNCH, "a2f_mm: cannot reserve %d bytes of LDS", smem);
-    attr_done = true;
-  }
-  dim3 grid((unsigned)(cdiv(a.N, 128) * cdiv(a.M, 128)), 1, (unsigned)a.split_k);
-  hipLaunchKernelGGL(kern, grid, dim3(TH), smem, st, a);
-  return A2F_OK;
-}
-
-template <int PREC>
-static int dispatch_img(const Args& a, bool at, bool bt, hipStream_t st) {
-  static const int mode = [] { const char* e = getenv("A2F_MM_IMG_MODE"); return e ? e[0] - '0' : 0; }();    // A-B hook: 0 | 1 | 2
-  if (mode == 1) {
-    if (!at && !bt) return launch_img<false, false, PREC, 1>(a, st);
-    if (!at && bt) return launch_img<false, true, PREC, 1>(a, st);
-    if (at && bt) return launch_img<true, true, PREC, 1>(a, st);
-    return launch_img<true, false, PREC, 1>(a, st);
-  }
-  if (mode == 2) {
-    if (!at && !bt) return launch_img<false, false, PREC, 2>(a, st);
-    if (!at && bt) return launch_img<false, true, PREC, 2>(a, st);
-    if (at && bt) return launch_img<true, true, PREC, 2>(a, st);
-    return launch_img<true, false, PREC, 2>(a, st);
-  }
-  if (!at && !bt) return launch_img<false, false, PREC, 0>(a, st);
-  if (!at && bt) return launch_img<false, true, PREC, 0>(a, st);
-  if (at && bt) return launch_img<true, true, PREC, 0>(a, st);
-  return launch_img<true, false, PREC, 0>(a, st);
-}
-
 __global__ __launch_bounds__(256) void gemm_mfma_fold_kernel(const Args a) {
   const long long total = (long long)a.batch * a.M * a.N;
   const long long mn = (long long)a.M * a.N;
@@ -1014,7 +589,7 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   if (d->A.format == 1) {
     A2F_CHECK_ARG(batch == 1 && d->K % BK == 0 && d->a_rowsum == nullptr && d->precision != 2, "a2f_mm: image operands need batch 1, K a multiple of %d, no a_rowsum, precision 0 | 1", BK);
     A2F_CHECK_ARG(d->precision == 0 || (d->A.p_lo && d->B.p_lo), "a2f_mm: image operands: precision 1 needs the lo images");
-    rc = d->precision == 1 ? dispatch_img<1>(a, at, bt, st) : dispatch_img<0>(a, at, bt, st);
+    rc = dispatch_img_precision(a, d->precision, at, bt, st);
     if (rc) return rc;
     A2F_CHECK_LAUNCH("a2f_mm (images)");
     if (split > 1) {

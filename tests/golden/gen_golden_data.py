@@ -89,5 +89,34 @@ with tempfile.TemporaryDirectory() as d_ref, tempfile.TemporaryDirectory() as d_
     assert len(fr) == len(fq) and all(np.array_equal(x["audio"], y["audio"]) for x, y in zip(fr, fq))
     out["framedatas::count"] = np.int64(len(fr))
     out["framedatas::audio0"] = fr[0]["audio"]
+    # whole clips (split_frame=False, the FaceFormer branch: vocaset.py:271-289).  The 22 kHz -> 16 kHz step is torchaudio's (absent here:
+    # PARITY UNPINNED, a2f_amd.data.resample_sinc_hann restates it) - both sides get the SAME stand-in resampler, so that everything around
+    # it is pinned: the unique (subject, sentence) list, int16 normalisation BEFORE the resampler, the call's (22000, 16000) arguments, the
+    # float32 cast, and the stack of every mesh of the sentence in wav_seq_to_idx order.
+    import torch                                   # noqa: E402
+
+    def stand_in_resample(wav, orig, new):
+        assert (orig, new) == (22000, 16000) and wav.dtype == torch.float32
+        n = -(-wav.shape[-1] * new // orig)
+        return wav[..., (torch.arange(n) * orig) // new] * 0.5 + 0.25
+
+    sys.modules["torchaudio"].functional = sys.modules["torchaudio.functional"]
+    sys.modules["torchaudio.functional"].resample = stand_in_resample
+    ref.torchaudio = sys.modules["torchaudio"]
+    mine_vs.resample_sinc_hann = stand_in_resample
+    for phase in ("train", "test"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = ref.ClipVocaSet(d_ref, phase=phase, split_frame=False)
+        q = mine_vs.ClipVocaSet(d_mine, phase=phase, split_frame=False)
+        keys = sorted(tuple(x) for x in r.datalist)
+        assert keys == sorted(tuple(x) for x in q.datalist) and len(set(keys)) == len(keys), phase      # the reference keeps set order: compared as sets
+        out[f"clips::{phase}::keys"] = np.array(["|".join(k) for k in keys])
+        for key in (keys[0], keys[len(keys) // 2], keys[-1]):
+            a, b = r[[tuple(x) for x in r.datalist].index(key)], q[[tuple(x) for x in q.datalist].index(key)]
+            for k in ("audio", "verts", "template_vert", "one_hot"):
+                assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), (phase, key, k)
+                out[f"clips::{phase}::{'|'.join(key)}::{k}"] = a[k]
+        fr, fq = r.get_framedatas(*keys[0]), q.get_framedatas(*keys[0])
+        assert len(fr) == len(fq) == 1 and np.array_equal(fr[0]["audio"], fq[0]["audio"]) and np.array_equal(fr[0]["verts"], fq[0]["verts"])
 np.savez_compressed(os.path.join(HERE, "g11_vocaset_loader.npz"), **out)
 print("wrote g11_vocaset_loader.npz:", len(out), "arrays,", sum(v.nbytes for v in out.values()) // 1024, "KiB raw")

@@ -32,6 +32,37 @@ def test_split_lists_and_items_match_reference_g11(tmp_path):
     assert any(h in V.VALIDATION_SUBJECTS and s == "sentence01" for h, s, *_ in test.datalist)
 
 
+def test_whole_clip_items_match_reference_g11(tmp_path, monkeypatch):
+    """split_frame=False (the FaceFormer branch, vocaset.py:271-289) against the reference's own ClipVocaSet: unique (subject, sentence)
+    list, int16 normalisation before the resampler, the (22000, 16000) call, float32 cast, every mesh of the sentence stacked in
+    wav_seq_to_idx order.  The resampler itself is torchaudio's (absent: PARITY UNPINNED) - the generator gave the reference the same
+    stand-in that is patched in here, so the fixture pins everything around it."""
+    g = load("g11_vocaset_loader")
+
+    def stand_in_resample(wav, orig, new):
+        assert (orig, new) == (22000, 16000) and wav.dtype == torch.float32
+        n = -(-wav.shape[-1] * new // orig)
+        return wav[..., (torch.arange(n) * orig) // new] * 0.5 + 0.25
+
+    monkeypatch.setattr(V, "resample_sinc_hann", stand_in_resample)
+    d = vocaset_synth.build(str(tmp_path / "voca"))
+    for phase in ("train", "test"):
+        ds = V.ClipVocaSet(d, phase=phase, split_frame=False)
+        keys = sorted(tuple(x) for x in ds.datalist)
+        assert ["|".join(k) for k in keys] == list(g[f"clips::{phase}::keys"])
+        n_items = 0
+        for name in g:
+            if not (name.startswith(f"clips::{phase}::") and name.endswith("::audio")):
+                continue
+            key = tuple(name.split("::")[2].split("|"))
+            item = ds[[tuple(x) for x in ds.datalist].index(key)]
+            for k in ("audio", "verts", "template_vert", "one_hot"):
+                ref = g[f"clips::{phase}::{'|'.join(key)}::{k}"]
+                assert item[k].dtype == ref.dtype and item[k].shape == ref.shape and np.array_equal(item[k], ref), (phase, key, k)
+            n_items += 1
+        assert n_items >= 2
+
+
 def test_data_module_batches_and_whole_clips(tmp_path):
     d = vocaset_synth.build(str(tmp_path / "voca"))
     dm = V.VocaDataModule(d, batch_size=4, num_workers=0)

@@ -203,7 +203,16 @@ class Faceformer(nn.Module):
 
     _pipe_stream = None
 
-    def train_step_pipelined(self, audio, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0):
+    @staticmethod
+    def grad_bucket_key(name: str):
+        """Data-parallel gradient buckets in parameter order (trainer.BucketedAllReduce): the encoder's front end (feature extractor,
+        feature projection, positional convolution), one bucket per Transformer layer, the decoder side - the order in which the backward
+        finishes them, reversed."""
+        if name.startswith("audio_encoder.encoder.layers."):
+            return "layer" + name.split(".")[3]
+        return "front" if name.startswith("audio_encoder.") else "decoder"
+
+    def train_step_pipelined(self, audio, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0, before_last_backward=None):
         """forward + FaceFormerLoss + backward of S >= 2 sequences (gradients ACCUMULATE into .grad, as loss.backward() does) with
         the latency-bound decoder recurrence hidden under encoder work.  The recurrence occupies one workgroup per sequence for
         ~17 ms (forward + backward at T = 600) whatever S is; run back to back with the encoder it leaves >= 75 % of the CUs idle
@@ -254,9 +263,11 @@ class Faceformer(nn.Module):
                 outs.append(out3.detach() * w)
                 halves.append((enc, enc_d.grad, side.record_event()))
                 del y, _pred, out3, enc_d
-        for enc, d_enc, done in halves:
+        for i, (enc, d_enc, done) in enumerate(halves):
             cur.wait_event(done)
             d_enc.record_stream(cur)
+            if before_last_backward is not None and i == len(halves) - 1:
+                before_last_backward()                                          # the gradient exchange may start: every earlier pass has been accumulated
             enc.backward(d_enc)                                                 # main stream: encoder backward of this half
         halves.clear()
         for side in sides[:1] if sides[0] is sides[1] else sides:

@@ -82,6 +82,72 @@ class FlatAdam:
                                 self.eps, self.wd, 1.0 / self.world(), self.step_count)
 
 
+class BucketedAllReduce:
+    """Gradient exchange overlapped with the backward (what the reference gets from Lightning's implicit DDP, train.py:48-59): the flat
+    gradient buffer is cut into contiguous buckets in parameter order - for FaceFormer: encoder front end | one per Transformer layer |
+    decoder side - and each bucket's sum all-reduce is started asynchronously as soon as the backward has moved past it.
+
+    Order.  The backward of a sequential network finishes parameters in REVERSE parameter order, so when a gradient of bucket b arrives
+    every bucket above b is complete (its AccumulateGrad nodes run before the next layer's backward node: leaf accumulations have the
+    highest priority in the autograd engine).  Buckets are therefore launched strictly in descending index order - on every rank the same
+    sequence of collectives whatever LayerDrop skipped on that rank (a skipped layer's gradients simply stay zero) - and ``finish()``
+    launches what is left (the first bucket) and waits for all of them.  The launches come from autograd's post-accumulate hooks; the
+    collective library orders each all-reduce behind the kernels already queued on the calling thread's current stream."""
+
+    def __init__(self, opt: FlatAdam, named_params, key_fn):
+        self.opt = opt
+        self.bounds, self.bucket_of = [], {}
+        last_key, lo = object(), 0
+        for name, p in named_params:
+            if id(p) not in opt._offsets:
+                continue
+            off, n = opt._offsets[id(p)]
+            k = key_fn(name)
+            if k != last_key:
+                if self.bounds:
+                    self.bounds[-1] = (self.bounds[-1][0], off)
+                self.bounds.append((off, off))
+                last_key = k
+            self.bucket_of[id(p)] = len(self.bounds) - 1
+            self.bounds[-1] = (self.bounds[-1][0], off + n)
+        assert self.bounds and self.bounds[0][0] == 0 and self.bounds[-1][1] == opt.numel and all(a[1] == b[0] for a, b in zip(self.bounds, self.bounds[1:])), \
+            "buckets must tile the flat buffer in parameter order"
+        self.active = False
+        self.next = len(self.bounds) - 1
+        self.works = []
+        self.launch_log = []                                   # bucket indices in launch order (tests)
+        for name, p in named_params:
+            if id(p) in self.bucket_of:
+                p.register_post_accumulate_grad_hook(self._hook)
+
+    def begin(self):
+        """Call right before the LAST backward pass of the step (gradients of earlier passes are already accumulated)."""
+        self.active, self.next, self.works, self.launch_log = True, len(self.bounds) - 1, [], []
+
+    def _launch_down_to(self, b):
+        while self.next > b:
+            lo, hi = self.bounds[self.next]
+            w = self.opt.allreduce_grads(lo, hi, async_op=True)
+            if w is not None:
+                self.works.append(w)
+            self.launch_log.append(self.next)
+            self.next -= 1
+
+    def _hook(self, p):
+        if self.active:
+            self._launch_down_to(self.bucket_of[id(p)])
+
+    def finish(self) -> bool:
+        """Launch the remaining buckets, wait for every all-reduce.  Returns True when the gradients are reduced (begin() was called)."""
+        if not self.active:
+            return False
+        self._launch_down_to(-1)
+        for w in self.works:
+            w.wait()
+        self.active, self.works = False, []
+        return True
+
+
 class StepOutput(dict):
     """{"loss", "rec_loss", "vel_loss"} of a step; "err" (mse_error of lightning_model.py:119-125 == rec_loss / 3 for
     3-vectors) is derived on every access instead of costing an extra launch in every step.  It is NOT cached: under
@@ -131,6 +197,12 @@ class TrainStep:
         self.pipeline_min_seqs = int(os.environ.get("A2F_FF_PIPELINE_MIN_SEQS", "48"))    # in sequences of 600 frames: the test is on frames per step
         self.pipeline_min_frames = int(os.environ.get("A2F_FF_PIPELINE_MIN_FRAMES", "1200"))
         self._graph2 = None
+        # models that expose `grad_bucket_key(name)` (FaceFormer: 386 MB of gradients) exchange them bucket by bucket under the backward
+        # (A2F_DP_BUCKETS=0: one blocking all-reduce after the backward, as round 2 did)
+        self.buckets = None
+        if (hasattr(model, "grad_bucket_key") and (self.opt.world() > 1 or self.opt.force_collectives)
+                and os.environ.get("A2F_DP_BUCKETS", "1") != "0"):
+            self.buckets = BucketedAllReduce(self.opt, list(model.named_parameters()), model.grad_bucket_key)
 
     def _direct(self, ins, phase):
         lf = getattr(self.loss_fn, "loss", self.loss_fn)
@@ -163,7 +235,7 @@ class TrainStep:
             self._finish_overlapped(lambda: self._direct(ins, 2))
             return loss
         loss = self._fwd_bwd(x, one_hot, gt, template)
-        self.opt.step()
+        self.opt.step(reduced=self.buckets.finish() if self.buckets is not None else False)
         return loss
 
     def _graph_step(self, x, one_hot, gt, template):
@@ -235,7 +307,8 @@ class TrainStep:
                 if (self.pipeline and x.is_cuda and x.shape[0] >= 2 and frames >= self.pipeline_min_frames
                         and x.shape[0] * frames >= self.pipeline_min_seqs * 600 and hasattr(self.model, "train_step_pipelined")):
                     # two half-batches on two streams: each half's decoder recurrence runs under the other half's encoder work
-                    loss = self.model.train_step_pipelined(x, one_hot, template, gt, lf.k_rec, lf.k_vel)
+                    loss = self.model.train_step_pipelined(x, one_hot, template, gt, lf.k_rec, lf.k_vel,
+                                                           before_last_backward=self.buckets.begin if self.buckets is not None else None)
                     loss["err"] = loss["rec_loss"] / 3.0
                     return loss
                 _pred, loss = self.model.forward_with_loss_batch(x, one_hot, template, gt, lf.k_rec, lf.k_vel)
@@ -244,6 +317,8 @@ class TrainStep:
         else:
             pred = self.model(x, one_hot, template)
             loss = self.loss_fn(pred, gt)
+        if self.buckets is not None:
+            self.buckets.begin()
         loss["loss"].backward()
         # mse_error (lightning_model.py:119-125) == rec_loss / 3 for 3-vectors: no extra pass over pred/gt
         loss["err"] = loss["rec_loss"].detach() / 3.0

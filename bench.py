@@ -486,7 +486,11 @@ def main():
                                       "reference train mode: wav2vec2 dropout x6 kinds of sites / LayerDrop 0.1 / SpecAugment (exactly the reference's); decoder + PPE "
                                       "dropout 0.1 with ONE mask per frame row - a deliberate deviation from the reference's per-loop-step redraw "
                                       "(faceformer.py:154-185; DESIGN 3.6, fixture G14); masks drawn on the device every step"),
-                       "mean_transformer_layers_run": round(layers_run, 3)},
+                       "mean_transformer_layers_run": round(layers_run, 3),
+                       "gradient_exchange": ("none (one rank)" if world == 1 and step.buckets is None else
+                                             f"{len(step.buckets.bounds)} buckets (encoder front end | Transformer layers | decoder side), async all-reduce "
+                                             "launched from autograd hooks as the backward passes each bucket" if step.buckets is not None
+                                             else "one blocking all-reduce of the flat gradient buffer after the backward")},
         }
         if want_roof:
             # whole step and the dominant GEMM variant against the pipe the kernels run on: the DENSE bf16 matrix peak.  A bf16x3 kernel
@@ -502,13 +506,13 @@ def main():
             # per-launch HIP events are only meaningful when nothing else shares the GPU: this pass runs the same kernels with the
             # two-stream half-batch pipeline and the weight-gradient lane switched off (one stream, launches back to back)
             from a2f_amd import encoder_ops
-            old_lane, old_pipe = encoder_ops.WGRAD_STREAM, step.pipeline
-            encoder_ops.WGRAD_STREAM, step.pipeline = False, False
+            old_lane, old_pipe, old_buckets = encoder_ops.WGRAD_STREAM, step.pipeline, step.buckets
+            encoder_ops.WGRAD_STREAM, step.pipeline, step.buckets = False, False, None       # buckets off: rank 0 runs this leg alone, no collective may start
             be.prof, be.prof_flops, be.prof_shapes = {}, {}, {}
             for _ in range(2):
-                step._fwd_bwd(audio, one_hot, gt, templ)         # forward + loss + backward only: rank 0 runs this leg alone, so no collective (no Adam either)
+                step._fwd_bwd(audio, one_hot, gt, templ)         # forward + loss + backward only (no gradient exchange, no Adam)
             torch.cuda.synchronize()
-            encoder_ops.WGRAD_STREAM, step.pipeline = old_lane, old_pipe
+            encoder_ops.WGRAD_STREAM, step.pipeline, step.buckets = old_lane, old_pipe, old_buckets
             tf, nl, ms = gemm_prof_summary(be)
             if tf is not None:
                 roof["gemm_family"] = {"name": "gemm_mfma_kernel (all encoder / decoder-side GEMM launches of 2 steps, single stream)", "launches_timed": nl,

@@ -111,7 +111,7 @@ def test_flat_adam_aliases_parameters_and_matches_torch_adam():
 # ---------------------------------------------------------------------------------------------------------------------------
 # FaceFormer: sequences shard over ranks (the reference trains batch = 1 per sequence; S sequences per step here)
 # ---------------------------------------------------------------------------------------------------------------------------
-def _run_ff(rank, world, port, out_path):
+def _run_ff(rank, world, port, out_path, layers=0, skip_by_rank=False):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -133,10 +133,20 @@ def _run_ff(rank, world, port, out_path):
         def __init__(self):
             super().__init__()
             self.proj = torch.nn.Linear(8, 768)
+            # `layers` residual blocks under the names of the real encoder's Transformer layers: one gradient bucket each
+            self.encoder = torch.nn.Module()
+            self.encoder.layers = torch.nn.ModuleList(torch.nn.Linear(768, 768) for _ in range(layers))
+            for lin in self.encoder.layers:
+                torch.nn.init.normal_(lin.weight, 0, 0.01)
 
         def forward(self, wave, dataset, frame_num=None):
             f = wave[:, : frame_num * 8].reshape(wave.shape[0], frame_num, 8)
-            return types.SimpleNamespace(last_hidden_state=self.proj(f))
+            h = self.proj(f)
+            for l, lin in enumerate(self.encoder.layers):
+                if skip_by_rank and l == rank:       # LayerDrop: every rank skips a different layer
+                    continue
+                h = h + torch.tanh(lin(h))
+            return types.SimpleNamespace(last_hidden_state=h)
 
     torch.manual_seed(21)
     model = a2f_amd.Faceformer(n_verts=nv, n_onehot=12, audio_encoder=_Enc())
@@ -154,11 +164,31 @@ def _run_ff(rank, world, port, out_path):
     sl = slice(rank * per, (rank + 1) * per)
     for _ in range(2):
         out = step(*TrainStep.unpack_batch({"audio": audio[sl], "one_hot": oh[sl], "verts": gt[sl], "template_vert": templ[sl]}))
-    if rank == 0:
-        torch.save({"flat": step.opt.flat_p.clone(), "loss": float(out["loss"].detach())}, out_path)
+    if world > 1 and layers:
+        assert step.buckets is not None and len(step.buckets.bounds) == layers + 2                       # front | layers | decoder side
+        assert step.buckets.launch_log == list(range(layers + 1, -1, -1)), step.buckets.launch_log       # the same descending order on every rank
+    if rank == 0 or skip_by_rank:
+        torch.save({"flat": step.opt.flat_p.clone(), "loss": float(out["loss"].detach())}, out_path if rank == 0 else out_path + f".rank{rank}")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def test_faceformer_dp2_bucketed_allreduce_matches_single_process():
+    """The FaceFormer gradient exchange in buckets under the backward (trainer.BucketedAllReduce: front end | one bucket per encoder layer
+    | decoder side, launched in descending order from autograd's post-accumulate hooks): two ranks against one process, and - with every
+    rank skipping a DIFFERENT layer, as per-rank LayerDrop masks do - the same launch order on both ranks and identical parameters."""
+    with tempfile.TemporaryDirectory() as d:
+        p1, p2, p3 = os.path.join(d, "f1.pt"), os.path.join(d, "f2.pt"), os.path.join(d, "f3.pt")
+        _run_ff(0, 1, 0, p1, 3)
+        from a2f_amd import ops
+        ops.set_backend(None)
+        mp.spawn(_run_ff, args=(2, _free_port(), p2, 3), nprocs=2, join=True)
+        a, b = torch.load(p1), torch.load(p2)
+        assert float((a["flat"] - b["flat"]).norm() / a["flat"].norm()) < 1e-5
+        mp.spawn(_run_ff, args=(2, _free_port(), p3, 3, True), nprocs=2, join=True)
+        r0, r1 = torch.load(p3), torch.load(p3 + ".rank1")
+        assert torch.equal(r0["flat"], r1["flat"])
 
 
 def test_faceformer_dp2_gloo_matches_single_process():

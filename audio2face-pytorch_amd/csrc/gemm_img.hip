@@ -114,16 +114,8 @@ __global__ __launch_bounds__(ImgCfg<MODE>::TH, ImgCfg<MODE>::WPS) void gemm_img_
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int tiles_n = (a.N + BN - 1) / BN;
   int m0, n0;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
-    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-    const int tm = wgid / tiles_n;
-    m0 = tm * BM;
-    n0 = (wgid - tm * tiles_n) * BN;
-  }
+  tile_origin(a, BM, BN, m0, n0);
   const int bz = 0;
   const int sk = __builtin_amdgcn_readfirstlane((int)blockIdx.z);
   int kbeg = 0, kend = a.K;

@@ -44,6 +44,7 @@ struct Args {
   int act, aux_mode, accumulate, split_k, batch;
   float alpha;
   float* a_rowsum;               // optional (A trans, plain operands, batch 1): a_rowsum[m] = sum_k A(m, k) - the bias gradient of a weight-gradient product
+  int group_n;                   // tile order: 0 = row-major (m-tile, n-tile); > 0 = panels of group_n n-tiles, m fastest across a panel (tile_origin)
   const unsigned* keep;          // dropout keep bits of C (csrc/dropout.hip: word (m, n >> 5), bit n & 31), applied after the activation
   long long keep_wpr;
   float keep_scale;
@@ -84,6 +85,39 @@ __device__ __forceinline__ void epilogue_store(const Args& a, int bz, int m, int
 __device__ __forceinline__ long long c_row_offset(const Args& a, int m) {
   if (a.c_rps <= 0) return (long long)m * a.ldc;
   return (long long)(m / a.c_rps) * a.c_seq_stride + (long long)(m % a.c_rps) * a.ldc;
+}
+
+// Workgroup -> output tile.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx.x % 8 labels the XCD group); the linear id is first
+// remapped so that every XCD owns ONE contiguous run of the tile order (speed only: any placement computes the same tiles), then the
+// order itself is either row-major - the n-tiles that share an A panel run together, right when the whole B operand fits the XCD's 4 MB
+// L2 - or PANEL-major: n-tiles in groups of `group_n`, all m-tiles of a group before the next group.  With a wide B (N x K x 4 bytes
+// beyond the L2: the 768 -> 2304 / 3072 projections) row-major streams the whole of B through every XCD once per ~3 m-tiles - PMC on
+// 38400 x 3072 x 768: 2.7 GB fetched for 0.13 GB of operands, the kernel ran at the fabric's rate, not the matrix pipe's - whereas a panel's
+// slice of B (<= 2 MB) stays resident while the A panels stream past it once per panel.
+__device__ __forceinline__ void tile_origin(const Args& a, int BM, int BN, int& m0, int& n0) {
+  const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
+  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  int tm, tn;
+  if (a.group_n <= 0) {
+    tm = wgid / tiles_n;
+    tn = wgid - tm * tiles_n;
+  } else {
+    const int full = (tiles_n / a.group_n) * a.group_n;               // n-tiles inside full panels
+    const int per_panel = tiles_m * a.group_n;
+    if (wgid < (full / a.group_n) * per_panel) {
+      const int p = wgid / per_panel, rem = wgid - p * per_panel;
+      tm = rem / a.group_n;
+      tn = p * a.group_n + (rem - tm * a.group_n);
+    } else {                                                            // the last, narrower panel
+      const int gw = tiles_n - full, rem = wgid - (full / a.group_n) * per_panel;
+      tm = rem / gw;
+      tn = full + (rem - tm * gw);
+    }
+  }
+  m0 = tm * BM;
+  n0 = tn * BN;
 }
 
 // NB: bit-cast the WHOLE vector first.  __builtin_bit_cast(float, raw.y) on a vector-element lvalue reads element 0 with

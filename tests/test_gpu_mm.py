@@ -198,3 +198,36 @@ def test_mm_image_operands(M, N, K, layout, precision):
     a, e = both(run)
     assert rel_l2(a[0], e[0]) < TOL[precision]
     assert rel_l2(a[1], e[1]) < TOL[precision]
+
+
+@pytest.mark.parametrize("M,N,K", [(600, 768, 768), (1200, 3072, 768), (1100, 2304, 768), (264, 136, 96), (130, 768, 3072), (5000, 3072, 768)])
+@pytest.mark.parametrize("precision", [1, 0])
+def test_mm_fp32_activations_against_presplit_weights(M, N, K, precision):
+    """Linear forward as the encoder runs it: fp32 activations (split on chip) against weights that arrive pre-split as bf16 hi / lo images
+    (format 1 on B only: chunks copied to LDS without conversion), every epilogue the layers use (bias, GELU + saved derivative, dropout
+    keep bits, residual add), split-K, and - for the wide outputs - the panel-major tile order (B beyond an XCD's L2), against the float64
+    emulator.  The row- and panel-major orders must give bit-identical results (the order only moves tiles between workgroups)."""
+    from a2f_amd.ops import MM_ACT_GELU_SAVE_GRAD, MM_AUX_ADD, MMImg
+    import a2f_amd.dropout as D
+    A, B = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=0.3)
+    bias, res = rnd(N, seed=23), rnd(M, N, seed=24)
+    gen = torch.Generator().manual_seed(25)
+    keep = D.pack_keep_bits(torch.rand(M, N, generator=gen) > 0.1)
+
+    def run(be, dev):
+        ib = be.split_bf16(B.to(dev))
+        a = A.to(dev)
+        c1, z = torch.zeros(M, N, device=dev), torch.zeros(M, N, device=dev)
+        be.mm(MMOp(a, K), MMImg(ib, K), c1, M, N, K, N, bias=bias.to(dev), act=MM_ACT_GELU_SAVE_GRAD, C2=z, keep=(keep.to(dev), 1.0 / 0.9), precision=precision)
+        c2 = torch.zeros(M, N, device=dev)
+        be.mm(MMOp(a, K), MMImg(ib, K), c2, M, N, K, N, bias=bias.to(dev), aux=res.to(dev), ldaux=N, aux_mode=MM_AUX_ADD, precision=precision)
+        c3 = torch.zeros(M, N, device=dev)
+        be.mm(MMOp(a, K), MMImg(ib, K), c3, M, N, K, N, split_k=3 if K >= 96 else 1, precision=precision)
+        c4 = torch.zeros(M, N, device=dev)
+        be.mm(MMOp(a, K), MMOp(B.to(dev), K), c4, M, N, K, N, bias=bias.to(dev), aux=res.to(dev), ldaux=N, aux_mode=MM_AUX_ADD, precision=precision)
+        return [c1, z, c2, c3, c4]
+    a, e = both(run)
+    for x, y in zip(a, e):
+        assert rel_l2(x, y) < TOL[precision]
+    if precision == 1:
+        assert torch.equal(a[2], a[4])                     # pre-split weights: the same hi / lo values as the on-chip split, the same products

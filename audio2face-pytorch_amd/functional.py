@@ -265,176 +265,10 @@ class VocaTrunkFn(torch.autograd.Function):
 # =================================================================================================
 A2M_CH = (1, 72, 108, 162, 243, 256)           # analysis channels; width 32 -> 16 -> 8 -> 4 -> 2 -> 1   (audio2face.py:13-29)
 A2M_BN_MOMENTUM, A2M_BN_EPS = 0.1, 1e-5
-# a2f_gemm_desc.precision of the Audio2Mesh GEMMs (the fp32-MFMA convolutions are matrix-pipe bound):
-#   2 (default) = bf16x6 split products: fp32-class results (G2 fixture: worst weight-gradient error 1.7e-5 of the
-#       reference vs 1.1e-5 with exact fp32 MFMA) at 2.7x less matrix time - B = 1024 step 13.0 -> 11.4 ms;
-#   1 = bf16x3: 9.8 ms, prediction still at 9e-6, but the batch-statistics BatchNorm backward amplifies the 2^-16 product
-#       error: weight gradients of the analysis stack move to 1e-3 .. 5e-3 of the reference (tools/a2m_grad_errors.py);
-#   0 = exact fp32 MFMA.
-A2M_GEMM_PRECISION = int(os.environ.get("A2F_A2M_PRECISION", "2"))
-
-
-@contextlib.contextmanager
-def _gemm_precision(be, prec):
-    old = getattr(be, "gemm_precision", 0)
-    be.gemm_precision = prec
-    try:
-        yield
-    finally:
-        be.gemm_precision = old
-
-
-class A2MTrunkFn(torch.autograd.Function):
-    """x (B,52,32), one_hot (B,n_onehot), training flag, BN buffers, parameters -> h3 (B,50).
-
-    Activations are channels-last: analysis stage (B*64 rows-of-W, W, C), articulation stage (B, H, 256).
-    args: x, one_hot, training, 20 buffers (10 x running_mean, running_var in layer order), then parameters:
-          10 conv (w,b) pairs in layer order, 10 BN (gamma,beta) pairs in layer order, 3 Linear (w,b) pairs.
-    """
-
-    @staticmethod
-    def forward(ctx, x, one_hot, training, *rest):
-        be = ops.backend()
-        with _gemm_precision(be, A2M_GEMM_PRECISION):
-            return A2MTrunkFn._forward(ctx, be, x, one_hot, training, *rest)
-
-    @staticmethod
-    def _forward(ctx, be, x, one_hot, training, *rest):
-        bufs, params = rest[:20], rest[20:]
-        convs = [(_f32c(params[2 * i]), _f32c(params[2 * i + 1])) for i in range(10)]
-        bns = [(_f32c(params[20 + 2 * i]), _f32c(params[21 + 2 * i])) for i in range(10)]
-        fcs = [(_f32c(params[40 + 2 * i]), _f32c(params[41 + 2 * i])) for i in range(3)]
-        B, no = x.shape[0], one_hot.shape[1]
-        H0 = 52 + no
-        dev = x.device
-        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
-        ncat = 256 + no
-        a0, cat = new(B, H0, 32), new(B, ncat)
-        be.a2m_pack(_f32c(x), _f32c(one_hot), B, no, a0, cat, ncat, 256)
-        sv = {"wg": [], "conv_in": [], "bn_x": [], "bn_y": [], "stats": []}
-
-        def bn(i, xin, R, C, relu):
-            g, b = bns[i]
-            y, mu, istd = new(R, C), new(C), new(C)
-            be.bn_fwd(xin, R, C, g, b, bufs[2 * i], bufs[2 * i + 1], A2M_BN_MOMENTUM, A2M_BN_EPS, training, relu, y, mu, istd)
-            sv["bn_x"].append(xin); sv["bn_y"].append(y); sv["stats"].append((mu, istd))
-            return y
-
-        def conv(i, xin, R, P_out, Ci, Co, KH=3, stride=2, pad=1, relu=False, out=None, ldc=None):
-            w, b = convs[i]
-            wg = new(Co, KH * Ci)
-            be.conv_weight_pack(w, wg, Co, Ci, KH, 0)
-            o = out if out is not None else new(R, Co)
-            ops.conv_fwd(be, xin, wg, b, o, R, P_out, Ci, Co, KH=KH, stride=stride, pad=pad, relu=relu, ldc=ldc)
-            sv["wg"].append(wg); sv["conv_in"].append(xin)
-            return o
-
-        act, Wd = a0, 32
-        for l in range(5):                                   # analysis: conv over W -> BN -> ReLU
-            ci, co = A2M_CH[l], A2M_CH[l + 1]
-            Wd //= 2
-            R = B * H0 * Wd
-            act = bn(l, conv(l, act, R, Wd, ci, co), R, co, True)
-        Hd = H0
-        for l in range(5, 8):                                # articulation: conv over H -> BN -> ReLU
-            Hd //= 2
-            R = B * Hd
-            act = bn(l, conv(l, act, R, Hd, 256, 256), R, 256, True)
-        act = bn(8, act, B * Hd, 256, False)                 # BN -> conv -> ReLU   (order flip, audio2face.py:41-43)
-        Hd //= 2
-        z = conv(8, act, B * Hd, Hd, 256, 256, relu=True)
-        zb = bn(9, z, B * Hd, 256, False)                    # BN -> conv(4,1)/s4 -> ReLU  (audio2face.py:44-46)
-        conv(9, zb, B, 1, 256, 256, KH=Hd, stride=Hd, pad=0, relu=True, out=cat, ldc=ncat)
-        z1, z2, h3 = new(B, 72), new(B, 128), new(B, 50)
-        ops.linear_fwd(be, cat, fcs[0][0], fcs[0][1], z1, B, 72, ncat)
-        ops.linear_fwd(be, z1, fcs[1][0], fcs[1][1], z2, B, 128, 72, act=ACT_TANH)
-        ops.linear_fwd(be, z2, fcs[2][0], fcs[2][1], h3, B, 50, 128)
-        ctx.sv = sv
-        ctx.misc = (B, no, H0, Hd, training, cat, z, z1, z2, [f[0] for f in fcs], [b[0] for b in bns])
-        return h3
-
-    @staticmethod
-    def backward(ctx, dh3):
-        be = ops.backend()
-        with _gemm_precision(be, A2M_GEMM_PRECISION):
-            return A2MTrunkFn._backward(ctx, be, dh3)
-
-    @staticmethod
-    def _backward(ctx, be, dh3):
-        sv = ctx.sv
-        B, no, H0, Hlast, training, cat, z, z1, z2, fw, gammas = ctx.misc
-        dev = cat.device
-        ncat = 256 + no
-        zeros = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
-        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
-        dh3 = _f32c(dh3)
-        g_conv, g_bn, g_fc = [None] * 20, [None] * 20, [None] * 6
-        # output_net.3, .1, .0
-        dW, db = new(50, 128), new(50)
-        ops.linear_bwd_weight(be, dh3, z2, dW, db, B, 50, 128); g_fc[4], g_fc[5] = dW, db
-        dz2 = new(B, 128)
-        ops.linear_bwd_input(be, dh3, fw[2], dz2, B, 50, 128, aux=z2, ldaux=128, aux_mode=AUX_TANH_BWD)
-        dW, db = new(128, 72), new(128)
-        ops.linear_bwd_weight(be, dz2, z1, dW, db, B, 128, 72); g_fc[2], g_fc[3] = dW, db
-        dz1 = new(B, 72)
-        ops.linear_bwd_input(be, dz2, fw[1], dz1, B, 128, 72)
-        dW, db = new(72, ncat), new(72)
-        ops.linear_bwd_weight(be, dz1, cat, dW, db, B, 72, ncat); g_fc[0], g_fc[1] = dW, db
-        d = new(B, 256)                                       # grad w.r.t. conv-9 pre-activation (ReLU mask of cat fused)
-        ops.linear_bwd_input(be, dz1, fw[0], d, B, 72, ncat, n_cols=256, aux=cat, ldaux=ncat, aux_mode=AUX_RELU_BWD)
-
-        def conv_wgrad(i, dout, R, P_out, Ci, Co, KH=3, stride=2, pad=1):
-            dwg, dbias = new(Co, KH * Ci), new(Co)
-            ops.conv_bwd_weight(be, sv["conv_in"][i], dout, dwg, dbias, R, P_out, Ci, Co, KH=KH, stride=stride, pad=pad)
-            shape = (Co, Ci, 1, KH) if i < 5 else (Co, Ci, KH, 1)
-            dw = new(*shape)
-            be.conv_weight_pack(dwg, dw, Co, Ci, KH, 1)
-            g_conv[2 * i], g_conv[2 * i + 1] = dw, dbias
-
-        def bn_bwd(i, dy, R, C, relu):
-            mu, istd = sv["stats"][i]
-            dx, dg, dbt = new(R, C), new(C), new(C)
-            be.bn_bwd(sv["bn_x"][i], sv["bn_y"][i], dy, R, C, gammas[i], mu, istd, training, relu, dx, dg, dbt)
-            g_bn[2 * i], g_bn[2 * i + 1] = dg, dbt
-            return dx
-
-        # conv 9: (4,1)/s4 no pad, input zb (B, Hlast*256)
-        KH9 = Hlast
-        conv_wgrad(9, d, B, 1, 256, 256, KH=KH9, stride=KH9, pad=0)
-        dzb = new(B, KH9 * 256)
-        ops.conv_nonoverlap_bwd_input(be, d, sv["wg"][9], dzb, B, 256, 256, KH9)
-        dz = bn_bwd(9, dzb, B * Hlast, 256, False)
-        # conv 8 output z carries a ReLU: mask dz by (z > 0) while forming its gradient -> done by a tiny masked copy GEMM-free:
-        dz = torch.where(z.view(B * Hlast, 256) > 0, dz, torch.zeros_like(dz))
-        conv_wgrad(8, dz, B * Hlast, Hlast, 256, 256)
-        Hd = 2 * Hlast
-        dact = new(B * Hd, 256)
-        ops.conv_k3s2_bwd_input(be, dz, sv["wg"][8], dact, B * Hlast, Hlast, 256, 256)
-        d = bn_bwd(8, dact, B * Hd, 256, False)               # BN 8 input = ReLU output of block 7 -> its BN bwd masks below
-        for l in (7, 6, 5):                                   # articulation conv -> BN -> ReLU blocks
-            R = B * Hd
-            draw = bn_bwd(l, d, R, 256, True)
-            conv_wgrad(l, draw, R, Hd, 256, 256)
-            din = new(B * 2 * Hd, 256)
-            ops.conv_k3s2_bwd_input(be, draw, sv["wg"][l], din, R, Hd, 256, 256)
-            d, Hd = din, 2 * Hd
-        Wd = 1
-        for l in (4, 3, 2, 1, 0):                             # analysis blocks
-            ci, co = A2M_CH[l], A2M_CH[l + 1]
-            R = B * H0 * Wd
-            draw = bn_bwd(l, d, R, co, True)
-            conv_wgrad(l, draw, R, Wd, ci, co)
-            if l > 0:
-                din = new(R * 2, ci)
-                ops.conv_k3s2_bwd_input(be, draw, sv["wg"][l], din, R, Wd, ci, co)
-                d = din
-            Wd *= 2
-        ctx.sv = None
-        return (None, None, None) + (None,) * 20 + tuple(g_conv) + tuple(g_bn) + tuple(g_fc)
 
 
 # =================================================================================================
-# Audio2Mesh trunk on the bf16-MFMA GEMM family (a2f_mm): same function as A2MTrunkFn, convolutions 1..9 as windowed implicit
+# Audio2Mesh trunk on the bf16-MFMA GEMM family (a2f_mm): convolutions 1..9 as windowed implicit
 # GEMMs with bf16x3 split products.  Channel counts that are not multiples of 4 (162, 243) are stored with a padded channel
 # stride (164, 244; the pad channels are identically zero through conv / BatchNorm / ReLU and carry zero gradients), so every
 # window starts on a 16-byte boundary.
@@ -458,7 +292,7 @@ def _unpack_conv_w(dwg, Co, Ci, KH, Cip):
     return dwg.view(-1, KH, Cip)[:Co, :, :Ci].permute(0, 2, 1).contiguous()
 
 
-# a2f_mm_desc.precision of the trunk on a2f_mm: 2 = bf16x6 (default: holds the G2 fixture's weight gradients like the legacy path),
+# a2f_mm_desc.precision of the trunk on a2f_mm: 2 = bf16x6 (default: holds the G2 fixture's weight gradients at 1e-5),
 # 1 = bf16x3 (faster; the batch-statistics BatchNorm backward amplifies its 2^-16 product error beyond the parity bar at B = 4)
 A2M_MM_PRECISION = int(os.environ.get("A2F_A2M_MM_PRECISION", "2"))
 
@@ -474,7 +308,9 @@ def _mm_precision(be, prec):
 
 
 class A2MTrunkMMFn(torch.autograd.Function):
-    """Same signature / outputs as A2MTrunkFn (x, one_hot, training, 20 BN buffers, 46 parameters -> h3 (B,50))."""
+    """x (B,52,32), one_hot (B,n_onehot), training flag, 20 BN buffers (10 x running_mean, running_var in layer order), then the parameters:
+    10 conv (w, b) pairs in layer order, 10 BN (gamma, beta) pairs, 3 Linear (w, b) pairs -> h3 (B,50).  Activations are channels-last:
+    analysis stage (B*64 rows-of-W, W, C), articulation stage (B, H, 256)."""
 
     @staticmethod
     def forward(ctx, x, one_hot, training, *rest):
@@ -645,12 +481,10 @@ class A2MTrunkMMFn(torch.autograd.Function):
         return (None, None, None) + (None,) * 20 + tuple(g_conv) + tuple(g_bn) + tuple(g_fc)
 
 
-# Which trunk Audio2Mesh uses.  Default "mm" = A2MTrunkMMFn on a2f_mm with bf16x6 products (A2M_MM_PRECISION = 2): the G2 fixture's weight
-# gradients at 1e-5 like the legacy path, bias gradients as row sums inside the weight-gradient products; B = 1024 step 8.4 ms.
-# "legacy" = A2MTrunkFn (bf16x6 on the generic GEMM of round 1, 11.4 ms) stays selectable for A/B.  A2F_A2M_MM_PRECISION=1 (bf16x3,
-# 7.6 ms) gives the same predictions (9e-6) but the batch-statistics BatchNorm backward amplifies its 2^-16 product error into 1e-2 on
-# the deepest weight gradients of the B = 4 fixture - outside the parity bar, so it is opt-in.
-A2M_USE_MM = os.environ.get("A2F_A2M_GEMM", "mm") == "mm"
+# (Round 1's trunk on the generic split GEMM of gemm.hip - 11.4 ms at B = 1024 against 7.9 ms - was removed in round 3; a2f_mm with
+# bf16x6 products is the only Audio2Mesh trunk.  A2F_A2M_MM_PRECISION=1 (bf16x3, 7.6 ms) gives the same predictions (9e-6) but the
+# batch-statistics BatchNorm backward amplifies its 2^-16 product error into 1e-2 on the deepest weight gradients of the B = 4 fixture -
+# outside the parity bar, so it is opt-in.)
 
 
 # =================================================================================================

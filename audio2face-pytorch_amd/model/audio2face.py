@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..functional import A2M_CH, A2M_USE_MM, A2MTrunkFn, A2MTrunkMMFn, HeadFn, HeadLossFusedFn
+from ..functional import A2M_CH, A2MTrunkMMFn, HeadFn, HeadLossFusedFn
 
 
 class Audio2Mesh(nn.Module):
@@ -32,7 +32,7 @@ class Audio2Mesh(nn.Module):
         self.output_net = nn.Sequential(nn.Linear(256 + n_onehot, 72), nn.Linear(72, 128), nn.Tanh(), nn.Linear(128, 50),
                                         nn.Linear(50, n_verts))               # audio2face.py:49-55
 
-    # layer order used by A2MTrunkFn: 5 analysis blocks, 3 conv->BN blocks, 2 BN->conv blocks
+    # layer order used by A2MTrunkMMFn: 5 analysis blocks, 3 conv->BN blocks, 2 BN->conv blocks
     def _convs(self):
         return [self.analysis_net[3 * l] for l in range(5)] + [self.articulation_net[i] for i in (0, 3, 6, 10, 13)]
 
@@ -51,7 +51,7 @@ class Audio2Mesh(nn.Module):
             params += [b.weight, b.bias]
         for i in (0, 1, 3):
             params += [self.output_net[i].weight, self.output_net[i].bias]
-        h3 = (A2MTrunkMMFn if A2M_USE_MM else A2MTrunkFn).apply(x, one_hot, self.training, *bufs, *params)
+        h3 = A2MTrunkMMFn.apply(x, one_hot, self.training, *bufs, *params)
         if self.training:
             for b in bns:
                 b.num_batches_tracked += 1

@@ -155,12 +155,9 @@ def test_voca_two_phase_graph_step_equals_single_graph():
 BN_CANCELLED = {f"analysis_net.{3 * l}.bias" for l in range(5)} | {f"articulation_net.{i}.bias" for i in (0, 3, 6)}
 
 
-@pytest.mark.parametrize("trunk", ["mm", "legacy"])
 @pytest.mark.parametrize("mode", ["train", "eval"])
-def test_audio2mesh_golden_g2(mode, trunk, monkeypatch):
-    """trunk "mm" (default) = convolutions as windowed a2f_mm products in bf16x6, "legacy" = the generic split GEMM of round 1."""
-    import a2f_amd.model.audio2face as a2m_module
-    monkeypatch.setattr(a2m_module, "A2M_USE_MM", trunk == "mm")
+def test_audio2mesh_golden_g2(mode):
+    """Convolutions as windowed a2f_mm products in bf16x6; forward, losses, EVERY gradient <= 1e-4, BN running statistics."""
     g = load("g2_audio2mesh")
     m = a2f_amd.Audio2Mesh(n_verts=NV, n_onehot=12)
     m.load_state_dict(W.formula_state_dict(W.audio2mesh_shapes(NV, 12), gains={"output_net.4": 4.0}))

@@ -1,5 +1,5 @@
 """Prediction and per-parameter gradient error of Audio2Mesh against the G2 golden fixture (train mode), e.g. to compare
-A2F_A2M_PRECISION=0 (exact fp32 MFMA) with 1 (bf16x3 split products)."""
+A2F_A2M_MM_PRECISION=2 (bf16x6, the default) with 1 (bf16x3 split products)."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch, a2f_amd

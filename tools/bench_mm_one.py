@@ -22,10 +22,11 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 for i in range(iters + 2):
     if i == 2:
         e0.record()
+    Wop = ops.weight_operand(be, W, N, K, M)              # pre-split bf16 images unless A2F_MM_PRESPLIT=0 (the split is part of the call, as in the model)
     if plain:
-        be.mm(MMOp(x, K), MMOp(W, K), y, M, N, K, N, precision=1)
+        be.mm(MMOp(x, K), Wop, y, M, N, K, N, precision=1)
     else:
-        be.mm(MMOp(x, K), MMOp(W, K), y, M, N, K, N, bias=b, act=MM_ACT_GELU_SAVE_GRAD, C2=z, precision=1)
+        be.mm(MMOp(x, K), Wop, y, M, N, K, N, bias=b, act=MM_ACT_GELU_SAVE_GRAD, C2=z, precision=1)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters

@@ -18,7 +18,6 @@
 //     8 (6) fragment reads for 12 (6) MFMAs in bf16x3;
 //   * split-K slabs + fixed-order fold for weight gradients (K = rows of the batch), batch index for grouped convolutions.
 #include "gemm_mfma.h"
-#include <type_traits>
 
 namespace a2f {
 namespace mm {
@@ -226,60 +225,6 @@ struct Stage {
   }
 };
 
-// A k-contiguous operand that ARRIVES as bf16 hi / lo images (a2f_mm_operand.format 1) beside an fp32 partner operand: the weights of a
-// Linear layer are split ONCE per step (a2f_split_bf16, 7 MB) instead of by every workgroup that streams them - their 16-byte chunks
-// travel global -> register -> LDS with no conversion (2 loads + 2 ds_write_b128 per thread and k-tile instead of 2 loads + 20 VALU + 4
-// ds_write_b64), into the same [line][32 k] swizzled image the fp32 path writes, read by the same one-ds_read_b128 fragment.  Together
-// with the activations' on-chip split this takes the kernel's non-MFMA issue load from ~24 to ~17 cycles per MFMA (an MFMA leaves 24 of
-// its 32 cycles to other instructions of the SIMD's four waves: the fp32 / fp32 form sits AT that limit).  Same interface as Stage<false, X>.
-template <int X, int TH, int PREC>
-struct StagePre {
-  static constexpr int NI = PREC == 1 ? 2 : 1;                 // images read
-  static constexpr int NC = (X * 4) / TH;                      // 16-byte chunks per thread and image (X lines x 4 chunks of 8 bf16)
-  static constexpr int NL = NI * NC;                           // registers (u32x4) per set
-  static constexpr int IMG = X * 64;
-  static_assert(NC >= 1 && (X * 4) % TH == 0, "pre-split operand tile must be a whole number of chunks per thread");
-  struct Rs { rsrc_t hi, lo; };
-  unsigned boff[NC];
-  int lds_w[NC];
-  __device__ __forceinline__ void init_plain(const Op& op, int x0, int xcount, int t) {
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-      const int c = t + TH * i, ll = c >> 2, ch = c & 3;
-      const int line = x0 + ll;
-      boff[i] = line < xcount ? ((unsigned)line * (unsigned)op.ld + (unsigned)(ch * 8)) * 2u : 0xFFFFFFFFu;
-      lds_w[i] = ll * 64 + ((ch ^ ((ll >> 2) & 3)) << 4);
-    }
-  }
-  __device__ __forceinline__ void init(const Op&, int, int, int, int) {}
-  __device__ __forceinline__ void advance(const Op&) {}
-  __device__ __forceinline__ void load(const Op&, rsrc_t, int, int, u32x4_t (&)[NL]) {}
-  __device__ __forceinline__ static Rs tile_rsrc(const Op& op, int k0, int kend) {
-    const long long adv = (long long)k0 * 2;                   // bytes; wave-uniform
-    const unsigned left = k0 < kend ? op.bytes - (unsigned)adv : 0u;
-    Rs r;
-    r.hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(op.p) + adv), 0, (int)left, 0x00020000);
-    r.lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(op.p_lo) + adv), 0, (int)(NI == 2 ? left : 0u), 0x00020000);
-    return r;
-  }
-  __device__ __forceinline__ void load_plain(const Rs rs, u32x4_t (&reg)[NL]) const {
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-      reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs.hi, boff[i], 0, 0);
-      if constexpr (NI == 2) reg[NC + i] = __builtin_amdgcn_raw_buffer_load_b128(rs.lo, boff[i], 0, 0);
-    }
-  }
-  template <int P>
-  __device__ __forceinline__ void commit(char* img, const u32x4_t (&reg)[NL]) const {
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-      *reinterpret_cast<u32x4_t*>(img + lds_w[i]) = reg[i];
-      if constexpr (NI == 2) *reinterpret_cast<u32x4_t*>(img + IMG + lds_w[i]) = reg[NC + i];
-    }
-  }
-  __device__ __forceinline__ static u32x4_t frag(const char* img, int rb, int ks, int lane) { return Stage<false, X, TH>::frag(img, rb, ks, lane); }
-};
-
 // CFG 0: 128 x 128 tile, 4 waves as 2 x 2, 2 x 2 accumulator tiles per wave.  CFG 1: 128 x 64 tile, waves 4 x 1, 1 x 2 tiles.
 // CFG 2: 256 x 128 tile, 8 waves as 4 x 2 (512 threads, one workgroup per CU): the same two waves per SIMD as two CFG-0
 // workgroups, but 384 instead of 512 operand rows are fetched / converted / written to LDS per 32 768 outputs and k-tile.
@@ -294,15 +239,14 @@ struct Cfg {
   static constexpr int WPS = CFG == 3 ? 4 : (CFG == 2 ? 2 : 2);
 };
 
-template <bool AT, bool BT, int PREC, int CFG, bool PLAIN, bool BPRE = false>
+template <bool AT, bool BT, int PREC, int CFG, bool PLAIN>
 __global__ __launch_bounds__(Cfg<CFG>::TH, PREC == 2 ? (CFG == 3 ? 2 : 1) : Cfg<CFG>::WPS) void gemm_mfma_kernel(const Args a) {   // bf16x6: three images per operand, one workgroup per CU
   constexpr int BM = Cfg<CFG>::BM, BN = Cfg<CFG>::BN, TH = Cfg<CFG>::TH;
   constexpr int WGN = Cfg<CFG>::WGN;
   constexpr int TM = Cfg<CFG>::TM, TN = Cfg<CFG>::TN;
   constexpr int NIMG = PREC == 2 ? 3 : PREC == 1 ? 2 : 1;
   using SA = Stage<AT, BM, TH>;
-  static_assert(!BPRE || (PLAIN && !BT && PREC != 2), "pre-split B: plain k-contiguous operand, bf16 / bf16x3");
-  using SB = std::conditional_t<BPRE, StagePre<BN, TH, PREC>, Stage<BT, BN, TH>>;
+  using SB = Stage<BT, BN, TH>;
   constexpr int A_BYTES = NIMG * SA::IMG, B_BYTES = NIMG * SB::IMG;
   constexpr int STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];          // two stages
@@ -501,12 +445,12 @@ __global__ __launch_bounds__(256) void gemm_mfma_fold_kernel(const Args a) {
   }
 }
 
-template <bool AT, bool BT, int PREC, int CFG, bool PLAIN, bool BPRE = false>
+template <bool AT, bool BT, int PREC, int CFG, bool PLAIN>
 static int launch(const Args& a, hipStream_t st) {
   constexpr int BM = Cfg<CFG>::BM, BN = Cfg<CFG>::BN, TH = Cfg<CFG>::TH;
   constexpr int NIMG = PREC == 2 ? 3 : PREC == 1 ? 2 : 1;
   constexpr int smem = 2 * NIMG * (Stage<AT, BM, TH>::IMG + Stage<BT, BN, TH>::IMG);
-  auto kern = gemm_mfma_kernel<AT, BT, PREC, CFG, PLAIN, BPRE>;
+  auto kern = gemm_mfma_kernel<AT, BT, PREC, CFG, PLAIN>;
   static bool attr_done = false;                        // set-once per instantiation (idempotent; safe to repeat)
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -649,24 +593,7 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
     if (force && force[0] >= '0' && force[0] <= '3') cfg = force[0] - '0';
   }
   hipStream_t st = (hipStream_t)stream;
-  if (d->A.format == 0 && d->B.format == 1) {
-    // fp32 activations against pre-split weights (Linear forward, and the data gradient through a transposed weight copy)
-    A2F_CHECK_ARG(!at && !bt && a.A.lps == 0 && batch == 1 && d->K % BK == 0 && d->N > 64 && (d->precision == 0 || d->precision == 1),
-                  "a2f_mm: an image B operand beside an fp32 A needs plain k-contiguous operands, batch 1, K a multiple of %d, N > 64, precision 0 | 1", BK);
-    A2F_CHECK_ARG(d->precision == 0 || d->B.p_lo, "a2f_mm: image operand B: precision 1 needs the lo image");
-    rc = d->precision == 1 ? launch<false, false, 1, 3, true, true>(a, st) : launch<false, false, 0, 3, true, true>(a, st);
-    if (rc) return rc;
-    A2F_CHECK_LAUNCH("a2f_mm (pre-split B)");
-    if (split > 1) {
-      const long long total = (long long)a.M * a.N;
-      long long blocks = (total + 255) / 256;
-      if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(gemm_mfma_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
-      A2F_CHECK_LAUNCH("a2f_mm fold");
-    }
-    return A2F_OK;
-  }
-  A2F_CHECK_ARG(d->A.format == d->B.format, "a2f_mm: both operands fp32, both bf16 hi / lo images, or fp32 A with an image B");
+  A2F_CHECK_ARG(d->A.format == d->B.format, "a2f_mm: both operands fp32 or both bf16 hi / lo images");
   if (d->A.format == 1) {
     A2F_CHECK_ARG(batch == 1 && d->K % BK == 0 && d->a_rowsum == nullptr && d->precision != 2, "a2f_mm: image operands need batch 1, K a multiple of %d, no a_rowsum, precision 0 | 1", BK);
     A2F_CHECK_ARG(d->precision == 0 || (d->A.p_lo && d->B.p_lo), "a2f_mm: image operands: precision 1 needs the lo images");

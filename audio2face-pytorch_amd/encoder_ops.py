@@ -127,7 +127,7 @@ class LinearMMFn(torch.autograd.Function):
         M, K = xc.shape
         N = Wc.shape[0]
         y = _new(xc, M, N)
-        be.mm(MMOp(xc, K), ops.weight_operand(be, Wc, N, K, M), y, M, N, K, N, bias=bc, keep=keep)
+        be.mm(MMOp(xc, K), MMOp(Wc, K), y, M, N, K, N, bias=bc, keep=keep)
         ctx.save_for_backward(xc, Wc)
         ctx.keep = keep
         return y
@@ -181,7 +181,7 @@ class EncoderLayerFn(torch.autograd.Function):
         Wqkv, bqkv = torch.cat((Wq, Wk, Wv), 0), torch.cat((bq, bk, bv), 0)
         qkv = _new(xc, M, 3 * d)
         if FUSED_QKV:
-            be.mm(MMOp(xc, d), ops.weight_operand(be, Wqkv, 3 * d, d, M), qkv, M, 3 * d, d, 3 * d, bias=bqkv)
+            be.mm(MMOp(xc, d), MMOp(Wqkv, d), qkv, M, 3 * d, d, 3 * d, bias=bqkv)
         else:
             for i in range(3):
                 be.mm(MMOp(xc, d), MMOp(Wqkv, d, ptr_off=i * d * d), qkv, M, d, d, 3 * d, c_off=i * d, bias=bqkv[i * d:(i + 1) * d])
@@ -192,15 +192,15 @@ class EncoderLayerFn(torch.autograd.Function):
         else:
             be.attn_fwd(qkv, S, T, heads, 3 * d, scale, att, d, lse)
         a1 = _new(xc, M, d)
-        be.mm(MMOp(att, d), ops.weight_operand(be, Wo, d, d, M), a1, M, d, d, d, bias=bo, aux=xc, ldaux=d, aux_mode=MM_AUX_ADD, keep=mk.get("hid1"))
+        be.mm(MMOp(att, d), MMOp(Wo, d), a1, M, d, d, d, bias=bo, aux=xc, ldaux=d, aux_mode=MM_AUX_ADD, keep=mk.get("hid1"))
         h1, m1, r1 = _new(xc, M, d), _new(xc, M), _new(xc, M)
         be.layernorm_fwd(a1, M, d, g1, b1, LN_EPS, h1, m1, r1)
         z = _new(xc, M, F) if keep else None                     # gelu'(pre-activation): what the backward multiplies by
         g = _new(xc, M, F)
-        be.mm(MMOp(h1, d), ops.weight_operand(be, W1, F, d, M), g, M, F, d, F, bias=c1, act=MM_ACT_GELU_SAVE_GRAD if (keep and GELU_SAVED) else MM_ACT_GELU, C2=z,
+        be.mm(MMOp(h1, d), MMOp(W1, d), g, M, F, d, F, bias=c1, act=MM_ACT_GELU_SAVE_GRAD if (keep and GELU_SAVED) else MM_ACT_GELU, C2=z,
               keep=mk.get("act"))
         a2 = _new(xc, M, d)
-        be.mm(MMOp(g, F), ops.weight_operand(be, W2, d, F, M), a2, M, d, F, d, bias=c2, aux=h1, ldaux=d, aux_mode=MM_AUX_ADD, keep=mk.get("hid2"))
+        be.mm(MMOp(g, F), MMOp(W2, F), a2, M, d, F, d, bias=c2, aux=h1, ldaux=d, aux_mode=MM_AUX_ADD, keep=mk.get("hid2"))
         h2, m2, r2 = _new(xc, M, d), _new(xc, M), _new(xc, M)
         be.layernorm_fwd(a2, M, d, g2, b2, LN_EPS, h2, m2, r2)
         if keep:

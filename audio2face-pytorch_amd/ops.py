@@ -610,21 +610,9 @@ def conv_nonoverlap_bwd_input(be, dout, wg, d_in, R, Cin, Co, KH, *, relu_of=Non
 _BIG = (1 << 31) - 16
 
 
-PRESPLIT_WEIGHTS = os.environ.get("A2F_MM_PRESPLIT", "1") != "0"     # A-B hook
-
-
-def weight_operand(be, W, N, K, M):
-    """The B operand of a Linear-layout product x[M,K] W[N,K]^T: for large M the weight is split ONCE into bf16 hi / lo images
-    (a2f_split_bf16: a few MB) instead of by every workgroup that streams it - the kernel then copies its chunks to LDS without
-    conversion (gemm_mfma.hip StagePre).  Small products keep the fp32 operand."""
-    if PRESPLIT_WEIGHTS and M >= 1024 and N > 64 and K % 32 == 0 and be.mm_precision in (0, 1) and hasattr(be, "split_bf16") and W.is_contiguous():
-        return MMImg(be.split_bf16(W), K)
-    return MMOp(W, K)
-
-
 def mm_linear_fwd(be, x, W, bias, out, M, N, K, *, act=MM_ACT_NONE, pre=None, aux=None, aux_mode=MM_AUX_NONE, tag="gemm_mfma"):
     """out[M,N] = act(x[M,K] W[N,K]^T + bias) (+ aux);  pre (optional) receives the pre-activation values."""
-    be.mm(MMOp(x, K), weight_operand(be, W, N, K, M), out, M, N, K, N, bias=bias, act=act, C2=pre, aux=aux, ldaux=N, aux_mode=aux_mode, tag=tag)
+    be.mm(MMOp(x, K), MMOp(W, K), out, M, N, K, N, bias=bias, act=act, C2=pre, aux=aux, ldaux=N, aux_mode=aux_mode, tag=tag)
 
 
 DGRAD_TRANSPOSED_W = os.environ.get("A2F_DGRAD_WT", "1") != "0"     # A-B hook
@@ -635,7 +623,7 @@ def mm_linear_dgrad(be, dy, W, dx, M, N, K, *, aux=None, aux_mode=MM_AUX_NONE, t
     transposed copy (K, N) so that BOTH operands are k-contiguous: the row-image staging path (one ds_read_b128 per fragment) is
     12-15 % faster than the transposing one, and the copy is 1/M of the product's traffic."""
     if DGRAD_TRANSPOSED_W and W.is_cuda and M >= 1024:
-        be.mm(MMOp(dy, N), weight_operand(be, W.t().contiguous(), K, N, M), dx, M, K, N, K, aux=aux, ldaux=K, aux_mode=aux_mode, tag=tag, keep=keep)
+        be.mm(MMOp(dy, N), MMOp(W.t().contiguous(), N), dx, M, K, N, K, aux=aux, ldaux=K, aux_mode=aux_mode, tag=tag, keep=keep)
         return
     be.mm(MMOp(dy, N), MMOp(W, K, trans=True), dx, M, K, N, K, aux=aux, ldaux=K, aux_mode=aux_mode, tag=tag, keep=keep)
 

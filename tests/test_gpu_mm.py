@@ -200,34 +200,36 @@ def test_mm_image_operands(M, N, K, layout, precision):
     assert rel_l2(a[1], e[1]) < TOL[precision]
 
 
-@pytest.mark.parametrize("M,N,K", [(600, 768, 768), (1200, 3072, 768), (1100, 2304, 768), (264, 136, 96), (130, 768, 3072), (5000, 3072, 768)])
-@pytest.mark.parametrize("precision", [1, 0])
-def test_mm_fp32_activations_against_presplit_weights(M, N, K, precision):
-    """Linear forward as the encoder runs it: fp32 activations (split on chip) against weights that arrive pre-split as bf16 hi / lo images
-    (format 1 on B only: chunks copied to LDS without conversion), every epilogue the layers use (bias, GELU + saved derivative, dropout
-    keep bits, residual add), split-K, and - for the wide outputs - the panel-major tile order (B beyond an XCD's L2), against the float64
-    emulator.  The row- and panel-major orders must give bit-identical results (the order only moves tiles between workgroups)."""
-    from a2f_amd.ops import MM_ACT_GELU_SAVE_GRAD, MM_AUX_ADD, MMImg
-    import a2f_amd.dropout as D
-    A, B = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=0.3)
-    bias, res = rnd(N, seed=23), rnd(M, N, seed=24)
-    gen = torch.Generator().manual_seed(25)
-    keep = D.pack_keep_bits(torch.rand(M, N, generator=gen) > 0.1)
+@pytest.mark.parametrize("M,N,K", [(1200, 3072, 768), (1100, 2304, 768), (5000, 3072, 768), (700, 768, 3072)])
+def test_mm_panel_major_tile_order_is_bitwise_the_row_major_result(M, N, K):
+    """The tile order (row-major, or panels of n-tiles when the B operand outgrows an XCD's L2: gemm_mfma.h tile_origin) only moves tiles
+    between workgroups: the Linear forward with the layers' epilogues gives bit-identical results under both (A2F_MM_GROUP_N=0 forces
+    row-major; read once per process, hence the child process)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import a2f_amd; from a2f_amd import ops; from a2f_amd.ops import MMOp, MM_ACT_GELU_SAVE_GRAD\n"
+        "g = torch.Generator().manual_seed(5); M, N, K = %d, %d, %d\n"
+        "x, W, b = torch.randn(M, K, generator=g).cuda(), (torch.randn(N, K, generator=g) * 0.3).cuda(), torch.randn(N, generator=g).cuda()\n"
+        "y, z = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')\n"
+        "ops.backend().mm(MMOp(x, K), MMOp(W, K), y, M, N, K, N, bias=b, act=MM_ACT_GELU_SAVE_GRAD, C2=z, precision=1)\n"
+        "torch.save((y.cpu(), z.cpu()), sys.argv[1])\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), M, N, K)
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        for i, env_extra in enumerate(({}, {"A2F_MM_GROUP_N": "0"})):
+            path = os.path.join(d, f"o{i}.pt")
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-1500:]
+            outs.append(torch.load(path))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = torch.nn.functional.gelu(torch.nn.functional.linear(*[t for t in _panel_inputs(M, N, K)]))
+    assert rel_l2(outs[0][0], ref) < 1e-4
 
-    def run(be, dev):
-        ib = be.split_bf16(B.to(dev))
-        a = A.to(dev)
-        c1, z = torch.zeros(M, N, device=dev), torch.zeros(M, N, device=dev)
-        be.mm(MMOp(a, K), MMImg(ib, K), c1, M, N, K, N, bias=bias.to(dev), act=MM_ACT_GELU_SAVE_GRAD, C2=z, keep=(keep.to(dev), 1.0 / 0.9), precision=precision)
-        c2 = torch.zeros(M, N, device=dev)
-        be.mm(MMOp(a, K), MMImg(ib, K), c2, M, N, K, N, bias=bias.to(dev), aux=res.to(dev), ldaux=N, aux_mode=MM_AUX_ADD, precision=precision)
-        c3 = torch.zeros(M, N, device=dev)
-        be.mm(MMOp(a, K), MMImg(ib, K), c3, M, N, K, N, split_k=3 if K >= 96 else 1, precision=precision)
-        c4 = torch.zeros(M, N, device=dev)
-        be.mm(MMOp(a, K), MMOp(B.to(dev), K), c4, M, N, K, N, bias=bias.to(dev), aux=res.to(dev), ldaux=N, aux_mode=MM_AUX_ADD, precision=precision)
-        return [c1, z, c2, c3, c4]
-    a, e = both(run)
-    for x, y in zip(a, e):
-        assert rel_l2(x, y) < TOL[precision]
-    if precision == 1:
-        assert torch.equal(a[2], a[4])                     # pre-split weights: the same hi / lo values as the on-chip split, the same products
+
+def _panel_inputs(M, N, K):
+    g = torch.Generator().manual_seed(5)
+    x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.3, torch.randn(N, generator=g)
+    return x.double(), W.double(), b.double()

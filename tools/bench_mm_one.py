@@ -22,7 +22,7 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 for i in range(iters + 2):
     if i == 2:
         e0.record()
-    Wop = ops.weight_operand(be, W, N, K, M)              # pre-split bf16 images unless A2F_MM_PRESPLIT=0 (the split is part of the call, as in the model)
+    Wop = MMOp(W, K)
     if plain:
         be.mm(MMOp(x, K), Wop, y, M, N, K, N, precision=1)
     else:

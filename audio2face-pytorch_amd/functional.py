@@ -292,9 +292,15 @@ def _unpack_conv_w(dwg, Co, Ci, KH, Cip):
     return dwg.view(-1, KH, Cip)[:Co, :, :Ci].permute(0, 2, 1).contiguous()
 
 
-# a2f_mm_desc.precision of the trunk on a2f_mm: 2 = bf16x6 (default: holds the G2 fixture's weight gradients at 1e-5),
-# 1 = bf16x3 (faster; the batch-statistics BatchNorm backward amplifies its 2^-16 product error beyond the parity bar at B = 4)
-A2M_MM_PRECISION = int(os.environ.get("A2F_A2M_MM_PRECISION", "2"))
+# a2f_mm_desc.precision of the trunk's products on a2f_mm, per kind: "fwd,wgrad,dgrad" (or one number for all three); 2 = bf16x6
+# (fp32-class), 1 = bf16x3.  Default 2,1,1: the FORWARD convolutions need the fp32-class form - their rounding reaches the batch
+# statistics of the next BatchNorm, whose (z - mean) / std amplifies it: with a bf16x3 forward the weight gradients of the analysis stack
+# sit 1.3e-2 from the reference on the B = 4 fixture (G2) whatever the backward products use - while the weight- and data-gradient
+# products are linear in their operands and hold 6e-5 / 2e-5 in bf16x3 (round 3 A-B on the GPU, tools/a2m_grad_errors.py: all-bf16x6
+# 2.1e-5 worst at 8.2 ms per B = 1024 step; 2,1,1: 6.0e-5 at 6.7 ms; 1,x,x: 1.3e-2).
+_a2m_prec = [int(v) for v in os.environ.get("A2F_A2M_MM_PRECISION", "2,1,1").split(",")]
+A2M_PREC_FWD, A2M_PREC_WGRAD, A2M_PREC_DGRAD = (_a2m_prec * 3)[:3] if len(_a2m_prec) == 1 else tuple(_a2m_prec)
+
 
 
 @contextlib.contextmanager
@@ -315,7 +321,7 @@ class A2MTrunkMMFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, one_hot, training, *rest):
         be = ops.backend()
-        with _mm_precision(be, A2M_MM_PRECISION):
+        with _mm_precision(be, A2M_PREC_FWD):
             return A2MTrunkMMFn._forward(ctx, be, x, one_hot, training, *rest)
 
     @staticmethod
@@ -404,7 +410,7 @@ class A2MTrunkMMFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh3):
         be = ops.backend()
-        with _mm_precision(be, A2M_MM_PRECISION):
+        with _mm_precision(be, A2M_PREC_DGRAD):
             return A2MTrunkMMFn._backward(ctx, be, dh3)
 
     @staticmethod
@@ -440,7 +446,8 @@ class A2MTrunkMMFn(torch.autograd.Function):
 
         # conv 9: (KH9,1)/s KH9, no pad: a plain GEMM over the (B, KH9*256) rows of zb
         dwg, dbv = new(256, KH9 * 256), new(256)
-        ops.mm_linear_wgrad(be, d, sv["conv_in"][9], dwg, B, 256, KH9 * 256, db=dbv)      # bias gradients: row sums inside the weight-gradient product
+        with _mm_precision(be, A2M_PREC_WGRAD):
+            ops.mm_linear_wgrad(be, d, sv["conv_in"][9], dwg, B, 256, KH9 * 256, db=dbv)  # bias gradients: row sums inside the weight-gradient product
         g_conv[18], g_conv[19] = _unpack_conv_w(dwg, 256, 256, KH9, 256).view(256, 256, KH9, 1), dbv
         dzb = new(B, KH9 * 256)
         ops.mm_linear_dgrad(be, d, sv["wg"][9], dzb, B, 256, KH9 * 256)
@@ -450,7 +457,8 @@ class A2MTrunkMMFn(torch.autograd.Function):
 
         def conv_bwd(i, dout, S, Lin, Lout, ci, co, cip, cop, shape, need_dx=True):
             dwg, dbv = new(cop, 3 * cip), new(cop)
-            ops.mm_conv_wgrad(be, sv["conv_in"][i], dout, dwg, S, Lin, Lout, cip, cop, 3, 2, pad=1, db=dbv)
+            with _mm_precision(be, A2M_PREC_WGRAD):
+                ops.mm_conv_wgrad(be, sv["conv_in"][i], dout, dwg, S, Lin, Lout, cip, cop, 3, 2, pad=1, db=dbv)
             g_conv[2 * i], g_conv[2 * i + 1] = _unpack_conv_w(dwg, co, ci, 3, cip).view(*shape), dbv[:co]
             if not need_dx:
                 return None

@@ -100,7 +100,6 @@ SIGNATURES = {
     "a2f_ff_decoder_bwd_drop": (C.c_int, [c_f32p, c_f32p, i64, i64, i32, C.c_void_p, sz, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, f32, C.c_void_p]),
     "a2f_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, f32, f32, f32, f32, f32, f32, i32, C.c_void_p]),
     "a2f_mm": (C.c_int, [C.POINTER(MMDesc), C.c_void_p]),
-    "a2f_split_bf16": (C.c_int, [c_f32p, i64, c_f32p, c_f32p, C.c_void_p]),
     "a2f_layernorm_fwd": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, f32, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "a2f_layernorm_bwd_ws_bytes": (sz, [i64, i64]),
     "a2f_layernorm_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),

@@ -1,5 +1,5 @@
-// Shared pieces of the bf16-MFMA GEMM family (csrc/gemm_mfma.hip: fp32 operands converted on chip; csrc/gemm_img.hip: operands that
-// arrive as bf16 hi / lo images): kernel argument block, epilogue, split / fragment helpers.  Contract: include/a2f_hip.h (a2f_mm).
+// Shared pieces of the bf16-MFMA GEMM family (csrc/gemm_mfma.hip): kernel argument block, tile order, epilogue, split / fragment helpers.
+// Contract: include/a2f_hip.h (a2f_mm).
 #pragma once
 #include "a2f_common.h"
 #include <stdlib.h>
@@ -23,7 +23,6 @@ constexpr int THREADS = 256;           // CFG 0 / 1; CFG 2 runs 512 threads (see
 
 struct Op {
   const float* p;
-  const void* p_lo;      // bf16 image operands (format 1): p = hi image, p_lo = lo image, `bytes` = size of ONE image, ld in bf16 elements
   unsigned bytes;
   int ld, lps, off, seq_elems;
   int lps_shift;         // log2(lps) when lps is a power of two, else -1 (short sequences: division -> shift)
@@ -245,9 +244,6 @@ __device__ __forceinline__ void tile_epilogue(const Args& a, const f32x16 (&acc)
   tile_epilogue_band<TM, TN, 0>(a, acc, m0, wm, h, bz, ncol, bv, generic);
 }
 
-
-// launchers of the image-operand kernels (csrc/gemm_img.hip)
-int dispatch_img_precision(const Args& a, int precision, bool at, bool bt, hipStream_t st);
 
 }  // namespace mm
 }  // namespace a2f

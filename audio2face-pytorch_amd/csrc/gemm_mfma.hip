@@ -481,16 +481,7 @@ static int dispatch_layout(const Args& a, bool at, bool bt, bool plain, hipStrea
 
 static int fill_op(const a2f_mm_operand& o, int64_t bstride, int64_t contiguous_extent, Op& k, const char* name) {
   A2F_CHECK_ARG(o.p != nullptr, "a2f_mm: operand %s is null", name);
-  k.p_lo = o.p_lo;
-  if (o.format == 1) {          // bf16 hi / lo images: plain matrices only
-    A2F_CHECK_ARG(o.lines_per_seq == 0 && bstride == 0, "a2f_mm: image operand %s must be a plain matrix (no windows, no batch)", name);
-    A2F_CHECK_ARG(((uintptr_t)o.p & 15) == 0 && ((uintptr_t)o.p_lo & 15) == 0 && o.ld % 8 == 0 && contiguous_extent % 8 == 0,
-                  "a2f_mm: image operand %s: 16-byte aligned images, ld and the contiguous extent multiples of 8 elements", name);
-    A2F_CHECK_ARG(o.bytes > 0 && o.bytes < (int64_t)0xFFFFFFF0ll, "a2f_mm: image operand %s spans %lld bytes per image (must be < 4 GiB)", name, (long long)o.bytes);
-    k.p = o.p; k.bytes = (unsigned)o.bytes; k.ld = (int)o.ld; k.lps = 0; k.lps_shift = -1; k.off = 0; k.seq_elems = 0x7FFFFFF0; k.seq_stride = 0; k.bstride = 0;
-    return A2F_OK;
-  }
-  A2F_CHECK_ARG(o.format == 0, "a2f_mm: operand %s: format %d", name, o.format);
+  A2F_CHECK_ARG(o.format == 0 && o.p_lo == nullptr, "a2f_mm: operand %s: format %d (only 0 = fp32 is defined; p_lo is reserved and must be null)", name, o.format);
   A2F_CHECK_ARG(((uintptr_t)o.p & 15) == 0, "a2f_mm: operand %s must be 16-byte aligned", name);
   A2F_CHECK_ARG(o.bytes > 0 && o.bytes < (int64_t)0xFFFFFFF0ll, "a2f_mm: operand %s spans %lld bytes (must be < 4 GiB)", name, (long long)o.bytes);
   A2F_CHECK_ARG(o.ld % 4 == 0 && o.off % 4 == 0 && o.seq_stride % 4 == 0 && bstride % 4 == 0 && contiguous_extent % 4 == 0,
@@ -593,22 +584,6 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
     if (force && force[0] >= '0' && force[0] <= '3') cfg = force[0] - '0';
   }
   hipStream_t st = (hipStream_t)stream;
-  A2F_CHECK_ARG(d->A.format == d->B.format, "a2f_mm: both operands fp32 or both bf16 hi / lo images");
-  if (d->A.format == 1) {
-    A2F_CHECK_ARG(batch == 1 && d->K % BK == 0 && d->a_rowsum == nullptr && d->precision != 2, "a2f_mm: image operands need batch 1, K a multiple of %d, no a_rowsum, precision 0 | 1", BK);
-    A2F_CHECK_ARG(d->precision == 0 || (d->A.p_lo && d->B.p_lo), "a2f_mm: image operands: precision 1 needs the lo images");
-    rc = dispatch_img_precision(a, d->precision, at, bt, st);
-    if (rc) return rc;
-    A2F_CHECK_LAUNCH("a2f_mm (images)");
-    if (split > 1) {
-      const long long total = (long long)a.M * a.N;
-      long long blocks = (total + 255) / 256;
-      if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(gemm_mfma_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
-      A2F_CHECK_LAUNCH("a2f_mm fold");
-    }
-    return A2F_OK;
-  }
   static const bool no_plain = [] { const char* e = getenv("A2F_MM_PLAIN"); return e && e[0] == '0'; }();     // A-B hook
   const bool plain = !no_plain && a.A.lps == 0 && a.B.lps == 0 && (d->K % BK) == 0;
   if (d->precision == 2) {                 // three images per operand: the 256 x 128 tile does not fit

@@ -22,33 +22,7 @@ __global__ __launch_bounds__(256) void stream_triad_kernel(float4* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void split_bf16_kernel(const float4* __restrict__ x, int64_t n4, uint2* __restrict__ hi, uint2* __restrict__ lo) {
-  using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
-  using f32x2_t = __attribute__((ext_vector_type(2))) float;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const float4 v = x[i];
-    const f32x2_t a = {v.x, v.y}, b = {v.z, v.w};
-    const bf16x2_t ha = __builtin_convertvector(a, bf16x2_t), hb = __builtin_convertvector(b, bf16x2_t);
-    const f32x2_t ra = a - __builtin_convertvector(ha, f32x2_t), rb = b - __builtin_convertvector(hb, f32x2_t);
-    const bf16x2_t la = __builtin_convertvector(ra, bf16x2_t), lb = __builtin_convertvector(rb, bf16x2_t);
-    hi[i] = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
-    lo[i] = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
-  }
-}
-
 }  // namespace a2f
-
-extern "C" int a2f_split_bf16(const float* x, int64_t n, uint16_t* hi, uint16_t* lo, a2f_stream_t stream) {
-  using namespace a2f;
-  A2F_CHECK_ARG(x && hi && lo && n > 0 && n % 4 == 0, "split_bf16: n=%lld must be a positive multiple of 4", (long long)n);
-  A2F_CHECK_ARG(((uintptr_t)x & 15) == 0 && (((uintptr_t)hi | (uintptr_t)lo) & 7) == 0, "split_bf16: x 16-byte, images 8-byte aligned");
-  long long blocks = cdiv(n / 4, 256);
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)x, n / 4, (uint2*)hi, (uint2*)lo);
-  A2F_CHECK_LAUNCH("split_bf16");
-  return A2F_OK;
-}
 
 extern "C" int a2f_stream_copy(float* dst, const float* src, int64_t n, a2f_stream_t stream) {
   using namespace a2f;

@@ -40,23 +40,6 @@ class MMOp:
         o.lines_per_seq, o.seq_stride, o.off, o.seq_elems = self.lines_per_seq, self.seq_stride, self.off, self.seq_elems
 
 
-class MMImg(MMOp):
-    """An a2f_mm operand that arrives as bf16 hi / lo images (a2f_mm_operand.format 1): ``img`` = (hi, lo) bfloat16 tensors of the matrix's
-    shape (``HipBackend.split_bf16`` or a producing kernel), ``ld`` in elements; plain matrices only."""
-
-    def __init__(self, img, ld: int, *, trans: bool = False):
-        self.hi, self.lo = img
-        super().__init__(self.hi, ld, trans=trans)
-
-    def fill(self, o: MMOperand):
-        for t in (self.hi, self.lo):
-            if t.device.type != "cuda" or t.dtype != torch.bfloat16 or not t.is_contiguous():
-                raise A2FError("image operands are contiguous bfloat16 HIP tensors")
-        o.p, o.p_lo = self.hi.data_ptr(), self.lo.data_ptr()
-        o.bytes = 2 * self.hi.numel()
-        o.ld, o.trans, o.format = self.ld, int(self.trans), 1
-
-
 def _ptr(t: Optional[torch.Tensor], off: int = 0) -> Optional[int]:
     if t is None:
         return None
@@ -156,7 +139,7 @@ class HipBackend:
            bias_bstride=0, aux_bstride=0, accumulate=False, alpha=1.0, tag="gemm_mfma", keep=None, a_rowsum=None):
         """C[m,n] = epi(alpha * sum_k A(m,k) B(k,n)) on the bf16 matrix pipe (contract: include/a2f_hip.h, a2f_mm).
         keep = (bits int32 (M, wpr), scale): train-mode dropout of C in the epilogue."""
-        _chk(*(t for t in (A.t, B.t) if t.dtype != torch.bfloat16), Cout, C2, bias, aux)
+        _chk(A.t, B.t, Cout, C2, bias, aux)
         d = MMDesc()
         A.fill(d.A)
         B.fill(d.B)
@@ -198,7 +181,7 @@ class HipBackend:
             ps = getattr(self, "prof_shapes", None)
             if ps is not None and ev is not None:                # per launch variant: layout / shape / precision -> events, flops per launch
                 key = (("T" if A.trans else "N") + ("T" if not B.trans else "N"), M, N, K, batch, bool(A.lines_per_seq or B.lines_per_seq),
-                       d.precision, getattr(A, "hi", None) is not None)
+                       d.precision, False)
                 ent = ps.setdefault(key, {"events": [], "flops": 2.0 * M * N * K * batch})
                 ent["events"].append(ev)
 
@@ -278,13 +261,6 @@ class HipBackend:
                                               self._attn_prec(precision), _ptr(dqkv), _ptr(ws), keep_q.data_ptr(),
                                               keep_k.data_ptr(), float(keep_scale), self._stream(qkv)), "a2f_attn_bwd_drop")
         self._prof_end("attn", ev)
-
-    def split_bf16(self, x):
-        """fp32 tensor -> (hi, lo) bfloat16 images of the same shape (a2f_split_bf16): the format-1 operand form of a2f_mm."""
-        _chk(x)
-        hi, lo = torch.empty_like(x, dtype=torch.bfloat16), torch.empty_like(x, dtype=torch.bfloat16)
-        _lib.check(self.lib.a2f_split_bf16(_ptr(x), x.numel(), hi.data_ptr(), lo.data_ptr(), self._stream(x)), "a2f_split_bf16")
-        return hi, lo
 
     # ---- dropout keep masks (csrc/dropout.hip) ---------------------------------------------------
     def attn_keep_words(self, T):

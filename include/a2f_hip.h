@@ -293,8 +293,8 @@ int a2f_stream_triad(float* dst, const float* a, const float* b, int64_t n, a2f_
  * v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  precision 1 (bf16x3): x = hi + lo, lo*hi' + hi*lo' + hi*hi', <= 2^-16
  * relative error per product - the setting the 1e-4 parity bar is met with; precision 0: plain bf16 operands (the
  * reference's `percision: 16-mixed`); precision 2 (bf16x6): x = hi + mid + lo, the six products down to 2^-16 of the leading
- * one - fp32-GEMM class (2e-6 on the result), three LDS images per operand, fp32 operands (format 0) only: the Audio2Mesh
- * trunk, whose batch-statistics BatchNorm backward amplifies the bf16x3 error beyond the parity bar.
+ * one - fp32-GEMM class (2e-6 on the result), three LDS images per operand: the forward convolutions of the Audio2Mesh trunk, whose
+ * rounding reaches the batch statistics of the next BatchNorm (bf16x3 there puts the weight gradients 1e-2 off the reference).
  * Operands (a2f_mm_operand): `trans` = 0: a line is a row of A (column of B) and k is the contiguous axis; `trans` = 1: a
  * line is one k and the m (n) index is contiguous.  Line i of an operand with lines_per_seq > 0 belongs to sequence
  * s = i / lines_per_seq, position q = i % lines_per_seq; element j of the line sits at element offset
@@ -304,10 +304,10 @@ int a2f_stream_triad(float* dst, const float* a, const float* b, int64_t n, a2f_
  * are lines with ld < K, zero padding and sequence ends are the bounds test.  `bytes` = addressable span from p (< 4 GiB):
  * anything beyond reads as zero.  All of p, ld, off, seq_stride and the contiguous extent must be multiples of 4 elements
  * (16-byte vector loads).
- * format 1 operands (both or neither): the matrix arrives as two row-major bf16 images hi = RNE_bf16(x), lo = RNE_bf16(x - hi) (a2f_split_bf16
- * or a producing kernel): p = hi image, p_lo = lo image, `bytes` = size of ONE image, ld in bf16 elements (a multiple of 8); plain matrices only,
- * K a multiple of 32.  The kernel copies k-tiles global -> LDS with LDS-DMA loads and multiplies the same three products: identical arithmetic to
- * format 0 without the on-chip conversion (precision 0 reads the hi image only).
+ * `format` must be 0 and `p_lo` null (reserved: rounds 2 / 3 measured operands that arrive as ready-made bf16 hi / lo images staged by LDS-DMA
+ * - +6..25 % at the kernel, not enough to pay for splitting passes; the kernel was removed until the producers emit images).
+ * Tile order: workgroups walk the (m-tile, n-tile) grid row-major, or - when B (N x K x 4 bytes) outgrows an XCD's 4 MB L2 - in panels of n-tiles
+ * whose slice of B stays resident while the A panels stream past (same results bit for bit; A2F_MM_GROUP_N=0 forces row-major).
  * Epilogue, per element: v = alpha*acc; if bias: v += bias[n]; C2 (optional) = v;  act: 0 none, 1 ReLU, 3 GELU (erf form), 4 GELU with
  * C2 = gelu'(v) instead of v (the derivative the backward multiplies by: no erf / exp pass there);
  * keep_bits (optional, batch == 1): v = bit (m, n) of the keep mask ? v * keep_scale : 0 (train-mode dropout of the layer's output,
@@ -327,9 +327,9 @@ typedef struct a2f_mm_operand {
   const float* p;
   int64_t bytes;
   int64_t ld;
-  int32_t trans, format;          /* format 0: fp32 (everything above); 1: bf16 hi / lo images, see below */
+  int32_t trans, format;          /* format: 0 (fp32); other values are reserved */
   int64_t lines_per_seq, seq_stride, off, seq_elems;
-  const void* p_lo;               /* format 1: the lo image */
+  const void* p_lo;               /* reserved: must be null */
 } a2f_mm_operand;
 
 typedef struct a2f_mm_desc {
@@ -350,9 +350,6 @@ typedef struct a2f_mm_desc {
 } a2f_mm_desc;
 
 int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream);
-/* x (n fp32, n % 4 == 0, 16-byte aligned) -> hi[i] = RNE_bf16(x[i]), lo[i] = RNE_bf16(x[i] - hi[i]) (bf16 bit patterns, n each): the image form of
- * an a2f_mm operand (format 1). */
-int a2f_split_bf16(const float* x, int64_t n, uint16_t* hi, uint16_t* lo, a2f_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row-wise kernels of the wav2vec2 encoder path (csrc/rowops.hip; HF Wav2Vec2Model as wrapped by

@@ -140,17 +140,10 @@ class EmuBackend:
     mm_precision = 1
     attn_precision = None
 
-    def split_bf16(self, x):
-        hi = x.to(torch.bfloat16)
-        return hi, (x - hi.float()).to(torch.bfloat16)
-
     @staticmethod
     def _mm_matrix(op, nlines, ncontig):
         """(nlines, ncontig) float64 matrix of an a2f_mm_operand by the header's contract (zeros outside the windows)."""
-        if hasattr(op, "hi"):                           # format 1: the value of the operand is hi + lo
-            flat = (op.hi.double() + op.lo.double()).reshape(-1)
-        else:
-            flat = op.t.reshape(-1)[op.ptr_off:].double()
+        flat = op.t.reshape(-1)[op.ptr_off:].double()
         i = torch.arange(nlines).view(-1, 1)
         j = torch.arange(ncontig).view(1, -1)
         if op.lines_per_seq > 0:

@@ -169,37 +169,6 @@ def test_mm_weight_gradient_with_fused_bias_gradient(M, N, K, split, precision):
     assert rel_l2(a[1], e[1]) < 1e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(600, 768, 768), (1200, 3072, 768), (264, 136, 96), (128, 128, 32), (96, 2304, 3072)])
-@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
-@pytest.mark.parametrize("precision", [1, 0])
-def test_mm_image_operands(M, N, K, layout, precision):
-    """format 1: operands as bf16 hi / lo images (a2f_split_bf16), k-tiles copied global -> LDS by LDS-DMA.  The three layouts of a
-    Linear (forward, data gradient, weight gradient), with a bias + residual epilogue and with split-K, against the float64 emulator;
-    and the images themselves bit for bit against RNE arithmetic in torch."""
-    from a2f_amd.ops import MM_AUX_ADD, MMImg
-    at, bt = layout[0] == "t", layout[1] == "n"
-    a_shape = (K, M) if at else (M, K)
-    b_shape = (K, N) if bt else (N, K)
-    A, B = rnd(*a_shape, seed=11), rnd(*b_shape, seed=12, scale=0.3)
-    bias, res = rnd(N, seed=13), rnd(M, N, seed=14)
-    hip = ops.HipBackend()
-    ah, al = hip.split_bf16(A.to(DEV))
-    eh = A.to(torch.bfloat16)
-    assert torch.equal(ah.cpu(), eh) and torch.equal(al.cpu(), (A - eh.float()).to(torch.bfloat16))
-
-    def run(be, dev):
-        ia, ib = be.split_bf16(A.to(dev)), be.split_bf16(B.to(dev))
-        c = torch.zeros(M, N, device=dev)
-        be.mm(MMImg(ia, a_shape[1], trans=at), MMImg(ib, b_shape[1], trans=bt), c, M, N, K, N, bias=bias.to(dev), aux=res.to(dev), ldaux=N,
-              aux_mode=MM_AUX_ADD, precision=precision)
-        cs = torch.zeros(M, N, device=dev)
-        be.mm(MMImg(ia, a_shape[1], trans=at), MMImg(ib, b_shape[1], trans=bt), cs, M, N, K, N, split_k=3 if K >= 96 else 1, precision=precision)
-        return [c, cs]
-    a, e = both(run)
-    assert rel_l2(a[0], e[0]) < TOL[precision]
-    assert rel_l2(a[1], e[1]) < TOL[precision]
-
-
 @pytest.mark.parametrize("M,N,K", [(1200, 3072, 768), (1100, 2304, 768), (5000, 3072, 768), (700, 768, 3072)])
 def test_mm_panel_major_tile_order_is_bitwise_the_row_major_result(M, N, K):
     """The tile order (row-major, or panels of n-tiles when the B operand outgrows an XCD's L2: gemm_mfma.h tile_origin) only moves tiles

@@ -7,7 +7,7 @@ from golden_util import load, packed_error
 from oracle import weights as W
 NV=5023*3
 g = load("g2_audio2mesh")
-for mode in ("train",):
+for mode in (os.environ.get("A2M_MODE", "train"),):
     m = a2f_amd.Audio2Mesh(n_verts=NV, n_onehot=12)
     m.load_state_dict(W.formula_state_dict(W.audio2mesh_shapes(NV, 12), gains={"output_net.4": 4.0}))
     m.to("cuda").train(mode == "train")

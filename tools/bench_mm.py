@@ -43,15 +43,6 @@ def shape(M, N, K, name):
         res[f"fwd_{tag}_TF"] = round(fl / (timeit(lambda: be.mm(MMOp(x, K), MMOp(W, K), y, M, N, K, N, precision=prec)) * 1e-3), 1)
         res[f"dgrad_{tag}_TF"] = round(fl / (timeit(lambda: be.mm(MMOp(dy, N), MMOp(W, K, trans=True), dx, M, K, N, K, precision=prec)) * 1e-3), 1)
         res[f"wgrad_{tag}_TF"] = round(fl / (timeit(lambda: be.mm(MMOp(dy, N, trans=True), MMOp(x, K, trans=True), dW, N, K, M, K, split_k=0, precision=prec)) * 1e-3), 1)
-    # the same products with the operands as ready-made bf16 hi / lo images (format 1: LDS-DMA staging, no conversion on chip)
-    from a2f_amd.ops import MMImg
-    ix, iW, idy = be.split_bf16(x), be.split_bf16(W), be.split_bf16(dy)
-    for prec, tag in ((1, "x3"), (0, "bf16")):
-        res[f"fwd_img_{tag}_TF"] = round(fl / (timeit(lambda: be.mm(MMImg(ix, K), MMImg(iW, K), y, M, N, K, N, precision=prec)) * 1e-3), 1)
-        res[f"dgrad_img_{tag}_TF"] = round(fl / (timeit(lambda: be.mm(MMImg(idy, N), MMImg(iW, K, trans=True), dx, M, K, N, K, precision=prec)) * 1e-3), 1)
-        res[f"wgrad_img_{tag}_TF"] = round(fl / (timeit(lambda: be.mm(MMImg(idy, N, trans=True), MMImg(ix, K, trans=True), dW, N, K, M, K, split_k=0,
-                                                                        precision=prec)) * 1e-3), 1)
-    res["split_ms_x"] = round(timeit(lambda: be.split_bf16(x)), 4)
     res["torch_f32_fwd_TF"] = round(fl / (timeit(lambda: torch.matmul(x, W.t())) * 1e-3), 1)
     res["torch_f32_wgrad_TF"] = round(fl / (timeit(lambda: torch.matmul(dy.t(), x)) * 1e-3), 1)
     res["torch_bf16_fwd_TF"] = round(fl / (timeit(lambda: torch.matmul(xb, Wb.t())) * 1e-3), 1)
@@ -76,40 +67,7 @@ def attention(S, T, H=12):
     print(json.dumps(res), flush=True)
 
 
-def images_only(M, N, K, name):
-    """A-B of the image-operand tile geometries (A2F_MM_IMG_MODE, one process per mode): bf16x3 products only."""
-    from a2f_amd.ops import MMImg
-    x = torch.randn(M, K, device=dev)
-    W = torch.randn(N, K, device=dev) * 0.05
-    dy = torch.randn(M, N, device=dev)
-    y, dx, dW = torch.empty(M, N, device=dev), torch.empty(M, K, device=dev), torch.empty(N, K, device=dev)
-    ix, iW, idy = be.split_bf16(x), be.split_bf16(W), be.split_bf16(dy)
-    iWt = be.split_bf16(W.t().contiguous())
-    fl = 2.0 * M * N * K / 1e12
-    res = {"shape": name, "M": M, "N": N, "K": K, "img_mode": os.environ.get("A2F_MM_IMG_MODE", "default")}
-    res["fwd_f32_x3_TF"] = round(fl / (timeit(lambda: be.mm(MMOp(x, K), MMOp(W, K), y, M, N, K, N, precision=1)) * 1e-3), 1)
-    res["fwd_img_x3_TF"] = round(fl / (timeit(lambda: be.mm(MMImg(ix, K), MMImg(iW, K), y, M, N, K, N, precision=1)) * 1e-3), 1)
-    res["dgrad_img_x3_TF"] = round(fl / (timeit(lambda: be.mm(MMImg(idy, N), MMImg(iWt, N), dx, M, K, N, K, precision=1)) * 1e-3), 1)      # transposed weight copy: both row images
-    res["wgrad_img_x3_TF"] = round(fl / (timeit(lambda: be.mm(MMImg(idy, N, trans=True), MMImg(ix, K, trans=True), dW, N, K, M, K, split_k=0, precision=1)) * 1e-3), 1)
-    res["fwd_img_bf16_TF"] = round(fl / (timeit(lambda: be.mm(MMImg(ix, K), MMImg(iW, K), y, M, N, K, N, precision=0)) * 1e-3), 1)
-    # correctness spot check of this geometry against torch fp32 on the same operands
-    be.mm(MMImg(ix, K), MMImg(iW, K), y, M, N, K, N, precision=1)
-    ref = x @ W.t()
-    res["fwd_rel_err"] = float(f"{float((y - ref).norm() / ref.norm()):.2e}")
-    be.mm(MMImg(idy, N, trans=True), MMImg(ix, K, trans=True), dW, N, K, M, K, split_k=0, precision=1)
-    ref = dy.t() @ x
-    res["wgrad_rel_err"] = float(f"{float((dW - ref).norm() / ref.norm()):.2e}")
-    print(json.dumps(res), flush=True)
-
-
 if __name__ == "__main__":
-    if os.environ.get("MM_IMG_AB") == "1":
-        for M in (9600, 38400):
-            images_only(M, 768, 768, f"out projection, M = {M}")
-            images_only(M, 2304, 768, f"qkv projection, M = {M}")
-            images_only(M, 3072, 768, f"ffn up, M = {M}")
-            images_only(M, 768, 3072, f"ffn down, M = {M}")
-        sys.exit(0)
     if os.environ.get("MM_QUICK") == "1":                 # PMC / ablation runs: two GEMM shapes and the attention kernels only
         shape(9600, 768, 768, "qkv/out projection, 16 x 600 frames")
         shape(9600, 768, 3072, "ffn down")

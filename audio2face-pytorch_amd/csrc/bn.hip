@@ -5,6 +5,10 @@
 // HBM-bound elementwise + column reductions.  Reductions are deterministic two-stage: every workgroup reduces a
 // slab of rows into double partials [block][2][C] in the workspace, one finishing workgroup folds them in fixed order.
 // Channel index = flat index mod C, so consecutive lanes read consecutive addresses (fully coalesced) for any C.
+// Round 3: (i) the backward no longer reads the saved output y for the ReLU mask - y > 0 <=> fma(x, invstd gamma, beta - mean invstd gamma) > 0,
+// the forward's own expression (bn_affine) re-evaluated from x: one (R, C) read less in each of the two backward passes; (ii) the two
+// apply kernels move one float4 per thread with one workgroup per 4 KB (the shape that streams at 6 TB/s on this chip, util.hip) instead of
+// 4-byte elements in a persistent grid-stride loop with an integer modulo per element.
 #include "a2f_common.h"
 
 namespace a2f {
@@ -22,14 +26,19 @@ __host__ __device__ inline int bn_blocks(int64_t R, int C) {
   return (int)b;
 }
 
+// the normalise-scale-shift of the forward, shared with the backward's ReLU mask (same instruction, same rounding)
+__device__ __forceinline__ float bn_affine(float x, float sc, float sh) { return fmaf(x, sc, sh); }
+__device__ __forceinline__ float bn_scale(float invstd, float gamma) { return invstd * gamma; }
+__device__ __forceinline__ float bn_shift(float beta, float mean, float sc) { return fmaf(-mean, sc, beta); }
+
 // part[blk][0][c] = sum_r u(r,c) ; part[blk][1][c] = sum_r u(r,c)*w(r,c)
 //   MODE 0 (fwd stats): u = x, w = x
-//   MODE 1 (bwd):       u = dy' , w = xhat   (dy' = relu ? dy*(y>0) : dy)
+//   MODE 1 (bwd):       u = dy' , w = xhat   (dy' = relu ? dy*(bn_affine(x) > 0) : dy; `y` = beta in this mode)
 template <int MODE>
 __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                  const float* __restrict__ dy, int64_t R, int C,
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                 int relu, double* __restrict__ part) {
+                                                                 const float* __restrict__ gamma, int relu, double* __restrict__ part) {
   const int t = threadIdx.x;
   double s0 = 0.0, s1 = 0.0;
   const int64_t rows_per_block = (R + gridDim.x - 1) / gridDim.x;
@@ -40,22 +49,25 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float* __r
     const int rpp = BN_THREADS / C;
     const int c = t % C, ro = t / C;
     if (ro < rpp) {
-      float mu = 0.f, is = 0.f;
-      if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+      float mu = 0.f, is = 0.f, sc = 0.f, sh = 1.f;                  // sc = 0, sh = 1: "always positive" when there is no ReLU
+      if (MODE == 1) {
+        mu = mean[c]; is = invstd[c];
+        if (relu) { sc = bn_scale(is, gamma[c]); sh = bn_shift(y[c], mu, sc); }
+      }
       // four rows per trip: the loads are independent, the double accumulation order stays fixed
       int64_t r = r0 + ro;
       for (; r + 3 * rpp < r1; r += 4 * rpp) {
-        float xv[4], gv[4], yv[4];
+        float xv[4], gv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int64_t i = (r + (int64_t)u * rpp) * C + c;
           xv[u] = x[i];
-          if (MODE == 1) { gv[u] = dy[i]; yv[u] = relu ? y[i] : 1.f; }
+          if (MODE == 1) gv[u] = dy[i];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (MODE == 0) { s0 += xv[u]; s1 += (double)xv[u] * xv[u]; }
-          else { const float g = yv[u] > 0.f ? gv[u] : 0.f; s0 += g; s1 += (double)g * ((xv[u] - mu) * is); }
+          else { const float g = bn_affine(xv[u], sc, sh) > 0.f ? gv[u] : 0.f; s0 += g; s1 += (double)g * ((xv[u] - mu) * is); }
         }
       }
       for (; r < r1; r += rpp) {
@@ -64,9 +76,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float* __r
           const float v = x[i];
           s0 += v; s1 += (double)v * v;
         } else {
-          float g = dy[i];
-          if (relu && !(y[i] > 0.f)) g = 0.f;
-          s0 += g; s1 += (double)g * ((x[i] - mu) * is);
+          const float xv1 = x[i];
+          const float g = bn_affine(xv1, sc, sh) > 0.f ? dy[i] : 0.f;
+          s0 += g; s1 += (double)g * ((xv1 - mu) * is);
         }
       }
     }
@@ -83,12 +95,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float* __r
   } else {
     for (int c = t; c < C; c += BN_THREADS) {
       s0 = 0.0; s1 = 0.0;
-      float mu = 0.f, is = 0.f;
-      if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+      float mu = 0.f, is = 0.f, sc = 0.f, sh = 1.f;
+      if (MODE == 1) {
+        mu = mean[c]; is = invstd[c];
+        if (relu) { sc = bn_scale(is, gamma[c]); sh = bn_shift(y[c], mu, sc); }
+      }
       for (int64_t r = r0; r < r1; ++r) {
         const int64_t i = r * C + c;
         if (MODE == 0) { const float v = x[i]; s0 += v; s1 += (double)v * v; }
-        else { float g = dy[i]; if (relu && !(y[i] > 0.f)) g = 0.f; s0 += g; s1 += (double)g * ((x[i] - mu) * is); }
+        else { const float xv1 = x[i]; const float g = bn_affine(xv1, sc, sh) > 0.f ? dy[i] : 0.f; s0 += g; s1 += (double)g * ((xv1 - mu) * is); }
       }
       part[((int64_t)blockIdx.x * 2 + 0) * C + c] = s0;
       part[((int64_t)blockIdx.x * 2 + 1) * C + c] = s1;
@@ -103,7 +118,7 @@ template <int MODE>
 __global__ __launch_bounds__(BN_THREADS) void bn_partial4_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                   const float* __restrict__ dy, int64_t R, int C,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                  int relu, double* __restrict__ part) {
+                                                                  const float* __restrict__ gamma, int relu, double* __restrict__ part) {
   const int t = threadIdx.x;
   const int Q = C >> 2, rpp = BN_THREADS / Q;
   const int q = t % Q, ro = t / Q;
@@ -112,14 +127,22 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial4_kernel(const float* __
   const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
   double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
   if (ro < rpp) {
-    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
-    if (MODE == 1) { mu = *reinterpret_cast<const float4*>(mean + 4 * q); is = *reinterpret_cast<const float4*>(invstd + 4 * q); }
-    auto acc = [&](const float4 xv, const float4 gv, const float4 yv) {
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu, sc = mu, sh = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (MODE == 1) {
+      mu = *reinterpret_cast<const float4*>(mean + 4 * q); is = *reinterpret_cast<const float4*>(invstd + 4 * q);
+      if (relu) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gamma + 4 * q), b4 = *reinterpret_cast<const float4*>(y + 4 * q);     // y = beta in this mode
+        sc = make_float4(bn_scale(is.x, g4.x), bn_scale(is.y, g4.y), bn_scale(is.z, g4.z), bn_scale(is.w, g4.w));
+        sh = make_float4(bn_shift(b4.x, mu.x, sc.x), bn_shift(b4.y, mu.y, sc.y), bn_shift(b4.z, mu.z, sc.z), bn_shift(b4.w, mu.w, sc.w));
+      }
+    }
+    auto acc = [&](const float4 xv, const float4 gv) {
       if (MODE == 0) {
         s0[0] += xv.x; s1[0] += (double)xv.x * xv.x; s0[1] += xv.y; s1[1] += (double)xv.y * xv.y;
         s0[2] += xv.z; s1[2] += (double)xv.z * xv.z; s0[3] += xv.w; s1[3] += (double)xv.w * xv.w;
       } else {
-        const float g0 = yv.x > 0.f ? gv.x : 0.f, g1 = yv.y > 0.f ? gv.y : 0.f, g2 = yv.z > 0.f ? gv.z : 0.f, g3 = yv.w > 0.f ? gv.w : 0.f;
+        const float g0 = bn_affine(xv.x, sc.x, sh.x) > 0.f ? gv.x : 0.f, g1 = bn_affine(xv.y, sc.y, sh.y) > 0.f ? gv.y : 0.f;
+        const float g2 = bn_affine(xv.z, sc.z, sh.z) > 0.f ? gv.z : 0.f, g3 = bn_affine(xv.w, sc.w, sh.w) > 0.f ? gv.w : 0.f;
         s0[0] += g0; s1[0] += (double)g0 * ((xv.x - mu.x) * is.x);
         s0[1] += g1; s1[1] += (double)g1 * ((xv.y - mu.y) * is.y);
         s0[2] += g2; s1[2] += (double)g2 * ((xv.z - mu.z) * is.z);
@@ -129,23 +152,21 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial4_kernel(const float* __
     const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
     int64_t r = r0 + ro;
     for (; r + 3 * rpp < r1; r += 4 * rpp) {
-      float4 xv[4], gv[4], yv[4];
+      float4 xv[4], gv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int64_t i = (r + (int64_t)u * rpp) * C + 4 * q;
         xv[u] = *reinterpret_cast<const float4*>(x + i);
-        if (MODE == 1) { gv[u] = *reinterpret_cast<const float4*>(dy + i); yv[u] = relu ? *reinterpret_cast<const float4*>(y + i) : one; }
-        else { gv[u] = one; yv[u] = one; }
+        gv[u] = MODE == 1 ? *reinterpret_cast<const float4*>(dy + i) : one;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc(xv[u], gv[u], yv[u]);
+      for (int u = 0; u < 4; ++u) acc(xv[u], gv[u]);
     }
     for (; r < r1; r += rpp) {
       const int64_t i = r * C + 4 * q;
       const float4 xv = *reinterpret_cast<const float4*>(x + i);
-      float4 gv = one, yv = one;
-      if (MODE == 1) { gv = *reinterpret_cast<const float4*>(dy + i); if (relu) yv = *reinterpret_cast<const float4*>(y + i); }
-      acc(xv, gv, yv);
+      const float4 gv = MODE == 1 ? *reinterpret_cast<const float4*>(dy + i) : one;
+      acc(xv, gv);
     }
   }
   __shared__ double sh[2][4][BN_THREADS];
@@ -226,50 +247,67 @@ __global__ __launch_bounds__(256) void bn_finish_bwd_kernel(const double* __rest
   dgamma[c] = (float)q;
 }
 
-// y = (x - mean) * invstd * gamma + beta  [relu]
+// y = (x - mean) * invstd * gamma + beta  [relu]        VEC: one float4 per thread (C % 4 == 0, 16-byte aligned), else one element
+template <bool VEC>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float* __restrict__ x, int64_t total, int C,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                int relu, float* __restrict__ y) {
-  __shared__ float sc[BN_MAX_C], sh[BN_MAX_C];
+  __shared__ __attribute__((aligned(16))) float sc[BN_MAX_C], sh[BN_MAX_C];
   for (int c = threadIdx.x; c < C; c += BN_THREADS) {
-    const float s = invstd[c] * gamma[c];
+    const float s = bn_scale(invstd[c], gamma[c]);
     sc[c] = s;
-    sh[c] = beta[c] - mean[c] * s;
+    sh[c] = bn_shift(beta[c], mean[c], s);
   }
   __syncthreads();
-  const int64_t stride = (int64_t)gridDim.x * BN_THREADS;
-  for (int64_t i = blockIdx.x * (int64_t)BN_THREADS + threadIdx.x; i < total; i += stride) {
-    const int c = (int)(i % C);
-    float v = x[i] * sc[c] + sh[c];
+  const int64_t i = (blockIdx.x * (int64_t)BN_THREADS + threadIdx.x) * (VEC ? 4 : 1);
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  if constexpr (VEC) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + i);
+    const float4 s4 = *reinterpret_cast<const float4*>(sc + c), h4 = *reinterpret_cast<const float4*>(sh + c);
+    float4 v = make_float4(bn_affine(xv.x, s4.x, h4.x), bn_affine(xv.y, s4.y, h4.y), bn_affine(xv.z, s4.z, h4.z), bn_affine(xv.w, s4.w, h4.w));
+    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    *reinterpret_cast<float4*>(y + i) = v;
+  } else {
+    float v = bn_affine(x[i], sc[c], sh[c]);
     if (relu) v = fmaxf(v, 0.f);
     y[i] = v;
   }
 }
 
-// training: dx = gamma*invstd/R * (R*dy' - dbeta - xhat*dgamma) ; eval: dx = dy'*gamma*invstd
-__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+// training: dx = gamma*invstd/R * (R*dy' - dbeta - xhat*dgamma) ; eval: dx = dy'*gamma*invstd        (dy' = dy where the forward output was > 0)
+template <bool VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ beta,
                                                                    const float* __restrict__ dy, int64_t total, int C, float invR,
                                                                    const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                    const float* __restrict__ invstd, const float* __restrict__ dgamma,
                                                                    const float* __restrict__ dbeta, int training, int relu,
                                                                    float* __restrict__ dx) {
-  __shared__ float s_gi[BN_MAX_C], s_mu[BN_MAX_C], s_is[BN_MAX_C], s_db[BN_MAX_C], s_dg[BN_MAX_C];
+  __shared__ __attribute__((aligned(16))) float s_gi[BN_MAX_C], s_mu[BN_MAX_C], s_is[BN_MAX_C], s_db[BN_MAX_C], s_dg[BN_MAX_C], s_sh[BN_MAX_C];
   for (int c = threadIdx.x; c < C; c += BN_THREADS) {
-    s_gi[c] = gamma[c] * invstd[c];
+    const float gi = bn_scale(invstd[c], gamma[c]);           // the forward's scale, bit for bit
+    s_gi[c] = gi;
     s_mu[c] = mean[c];
     s_is[c] = invstd[c];
     s_db[c] = training ? dbeta[c] * invR : 0.f;
     s_dg[c] = training ? dgamma[c] * invR : 0.f;
+    s_sh[c] = relu ? bn_shift(beta[c], mean[c], gi) : 1.f;
   }
   __syncthreads();
-  const int64_t stride = (int64_t)gridDim.x * BN_THREADS;
-  for (int64_t i = blockIdx.x * (int64_t)BN_THREADS + threadIdx.x; i < total; i += stride) {
-    const int c = (int)(i % C);
-    float g = dy[i];
-    if (relu && !(y[i] > 0.f)) g = 0.f;
-    const float xhat = (x[i] - s_mu[c]) * s_is[c];
-    dx[i] = s_gi[c] * (g - s_db[c] - xhat * s_dg[c]);
+  const int64_t i = (blockIdx.x * (int64_t)BN_THREADS + threadIdx.x) * (VEC ? 4 : 1);
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  auto one = [&](float xv, float g, int cc) {
+    if (!(bn_affine(xv, relu ? s_gi[cc] : 0.f, s_sh[cc]) > 0.f)) g = 0.f;
+    const float xhat = (xv - s_mu[cc]) * s_is[cc];
+    return s_gi[cc] * (g - s_db[cc] - xhat * s_dg[cc]);
+  };
+  if constexpr (VEC) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + i), gv = *reinterpret_cast<const float4*>(dy + i);
+    *reinterpret_cast<float4*>(dx + i) = make_float4(one(xv.x, gv.x, c), one(xv.y, gv.y, c + 1), one(xv.z, gv.z, c + 2), one(xv.w, gv.w, c + 3));
+  } else {
+    dx[i] = one(x[i], dy[i], c);
   }
 }
 
@@ -294,47 +332,51 @@ extern "C" int a2f_bn_fwd(const float* x, int64_t R, int64_t C, const float* gam
     const int nblk = bn_blocks(R, (int)C);
     if (bn_vec4_ok(x, nullptr, nullptr, C))
       hipLaunchKernelGGL(bn_partial4_kernel<0>, dim3(nblk), dim3(BN_THREADS), 0, s, x, (const float*)nullptr, (const float*)nullptr, R,
-                         (int)C, (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
+                         (int)C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
     else
       hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblk), dim3(BN_THREADS), 0, s, x, (const float*)nullptr, (const float*)nullptr, R,
-                         (int)C, (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
+                         (int)C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
     hipLaunchKernelGGL(bn_finish_stats_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, s, (const double*)ws, nblk, R, (int)C, momentum, eps,
                        running_mean, running_var, save_mean, save_invstd);
   } else {
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cb), dim3(256), 0, s, running_mean, running_var, (int)C, eps, save_mean, save_invstd);
   }
   const int64_t total = R * C;
-  int64_t blocks = cdiv(total, BN_THREADS * 4);
-  if (blocks > 4096) blocks = 4096;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(BN_THREADS), 0, s, x, total, (int)C, gamma, beta, save_mean,
-                     save_invstd, (int)relu, y);
+  A2F_CHECK_ARG(total / BN_THREADS < 0x7FFFFFFFll, "bn_fwd: R * C too large for one element per thread");
+  if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3((unsigned)cdiv(total / 4, BN_THREADS)), dim3(BN_THREADS), 0, s, x, total, (int)C, gamma, beta, save_mean,
+                       save_invstd, (int)relu, y);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3((unsigned)cdiv(total, BN_THREADS)), dim3(BN_THREADS), 0, s, x, total, (int)C, gamma, beta, save_mean,
+                       save_invstd, (int)relu, y);
   A2F_CHECK_LAUNCH("bn_fwd");
   return A2F_OK;
 }
 
-extern "C" int a2f_bn_bwd(const float* x, const float* y, const float* dy, int64_t R, int64_t C, const float* gamma,
+extern "C" int a2f_bn_bwd(const float* x, const float* beta, const float* dy, int64_t R, int64_t C, const float* gamma,
                           const float* save_mean, const float* save_invstd, int32_t training, int32_t relu, float* dx,
                           float* dgamma, float* dbeta, void* ws, size_t ws_bytes, a2f_stream_t stream) {
   using namespace a2f;
-  A2F_CHECK_ARG(x && y && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws, "bn_bwd: null pointer");
+  A2F_CHECK_ARG(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws && (beta || !relu), "bn_bwd: null pointer (beta is needed with relu)");
   A2F_CHECK_ARG(R > 0 && C > 0 && C <= BN_MAX_C, "bn_bwd: R=%lld C=%lld (C <= %d)", (long long)R, (long long)C, BN_MAX_C);
   if (ws_bytes < a2f_bn_ws_bytes(R, C)) return set_err(A2F_EWORKSPACE, "bn_bwd: workspace %zu < %zu", ws_bytes, a2f_bn_ws_bytes(R, C));
   hipStream_t s = (hipStream_t)stream;
   const int nblk = bn_blocks(R, (int)C);
-  if (bn_vec4_ok(x, y, dy, C) && (((uintptr_t)save_mean | (uintptr_t)save_invstd) & 15) == 0)
-    hipLaunchKernelGGL(bn_partial4_kernel<1>, dim3(nblk), dim3(BN_THREADS), 0, s, x, y, dy, R, (int)C, save_mean, save_invstd, (int)relu,
+  if (bn_vec4_ok(x, nullptr, dy, C) && (((uintptr_t)save_mean | (uintptr_t)save_invstd | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0)
+    hipLaunchKernelGGL(bn_partial4_kernel<1>, dim3(nblk), dim3(BN_THREADS), 0, s, x, beta, dy, R, (int)C, save_mean, save_invstd, gamma, (int)relu,
                        (double*)ws);
   else
-    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(BN_THREADS), 0, s, x, y, dy, R, (int)C, save_mean, save_invstd, (int)relu,
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(BN_THREADS), 0, s, x, beta, dy, R, (int)C, save_mean, save_invstd, gamma, (int)relu,
                        (double*)ws);
   hipLaunchKernelGGL(bn_finish_bwd_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, s, (const double*)ws, nblk, (int)C, dgamma, dbeta);
   const int64_t total = R * C;
-  int64_t blocks = cdiv(total, BN_THREADS * 4);
-  if (blocks > 4096) blocks = 4096;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(BN_THREADS), 0, s, x, y, dy, total, (int)C, 1.0f / (float)R, gamma,
-                     save_mean, save_invstd, dgamma, dbeta, (int)training, (int)relu, dx);
+  A2F_CHECK_ARG(total / BN_THREADS < 0x7FFFFFFFll, "bn_bwd: R * C too large for one element per thread");
+  if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)cdiv(total / 4, BN_THREADS)), dim3(BN_THREADS), 0, s, x, beta, dy, total, (int)C, 1.0f / (float)R,
+                       gamma, save_mean, save_invstd, dgamma, dbeta, (int)training, (int)relu, dx);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3((unsigned)cdiv(total, BN_THREADS)), dim3(BN_THREADS), 0, s, x, beta, dy, total, (int)C, 1.0f / (float)R,
+                       gamma, save_mean, save_invstd, dgamma, dbeta, (int)training, (int)relu, dx);
   A2F_CHECK_LAUNCH("bn_bwd");
   return A2F_OK;
 }

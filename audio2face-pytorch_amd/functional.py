@@ -337,7 +337,7 @@ class A2MTrunkMMFn(torch.autograd.Function):
         ncat = 256 + no
         a0, cat = new(B, H0, 32), new(B, ncat)
         be.a2m_pack(_f32c(x), _f32c(one_hot), B, no, a0, cat, ncat, 256)
-        sv = {"wg": [None] * 10, "conv_in": [None] * 10, "bn_x": [None] * 10, "bn_y": [None] * 10, "stats": [None] * 10, "bn_g": [None] * 10}
+        sv = {"wg": [None] * 10, "conv_in": [None] * 10, "bn_x": [None] * 10, "bn_b": [None] * 10, "stats": [None] * 10, "bn_g": [None] * 10}
 
         def bn(i, xin, R, C, Cp, relu):
             g, b = bns[i]
@@ -348,7 +348,7 @@ class A2MTrunkMMFn(torch.autograd.Function):
             be.bn_fwd(xin, R, Cp, gp, bp, rmp, rvp, A2M_BN_MOMENTUM, A2M_BN_EPS, training, relu, y, mu, istd)
             if Cp != C and training:
                 rm.copy_(rmp[:C]); rv.copy_(rvp[:C])
-            sv["bn_x"][i], sv["bn_y"][i], sv["stats"][i], sv["bn_g"][i] = xin, y, (mu, istd), gp
+            sv["bn_x"][i], sv["bn_b"][i], sv["stats"][i], sv["bn_g"][i] = xin, bp, (mu, istd), gp
             return y
 
         # analysis layer 0 (one input channel, K = 3): the exact-fp32 generic GEMM (three multiply-adds per output)
@@ -444,7 +444,7 @@ class A2MTrunkMMFn(torch.autograd.Function):
         def bn_bwd(i, dy, R, C, Cp, relu):
             mu, istd = sv["stats"][i]
             dx, dg, dbt = new(R, Cp), new(Cp), new(Cp)
-            be.bn_bwd(sv["bn_x"][i], sv["bn_y"][i], dy, R, Cp, sv["bn_g"][i], mu, istd, training, relu, dx, dg, dbt)
+            be.bn_bwd(sv["bn_x"][i], sv["bn_b"][i], dy, R, Cp, sv["bn_g"][i], mu, istd, training, relu, dx, dg, dbt)
             g_bn[2 * i], g_bn[2 * i + 1] = dg[:C], dbt[:C]
             return dx
 

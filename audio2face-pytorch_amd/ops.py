@@ -403,11 +403,12 @@ class HipBackend:
                                        int(training), int(relu), _ptr(y), _ptr(save_mean), _ptr(save_invstd), _ptr(ws), nb,
                                        self._stream(x)), "a2f_bn_fwd")
 
-    def bn_bwd(self, x, y, dy, R, Cc, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta):
-        _chk(x, y, dy, gamma, save_mean, save_invstd, dx, dgamma, dbeta)
+    def bn_bwd(self, x, beta, dy, R, Cc, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta):
+        """beta: the layer's shift - the ReLU mask of the forward is re-derived from x (the saved output is not read)."""
+        _chk(x, beta, dy, gamma, save_mean, save_invstd, dx, dgamma, dbeta)
         nb = self.lib.a2f_bn_ws_bytes(R, Cc)
         ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=x.device)
-        _lib.check(self.lib.a2f_bn_bwd(_ptr(x), _ptr(y), _ptr(dy), R, Cc, _ptr(gamma), _ptr(save_mean), _ptr(save_invstd),
+        _lib.check(self.lib.a2f_bn_bwd(_ptr(x), _ptr(beta), _ptr(dy), R, Cc, _ptr(gamma), _ptr(save_mean), _ptr(save_invstd),
                                        int(training), int(relu), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb,
                                        self._stream(x)), "a2f_bn_bwd")
 

@@ -196,8 +196,9 @@ size_t a2f_bn_ws_bytes(int64_t R, int64_t C);
 int a2f_bn_fwd(const float* x, int64_t R, int64_t C, const float* gamma, const float* beta,
                float* running_mean, float* running_var, float momentum, float eps, int32_t training, int32_t relu,
                float* y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, a2f_stream_t stream);
-/* dy is the gradient w.r.t. the (post-ReLU if relu) output y; y is the saved forward output. */
-int a2f_bn_bwd(const float* x, const float* y, const float* dy, int64_t R, int64_t C, const float* gamma,
+/* dy is the gradient w.r.t. the (post-ReLU if relu) output.  The ReLU mask is re-derived from x (y > 0 <=> the forward's own
+ * fma(x, invstd gamma, beta - mean invstd gamma) > 0), so the saved output is not read: pass beta (needed when relu != 0). */
+int a2f_bn_bwd(const float* x, const float* beta, const float* dy, int64_t R, int64_t C, const float* gamma,
                const float* save_mean, const float* save_invstd, int32_t training, int32_t relu,
                float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, a2f_stream_t stream);
 

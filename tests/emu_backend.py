@@ -446,12 +446,12 @@ class EmuBackend:
         y.reshape(R, Cc).copy_(out.float())
         save_mean.copy_(mean.float()); save_invstd.copy_(invstd.float())
 
-    def bn_bwd(self, x, y, dy, R, Cc, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta):
+    def bn_bwd(self, x, beta, dy, R, Cc, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta):
         xv, dyv = x.reshape(R, Cc).double(), dy.reshape(R, Cc).double()
-        if relu:
-            dyv = torch.where(y.reshape(R, Cc) > 0, dyv, torch.zeros_like(dyv))
         mean, invstd, g = save_mean.double(), save_invstd.double(), gamma.double()
         xhat = (xv - mean) * invstd
+        if relu:                                           # the mask is re-derived from x: forward output > 0
+            dyv = torch.where(xhat * g + beta.double() > 0, dyv, torch.zeros_like(dyv))
         db = dyv.sum(dim=0)
         dg = (dyv * xhat).sum(dim=0)
         if training:

@@ -332,7 +332,7 @@ def test_batchnorm_fwd_bwd(R, C, training, relu):
         y, mu, istd = torch.empty(R, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
         be.bn_fwd(x.to(dev), R, C, gamma.to(dev), beta.to(dev), rm, rv, 0.1, 1e-5, training, relu, y, mu, istd)
         dx, dg, dbt = torch.empty(R, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
-        be.bn_bwd(x.to(dev), y, dy.to(dev), R, C, gamma.to(dev), mu, istd, training, relu, dx, dg, dbt)
+        be.bn_bwd(x.to(dev), beta.to(dev), dy.to(dev), R, C, gamma.to(dev), mu, istd, training, relu, dx, dg, dbt)
         res.append([t.cpu() for t in (y, rm, rv, dx, dg, dbt)])
     for name, a, b in zip(("y", "running_mean", "running_var", "dx", "dgamma", "dbeta"), res[0], res[1]):
         assert rel_l2(a, b) < 2e-5, name

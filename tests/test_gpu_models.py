@@ -687,7 +687,8 @@ def test_faceformer_config5_T3000_encoder_vs_oracle():
     assert errs["bf16x3_gemms_fp8_attention"] > 1e-3
 
 
-def test_bench_self_launches_two_ranks():
+@pytest.mark.parametrize("force_pipeline", [False, True])
+def test_bench_self_launches_two_ranks(force_pipeline):
     """`python bench.py --gpus 2` with no torchrun environment (as the driver starts it): the script must launch the two
     ranks itself as a child torchrun before touching the GPU, relay ONE JSON line and exit 0.  Rehearsal mode on the one-GPU
     box: both ranks share cuda:0, collectives over gloo."""
@@ -697,6 +698,10 @@ def test_bench_self_launches_two_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(A2F_BENCH_BACKEND="gloo", A2F_BENCH_SHARE_GPU="1")
+    if force_pipeline:
+        # the two-half-batch FaceFormer step (side streams) at small shapes: the bucketed gradient exchange is then armed before the LAST encoder
+        # backward only (trainer.BucketedAllReduce.begin via before_last_backward) and its collectives are issued from autograd hooks on the main stream
+        env.update(A2F_FF_PIPELINE_MIN_FRAMES="60", A2F_FF_PIPELINE_MIN_SEQS="0")
     # the secondary entries run too (small shapes): every rank must issue the same collectives in every leg, the rank-0-only roofline passes included
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "3", "--seqs", "4",
                         "--frames", "64", "--ff-seqs", "2", "--ff-frames", "60", "--ff-long-seqs", "2", "--ff-long-frames", "120", "--a2m-batch", "64",
@@ -708,6 +713,9 @@ def test_bench_self_launches_two_ranks():
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["value"] > 0
     assert {e["model"] for e in out["secondary"]} == {"faceformer", "audio2mesh", "faceformer_long"}
     assert all(e["config"]["parallelism"] == "dp2" and e["value"] > 0 for e in out["secondary"])
+    assert out["distributed"]["rccl_world"] == 2 and "expected 3" in out["distributed"]["allreduce_selfcheck"] and len(out["distributed"]["ranks"]) == 2
+    ff = next(e for e in out["secondary"] if e["model"] == "faceformer")
+    assert "buckets" in ff["config"]["gradient_exchange"]
 
 
 def test_bench_secondary_lines_small():

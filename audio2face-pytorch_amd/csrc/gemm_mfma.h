@@ -182,6 +182,12 @@ __device__ __forceinline__ f32x16 mfma(u32x4_t a, u32x4_t b, f32x16 c) {
 template <int TM, int TN, int I>
 __device__ __forceinline__ void tile_epilogue_band(const Args& a, const f32x16 (&acc)[TM][TN], int m0, int wm, int h, int bz, const int (&ncol)[TN],
                                                    const float (&bv)[TN], bool generic) {
+#ifdef MM_ABL_NOEPI         // timing ablation only (wrong results): the accumulators stay live, nothing is stored
+#pragma unroll
+  for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[I][j]));
+  if constexpr (I + 1 < TM) tile_epilogue_band<TM, TN, I + 1>(a, acc, m0, wm, h, bz, ncol, bv, generic);
+  return;
+#endif
   if (a.split_k > 1) {
     float* wsz = a.ws + (long long)blockIdx.z * a.M * a.N;
 #pragma unroll

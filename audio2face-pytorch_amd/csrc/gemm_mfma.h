@@ -44,6 +44,7 @@ struct Args {
   float alpha;
   float* a_rowsum;               // optional (A trans, plain operands, batch 1): a_rowsum[m] = sum_k A(m, k) - the bias gradient of a weight-gradient product
   int group_n;                   // tile order: 0 = row-major (m-tile, n-tile); > 0 = panels of group_n n-tiles, m fastest across a panel (tile_origin)
+  int epi32;                     // every byte offset the epilogue forms (C, C2, aux, keep words, split-K slab) fits 32 bits: buffer-resource epilogue
   const unsigned* keep;          // dropout keep bits of C (csrc/dropout.hip: word (m, n >> 5), bit n & 31), applied after the activation
   long long keep_wpr;
   float keep_scale;
@@ -188,7 +189,75 @@ __device__ __forceinline__ void tile_epilogue_band(const Args& a, const f32x16 (
   if constexpr (I + 1 < TM) tile_epilogue_band<TM, TN, I + 1>(a, acc, m0, wm, h, bz, ncol, bv, generic);
   return;
 #endif
-  if (a.split_k > 1) {
+  if (a.epi32) {
+    // Buffer-resource epilogue: wave-uniform bases in SGPRs, one 32-bit byte offset per element, out-of-tile elements get offset 2^31
+    // (= num_records: dropped / zero-filled by the hardware range check) - no 64-bit address arithmetic and no branch per element (the pointer form below
+    // compiles to a compare-and-branch around every one of the 32 stores of a band).
+    constexpr unsigned NOWHERE = 0x80000000u;          // == num_records: out of range without relying on how offset + size wraps
+    auto rsrc_of = [](const void* p) {
+      const unsigned long long v = (unsigned long long)p;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)0x80000000u, 0x00020000);
+    };
+    if (a.split_k > 1) {
+      const rsrc_t rw = rsrc_of(a.ws + (long long)blockIdx.z * a.M * a.N);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + I) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const unsigned rowoff = (unsigned)m * (unsigned)a.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const unsigned off = (m < a.M && ncol[j] < a.N) ? (rowoff + (unsigned)ncol[j]) * 4u : NOWHERE;
+          const float w = acc[I][j][r];       // a copy: __builtin_bit_cast applied to the vector-element expression itself reads element 0 whatever r is
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, w), rw, off, 0, 0);
+        }
+      }
+    } else {
+      const rsrc_t rc = rsrc_of(a.C + bz * a.c_bstride);
+      const rsrc_t rc2 = rsrc_of(a.C2 ? a.C2 + bz * a.c_bstride : a.C);
+      const rsrc_t rax = rsrc_of(a.aux ? (a.aux_mode == 4 ? a.aux + bz * a.c_bstride : a.aux + bz * a.aux_bstride) : a.C);
+      const rsrc_t rk = rsrc_of(a.keep ? (const void*)a.keep : (const void*)a.C);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + I) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool mok = m < a.M;
+        unsigned crow;
+        if (a.c_rps <= 0) crow = (unsigned)m * (unsigned)a.ldc;
+        else { const int sq = m / a.c_rps; crow = (unsigned)sq * (unsigned)a.c_seq_stride + (unsigned)(m - sq * a.c_rps) * (unsigned)a.ldc; }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const bool ok = mok && ncol[j] < a.N;
+          const unsigned off = ok ? (crow + (unsigned)ncol[j]) * 4u : NOWHERE;
+          float v = acc[I][j][r] * a.alpha + bv[j];
+          if (generic) {
+            if (a.act == 4) {
+              const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+              if (a.C2) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cdf + v * 0.3989422804014327f * __expf(-0.5f * v * v)), rc2, off, 0, 0);
+              v *= cdf;
+            } else {
+              if (a.C2) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc2, off, 0, 0);
+              if (a.act == 1) v = fmaxf(v, 0.f);
+              else if (a.act == 3) v = gelu_f(v);
+            }
+            if (a.keep) {
+              const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(rk, ok ? ((unsigned)m * (unsigned)a.keep_wpr + (unsigned)(ncol[j] >> 5)) * 4u : NOWHERE, 0, 0);
+              v = ((w >> (ncol[j] & 31)) & 1u) ? v * a.keep_scale : 0.f;
+            }
+            if (a.aux_mode == 4) {
+              v *= __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rax, off, 0, 0));
+            } else if (a.aux_mode) {
+              const float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rax, ok ? ((unsigned)m * (unsigned)a.ldaux + (unsigned)ncol[j]) * 4u : NOWHERE, 0, 0));
+              if (a.aux_mode == 1) v += x;
+              else if (a.aux_mode == 2) v *= gelu_grad_f(x);
+              else v *= (x > 0.f ? 1.f : 0.f);
+            }
+            if (a.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, off, 0, 0));
+          }
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, off, 0, 0);
+        }
+      }
+    }
+  } else if (a.split_k > 1) {
     float* wsz = a.ws + (long long)blockIdx.z * a.M * a.N;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

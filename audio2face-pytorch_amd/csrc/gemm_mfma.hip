@@ -554,6 +554,18 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   a.keep_wpr = d->keep_wpr;
   a.keep_scale = d->keep_scale;
   const bool at = d->A.trans != 0, bt = d->B.trans != 0;
+  // 32-bit epilogue offsets (gemm_mfma.h tile_epilogue_band): every element offset of C / C2 / like-C aux, of the (m, ldaux) aux, of the keep words and
+  // of one split-K slab, in bytes from its (per-batch) base, below 2^31
+  {
+    static const bool off32 = [] { const char* e = getenv("A2F_MM_EPI32"); return !(e && e[0] == '0'); }();       // A-B hook
+    const long long lim = 0x80000000ll / 4;
+    const long long M1 = d->M - 1;
+    const long long c_max = (d->c_rows_per_seq > 0 ? (M1 / d->c_rows_per_seq) * d->c_seq_stride + (M1 % d->c_rows_per_seq) * d->ldc : M1 * d->ldc) + d->N;
+    bool ok = off32 && c_max < lim && d->ldc >= 0 && d->c_seq_stride >= 0 && d->M * d->N < lim;
+    if (d->aux_mode >= 1 && d->aux_mode <= 3) ok = ok && d->ldaux >= 0 && M1 * d->ldaux + d->N < lim;
+    if (d->keep_bits) ok = ok && d->M * d->keep_wpr < lim;
+    a.epi32 = ok ? 1 : 0;
+  }
   // tile order (tile_origin): panel-major when the B operand does not fit an XCD's L2 and panels re-read A less than row-major re-reads B
   a.group_n = 0;
   {

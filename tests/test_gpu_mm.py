@@ -198,6 +198,42 @@ def test_mm_panel_major_tile_order_is_bitwise_the_row_major_result(M, N, K):
     assert rel_l2(outs[0][0], ref) < 1e-4
 
 
+def test_mm_pointer_epilogue_is_bitwise_the_buffer_epilogue():
+    """The epilogue addresses C / C2 / aux / keep words through buffer resources with 32-bit offsets when every span is below 2 GiB and
+    through 64-bit pointers otherwise (gemm_mfma.h tile_epilogue_band, Args.epi32).  A2F_MM_EPI32=0 forces the pointer form (read once
+    per process): every epilogue variant, ragged tile edges, a padded ldc, row-sequence output and split-K give the same bits."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import a2f_amd; from a2f_amd import ops; from a2f_amd.ops import MMOp\n"
+        "g = torch.Generator().manual_seed(9); M, N, K = 333, 200, 96\n"
+        "r = lambda *s: torch.randn(*s, generator=g).cuda()\n"
+        "A, B, bias, aux, like = r(M, K), r(N, K), r(N), r(M, N), r(M, N + 8)\n"
+        "keep = torch.randint(0, 2**31 - 1, (M, (N + 31) // 32), generator=g, dtype=torch.int32).cuda()\n"
+        "outs = []\n"
+        "for kw in (dict(), dict(bias=bias, act=ops.MM_ACT_GELU_SAVE_GRAD, C2=True), dict(bias=bias, act=ops.MM_ACT_GELU, C2=True),\n"
+        "           dict(act=ops.MM_ACT_RELU, aux=aux, aux_mode=ops.MM_AUX_ADD), dict(aux=aux, aux_mode=ops.MM_AUX_GELU_BWD, accumulate=True, alpha=0.5),\n"
+        "           dict(aux=aux, aux_mode=ops.MM_AUX_RELU_BWD), dict(split_k=3, bias=bias), dict(bias=bias, keep=(keep, 1.25)),\n"
+        "           dict(aux=like, aux_mode=ops.MM_AUX_MUL_LIKE_C), dict(c_rows_per_seq=37, c_seq_stride=37 * (N + 8) + 16, big=True)):\n"
+        "    kw = dict(kw); C = torch.zeros(9 * (37 * (N + 8) + 16) + 8, device='cuda') if kw.pop('big', False) else like.clone(); C2 = torch.zeros(M, N + 8, device='cuda') if kw.pop('C2', False) else None\n"
+        "    ops.backend().mm(MMOp(A, K), MMOp(B, K), C, M, N, K, N + 8, C2=C2, ldaux=N, precision=1, **kw)\n"
+        "    outs += [C.cpu()] + ([C2.cpu()] if C2 is not None else [])\n"
+        "torch.save(outs, sys.argv[1])\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        for i, env_extra in enumerate(({}, {"A2F_MM_EPI32": "0"})):
+            path = os.path.join(d, f"o{i}.pt")
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-1500:]
+            outs.append(torch.load(path))
+    assert len(outs[0]) == len(outs[1]) == 12
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def _panel_inputs(M, N, K):
     g = torch.Generator().manual_seed(5)
     x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.3, torch.randn(N, generator=g)

@@ -16,6 +16,7 @@
 // lane) in REGISTERS for the life of the persistent kernel - one wave per SIMD owns the full 512-entry register file -
 // so a layer is nothing but A-fragment LDS reads feeding back-to-back MFMAs, with one barrier per layer.
 #include "a2f_common.h"
+#include <stdlib.h>
 
 namespace a2f {
 
@@ -77,38 +78,101 @@ struct TrunkArgs {
   int T;                                                   // 0: x holds (B,29,16) windows; > 0: x holds (B/T, T, 29) per-frame features
 };
 
-// B-operand fragments of one 32-column weight tile, kept in REGISTERS for the whole (persistent) kernel:
-//   bw[s] = W(n = n0 + lane&31, k = 2s + (lane>>5)),  zero beyond N / K.
-// conv weights are read in the reference layout w[n][ci][kh] with k = kh*Ci + ci (TAP0 = first tap staged).
-template <int KS, int K, int CI, int TAP0, bool CONV>
-__device__ __forceinline__ void vt_load_frags(const float* __restrict__ w, int N, int n0, int lane, float (&bw)[KS]) {
-  const int n = n0 + (lane & 31), h = lane >> 5;
+// B-operand fragments of one 32-column weight tile (contraction length K), kept in REGISTERS for the whole (persistent) kernel.
+//   exact form (X3 = false, v_mfma_f32_32x32x2f32):  w[s] = W(k = 2s + h) of this lane's column, h = lane >> 5
+//   split form (X3 = true, v_mfma_f32_32x32x16_bf16): k-step s covers k = 16s .. 16s + 15, lane half h owns k = 16s + 8h + j (j < 8);
+//     every weight is x = hi + lo (bf16 each, round to nearest) and a product is lo*hi' + hi*lo' + hi*hi' with fp32 accumulation
+//     (<= 2^-16 relative per product, the device of head_fused.hip / wgrad.hip / gemm_mfma.hip): 3 x 32 matrix-pipe cycles per 16 k
+//     instead of 8 x 64 - the exact kernel spends two thirds of its time waiting on the fp32 matrix pipe (tools/trunk_stamps.py).
+// Both forms hold K/2 registers per tile (K rounded up to 16 in the split form); weights beyond K are zero.
+// WHERE the split form is used: the three Linear layers of the forward and the whole data-gradient chain.  The four convolutions of the
+// forward stay exact: their pre-activations decide ReLU masks, and a pre-activation that rounds across zero switches a whole gradient path
+// on or off - at 2^-16 per product that happens ~50x more often than at fp32 rounding (test_voca_vs_oracle_seeded at B = 1024: one flipped
+// unit = 4e-3 on time_conv.0.weight.grad; the all-split forward ran 69.6 us instead of 90.4 and was withdrawn for that reason).
+using vt_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using vt_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using vt_bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using vt_f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// One storage type for both forms (conv4 and decoder.3 share one register array across waves but not the form): K/2 dwords, K rounded up to 16.
+template <int K> struct VtFrag { unsigned r[(K + 15) / 16 * 8]; };
+
+__device__ __forceinline__ void vt_split2(float a, float b, unsigned& hi, unsigned& lo) {
+  const vt_f32x2 v = {a, b};
+  const vt_bf16x2 hb = __builtin_convertvector(v, vt_bf16x2);
+  const vt_f32x2 r = v - __builtin_convertvector(hb, vt_f32x2);
+  hi = __builtin_bit_cast(unsigned, hb);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, vt_bf16x2));
+}
+
+// wt(k) = the weight of this lane's column at contraction index k < K (the caller returns 0 for columns beyond the layer's width)
+template <bool X3, int K, class F>
+__device__ __forceinline__ void vt_load_frags(VtFrag<K>& fr, int h, F wt) {
+  if constexpr (!X3) {
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const int k = 2 * s + h;
-    float v = 0.f;
-    if (n < N && k < K) {
-      if (CONV) { const int kh = TAP0 + k / CI, ci = k % CI; v = w[(n * CI + ci) * 3 + kh]; }
-      else v = w[n * K + k];
+    for (int s = 0; s < (K + 1) / 2; ++s) {
+      const int k = 2 * s + h;
+      const float w = k < K ? wt(k) : 0.f;
+      fr.r[s] = __builtin_bit_cast(unsigned, w);
     }
-    bw[s] = v;
+  } else {
+#pragma unroll
+    for (int s = 0; s < (K + 15) / 16; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {               // dwords 8s .. 8s+3: hi pairs, 8s+4 .. 8s+7: lo pairs
+        const int k = 16 * s + 8 * h + 2 * j;
+        vt_split2(k < K ? wt(k) : 0.f, k + 1 < K ? wt(k + 1) : 0.f, fr.r[8 * s + j], fr.r[8 * s + 4 + j]);
+      }
   }
 }
 
-// one 32-row x 32-col tile: A fragment from LDS (row of this lane at ap[0..2*KS)), B fragments from registers
-template <int KS>
-__device__ __forceinline__ f32x16 vt_tile(const float* ap, const float (&bw)[KS]) {
+__device__ __forceinline__ f32x16 vt_mfma_bf16(vt_u32x4 a, vt_u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vt_bf16x8, a), __builtin_bit_cast(vt_bf16x8, b), c, 0, 0, 0);
+}
+
+// one 32-row x 32-col tile over the first KU <= K contraction indices: A fragment from LDS (ap = this lane's row, fp32, k contiguous),
+// B fragments from registers
+template <bool X3, int KU, int K>
+__device__ __forceinline__ f32x16 vt_tile(const float* ap, int h, const VtFrag<K>& fr) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if constexpr (!X3) {
+    ap += h;
 #pragma unroll
-  for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bw[s], acc, 0, 0, 0);
+    for (int s = 0; s < (KU + 1) / 2; ++s) {
+      const unsigned w = fr.r[s];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], __builtin_bit_cast(float, w), acc, 0, 0, 0);
+    }
+  } else {
+    ap += 8 * h;
+#pragma unroll
+    for (int s = 0; s < (KU + 15) / 16; ++s) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] = ap[16 * s + j];
+        // the rows are KU floats long: what lies behind them (the neighbouring frame, another layer's tile) meets a zero weight, but 0 x inf / NaN
+        // of a neighbouring frame must not reach this one - select, only in the step that crosses KU
+        if (16 * s + 8 + j >= KU) v[j] = (16 * s + 8 * h + j < KU) ? v[j] : 0.f;
+      }
+      unsigned hh[4], ll[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vt_split2(v[2 * j], v[2 * j + 1], hh[j], ll[j]);
+      const vt_u32x4 ah = {hh[0], hh[1], hh[2], hh[3]}, al = {ll[0], ll[1], ll[2], ll[3]};
+      const vt_u32x4 bh = {fr.r[8 * s], fr.r[8 * s + 1], fr.r[8 * s + 2], fr.r[8 * s + 3]};
+      const vt_u32x4 bl = {fr.r[8 * s + 4], fr.r[8 * s + 5], fr.r[8 * s + 6], fr.r[8 * s + 7]};
+      acc = vt_mfma_bf16(al, bh, acc);
+      acc = vt_mfma_bf16(ah, bl, acc);
+      acc = vt_mfma_bf16(ah, bh, acc);
+    }
+  }
   return acc;
 }
 
 // SEQ: the input is the per-frame feature tensor (a.T = sequence length); a separate instantiation so the window-mode
-// kernel keeps its register allocation
-template <bool SEQ>
+// kernel keeps its register allocation; X3: the Linear layers on the split-bf16 matrix instructions (default) or the exact fp32 ones (A2F_TRUNK_EXACT=1)
+template <bool SEQ, bool X3>
 __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const TrunkArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* R0 = lds;
@@ -119,14 +183,18 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
 
   // ---- every weight this wave will ever need, as MFMA B fragments in registers (one wave per SIMD) ----
   // conv4 runs on waves 0,1 and decoder.3 on waves 2,3: their 64 fragments share one array (w47), 288 VGPRs in all
-  float w1[56], w2[48], w3[48], w47[64], w5[36], w6[36];
-  vt_load_frags<56, 111, 37, 0, true>(a.cw[0], 32, 0, lane, w1);
-  vt_load_frags<48, 96, 32, 0, true>(a.cw[1], 32, 0, lane, w2);
-  vt_load_frags<48, 96, 32, 0, true>(a.cw[2], 64, (wave & 1) * 32, lane, w3);
-  if (wave < 2) vt_load_frags<64, 128, 64, 1, true>(a.cw[3], 64, wave * 32, lane, w47);   // taps 1,2: tap 0 always meets the padding
-  else vt_load_frags<64, 128, 1, 0, false>(a.fw[2], 50, (wave - 2) * 32, lane, w47);
-  vt_load_frags<36, 72, 1, 0, false>(a.fw[0], 72, (wave < 3 ? wave : 0) * 32, lane, w5);
-  vt_load_frags<36, 72, 1, 0, false>(a.fw[1], 128, wave * 32, lane, w6);
+  VtFrag<111> w1;
+  VtFrag<96> w2, w3;
+  VtFrag<128> w47;
+  VtFrag<72> w5, w6;
+  // conv weights are in the reference layout w[n][ci][kh], contraction index k = kh * Ci + ci
+  vt_load_frags<false>(w1, h, [&](int k) { return a.cw[0][(l31 * 37 + k % 37) * 3 + k / 37]; });
+  vt_load_frags<false>(w2, h, [&](int k) { return a.cw[1][(l31 * 32 + k % 32) * 3 + k / 32]; });
+  vt_load_frags<false>(w3, h, [&](int k) { return a.cw[2][(((wave & 1) * 32 + l31) * 32 + k % 32) * 3 + k / 32]; });
+  if (wave < 2) vt_load_frags<false>(w47, h, [&](int k) { return a.cw[3][((wave * 32 + l31) * 64 + k % 64) * 3 + 1 + k / 64]; });   // taps 1,2: tap 0 always meets the padding
+  else { const int n = (wave - 2) * 32 + l31; vt_load_frags<X3>(w47, h, [&](int k) { return n < 50 ? a.fw[2][n * 128 + k] : 0.f; }); }
+  { const int n = (wave < 3 ? wave : 0) * 32 + l31; vt_load_frags<X3>(w5, h, [&](int k) { return n < 72 ? a.fw[0][n * 72 + k] : 0.f; }); }
+  vt_load_frags<X3>(w6, h, [&](int k) { return a.fw[1][(wave * 32 + l31) * 72 + k]; });
   const float cb1 = a.cb[0][l31], cb2 = a.cb[1][l31], cb3 = a.cb[2][(wave & 1) * 32 + l31], cb4 = a.cb[3][(wave & 1) * 32 + l31];
   const int c5 = (wave < 3 ? wave : 0) * 32 + l31, c7 = (wave & 1) * 32 + l31;
   const float fb5 = c5 < 72 ? a.fb[0][c5] : 0.f, fb6 = a.fb[1][wave * 32 + l31], fb7 = c7 < 50 ? a.fb[2][c7] : 0.f;
@@ -229,7 +297,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
     for (int it = 0; it < 2; ++it) {
       const int mt = wave + 4 * it;
       const int row = mt * 32 + l31, f = row >> 3, p = row & 7;
-      const f32x16 acc = vt_tile<56>(R0 + f * VT_S0 + 2 * p * 37 + h, w1);
+      const f32x16 acc = vt_tile<false, 111>(R0 + f * VT_S0 + 2 * p * 37, h, w1);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int orow = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 3, op = orow & 7;
@@ -251,7 +319,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
     // ---- conv2: rows (f,p<4) = 128 = 4 tiles, 1 per wave (reads R1, writes the A2 area of R0: no hazard with the zeroing) ----
     {
       const int row = wave * 32 + l31, f = row >> 2, p = row & 3;
-      const f32x16 acc = vt_tile<48>(R1 + f * VT_S1 + 2 * p * 32 + h, w2);
+      const f32x16 acc = vt_tile<false, 96>(R1 + f * VT_S1 + 2 * p * 32, h, w2);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int orow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 2, op = orow & 3;
@@ -266,7 +334,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
     {
       const int mt = wave >> 1, nt = wave & 1;
       const int row = mt * 32 + l31, f = row >> 1, p = row & 1;
-      const f32x16 acc = vt_tile<48>(R0 + VT_A2 + f * VT_S2 + 2 * p * 32 + h, w3);
+      const f32x16 acc = vt_tile<false, 96>(R0 + VT_A2 + f * VT_S2 + 2 * p * 32, h, w3);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int orow = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 1, op = orow & 1;
@@ -279,7 +347,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
     VT_STAMP(0, 4);
     // ---- conv4: rows f = 32 = 1 M-tile x 2 N-tiles (waves 0,1); window = positions 0,1 (taps 1,2) ----
     if (wave < 2) {
-      const f32x16 acc = vt_tile<64>(R0 + VT_A3 + l31 * VT_S3 + 64 + h, w47);
+      const f32x16 acc = vt_tile<false, 128>(R0 + VT_A3 + l31 * VT_S3 + 64, h, w47);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int of = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -292,7 +360,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
     VT_STAMP(0, 5);
     // ---- decoder.0: 72 -> 72 (3 N-tiles, waves 0..2), no activation ----
     if (wave < 3) {
-      const f32x16 acc = vt_tile<36>(R0 + VT_CAT + l31 * VT_SC + h, w5);
+      const f32x16 acc = vt_tile<X3, 72>(R0 + VT_CAT + l31 * VT_SC, h, w5);
       if (c5 < 72) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -307,7 +375,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
     VT_STAMP(0, 6);
     // ---- decoder.1: 72 -> 128 + tanh (4 N-tiles) ----
     {
-      const f32x16 acc = vt_tile<36>(R0 + VT_Z1 + l31 * VT_SC + h, w6);
+      const f32x16 acc = vt_tile<X3, 72>(R0 + VT_Z1 + l31 * VT_SC, h, w6);
       const int col = wave * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -321,7 +389,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_fwd_kernel(const Tru
     VT_STAMP(0, 7);
     // ---- decoder.3: 128 -> 50 (2 N-tiles, waves 2,3), output to global only ----
     if (wave >= 2) {
-      const f32x16 acc = vt_tile<64>(R0 + VT_Z2 + l31 * VT_SZ2 + h, w47);
+      const f32x16 acc = vt_tile<X3, 128>(R0 + VT_Z2 + l31 * VT_SZ2, h, w47);
       if (c7 < 50) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -359,6 +427,7 @@ struct TrunkBwdArgs {
   int B, NB;
 };
 
+template <bool X3>
 __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(const TrunkBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
@@ -366,46 +435,19 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
   const int B = a.B;
 
   // ---- weight fragments (B operand: lane -> output column n, lane>>5 -> contraction parity) ----
-  float q3[25], q1[64], q0[36], q4[32], q5[64], q6e[16], q6o[32];
-  {
-    const int n = wave * 32 + l31;                                           // fc3': n < 128, k = j < 50: W3[j][n]
-#pragma unroll
-    for (int s = 0; s < 25; ++s) q3[s] = a.fw3[(2 * s + h) * 128 + n];
-  }
-  {
-    const int n = (wave < 3 ? wave : 0) * 32 + l31;                          // fc1': n < 72, k < 128: W1[k][n]
-#pragma unroll
-    for (int s = 0; s < 64; ++s) q1[s] = n < 72 ? a.fw1[(2 * s + h) * 72 + n] : 0.f;
-  }
-  {
-    const int n = (wave & 1) * 32 + l31;                                     // fc0': n < 64 (conv features only), k < 72: W0[k][n]
-#pragma unroll
-    for (int s = 0; s < 36; ++s) q0[s] = a.fw0[(2 * s + h) * 72 + n];
-  }
-  {
-    const int hp = wave >> 1, ci = (wave & 1) * 32 + l31;                    // conv4': column (h', ci), k = co: w4[co][ci][h'+1]
-#pragma unroll
-    for (int s = 0; s < 32; ++s) q4[s] = a.cw4[((2 * s + h) * 64 + ci) * 3 + hp + 1];
-  }
-  if (wave < 2) {                                                            // conv3' even rows: tap 1, k = co < 64
-#pragma unroll
-    for (int s = 0; s < 32; ++s) q5[s] = a.cw3[((2 * s + h) * 32 + l31) * 3 + 1];
-#pragma unroll
-    for (int s = 32; s < 64; ++s) q5[s] = 0.f;
-  } else {                                                                   // conv3' odd rows: [tap 2 ; tap 0], k < 128
-#pragma unroll
-    for (int s = 0; s < 64; ++s) {
-      const int k = 2 * s + h;
-      q5[s] = k < 64 ? a.cw3[(k * 32 + l31) * 3 + 2] : a.cw3[((k - 64) * 32 + l31) * 3 + 0];
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < 16; ++s) q6e[s] = a.cw2[((2 * s + h) * 32 + l31) * 3 + 1];       // conv2' even: tap 1, k = co < 32
-#pragma unroll
-  for (int s = 0; s < 32; ++s) {                                                       // conv2' odd: [tap 2 ; tap 0], k < 64
-    const int k = 2 * s + h;
-    q6o[s] = k < 32 ? a.cw2[(k * 32 + l31) * 3 + 2] : a.cw2[((k - 32) * 32 + l31) * 3 + 0];
-  }
+  VtFrag<50> q3;
+  VtFrag<128> q1, q5;
+  VtFrag<72> q0;
+  VtFrag<64> q4, q6o;
+  VtFrag<32> q6e;
+  vt_load_frags<X3>(q3, h, [&](int k) { return a.fw3[k * 128 + wave * 32 + l31]; });                               // fc3': n < 128, k = j < 50: W3[j][n]
+  { const int n = (wave < 3 ? wave : 0) * 32 + l31; vt_load_frags<X3>(q1, h, [&](int k) { return n < 72 ? a.fw1[k * 72 + n] : 0.f; }); }   // fc1': n < 72, k < 128: W1[k][n]
+  vt_load_frags<X3>(q0, h, [&](int k) { return a.fw0[k * 72 + (wave & 1) * 32 + l31]; });                          // fc0': n < 64 (conv features only), k < 72: W0[k][n]
+  { const int hp = wave >> 1, ci = (wave & 1) * 32 + l31; vt_load_frags<X3>(q4, h, [&](int k) { return a.cw4[(k * 64 + ci) * 3 + hp + 1]; }); }   // conv4': column (h', ci), k = co
+  if (wave < 2) vt_load_frags<X3>(q5, h, [&](int k) { return k < 64 ? a.cw3[(k * 32 + l31) * 3 + 1] : 0.f; });      // conv3' even rows: tap 1, k = co < 64 (the tile runs KU = 64)
+  else vt_load_frags<X3>(q5, h, [&](int k) { return k < 64 ? a.cw3[(k * 32 + l31) * 3 + 2] : a.cw3[((k - 64) * 32 + l31) * 3 + 0]; });   // odd rows: [tap 2 ; tap 0], k < 128
+  vt_load_frags<X3>(q6e, h, [&](int k) { return a.cw2[(k * 32 + l31) * 3 + 1]; });                                 // conv2' even: tap 1, k = co < 32
+  vt_load_frags<X3>(q6o, h, [&](int k) { return k < 32 ? a.cw2[(k * 32 + l31) * 3 + 2] : a.cw2[((k - 32) * 32 + l31) * 3 + 0]; });        // conv2' odd: [tap 2 ; tap 0], k < 64
   // trailing zero rows of the two convolution-gradient tiles (never overwritten)
   for (int e = t; e < VT_F * 65; e += VT_THREADS) { const int f = e / 65, c = e - f * 65; lds[VB_C3 + f * 193 + 128 + c] = 0.f; }
   for (int e = t; e < VT_F * 33; e += VT_THREADS) { const int f = e / 33, c = e - f * 33; lds[VB_C2 + f * 161 + 128 + c] = 0.f; }
@@ -471,7 +513,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
     VT_STAMP(1, 1);
     // ---- decoder.3 backward: dz2pre = (dh3 W3) * (1 - z2^2) ----
     {
-      const f32x16 acc = vt_tile<25>(lds + VB_DH + l31 * 51 + h, q3);
+      const f32x16 acc = vt_tile<X3, 50>(lds + VB_DH + l31 * 51, h, q3);
       const int col = wave * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -486,7 +528,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
     VT_STAMP(1, 2);
     // ---- decoder.1 backward: dz1 = dz2pre W1 ----
     if (wave < 3) {
-      const f32x16 acc = vt_tile<64>(lds + VB_Z2 + l31 * 129 + h, q1);
+      const f32x16 acc = vt_tile<X3, 128>(lds + VB_Z2 + l31 * 129, h, q1);
       const int col = wave * 32 + l31;
       if (col < 72) {
 #pragma unroll
@@ -501,7 +543,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
     VT_STAMP(1, 3);
     // ---- decoder.0 backward (conv features only) + ReLU mask of conv4's output ----
     if (wave < 2) {
-      const f32x16 acc = vt_tile<36>(lds + VB_Z1 + l31 * 73 + h, q0);
+      const f32x16 acc = vt_tile<X3, 72>(lds + VB_Z1 + l31 * 73, h, q0);
       const int col = wave * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -515,7 +557,7 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
     VT_STAMP(1, 4);
     // ---- conv4 data gradient: d3[f][h'][ci] = sum_co g4[f][co] w4[co][ci][h'+1], masked by a3 > 0 ----
     {
-      const f32x16 acc = vt_tile<32>(lds + VB_C4 + l31 * 65 + h, q4);
+      const f32x16 acc = vt_tile<X3, 64>(lds + VB_C4 + l31 * 65, h, q4);
       const int hp = wave >> 1, ci = (wave & 1) * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -531,8 +573,8 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
     {
       const int mt = wave & 1, odd = wave >> 1;
       const int row = mt * 32 + l31, f = row >> 1, p = row & 1;
-      const float* ap = lds + VB_C3 + f * 193 + p * 64 + h;
-      const f32x16 acc = odd ? vt_tile<64>(ap, q5) : vt_tile<32>(ap, reinterpret_cast<const float(&)[32]>(q5));
+      const float* ap = lds + VB_C3 + f * 193 + p * 64;
+      const f32x16 acc = odd ? vt_tile<X3, 128>(ap, h, q5) : vt_tile<X3, 64>(ap, h, q5);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int orow = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 1, hin = 2 * (orow & 1) + odd;
@@ -546,10 +588,10 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
     // ---- conv2 data gradient: rows (f, p<4) = 4 tiles, one per wave: even rows 2p, then odd rows 2p+1 ----
     {
       const int row = wave * 32 + l31, f = row >> 2, p = row & 3;
-      const float* ap = lds + VB_C2 + f * 161 + p * 32 + h;
+      const float* ap = lds + VB_C2 + f * 161 + p * 32;
 #pragma unroll
       for (int odd = 0; odd < 2; ++odd) {
-        const f32x16 acc = odd ? vt_tile<32>(ap, q6o) : vt_tile<16>(ap, q6e);
+        const f32x16 acc = odd ? vt_tile<X3, 64>(ap, h, q6o) : vt_tile<X3, 32>(ap, h, q6e);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int orow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, of = orow >> 2, hin = 2 * (orow & 3) + odd;
@@ -562,6 +604,13 @@ __global__ __launch_bounds__(VT_THREADS, 1) void voca_trunk_bwd_data_kernel(cons
 }
 
 }  // namespace a2f
+
+// A2F_TRUNK_EXACT=1: the exact fp32 matrix instructions instead of the split-bf16 ones (A-B hook and the reference point of the kernel
+// tests; read per call, so a captured graph keeps the form it was captured with)
+static bool trunk_exact() {
+  const char* e = getenv("A2F_TRUNK_EXACT");
+  return e && e[0] == '1';
+}
 
 static int voca_trunk_fwd_impl(const float* x, int64_t seq_len, const float* one_hot, int64_t B, int64_t n_onehot, const float* const* conv_w,
                                const float* const* conv_b, const float* const* fc_w, const float* const* fc_b, float* a0, float* a1,
@@ -577,14 +626,19 @@ static int voca_trunk_fwd_impl(const float* x, int64_t seq_len, const float* one
   a.B = (int)B; a.no = (int)n_onehot; a.NB = (int)cdiv(B, VT_F); a.T = (int)seq_len;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&voca_trunk_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VT_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&voca_trunk_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VT_LDS_BYTES);
-    if (e != hipSuccess) return set_err(A2F_ELAUNCH, "voca_trunk_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    const void* kernels[4] = {reinterpret_cast<const void*>(&voca_trunk_fwd_kernel<false, false>), reinterpret_cast<const void*>(&voca_trunk_fwd_kernel<false, true>),
+                              reinterpret_cast<const void*>(&voca_trunk_fwd_kernel<true, false>), reinterpret_cast<const void*>(&voca_trunk_fwd_kernel<true, true>)};
+    for (const void* k : kernels) {
+      const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VT_LDS_BYTES);
+      if (e != hipSuccess) return set_err(A2F_ELAUNCH, "voca_trunk_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
     attr_set = true;
   }
   const int grid = a.NB < 256 ? a.NB : 256;
-  if (a.T > 0) hipLaunchKernelGGL(voca_trunk_fwd_kernel<true>, dim3(grid), dim3(VT_THREADS), VT_LDS_BYTES, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(voca_trunk_fwd_kernel<false>, dim3(grid), dim3(VT_THREADS), VT_LDS_BYTES, (hipStream_t)stream, a);
+  const bool seq = a.T > 0;
+  auto* kernel = trunk_exact() ? (seq ? &voca_trunk_fwd_kernel<true, false> : &voca_trunk_fwd_kernel<false, false>)
+                               : (seq ? &voca_trunk_fwd_kernel<true, true> : &voca_trunk_fwd_kernel<false, true>);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(VT_THREADS), VT_LDS_BYTES, (hipStream_t)stream, a);
   A2F_CHECK_LAUNCH("voca_trunk_fwd");
   return A2F_OK;
 }
@@ -619,12 +673,16 @@ extern "C" int a2f_voca_trunk_bwd_data(const float* dh3, const float* z2, const 
   a.B = (int)B; a.NB = (int)cdiv(B, VT_F);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&voca_trunk_bwd_data_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VB_LDS_BYTES);
-    if (e != hipSuccess) return set_err(A2F_ELAUNCH, "voca_trunk_bwd_data: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    const void* kernels[2] = {reinterpret_cast<const void*>(&voca_trunk_bwd_data_kernel<false>), reinterpret_cast<const void*>(&voca_trunk_bwd_data_kernel<true>)};
+    for (const void* k : kernels) {
+      const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VB_LDS_BYTES);
+      if (e != hipSuccess) return set_err(A2F_ELAUNCH, "voca_trunk_bwd_data: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
     attr_set = true;
   }
   const int grid = a.NB < 256 ? a.NB : 256;
-  hipLaunchKernelGGL(voca_trunk_bwd_data_kernel, dim3(grid), dim3(VT_THREADS), VB_LDS_BYTES, (hipStream_t)stream, a);
+  auto* kernel = trunk_exact() ? &voca_trunk_bwd_data_kernel<false> : &voca_trunk_bwd_data_kernel<true>;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(VT_THREADS), VB_LDS_BYTES, (hipStream_t)stream, a);
   A2F_CHECK_LAUNCH("voca_trunk_bwd_data");
   return A2F_OK;
 }

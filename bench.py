@@ -289,7 +289,7 @@ def timed(step_fn, steps, warmup, barrier, world, device, budget_s=8.0, max_bloc
     want = max(1, min(want, int(budget_s / max(blocks[0], 1e-9))))
     while len(blocks) < want:
         blocks.append(one_block())
-    loss_val = float(out["loss"])
+    loss_val = float(out["loss"].detach())
     assert loss_val == loss_val, "loss is NaN"
     srt = sorted(blocks)
     med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])

@@ -156,7 +156,11 @@ int a2f_a2m_pack(const float* x, const float* one_hot, int64_t B, int64_t n_oneh
  * also stored once, channels-last, in exactly the layout the backward entry points read:
  *   a0 (B,16,37) a1 (B,8,32) a2 (B,4,32) a3 (B,2,64) cat72 (B,72) z1 (B,72) z2 (B,128, post-tanh) h3 (B,50).
  * conv_w[i]: time_conv.{0,2,4,6}.weight (Co,Ci,3,1) in the reference layout, conv_b[i] its bias; fc_w/fc_b: decoder.{0,1,3}.
- * The four pointer arrays are HOST arrays of device pointers. */
+ * The four pointer arrays are HOST arrays of device pointers.
+ * Arithmetic: the four convolutions in exact fp32 (their pre-activations decide ReLU masks); the three Linear layers, and every product of
+ * a2f_voca_trunk_bwd_data, in split bf16 (x = hi + lo; lo*hi' + hi*lo' + hi*hi' on the bf16 matrix instructions, fp32 accumulation:
+ * <= 2^-16 relative per product, the same device as the head and a2f_mm's precision 1).  The environment variable A2F_TRUNK_EXACT=1
+ * (read per call by both entry points) selects the exact fp32 matrix instructions everywhere. */
 int a2f_voca_trunk_fwd(const float* x, const float* one_hot, int64_t B, int64_t n_onehot, const float* const* conv_w,
                        const float* const* conv_b, const float* const* fc_w, const float* const* fc_b, float* a0, float* a1,
                        float* a2, float* a3, float* cat72, float* z1, float* z2, float* h3, a2f_stream_t stream);

@@ -43,12 +43,12 @@ constexpr int GR_QKV = 0, GR_SA = 192, GR_HP = 256, GR_F = 384, GR_EMB = 448, GR
 // boundary are batched over the whole chip (ff_bwd_prep_kernel / ff_bwd_rect_kernel below).  FF_NREC floats per frame: Nt[h][a'][b], then n[h][b]
 constexpr int FF_BLK = 128, FF_BLK_MIN = 256, FF_NREC = 4 * 272, NR_N = 1024;
 #ifndef FA_U_SET
-#define FA_U_SET 4
+#define FA_U_SET 1
 #endif
 #ifndef FB_U_SET
 #define FB_U_SET 8
 #endif
-constexpr int FA_U = FA_U_SET, FB_U = FB_U_SET;   // key slots (of 16 keys) per attention trip, forward / backward
+constexpr int FA_U = FA_U_SET, FB_U = FB_U_SET;   // keys per lane and attention trip, forward (lane = key: 64 FA_U keys per wave and trip) / key slots of 16 keys, backward
 // per-step save row (floats); K/V/dK/dV sub-rows are 256-byte aligned
 constexpr int SV_X = 0, SV_Q = 64, SV_CTX = 128, SV_XH1 = 192, SV_XH2 = 256, SV_H = 320, SV_XH3 = 448, SV_ST = 512;
 constexpr int SV_K = 576, SV_V = 640, SV_DK = 704, SV_DV = 768, SV_STRIDE = 896;
@@ -103,7 +103,7 @@ template <bool DROP>
 __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const float* __restrict__ P, const float* __restrict__ pe,
                                                                         const float* __restrict__ cross, const float* __restrict__ style,
                                                                         int T, int period, float* __restrict__ y, float* __restrict__ save,
-                                                                        const FFDrop dm) {
+                                                                        float* __restrict__ kvp, const FFDrop dm) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __builtin_amdgcn_s_setprio(3);          // a latency-bound chain: when it shares a CU with GEMM waves of another stream (the pipelined step), its waves issue first
   float* WqkvT = lds;                       // [64][192]  WqkvT[k*192 + o] = Wqkv[o][k]
@@ -118,11 +118,17 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
   float* ys = part + 4 * FD;                // [64]
   float* mrg_c = ys + FD;                   // [2][64] unnormalised context partials of the two waves of each head
   float* mrg_s = mrg_c + 2 * FD;            // [2][4][2] their running maximum / exponential sum
+  float* sweep_red = mrg_s + 2 * FH * 2;    // [8 waves][16][64] the waves' per-lane context partials on their way to one sum per component
+  float* W1T = sweep_red + 8 * FHD * 64;    // [64][128]  W1T[k*128 + o] = W1[o][k]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int head = wave & 3, apart = wave >> 2;     // self-attention: head and which half of the key trips this wave sweeps
   const int64_t s = blockIdx.x;
   float* svbase = save + s * (int64_t)T * SV_STRIDE;
+  // The sweep's own copy of K and V (kvp; the records keep theirs for the backward): per (sequence, head) four planes of float4 per key,
+  // [c][T][4] with head dimension d = 4c + e - lane = key, so one load instruction of a wave is 1 KB of consecutive keys (the records are 3.5 KB apart).
+  float* kp_seq = kvp + s * (int64_t)T * (2 * FD);               // K planes of the four heads, then V planes
+  float* vp_seq = kp_seq + (int64_t)T * FD;
 #ifdef FF_STAMPS
   long long* stamp_out = reinterpret_cast<long long*>(save + (int64_t)gridDim.x * T * SV_STRIDE + A2F_FF_A);
 #endif
@@ -133,10 +139,10 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
     WoT[k * FD + o] = P[A2F_FF_WO + e];
     AT[k * FD + o] = P[A2F_FF_A + e];
   }
-  // FFN weights in registers: linear1 row t (t < 128); linear2 slice: output o = t & 63, inputs [32*(t>>6), +32)
-  float w1r[FD], w2r[32];
-#pragma unroll
-  for (int k = 0; k < FD; ++k) w1r[k] = t < FFF ? P[A2F_FF_W1 + t * FD + k] : 0.f;
+  // FFN weights: linear1 transposed in LDS (W1T[k][o]: its 64 registers per lane are what lets the sweep keep two keys per lane in flight);
+  // linear2 slice in registers: output o = t & 63, inputs [32*(t>>6), +32)
+  float w2r[32];
+  for (int e = t; e < FFF * FD; e += FF_FWD_THREADS) { const int o = e / FD, k = e - o * FD; W1T[k * FFF + o] = P[A2F_FF_W1 + e]; }
 #pragma unroll
   for (int k = 0; k < 32; ++k) w2r[k] = t < FF_THREADS ? P[A2F_FF_W2 + (t & 63) * FFF + (t >> 6) * 32 + k] : 0.f;
   const float bqkv = t < 192 ? P[A2F_FF_BQKV + t] : 0.f;
@@ -190,32 +196,45 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
       }
       float acc = (a0 + a1) + (a2 + a3);
       if (t < 64) { acc *= 0.25f; qs[t] = acc; sv[SV_Q + t] = acc; }
-      else if (t < 128) sv[SV_K + (t - 64)] = acc;
-      else sv[SV_V + (t - 128)] = acc;
+      else {
+        const int d = t & 63;                                    // head = d >> 4, plane c = (d >> 2) & 3, e = d & 3
+        float* plane = (t < 128 ? kp_seq : vp_seq) + ((int64_t)(d >> 2) * T + i) * 4 + (d & 3);
+        *plane = acc;
+        sv[(t < 128 ? SV_K : SV_V) + d] = acc;
+      }
     }
     __syncthreads();
     FF_STAMP(2);                                            // K/V row i visible to the whole workgroup
     {
-      // ---- self-attention for `head` over keys j <= i; the head's two waves take alternate trips of 16 FA_U keys ----
-      const float4 qv = *reinterpret_cast<const float4*>(qs + head * FHD + dq * 4);
-      const float* kbase = svbase + SV_K + head * FHD + dq * 4;
-      const float* vbase = svbase + SV_V + head * FHD + dq * 4;
-      // ONE pass over the keys with a running maximum (online softmax), FA_U key slots per trip: the K/V rows come from
-      // L2, so the eight loads of a trip are issued before any of them is used; a head's two waves share a SIMD, one reduces while the
-      // other waits - the sweep is bound by the instructions per key (s_memtime stamps: ~1 400 clk per trip and wave), not by the round trips.
-      // A slot past i re-reads row i (always valid memory) and is masked out.
+      // ---- self-attention for `head` over keys j <= i: lane = key.  A wave takes FA_U x 64 consecutive keys per trip, the head's two waves alternate
+      // trips; every lane runs its own online softmax (running maximum, sum, 16 context components) over its keys - no cross-lane traffic and one
+      // exponential per key inside the loop (the (16 key slots x 4 quarter-heads) form computed every exponential four times and spent two shuffles per
+      // key: ~190 vector instructions per 64 keys against ~65 here; s_memtime stamps at T = 3000: the sweep was 70-82 % of a step) - and the 64 partial
+      // softmaxes of a wave are merged once per step.  A key past i re-reads key i (valid memory) and is masked out.
+      float q[FHD];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 qv = *reinterpret_cast<const float4*>(qs + head * FHD + c * 4);
+        q[4 * c] = qv.x; q[4 * c + 1] = qv.y; q[4 * c + 2] = qv.z; q[4 * c + 3] = qv.w;
+      }
+      const float* kph = kp_seq + (int64_t)head * 4 * T * 4;
+      const float* vph = vp_seq + (int64_t)head * 4 * T * 4;
       float mrun = -INFINITY, lsum = 0.f;
-      float4 cacc = make_float4(0.f, 0.f, 0.f, 0.f);
+      float cacc[FHD];
+#pragma unroll
+      for (int d = 0; d < FHD; ++d) cacc[d] = 0.f;
       const unsigned* abits = DROP ? dm.attn + ((s * FH + head) * T + i) * dm.TW : nullptr;     // this frame's, this head's keys
-      for (int j0 = js + apart * 16 * FA_U; j0 <= i; j0 += 2 * 16 * FA_U) {
-        float4 kk[FA_U], vv[FA_U];
+      for (int j0 = apart * 64 * FA_U; j0 <= i; j0 += 2 * 64 * FA_U) {
+        float4 kk[FA_U][4], vv[FA_U][4];
         unsigned kw[FA_U];
 #pragma unroll
         for (int u = 0; u < FA_U; ++u) {
-          const int jj = min(j0 + 16 * u, i);
-          const int64_t off = (int64_t)jj * SV_STRIDE;
-          kk[u] = *reinterpret_cast<const float4*>(kbase + off);
-          vv[u] = *reinterpret_cast<const float4*>(vbase + off);
+          const int jj = min(j0 + 64 * u + lane, i);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            kk[u][c] = *reinterpret_cast<const float4*>(kph + ((int64_t)c * T + jj) * 4);
+            vv[u][c] = *reinterpret_cast<const float4*>(vph + ((int64_t)c * T + jj) * 4);
+          }
           if constexpr (DROP) kw[u] = abits[jj >> 5];
         }
         // scores of the trip first, ONE rescale of the running sums per trip (trip maximum), one exponential per key; the periodic bias
@@ -224,43 +243,60 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
         float mt = mrun;
 #pragma unroll
         for (int u = 0; u < FA_U; ++u) {
-          const int j = j0 + 16 * u;
-          float p = dot4(qv, kk[u]);
-          p += __shfl_xor(p, 1, 64);
-          p += __shfl_xor(p, 2, 64);
+          const int j = j0 + 64 * u + lane;
+          float pc[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) pc[c] = dot4(make_float4(q[4 * c], q[4 * c + 1], q[4 * c + 2], q[4 * c + 3]), kk[u][c]);
+          float p = (pc[0] + pc[1]) + (pc[2] + pc[3]);
           p = j <= i ? p - slope * floorf(((float)(i - j) + 0.5f) * inv_period) : -INFINITY;
           pu[u] = p;
           mt = fmaxf(mt, p);
         }
         const float sc = mt == -INFINITY ? 1.f : expf(mrun - mt);
         lsum *= sc;
-        cacc.x *= sc; cacc.y *= sc; cacc.z *= sc; cacc.w *= sc;
+#pragma unroll
+        for (int d = 0; d < FHD; ++d) cacc[d] *= sc;
 #pragma unroll
         for (int u = 0; u < FA_U; ++u) {
-          const int j = j0 + 16 * u;
+          const int j = j0 + 64 * u + lane;
           const float e = pu[u] == -INFINITY ? 0.f : expf(pu[u] - mt);
           lsum += e;                                               // the normaliser keeps every key; only the value sum is thinned
           float ev = e;
           if constexpr (DROP) ev = ((kw[u] >> (j & 31)) & 1u) ? e * dm.scale : 0.f;
-          cacc.x += ev * vv[u].x; cacc.y += ev * vv[u].y; cacc.z += ev * vv[u].z; cacc.w += ev * vv[u].w;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            cacc[4 * c] += ev * vv[u][c].x; cacc[4 * c + 1] += ev * vv[u][c].y;
+            cacc[4 * c + 2] += ev * vv[u][c].z; cacc[4 * c + 3] += ev * vv[u][c].w;
+          }
         }
         mrun = mt;
       }
+      // merge the wave's 64 partial softmaxes in a fixed order (deterministic).  The 16 context components go through a [component][lane] tile in LDS:
+      // lane (d = lane >> 2, quarter = lane & 3) adds 16 lanes' worth of component d, two shuffles join the quarters (18 butterfly reductions of 6
+      // shuffles each cost ~7 000 clk per step - more than the keys of a T = 600 sequence)
       const float m = wave_max(mrun);
-      {
-        const float sc = mrun == -INFINITY ? 0.f : expf(mrun - m);       // slots that saw no key contribute nothing
-        lsum *= sc;
-        cacc.x *= sc; cacc.y *= sc; cacc.z *= sc; cacc.w *= sc;
-      }
-      // fold the 16 key slots (lanes with equal dq): xor 4, 8, 16, 32
+      const float scw = mrun == -INFINITY ? 0.f : expf(mrun - m);           // lanes that saw no key contribute nothing
+      lsum = wave_sum(lsum * scw);
+      float* red = sweep_red + wave * (FHD * 64);
 #pragma unroll
-      for (int off = 4; off < 64; off <<= 1) {
-        lsum += __shfl_xor(lsum, off, 64);
-        cacc.x += __shfl_xor(cacc.x, off, 64); cacc.y += __shfl_xor(cacc.y, off, 64);
-        cacc.z += __shfl_xor(cacc.z, off, 64); cacc.w += __shfl_xor(cacc.w, off, 64);
+      for (int d = 0; d < FHD; ++d) red[d * 64 + lane] = cacc[d] * scw;
+      // (same wave: LDS operations complete in order, no barrier)
+      float tot = 0.f;
+      {
+        const float* src = red + (lane >> 2) * 64 + (lane & 3) * 16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 v4 = *reinterpret_cast<const float4*>(src + 4 * c);
+          tot += (v4.x + v4.y) + (v4.z + v4.w);
+        }
+        tot += __shfl_xor(tot, 1, 64);
+        tot += __shfl_xor(tot, 2, 64);
       }
-      if (js == 0) *reinterpret_cast<float4*>(mrg_c + apart * FD + head * FHD + dq * 4) = cacc;      // relative to this wave's maximum m
-      if (lane == 0) { mrg_s[(apart * FH + head) * 2] = m; mrg_s[(apart * FH + head) * 2 + 1] = lsum; }
+      if ((lane & 3) == 0) mrg_c[apart * FD + head * FHD + (lane >> 2)] = tot;          // relative to this wave's maximum m
+      if (lane == 0) {
+        mrg_s[(apart * FH + head) * 2] = m;
+        mrg_s[(apart * FH + head) * 2 + 1] = lsum;
+      }
     }
     __syncthreads();
     FF_STAMP(3);
@@ -298,9 +334,14 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
     __syncthreads();
     FF_STAMP(5);
     if (t < FFF) {                                                          // linear1 + ReLU
-      float acc = b1;
+      float a0 = b1, a1 = 0.f, a2 = 0.f, a3 = 0.f;                          // four independent partial sums (cf. the q | k | v product)
 #pragma unroll
-      for (int k = 0; k < FD; ++k) acc += w1r[k] * y2s[k];
+      for (int k = 0; k < FD; k += 4) {
+        const float4 yv = *reinterpret_cast<const float4*>(y2s + k);
+        a0 += W1T[k * FFF + t] * yv.x; a1 += W1T[(k + 1) * FFF + t] * yv.y;
+        a2 += W1T[(k + 2) * FFF + t] * yv.z; a3 += W1T[(k + 3) * FFF + t] * yv.w;
+      }
+      float acc = (a0 + a1) + (a2 + a3);
       acc = fmaxf(acc, 0.f);
       if constexpr (DROP) acc = ((kw_act >> (t & 31)) & 1u) ? acc * dm.scale : 0.f;          // dropout after the activation
       hs[t] = acc;
@@ -1064,7 +1105,7 @@ __global__ __launch_bounds__(256) void ff_decoder_fold_kernel(const float* __res
   dP[i] = acc;
 }
 
-constexpr size_t FF_FWD_LDS = (size_t)(FD * 192 + 2 * FD * FD + 4 * FD + FFF + 4 * FD + FD + 2 * FD + 2 * FH * 2) * sizeof(float);
+constexpr size_t FF_FWD_LDS = (size_t)(FD * 192 + 2 * FD * FD + 4 * FD + FFF + 4 * FD + FD + 2 * FD + 2 * FH * 2 + 8 * FHD * 64 + FD * FFF) * sizeof(float);
 __global__ __launch_bounds__(256) void ff_decoder_fold_range_kernel(const float* __restrict__ slabs, int S, float* __restrict__ dP, int off, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -1080,12 +1121,17 @@ constexpr size_t FF_BWD_LDS = (size_t)(192 * FD + 2 * FD * FD + 2 * FD + FFF + 3
 
 }  // namespace a2f
 
+// floats in front of the forward sweep's K / V planes (the last region of the save buffer): per-step save rows + one gradient slab per sequence
+// (written by the backward kernel, folded in sequence order) + the backward's per-frame gradient records and the split-K workspace of its
+// weight-gradient products
+static size_t ff_kv_planes_offset(int64_t S, int64_t T) {
+  return (size_t)S * (size_t)T * a2f::SV_STRIDE + (size_t)S * A2F_FF_PARAM_FLOATS + (size_t)S * (size_t)T * a2f::FF_GREC + a2f::FF_GEMM_WS_FLOATS +
+         (T >= a2f::FF_BLK_MIN ? (size_t)S * (size_t)T * a2f::FF_NREC : 0);
+}
+
 extern "C" size_t a2f_ff_save_bytes(int64_t S, int64_t T) {
   if (S <= 0 || T <= 0) return 16;
-  // per-step save rows + one gradient slab per sequence (written by the backward kernel, folded in sequence order) + the backward's
-  // per-frame gradient records and the split-K workspace of its weight-gradient products
-  return ((size_t)S * (size_t)T * a2f::SV_STRIDE + (size_t)S * A2F_FF_PARAM_FLOATS + (size_t)S * (size_t)T * a2f::FF_GREC + a2f::FF_GEMM_WS_FLOATS +
-          (T >= a2f::FF_BLK_MIN ? (size_t)S * (size_t)T * a2f::FF_NREC : 0)) * sizeof(float);
+  return (ff_kv_planes_offset(S, T) + (size_t)S * (size_t)T * 2 * a2f::FD) * sizeof(float);
 }
 
 static int ff_check_drop(const uint32_t* row_bits, const uint32_t* attn_bits, float keep_scale, const char* who) {
@@ -1112,10 +1158,10 @@ static int ff_fwd_impl(const float* params, const float* pe, const float* cross,
   const FFDrop dm{row_bits, attn_bits, (int)a2f_attn_keep_words(T), keep_scale};
   if (drop)
     hipLaunchKernelGGL(ff_decoder_fwd_kernel<true>, dim3((unsigned)S), dim3(FF_FWD_THREADS), FF_FWD_LDS, (hipStream_t)stream, params, pe, cross, style, (int)T,
-                       (int)period, y, (float*)save, dm);
+                       (int)period, y, (float*)save, (float*)save + ff_kv_planes_offset(S, T), dm);
   else
     hipLaunchKernelGGL(ff_decoder_fwd_kernel<false>, dim3((unsigned)S), dim3(FF_FWD_THREADS), FF_FWD_LDS, (hipStream_t)stream, params, pe, cross, style, (int)T,
-                       (int)period, y, (float*)save, dm);
+                       (int)period, y, (float*)save, (float*)save + ff_kv_planes_offset(S, T), dm);
   A2F_CHECK_LAUNCH("ff_decoder_fwd");
   return A2F_OK;
 }

@@ -57,18 +57,73 @@ constexpr float LN_EPS = 1e-5f;
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
+// Sum / maximum over the 64 lanes of a wave on the DPP network (every lane gets the result; all lanes must be active): two quad permutes and two
+// row mirrors leave each row of 16 with its total, four v_readlane join the rows in a fixed order.  The butterfly of six __shfl_xor (ds_bpermute: an
+// LDS round trip each) that a2f_common.h's wave_sum compiles to is ~4x the latency, and these reductions sit on the recurrence's critical path
+// (three LayerNorms and the softmax merge per step).
+template <int CTRL>
+__device__ __forceinline__ float ff_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float ff_lane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ float ffw_sum(float v) {
+  v += ff_dpp<0xB1>(v);                    // quad_perm [1,0,3,2]
+  v += ff_dpp<0x4E>(v);                    // quad_perm [2,3,0,1]
+  v += ff_dpp<0x141>(v);                   // row_half_mirror
+  v += ff_dpp<0x140>(v);                   // row_mirror
+#ifdef FF_REDUCE_BPERM
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+#else
+  return (ff_lane(v, 0) + ff_lane(v, 16)) + (ff_lane(v, 32) + ff_lane(v, 48));
+#endif
+}
+__device__ __forceinline__ float ffw_max(float v) {
+  v = fmaxf(v, ff_dpp<0xB1>(v));
+  v = fmaxf(v, ff_dpp<0x4E>(v));
+  v = fmaxf(v, ff_dpp<0x141>(v));
+  v = fmaxf(v, ff_dpp<0x140>(v));
+#ifdef FF_REDUCE_BPERM
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+#else
+  return fmaxf(fmaxf(ff_lane(v, 0), ff_lane(v, 16)), fmaxf(ff_lane(v, 32), ff_lane(v, 48)));
+#endif
+}
+
+// y[col] = bias + sum_k Wt[k * stride + col] * x[k], k < 64, both operands in LDS (Wt transposed: lanes read consecutive columns; x broadcast as float4).
+// All 80 LDS reads are issued before the first multiply-add (sched_barrier): left to itself the scheduler - register-shy in the kernels that do not
+// fit a third wave per SIMD anyway - put every read directly in front of its use, one LDS round trip per k (s_memtime stamps of the train-mode
+// forward: linear1 2 600 clk instead of 1 190).  Four partial sums by k mod 4.
+__device__ __forceinline__ float ff_matvec64(const float* __restrict__ Wt, int stride, int col, const float* __restrict__ x, float bias) {
+  float w[FD];
+  float4 xv[FD / 4];
+#pragma unroll
+  for (int k = 0; k < FD; ++k) w[k] = Wt[k * stride + col];
+#pragma unroll
+  for (int q = 0; q < FD / 4; ++q) xv[q] = *reinterpret_cast<const float4*>(x + 4 * q);
+  __builtin_amdgcn_sched_barrier(0);
+  float a0 = bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int q = 0; q < FD / 4; ++q) {
+    a0 += w[4 * q] * xv[q].x; a1 += w[4 * q + 1] * xv[q].y;
+    a2 += w[4 * q + 2] * xv[q].z; a3 += w[4 * q + 3] * xv[q].w;
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
 // LayerNorm over the 64 lanes of one wave: returns normalised value, writes rstd
 __device__ __forceinline__ float wave_layernorm(float u, float& rstd) {
-  const float mean = wave_sum(u) * (1.f / FD);
+  const float mean = ffw_sum(u) * (1.f / FD);
   const float d = u - mean;
-  const float var = wave_sum(d * d) * (1.f / FD);
+  const float var = ffw_sum(d * d) * (1.f / FD);
   rstd = 1.f / sqrtf(var + LN_EPS);
   return d * rstd;
 }
 // LayerNorm backward over one wave: dxhat -> du
 __device__ __forceinline__ float wave_layernorm_bwd(float dxhat, float xhat, float rstd) {
-  const float m1 = wave_sum(dxhat) * (1.f / FD);
-  const float m2 = wave_sum(dxhat * xhat) * (1.f / FD);
+  const float m1 = ffw_sum(dxhat) * (1.f / FD);
+  const float m2 = ffw_sum(dxhat * xhat) * (1.f / FD);
   return rstd * (dxhat - m1 - xhat * m2);
 }
 
@@ -99,8 +154,12 @@ constexpr int FF_ROW_WORDS = 10;
 #else
 #define FF_STAMP(n) do { } while (0)
 #endif
+// amdgpu_waves_per_eu(2, 2): one workgroup of 8 waves per CU is all there ever is, so the scheduler may spend the 256 registers of a wave on
+// latency.  Without the attribute it scheduled the train-mode variant for a third wave per SIMD it could not reach anyway (181 registers, limit
+// 168): every LDS read of linear1 / the out-projection directly in front of its use, one at a time - those phases ran 2x longer than in the
+// variant that happened to fit 168 (s_memtime stamps: 2 600 vs 1 190 and 3 460 vs 2 050 clk per step).
 template <bool DROP>
-__global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const float* __restrict__ P, const float* __restrict__ pe,
+__global__ __launch_bounds__(FF_FWD_THREADS, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void ff_decoder_fwd_kernel(const float* __restrict__ P, const float* __restrict__ pe,
                                                                         const float* __restrict__ cross, const float* __restrict__ style,
                                                                         int T, int period, float* __restrict__ y, float* __restrict__ save,
                                                                         float* __restrict__ kvp, const FFDrop dm) {
@@ -120,6 +179,9 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
   float* mrg_s = mrg_c + 2 * FD;            // [2][4][2] their running maximum / exponential sum
   float* sweep_red = mrg_s + 2 * FH * 2;    // [8 waves][16][64] the waves' per-lane context partials on their way to one sum per component
   float* W1T = sweep_red + 8 * FHD * 64;    // [64][128]  W1T[k*128 + o] = W1[o][k]
+  float* nx_pe = W1T + FD * FFF;            // [2][64]  positional-encoding row of step i, in buffer i & 1 (written during step i - 1 by the helper wave)
+  float* nx_cross = nx_pe + 2 * FD;         // [2][64]  cross-attention row of step i
+  unsigned* nx_kw = reinterpret_cast<unsigned*>(nx_cross + 2 * FD);   // [2][16] the frame's keep words (DROP; FF_ROW_WORDS = 10 used)
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int head = wave & 3, apart = wave >> 2;     // self-attention: head and which half of the key trips this wave sweeps
@@ -158,43 +220,59 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
   const int js = lane >> 2, dq = lane & 3;                      // attention lanes: 16 key slots x 4 quarter-heads
   float emb = sty;                                              // wave 0: embedding fed to the next step
   float y2 = 0.f;
-  // Inputs of a step that do not depend on the recurrence (positional-encoding row, cross-attention row, keep words) are fetched one step
-  // ahead into registers: issued where they are used, each of these L2 round trips (~1 us) would sit on the critical path of the step.
-  float pe_nx = wave == 0 ? pe[lane] : 0.f;                    // wave 0: pe row of the coming step
-  int ph = 0;                                                   // i % period
+  // Inputs of a step that do not depend on the recurrence (positional-encoding row, cross-attention row, keep words) reach their consumers through
+  // LDS: at the top of step i the HELPER wave (wave 7: it only takes part in the sweep) parks the rows of step i + 1, requested one step earlier,
+  // in buffer (i + 1) & 1 and requests those of step i + 2 - ONE branch, its registers carried around the loop.  Why so roundabout: a vector-memory
+  // load whose result is used (or whose destination register is re-used) somewhere in the chain makes the compiler place a vmcnt wait there for
+  // EVERY wave, and for the waves on the critical path that wait is for their own global stores (the save rows): an L2 write acknowledgement per
+  // phase (s_memtime stamps, train mode: linear1 2 736 clk with the keep word loaded by its own wave - or merely sharing a register with a
+  // prefetch of the helper - against 1 184 without).
+  constexpr int HELPER = FF_FWD_THREADS / 64 - 1;
+  int ph_nx = T > 1 ? 1 % period : 0;                           // helper: row of the pe table for the step its registers hold
+  float pf_pe = 0.f, pf_cross = 0.f;
+  unsigned pf_kw = 0;
+  if (wave == HELPER) {
+    nx_pe[lane] = pe[lane];
+    nx_cross[lane] = cross[(s * T) * FD + lane];
+    if constexpr (DROP) { if (lane < FF_ROW_WORDS) nx_kw[lane] = dm.row[(s * T) * FF_ROW_WORDS + lane]; }
+    const int i1 = min(1, T - 1);
+    pf_pe = pe[ph_nx * FD + lane];
+    pf_cross = cross[(s * T + i1) * FD + lane];
+    if constexpr (DROP) pf_kw = dm.row[(s * T + i1) * FF_ROW_WORDS + min(lane, FF_ROW_WORDS - 1)];
+  }
   __syncthreads();
 
   for (int i = 0; i < T; ++i) {
     FF_STAMP(0);
     float* sv = svbase + (int64_t)i * SV_STRIDE;
-    const unsigned* rowbits = DROP ? dm.row + (s * T + i) * FF_ROW_WORDS : nullptr;
+    const int buf = i & 1;
     float cross_i = 0.f;
-    unsigned kw_x = 0, kw_d1 = 0, kw_d3 = 0, kw_act = 0;
+    unsigned kw_d1 = 0, kw_d3 = 0, kw_act = 0;
+    if (wave == HELPER) {
+      nx_pe[(buf ^ 1) * FD + lane] = pf_pe;                     // rows of step i + 1 (buffer (i + 1) & 1 was last read during step i - 1)
+      nx_cross[(buf ^ 1) * FD + lane] = pf_cross;
+      if constexpr (DROP) { if (lane < FF_ROW_WORDS) nx_kw[(buf ^ 1) * 16 + lane] = pf_kw; }
+      const int i2 = min(i + 2, T - 1);                         // rows of step i + 2 (past the end: the last step's, never consumed)
+      if (++ph_nx == period) ph_nx = 0;
+      pf_pe = pe[ph_nx * FD + lane];                            // the table has `period` rows: always in range
+      pf_cross = cross[(s * T + i2) * FD + lane];
+      if constexpr (DROP) pf_kw = dm.row[(s * T + i2) * FF_ROW_WORDS + min(lane, FF_ROW_WORDS - 1)];
+    }
     if (wave == 0) {
-      const float pe_i = pe_nx;
-      cross_i = cross[(s * T + i) * FD + lane];                 // used after the self-attention: in flight across the projections and the sweep
-      if constexpr (DROP) { kw_x = rowbits[lane >> 5]; kw_d1 = rowbits[2 + (lane >> 5)]; kw_d3 = rowbits[8 + (lane >> 5)]; }
-      if (++ph == period) ph = 0;
-      pe_nx = pe[ph * FD + lane];                               // next step's row (the table has `period` rows: always in range)
+      const float pe_i = nx_pe[buf * FD + lane];
+      cross_i = nx_cross[buf * FD + lane];                      // used after the self-attention
+      unsigned kw_x = 0;
+      if constexpr (DROP) { kw_x = nx_kw[buf * 16 + (lane >> 5)]; kw_d1 = nx_kw[buf * 16 + 2 + (lane >> 5)]; kw_d3 = nx_kw[buf * 16 + 8 + (lane >> 5)]; }
       float x = emb + pe_i;                                     // periodic positional encoding
       if constexpr (DROP) x = ((kw_x >> (lane & 31)) & 1u) ? x * dm.scale : 0.f;
       xs[lane] = x;
       sv[SV_X + lane] = x;
     }
-    if constexpr (DROP) { if (t < FFF) kw_act = rowbits[4 + (t >> 5)]; }
+    if constexpr (DROP) { if (t < FFF) kw_act = nx_kw[buf * 16 + 4 + (t >> 5)]; }
     __syncthreads();
     FF_STAMP(1);
     if (t < 192) {                                              // q | k | v projections
-      // four independent partial sums, the broadcast operand read as float4: the 64-long dependent multiply-add chain and its 128 LDS reads were
-      // the phase's latency (s_memtime stamps: 2 700 clk for this product)
-      float a0 = bqkv, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-      for (int k = 0; k < FD; k += 4) {
-        const float4 xv = *reinterpret_cast<const float4*>(xs + k);
-        a0 += WqkvT[k * 192 + t] * xv.x; a1 += WqkvT[(k + 1) * 192 + t] * xv.y;
-        a2 += WqkvT[(k + 2) * 192 + t] * xv.z; a3 += WqkvT[(k + 3) * 192 + t] * xv.w;
-      }
-      float acc = (a0 + a1) + (a2 + a3);
+      float acc = ff_matvec64(WqkvT, 192, t, xs, bqkv);
       if (t < 64) { acc *= 0.25f; qs[t] = acc; sv[SV_Q + t] = acc; }
       else {
         const int d = t & 63;                                    // head = d >> 4, plane c = (d >> 2) & 3, e = d & 3
@@ -237,6 +315,7 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
           }
           if constexpr (DROP) kw[u] = abits[jj >> 5];
         }
+        __builtin_amdgcn_sched_barrier(0);        // every load of the trip is issued HERE: the machine scheduler otherwise sinks the V loads below the scores (a second exposed round trip per trip)
         // scores of the trip first, ONE rescale of the running sums per trip (trip maximum), one exponential per key; the periodic bias
         // floor((i - j) / period) through a float reciprocal ((d + 0.5) / period is never within 0.5 / period of an integer: exact for T < 2^21)
         float pu[FA_U];
@@ -274,9 +353,9 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
       // merge the wave's 64 partial softmaxes in a fixed order (deterministic).  The 16 context components go through a [component][lane] tile in LDS:
       // lane (d = lane >> 2, quarter = lane & 3) adds 16 lanes' worth of component d, two shuffles join the quarters (18 butterfly reductions of 6
       // shuffles each cost ~7 000 clk per step - more than the keys of a T = 600 sequence)
-      const float m = wave_max(mrun);
+      const float m = ffw_max(mrun);
       const float scw = mrun == -INFINITY ? 0.f : expf(mrun - m);           // lanes that saw no key contribute nothing
-      lsum = wave_sum(lsum * scw);
+      lsum = ffw_sum(lsum * scw);
       float* red = sweep_red + wave * (FHD * 64);
 #pragma unroll
       for (int d = 0; d < FHD; ++d) red[d * 64 + lane] = cacc[d] * scw;
@@ -316,9 +395,7 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
     __syncthreads();
     FF_STAMP(4);
     if (wave == 0) {
-      float sa = bo;
-#pragma unroll 16
-      for (int k = 0; k < FD; ++k) sa += WoT[k * FD + lane] * cs[k];
+      float sa = ff_matvec64(WoT, FD, lane, cs, bo);
       if constexpr (DROP) sa = ((kw_d1 >> (lane & 31)) & 1u) ? sa * dm.scale : 0.f;     // dropout1
       float rstd;
       float xh = wave_layernorm(xs[lane] + sa, rstd);                       // norm1(x + self_attn)
@@ -334,14 +411,7 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
     __syncthreads();
     FF_STAMP(5);
     if (t < FFF) {                                                          // linear1 + ReLU
-      float a0 = b1, a1 = 0.f, a2 = 0.f, a3 = 0.f;                          // four independent partial sums (cf. the q | k | v product)
-#pragma unroll
-      for (int k = 0; k < FD; k += 4) {
-        const float4 yv = *reinterpret_cast<const float4*>(y2s + k);
-        a0 += W1T[k * FFF + t] * yv.x; a1 += W1T[(k + 1) * FFF + t] * yv.y;
-        a2 += W1T[(k + 2) * FFF + t] * yv.z; a3 += W1T[(k + 3) * FFF + t] * yv.w;
-      }
-      float acc = (a0 + a1) + (a2 + a3);
+      float acc = ff_matvec64(W1T, FFF, t, y2s, b1);
       acc = fmaxf(acc, 0.f);
       if constexpr (DROP) acc = ((kw_act >> (t & 31)) & 1u) ? acc * dm.scale : 0.f;          // dropout after the activation
       hs[t] = acc;
@@ -371,10 +441,7 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) void ff_decoder_fwd_kernel(const
     __syncthreads();
     FF_STAMP(8);
     if (wave == 0) {                                                        // feedback: emb = A y + c + style
-      float acc = cfb + sty;
-#pragma unroll 16
-      for (int k = 0; k < FD; ++k) acc += AT[k * FD + lane] * ys[k];
-      emb = acc;
+      emb = ff_matvec64(AT, FD, lane, ys, cfb + sty);
     }
   }
 }
@@ -1105,7 +1172,7 @@ __global__ __launch_bounds__(256) void ff_decoder_fold_kernel(const float* __res
   dP[i] = acc;
 }
 
-constexpr size_t FF_FWD_LDS = (size_t)(FD * 192 + 2 * FD * FD + 4 * FD + FFF + 4 * FD + FD + 2 * FD + 2 * FH * 2 + 8 * FHD * 64 + FD * FFF) * sizeof(float);
+constexpr size_t FF_FWD_LDS = (size_t)(FD * 192 + 2 * FD * FD + 4 * FD + FFF + 4 * FD + FD + 2 * FD + 2 * FH * 2 + 8 * FHD * 64 + FD * FFF + 4 * FD + 32) * sizeof(float);
 __global__ __launch_bounds__(256) void ff_decoder_fold_range_kernel(const float* __restrict__ slabs, int S, float* __restrict__ dP, int off, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;

@@ -20,8 +20,13 @@ pe = torch.randn(period, 64, generator=g).to(dev)
 cross, style = torch.randn(S, T, 64, generator=g).to(dev), torch.randn(S, 64, generator=g).to(dev)
 y = torch.empty(S, T, 64, device=dev)
 save = torch.zeros(be.ff_save_floats(S, T), device=dev)
+drop = None
+if os.environ.get("FF_DROP") == "1":          # the train-mode variant (keep bits for every dropout site)
+    row = torch.empty(S * T, 10, dtype=torch.int32, device=dev); attn = torch.empty(S * 4 * T, be.attn_keep_words(T), dtype=torch.int32, device=dev)
+    be.keep_bits(1, 1000, S * T, 320, 0.1, row); be.keep_bits(1, 1001, S * 4 * T, T, 0.1, attn)
+    drop = (row, attn, 1 / 0.9)
 for _ in range(2):
-    be.ff_decoder_fwd(P, pe, cross, style, S, T, period, y, save)
+    be.ff_decoder_fwd(P, pe, cross, style, S, T, period, y, save, drop=drop)
 torch.cuda.synchronize()
 off = S * T * 896 + 33600
 st = save[off:off + 64].view(torch.int64).cpu().tolist()

@@ -150,8 +150,11 @@ constexpr int FF_ROW_WORDS = 10;
 // -DFF_STAMPS: timing build only - thread 0 of sequence 0 leaves s_memtime stamps of step FF_STAMP_STEP after every barrier in the (then unused)
 // A / c block of its gradient slab (tools/ff_stamps.py)
 #ifdef FF_STAMPS
+__device__ long long ffb_dbg[16];           // backward: stamps of step FF_STAMP_STEP of sequence 0 (a2f_debug_ff_bwd_stamps, tools/ff_stamps_bwd.py)
+#define FFB_STAMP(n) do { if (t == 0 && s == 0 && i == FF_STAMP_STEP) ffb_dbg[n] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define FF_STAMP(n) do { if (t == 0 && s == 0 && i == FF_STAMP_STEP) stamp_out[n] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define FFB_STAMP(n) do { } while (0)
 #define FF_STAMP(n) do { } while (0)
 #endif
 // amdgpu_waves_per_eu(2, 2): one workgroup of 8 waves per CU is all there ever is, so the scheduler may spend the 256 registers of a wave on
@@ -820,6 +823,7 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
   __syncthreads();
 
   for (int i = i_hi - 1; i >= i_lo; --i) {
+    FFB_STAMP(0);
     float* sv = svbase + (int64_t)i * SV_STRIDE;
     float* gr = gbase + (int64_t)i * FF_GREC;
     float dy2 = 0.f, xh2 = 0.f, xh1 = 0.f;
@@ -854,6 +858,7 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
       qs[lane] = sv[SV_Q + lane];
     }
     __syncthreads();
+    FFB_STAMP(1);
     // ---- S2: dW2 += df (x) h ; dh = W2^T df (partials) ; dA += demb_{i+1} (x) y_i ; dc += demb_{i+1} ----
     if (t < FF_THREADS) {
       float acc = 0.f;
@@ -863,6 +868,7 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
       pbuf[half * FFF + (t & 127)] = acc;
     }
     __syncthreads();
+    FFB_STAMP(2);
     // ---- S3: ReLU backward ; dW1 += dhp (x) y2 ----
     if (t < FFF) {
       const float dh = pbuf[t] + pbuf[FFF + t];
@@ -872,6 +878,7 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
       gr[GR_HP + t] = dhp;
     }
     __syncthreads();
+    FFB_STAMP(3);
     // ---- S4: W1^T dhp (4 partial sums per output) ----
     {
       float acc = 0.f;
@@ -880,9 +887,11 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
         for (int r = 0; r < 32; ++r) acc += w1c[r] * dhps[wave * 32 + r];
       }
       __syncthreads();                                 // pbuf readers of S3 are done
+      FFB_STAMP(4);
       if (wave < 4) pbuf[wave * FD + lane] = acc;
     }
     __syncthreads();
+    FFB_STAMP(5);
     // ---- S5: wave 0: LayerNorm-2 and LayerNorm-1 backward ----
     float dx = 0.f;
     if (wave == 0) {
@@ -903,6 +912,7 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
       gr[GR_SA + lane] = dsa;
     }
     __syncthreads();
+    FFB_STAMP(6);
     // ---- S6: out-projection: dWo += dsa (x) ctx (wave 3) ; dctx = Wo^T dsa (wave 0) ----
     if (wave == 0) {
       float acc = 0.f;
@@ -912,6 +922,7 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
       gr[GR_DC + lane] = acc;
     }
     __syncthreads();
+    FFB_STAMP(7);
     // ---- S7: attention backward for head = wave ----
     {
       const float4 qv = *reinterpret_cast<const float4*>(qs + head * FHD + dq * 4);
@@ -988,6 +999,7 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
       }
       if (js == 0 && apart == 1) *reinterpret_cast<float4*>(mrg + head * FHD + dq * 4) = dqa;
       __syncthreads();                                 // dK / dV row i complete (includes this step's j = i term); second-wave dq partials visible
+      FFB_STAMP(8);
       if (js == 0 && apart == 0) {                     // q was stored pre-scaled: d(q_raw) = 0.25 d(q_scaled)
         const float4 o = *reinterpret_cast<const float4*>(mrg + head * FHD + dq * 4);
         const float4 r = make_float4(0.25f * (dqa.x + o.x), 0.25f * (dqa.y + o.y), 0.25f * (dqa.z + o.z), 0.25f * (dqa.w + o.w));
@@ -997,6 +1009,7 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
     }
     if (t >= 64 && t < 192) { const float g = sv[SV_DK + (t - 64)]; dqkvs[t] = g; gr[GR_QKV + t] = g; }     // SV_DV follows SV_DK: columns 64..127 are dV
     __syncthreads();
+    FFB_STAMP(9);
     // ---- S9: dWqkv += dqkv (x) x ; dx += Wqkv^T dqkv (4 partial sums per output) ----
     if (wave < 4) {
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;        // four partial sums, the broadcast operand as float4 (as in the forward's projection)
@@ -1009,6 +1022,7 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
       pbuf[wave * FD + lane] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
+    FFB_STAMP(10);
     // ---- S10: wave 0: gradient w.r.t. emb_i; carry A^T demb to step i-1 ----
     if (wave == 0) {
       float demb = dx + pbuf[lane] + pbuf[FD + lane] + pbuf[2 * FD + lane] + pbuf[3 * FD + lane];
@@ -1018,6 +1032,7 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
       gr[GR_EMB + lane] = demb;
     }
     __syncthreads();
+    FFB_STAMP(11);
     if (wave == 0) {
       float acc = 0.f;
 #pragma unroll 16
@@ -1366,3 +1381,10 @@ extern "C" int a2f_ff_decoder_bwd_drop(const float* params, const float* dy, int
   if (rc) return rc;
   return ff_bwd_impl(params, dy, S, T, period, save, save_bytes, dparams, dcross, dstyle, row_bits, attn_bits, keep_scale, stream);
 }
+
+#ifdef FF_STAMPS
+// diagnostic build only: the backward recurrence's stamps (s_memtime after every barrier of step FF_STAMP_STEP, sequence 0)
+extern "C" int a2f_debug_ff_bwd_stamps(long long* out16) {
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(a2f::ffb_dbg), 16 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -24,10 +24,13 @@ dP, dc, ds = torch.empty(nP, device=dev), torch.empty(S, T, 64, device=dev), tor
 be.ff_decoder_fwd(P, pe, cross, style, S, T, period, y, save)
 be.ff_decoder_bwd(P, dy, S, T, period, save, dP, dc, ds)
 torch.cuda.synchronize()
-off = S * T * 896 + 33600 + 256
-st = save[off:off + 64].view(torch.int64).cpu().tolist()
-st = [v for v in st if v != 0]
+import ctypes
+buf = (ctypes.c_longlong * 16)()
+be.lib.a2f_debug_ff_bwd_stamps.argtypes = [ctypes.c_void_p]
+assert be.lib.a2f_debug_ff_bwd_stamps(buf) == 0
+st = [v for v in buf if v != 0]
+names = ["", "S1 stage saved rows, LN3'", "S2 W2^T df", "S3 ReLU'", "S4a", "S4 W1^T dhp", "S5 LN2', LN1'", "S6 Wo^T dsa", "S7 attention sweep", "S8 dK/dV row, dq", "S9 Wqkv^T dqkv", "S10 demb, carry"]
 print("stamps:", len(st))
 for n in range(1, len(st)):
-    print("phase ending at barrier %2d: %6d clk" % (n, st[n] - st[n - 1]))
+    print("%-28s %6d clk" % (names[n] if n < len(names) else n, st[n] - st[n - 1]))
 print("step total:", st[-1] - st[0], "clk")

@@ -60,7 +60,8 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a
 // Sum / maximum over the 64 lanes of a wave on the DPP network (every lane gets the result; all lanes must be active): two quad permutes and two
 // row mirrors leave each row of 16 with its total, four v_readlane join the rows in a fixed order.  The butterfly of six __shfl_xor (ds_bpermute: an
 // LDS round trip each) that a2f_common.h's wave_sum compiles to is ~4x the latency, and these reductions sit on the recurrence's critical path
-// (three LayerNorms and the softmax merge per step).
+// (three LayerNorms and the softmax merge per step).  ff_dpp<0xB1> / <0x4E> alone are __shfl_xor(v, 1) / (v, 2) as register moves (the compiler
+// lowers every __shfl_xor to ds_bpermute, constant mask or not).
 template <int CTRL>
 __device__ __forceinline__ float ff_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
@@ -371,8 +372,8 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) __attribute__((amdgpu_waves_per_
           const float4 v4 = *reinterpret_cast<const float4*>(src + 4 * c);
           tot += (v4.x + v4.y) + (v4.z + v4.w);
         }
-        tot += __shfl_xor(tot, 1, 64);
-        tot += __shfl_xor(tot, 2, 64);
+        tot += ff_dpp<0xB1>(tot);
+        tot += ff_dpp<0x4E>(tot);
       }
       if ((lane & 3) == 0) mrg_c[apart * FD + head * FHD + (lane >> 2)] = tot;          // relative to this wave's maximum m
       if (lane == 0) {
@@ -628,8 +629,8 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
       // dq, dK += ds q, dV += a dctx.  FB_U key slots per trip, all loads issued before use (L2 latency bound);
       // a slot past i re-reads row i and neither accumulates nor stores.
       float rowsum = dot4(dcv, *reinterpret_cast<const float4*>(cs + wave * FHD + dq * 4));
-      rowsum += __shfl_xor(rowsum, 1, 64);
-      rowsum += __shfl_xor(rowsum, 2, 64);
+      rowsum += ff_dpp<0xB1>(rowsum);
+      rowsum += ff_dpp<0x4E>(rowsum);
       float4 dqa = make_float4(0.f, 0.f, 0.f, 0.f);
       const unsigned* abits = DROP ? dm.attn + ((s * FH + wave) * T + i) * dm.TW : nullptr;
       for (int j0 = js; j0 <= i; j0 += 16 * FB_U) {
@@ -650,11 +651,11 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
           const int j = j0 + 16 * u;
           const bool valid = j <= i;
           float p = dot4(qv, kk[u]);
-          p += __shfl_xor(p, 1, 64);
-          p += __shfl_xor(p, 2, 64);
+          p += ff_dpp<0xB1>(p);
+          p += ff_dpp<0x4E>(p);
           float da = dot4(dcv, vv[u]);
-          da += __shfl_xor(da, 1, 64);
-          da += __shfl_xor(da, 2, 64);
+          da += ff_dpp<0xB1>(da);
+          da += ff_dpp<0x4E>(da);
           const float a = valid ? expf(p - slope * (float)((i - min(j, i)) / period) - m) * invl : 0.f;
           float ad = a;                                // ctx = sum_j a_j D_j v_j: dV sees a D, da_j = D_j (dctx . v_j); sum_j a_j da_j = dctx . ctx still
           if constexpr (DROP) {
@@ -671,8 +672,12 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
           }
         }
       }
+      // fold the 16 key slots into lanes 0..3 (js == 0: the only readers): row rotations by 4 and 8 pair those lanes exactly like the xor butterfly
+      // did ((v[l] + v[l+4]) + (v[l+8] + v[l+12])), the rows are joined by two shuffles
+      dqa.x += ff_dpp<0x124>(dqa.x); dqa.y += ff_dpp<0x124>(dqa.y); dqa.z += ff_dpp<0x124>(dqa.z); dqa.w += ff_dpp<0x124>(dqa.w);
+      dqa.x += ff_dpp<0x128>(dqa.x); dqa.y += ff_dpp<0x128>(dqa.y); dqa.z += ff_dpp<0x128>(dqa.z); dqa.w += ff_dpp<0x128>(dqa.w);
 #pragma unroll
-      for (int off = 4; off < 64; off <<= 1) {
+      for (int off = 16; off < 64; off <<= 1) {
         dqa.x += __shfl_xor(dqa.x, off, 64); dqa.y += __shfl_xor(dqa.y, off, 64);
         dqa.z += __shfl_xor(dqa.z, off, 64); dqa.w += __shfl_xor(dqa.w, off, 64);
       }
@@ -937,8 +942,8 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
       // dq, dK += ds q, dV += a dctx.  FB_U key slots per trip, all loads issued before use (L2 latency bound);
       // a slot past i re-reads row i and neither accumulates nor stores.
       float rowsum = dot4(dcv, *reinterpret_cast<const float4*>(cs + head * FHD + dq * 4));
-      rowsum += __shfl_xor(rowsum, 1, 64);
-      rowsum += __shfl_xor(rowsum, 2, 64);
+      rowsum += ff_dpp<0xB1>(rowsum);
+      rowsum += ff_dpp<0x4E>(rowsum);
       float4 dqa = make_float4(0.f, 0.f, 0.f, 0.f);
       if (lane == 0 && apart == 0) gr[GR_RS + head] = rowsum;
       if (i_lo > 0 && apart == 0) {                        // keys of the earlier blocks: dq += Nt^T dctx - rowsum n  (lane: a' = js, b = 4 dq ..)
@@ -971,11 +976,11 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
           const int j = j0 + 16 * u;
           const bool valid = j <= i;
           float p = dot4(qv, kk[u]);
-          p += __shfl_xor(p, 1, 64);
-          p += __shfl_xor(p, 2, 64);
+          p += ff_dpp<0xB1>(p);
+          p += ff_dpp<0x4E>(p);
           float da = dot4(dcv, vv[u]);
-          da += __shfl_xor(da, 1, 64);
-          da += __shfl_xor(da, 2, 64);
+          da += ff_dpp<0xB1>(da);
+          da += ff_dpp<0x4E>(da);
           const float a = valid ? expf(p - slope * floorf(((float)(i - min(j, i)) + 0.5f) * inv_period) - m) * invl : 0.f;   // exact floor for T < 2^21
           float ad = a;                                // ctx = sum_j a_j D_j v_j: dV sees a D, da_j = D_j (dctx . v_j); sum_j a_j da_j = dctx . ctx still
           if constexpr (DROP) {
@@ -992,8 +997,12 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
           }
         }
       }
+      // fold the 16 key slots into lanes 0..3 (js == 0: the only readers): row rotations by 4 and 8 pair those lanes exactly like the xor butterfly
+      // did ((v[l] + v[l+4]) + (v[l+8] + v[l+12])), the rows are joined by two shuffles
+      dqa.x += ff_dpp<0x124>(dqa.x); dqa.y += ff_dpp<0x124>(dqa.y); dqa.z += ff_dpp<0x124>(dqa.z); dqa.w += ff_dpp<0x124>(dqa.w);
+      dqa.x += ff_dpp<0x128>(dqa.x); dqa.y += ff_dpp<0x128>(dqa.y); dqa.z += ff_dpp<0x128>(dqa.z); dqa.w += ff_dpp<0x128>(dqa.w);
 #pragma unroll
-      for (int off = 4; off < 64; off <<= 1) {
+      for (int off = 16; off < 64; off <<= 1) {
         dqa.x += __shfl_xor(dqa.x, off, 64); dqa.y += __shfl_xor(dqa.y, off, 64);
         dqa.z += __shfl_xor(dqa.z, off, 64); dqa.w += __shfl_xor(dqa.w, off, 64);
       }

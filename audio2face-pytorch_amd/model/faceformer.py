@@ -24,6 +24,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -241,15 +243,22 @@ class Faceformer(nn.Module):
             # at 600 frames a half's recurrence (11 ms) is over long before the other half's starts: one side stream does - and a further stream
             # can land on a hardware queue another stream of the process already uses (measured inside the full bench run: 182 vs 157 ms)
             sides = [sides[0], sides[0]]
-        cuts = (0, (S + 1) // 2, S)                             # equal halves measured best (7/16 .. 5/16 for the first half: +0.4 .. +1.4 %)
+        # Parts: two equal halves (measured best at 600 frames: 7/16 .. 5/16 for the first half +0.4 .. +1.4 %).  More parts would start the first
+        # recurrence earlier (at long T a part's recurrence outlasts a half's encoder forward), but measured at 12 x 3000 they lose more in the
+        # products than they win: 2 parts 239.1 ms, 3 parts 248.4, 4 parts 250.5, 6 parts 299.0 (same box) - A2F_FF_PIPELINE_PARTS keeps the hook.
+        parts = 2
+        env_parts = os.environ.get("A2F_FF_PIPELINE_PARTS")                    # A-B hook
+        if env_parts:
+            parts = max(2, min(int(env_parts), S))
+        cuts = [(S * g + parts - 1) // parts for g in range(parts)] + [S]
         enc_params = {id(p) for p in self.audio_encoder.parameters()}
         dec_params = [p for p in self.parameters() if p.requires_grad and id(p) not in enc_params]
         halves, outs = [], []
-        for g in range(2):
+        for g in range(parts):
             lo, hi = cuts[g], cuts[g + 1]
             enc = self.encode(audio[lo:hi], frame_num)                          # main stream
             ready = cur.record_event()
-            side = sides[g]
+            side = sides[g % 2]
             with torch.cuda.stream(side):
                 side.wait_event(ready)
                 enc.record_stream(side)
@@ -274,5 +283,7 @@ class Faceformer(nn.Module):
             cur.wait_stream(side)
         for o in outs:
             o.record_stream(cur)
-        tot = outs[0] + outs[1]
+        tot = outs[0]
+        for o in outs[1:]:
+            tot = tot + o
         return {"loss": tot[0], "rec_loss": tot[1], "vel_loss": tot[2]}

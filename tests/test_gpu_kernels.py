@@ -268,7 +268,9 @@ def test_adam_matches_torch_optim():
                                                  (601, 15069, 64, 1, 600), (1031, 4002, 50, 1031, 1030),
                                                  # one template row per sequence (FaceFormer: S sequences of T frames in one launch)
                                                  (120, 15069, 64, 3, 120), (1200, 4002, 64, 2, 1200), (96, 15069, 50, 6, 96), (38, 999, 64, 19, 38),
-                                                 (130, 1536, 64, 5, 104)])
+                                                 (130, 1536, 64, 5, 104),
+                                                 # ... several row blocks per workgroup AND template rows that change inside a block, full width
+                                                 (216, 15069, 64, 9, 216), (240, 15069, 64, 8, 240), (1200, 15069, 64, 2, 1200)])
 def test_head_fused_vs_contract(B_, n, K, trows, Bloss):
     if trows not in (1, B_) and os.environ.get("A2F_HEAD_CFG", "5") != "5":
         pytest.skip("per-sequence template rows exist in the bf16x3 kernel only")
@@ -342,7 +344,7 @@ _FF_SPEC = {}
 
 
 @pytest.mark.parametrize("form", ["0", "1", "2"])
-@pytest.mark.parametrize("S,T,period", [(1, 5, 60), (3, 70, 60), (2, 33, 7), (2, 1, 7), (2, 300, 60), (1, 257, 7)])
+@pytest.mark.parametrize("S,T,period", [(1, 5, 60), (3, 70, 60), (2, 33, 7), (2, 1, 7), (2, 300, 60), (1, 257, 7), (9, 24, 60), (8, 30, 60), (16, 40, 60)])
 def test_ff_decoder_kernels_vs_spec(S, T, period, form, monkeypatch):
     """Recurrence forward + reverse-time backward against autograd on the float64 statement of the same recurrence.  form 0 = record
     form of the backward (recurrence kernel + weight-gradient products over all frames; from 256 frames on in blocks of 128 steps with the

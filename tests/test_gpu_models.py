@@ -940,12 +940,13 @@ def test_faceformer_batch_step_one_head_launch_equals_per_sequence_steps(T):
             assert rel_l2(gb[k].cpu(), p.grad.cpu()) < TOL, k
 
 
-@pytest.mark.parametrize("S,T", [(3, 30), (4, 61)])
-def test_faceformer_pipelined_step_equals_single_stream_step(S, T):
-    """Faceformer.train_step_pipelined (two half-batches on two HIP streams, decoder recurrence under the other half's encoder work):
-    BITWISE equal to the same two half-batches run one after the other on one stream (same kernels, same accumulation order - any
+@pytest.mark.parametrize("S,T,parts", [(3, 30, 2), (4, 61, 2), (5, 30, 4), (9, 24, 4)])
+def test_faceformer_pipelined_step_equals_single_stream_step(S, T, parts, monkeypatch):
+    """Faceformer.train_step_pipelined (two or four parts of the batch on two HIP streams, decoder recurrence under the other parts' encoder work):
+    BITWISE equal to the same parts run one after the other on one stream (same kernels, same accumulation order - any
     missing stream dependency or allocator reuse hazard shows as a difference), twice in a row (the second step reuses freed
     blocks); and equal within the summation-order noise of the weight-gradient GEMMs to the unsplit batch step."""
+    monkeypatch.setenv("A2F_FF_PIPELINE_PARTS", str(parts))                     # two parts is the shipped setting; more parts stay selectable (A-B hook)
     m, _, _ = _faceformer_full()
     m.train()
     m.audio_encoder.train_regularisers = m.decoder_regularisers = False          # every call of this comparison must compute the same function
@@ -960,13 +961,18 @@ def test_faceformer_pipelined_step_equals_single_stream_step(S, T):
     loss["loss"].backward()
     whole = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
     m.zero_grad()
-    h = (S + 1) // 2
+    cuts = [(S * g + parts - 1) // parts for g in range(parts)] + [S]
     seq_loss = 0.0
-    for lo, hi in ((0, h), (h, S)):
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
         _p, l = m.forward_with_loss_batch(audio[lo:hi], oh[lo:hi], template[lo:hi], gt[lo:hi])
         (l["loss"] * ((hi - lo) / S)).backward()
         seq_loss = seq_loss + l["loss"].detach() * ((hi - lo) / S)
     halves = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    # The unsplit step is the same function to rounding, but not to 1e-4 in every case: encoder states that differ at the 1e-5 level (other tiles, other
+    # summation order at another batch size) can put ONE ReLU unit of the decoder's feed-forward layer on the other side of zero, which moves that
+    # sequence's gradients by ~2e-2 (tools/ff_short_diag2.py: sequence 3 of the (9, 24) case - alone 2.1e-2 from the float64 oracle, inside the batch
+    # 2.5e-5; every other sequence <= 1e-4 both ways).  The four-part cases hit such a unit, so they assert the bitwise half only.
+    whole_comparable = parts == 2
     for _rep in range(2):
         m.zero_grad()
         lp = m.train_step_pipelined(audio, oh, template, gt)
@@ -980,10 +986,11 @@ def test_faceformer_pipelined_step_equals_single_stream_step(S, T):
             # against the unsplit step: q / k projection gradients of the deeper layers are ~1e-5 in magnitude with this synthetic
             # model (near-uniform attention; k_proj.bias is analytically zero) and carry only summation-order noise - held as part of
             # the whole gradient vector below, every other tensor individually
-            if ".q_proj." not in k and ".k_proj." not in k:
+            if ".q_proj." not in k and ".k_proj." not in k and whole_comparable:
                 assert rel_l2(got[k].cpu(), whole[k].cpu()) < TOL, k
         keys = sorted(halves)
-        assert rel_l2(torch.cat([got[k].flatten() for k in keys]).cpu(), torch.cat([whole[k].flatten() for k in keys]).cpu()) < 2e-5
+        if whole_comparable:
+            assert rel_l2(torch.cat([got[k].flatten() for k in keys]).cpu(), torch.cat([whole[k].flatten() for k in keys]).cpu()) < 2e-5
 
 
 def test_wav2vec2_train_mode_with_reference_masks_g13():
@@ -1080,12 +1087,12 @@ def test_mfcc_extractor_hip_products_vs_torch_ops():
     assert rel_l2(hip.cpu(), cpu) < 1e-4 and rel_l2(hip.cpu(), fft_gpu.cpu()) < 1e-4
 
 
-@pytest.mark.parametrize("S,T", [(48, 600), (6, 3000)])
+@pytest.mark.parametrize("S,T", [(48, 600), (8, 3000)])
 def test_faceformer_full_size_pipelined_step_is_bitwise_reproducible(S, T):
     """The train step at bench scale (48 sequences x 600 frames: two half-batches, each with its own side stream, decoder beside encoder work,
     weight gradients on their lane, masks drawn on the device) run twice from the same state and seed: parameters after two optimizer steps
     must be BITWISE equal.  Every kernel is deterministic, so any difference is a missing stream dependency or an allocator reuse
-    hazard - which only long-running kernels at this size would expose.  6 x 3000 frames (configs[4]'s length): there the second half's
+    hazard - which only long-running kernels at this size would expose.  8 x 3000 frames (configs[4]'s length): there the second half's
     recurrence runs WHILE the first half's is still going (89 ms each), the blocked backward issues ~50 launches per half."""
     import bench
     from a2f_amd.trainer import TrainStep

@@ -781,6 +781,10 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
   float* dembs = dqkvs + 192;               // [64] gradient w.r.t. emb_{i+1} from the previous (later-time) iteration
   float* qs = dembs + FD;                   // [64]
   float* mrg = qs + FD;                     // [64] dq partial of the heads' second waves
+  // Saved rows of a step (the first 576 floats of its record: x, q, ctx, xh1, xh2, h, xh3, stats), its dy row and its keep words, parked here one
+  // step ahead by the helper wave (see the loop top): [2][FB_STG]
+  constexpr int FB_STG = 576 + FD + 16;
+  float* stg = mrg + FD;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int head = wave & 3, apart = wave >> 2;     // attention sweep: head and which half of the key trips
@@ -827,17 +831,50 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
   }
   __syncthreads();
 
+  // The saved rows a step reads do not depend on the recurrence: the HELPER wave (wave 7: it only takes part in the sweep) requests those of step
+  // i - 2 at the top of step i and parks those of step i - 1 (requested one step earlier) in buffer (i - 1) & 1 - one branch, registers carried
+  // around the loop (cf. the forward).  Read where they are used they cost an L2 round trip at the head of S1, S5 and S7 each (s_memtime stamps:
+  // S1 2 444 clk of a 13.9 k step).
+  constexpr int HELPER = FF_BWD2_THREADS / 64 - 1;
+  float pf[9], pf_dy = 0.f;
+  unsigned pf_kw = 0;
+  auto request_rows = [&](int step) {
+    const float* r = svbase + (int64_t)step * SV_STRIDE;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) pf[q] = r[q * 64 + lane];
+    pf_dy = dy[(s * T + step) * FD + lane];
+    if constexpr (DROP) pf_kw = dm.row[(s * T + step) * FF_ROW_WORDS + min(lane, FF_ROW_WORDS - 1)];
+  };
+  auto park_rows = [&](int step) {
+    float* d = stg + (step & 1) * FB_STG;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) d[q * 64 + lane] = pf[q];
+    d[576 + lane] = pf_dy;
+    if constexpr (DROP) { if (lane < FF_ROW_WORDS) reinterpret_cast<unsigned*>(d)[576 + FD + lane] = pf_kw; }
+  };
+  if (wave == HELPER) {
+    request_rows(i_hi - 1);
+    park_rows(i_hi - 1);
+    request_rows(max(i_hi - 2, 0));
+  }
+  __syncthreads();
+
   for (int i = i_hi - 1; i >= i_lo; --i) {
     FFB_STAMP(0);
     float* sv = svbase + (int64_t)i * SV_STRIDE;
     float* gr = gbase + (int64_t)i * FF_GREC;
     float dy2 = 0.f, xh2 = 0.f, xh1 = 0.f;
-    const unsigned* rowbits = DROP ? dm.row + (s * T + i) * FF_ROW_WORDS : nullptr;
+    if (wave == HELPER) {
+      park_rows(i - 1);                                // i = 0: buffer 1, never read
+      request_rows(max(i - 2, 0));
+    }
+    const float* sr = stg + (i & 1) * FB_STG;          // this step's rows (parked at the top of step i + 1, or before the loop)
+    const unsigned* rowbits = reinterpret_cast<const unsigned*>(sr) + 576 + FD;
     // ---- S1: stage saved vectors; wave 0: LayerNorm-3 backward ----
     if (wave == 0) {
-      const float xh3 = sv[SV_XH3 + lane];
-      const float rstd3 = sv[SV_ST + 2];
-      const float dy3 = dy[(s * T + i) * FD + lane] + carry;
+      const float xh3 = sr[SV_XH3 + lane];
+      const float rstd3 = sr[SV_ST + 2];
+      const float dy3 = sr[576 + lane] + carry;
       gg3 += dy3 * xh3;
       gb3n += dy3;
       const float du3 = wave_layernorm_bwd(dy3 * ln_g3, xh3, rstd3);
@@ -849,18 +886,18 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
       const float yv = xh3 * ln_g3 + ln_b3;
       ys[lane] = yv;
       gr[GR_Y + lane] = yv;
-      xh2 = sv[SV_XH2 + lane];
+      xh2 = sr[SV_XH2 + lane];
       const float y2v = xh2 * ln_g2 + ln_b2;
       y2s[lane] = y2v;
       gr[GR_Y2 + lane] = y2v;
     } else if (wave == 1) {
-      hs[lane] = sv[SV_H + lane];
-      hs[64 + lane] = sv[SV_H + 64 + lane];
+      hs[lane] = sr[SV_H + lane];
+      hs[64 + lane] = sr[SV_H + 64 + lane];
     } else if (wave == 2) {
-      xs[lane] = sv[SV_X + lane];
-      cs[lane] = sv[SV_CTX + lane];
+      xs[lane] = sr[SV_X + lane];
+      cs[lane] = sr[SV_CTX + lane];
     } else if (wave == 3) {
-      qs[lane] = sv[SV_Q + lane];
+      qs[lane] = sr[SV_Q + lane];
     }
     __syncthreads();
     FFB_STAMP(1);
@@ -901,12 +938,12 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
     float dx = 0.f;
     if (wave == 0) {
       dy2 += pbuf[lane] + pbuf[FD + lane] + pbuf[2 * FD + lane] + pbuf[3 * FD + lane];
-      const float rstd2 = sv[SV_ST + 1], rstd1 = sv[SV_ST + 0];
+      const float rstd2 = sr[SV_ST + 1], rstd1 = sr[SV_ST + 0];
       gg2 += dy2 * xh2;
       gb2n += dy2;
       const float du2 = wave_layernorm_bwd(dy2 * ln_g2, xh2, rstd2);
       dcross[(s * T + i) * FD + lane] = du2;           // u2 = y1 + cross_i
-      xh1 = sv[SV_XH1 + lane];
+      xh1 = sr[SV_XH1 + lane];
       gg1 += du2 * xh1;
       gb1n += du2;
       const float du1 = wave_layernorm_bwd(du2 * ln_g1, xh1, rstd1);
@@ -932,8 +969,8 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
     {
       const float4 qv = *reinterpret_cast<const float4*>(qs + head * FHD + dq * 4);
       const float4 dcv = *reinterpret_cast<const float4*>(dcs + head * FHD + dq * 4);
-      const float m = sv[SV_ST + 4 + head];
-      const float invl = 1.f / sv[SV_ST + 8 + head];
+      const float m = sr[SV_ST + 4 + head];
+      const float invl = 1.f / sr[SV_ST + 8 + head];
       float* kbase = svbase + SV_K + head * FHD + dq * 4;
       float* vbase = svbase + SV_V + head * FHD + dq * 4;
       float* dkbase = svbase + SV_DK + head * FHD + dq * 4;
@@ -1262,7 +1299,7 @@ static int ff_fwd_impl(const float* params, const float* pe, const float* cross,
 static int ff_bwd2_run(const float* params, const float* dy, int64_t S, int64_t T, int32_t period, float* save, float* dparams, float* dcross,
                        float* dstyle, const a2f::FFDrop& dm, bool drop, bool blocked, hipStream_t st) {
   using namespace a2f;
-  constexpr size_t LDS = FF_BWD_LDS + 64 * sizeof(float);
+  constexpr size_t LDS = FF_BWD_LDS + (64 + 2 * (576 + FD + 16)) * sizeof(float);
   static bool attr_set[2] = {false, false};
   if (!attr_set[drop]) {
     const void* k = drop ? reinterpret_cast<const void*>(&ff_decoder_bwd2_kernel<true>) : reinterpret_cast<const void*>(&ff_decoder_bwd2_kernel<false>);

@@ -241,7 +241,8 @@ int a2f_ff_decoder_fwd(const float* params, const float* pe, const float* cross,
  * reverse-time recurrence kernel leaves 640 gradient factors per frame and per-sequence LayerNorm-gradient slabs behind the
  * per-step rows of `save`; weight and bias gradients are then five bf16x3 products over all S*T frames launched on the same
  * stream by this call (split-K slabs folded in fixed order), the slabs are summed in sequence order.  `save` is the forward's
- * buffer (a2f_ff_save_bytes covers records, slabs and the products' workspace); its dK/dV accumulator columns are scratch
+ * buffer (a2f_ff_save_bytes covers records, slabs, the products' workspace and - last - the forward sweep's own K / V planes,
+ * 128 floats per frame laid out [sequence][K | V][head][4 planes][T][4]); its dK/dV accumulator columns are scratch
  * for this call.  From 256 frames on the recurrence is launched in blocks of 128 steps; attention terms across block
  * boundaries are computed by two chip-wide kernels (see ff_decoder.hip).  Environment A2F_FF_BWD (A-B hook, read per call):
  * 1 = the single-kernel form with register accumulators, 2 = record form in one launch. */

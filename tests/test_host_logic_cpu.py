@@ -284,3 +284,34 @@ def test_hip_encoder_composition_matches_oracle(emu):
         if v.grad is None or k.endswith("k_proj.bias"):          # d/d(k bias) is identically zero in exact arithmetic (softmax shift invariance)
             continue
         assert rel_l2(P[k].grad, v.grad) < 1e-4, k
+
+
+def test_flat_adam_release_and_collect_grads(emu):
+    """trainer.FlatAdam.release_grads / collect_grads: gradients autograd hands over (fresh tensors, views, a parameter that received none - a
+    layer LayerDrop skipped) end up in the flat buffer exactly as zero-fill + accumulation would have left them, and ``p.grad`` is the flat view
+    again; a second backward before the collect accumulates in place."""
+    from a2f_amd.trainer import FlatAdam
+    torch.manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2))]
+    opt = FlatAdam(ps, lr=1e-3)
+    views = [p.grad for p in ps]
+    x = torch.randn(4, 5)
+
+    def loss():
+        return (x @ ps[0]).pow(2).sum() + (ps[1][:3] * 2.0).sum()           # ps[2] takes no part
+
+    opt.zero_grad()
+    loss().backward(); loss().backward()
+    want = opt.flat_g.clone()
+    opt.flat_g.fill_(7.0)                                                    # stale values must not survive
+    opt.release_grads()
+    assert all(p.grad is None for p in ps)
+    loss().backward(); loss().backward()
+    assert ps[2].grad is None
+    opt.collect_grads()
+    assert all(p.grad is v for p, v in zip(ps, views))
+    o2, n2 = opt._offsets[id(ps[2])][0], ps[2].numel()
+    assert torch.equal(opt.flat_g[o2:o2 + n2], torch.zeros(n2))
+    for p in ps[:2]:
+        o, n = opt._offsets[id(p)][0], p.numel()
+        assert torch.equal(opt.flat_g[o:o + n], want[o:o + n])

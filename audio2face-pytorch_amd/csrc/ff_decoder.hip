@@ -310,6 +310,7 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) __attribute__((amdgpu_waves_per_
           if constexpr (DROP) kw[u] = abits[jj >> 5];
         }
         __builtin_amdgcn_sched_barrier(0);        // every load of the trip is issued HERE: the machine scheduler otherwise sinks the V loads below the scores (a second exposed round trip per trip)
+        // (requesting the NEXT trip before evaluating this one - two register sets - spilled 59 / 93 registers as written; not kept)
         // scores of the trip first, ONE rescale of the running sums per trip (trip maximum), one exponential per key; the periodic bias
         // floor((i - j) / period) through a float reciprocal ((d + 0.5) / period is never within 0.5 / period of an integer: exact for T < 2^21)
         float pu[FA_U];
@@ -373,22 +374,22 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) __attribute__((amdgpu_waves_per_
     }
     __syncthreads();
     FF_STAMP(3);
-    if (wave < FH && js == 0) {                                  // merge the two partial softmaxes of head = wave (a wave that saw no key has m = -inf, l = 0)
-      const float m0 = mrg_s[wave * 2], l0 = mrg_s[wave * 2 + 1], m1 = mrg_s[(FH + wave) * 2], l1 = mrg_s[(FH + wave) * 2 + 1];
-      const float mm = fmaxf(m0, m1);
-      const float w0 = m0 == -INFINITY ? 0.f : expf(m0 - mm), w1 = m1 == -INFINITY ? 0.f : expf(m1 - mm);
-      const float lt = l0 * w0 + l1 * w1;
-      const float4 c0 = *reinterpret_cast<const float4*>(mrg_c + wave * FHD + dq * 4);
-      const float4 c1 = *reinterpret_cast<const float4*>(mrg_c + FD + wave * FHD + dq * 4);
-      const float inv = 1.f / lt;
-      const float4 c4 = make_float4((c0.x * w0 + c1.x * w1) * inv, (c0.y * w0 + c1.y * w1) * inv, (c0.z * w0 + c1.z * w1) * inv, (c0.w * w0 + c1.w * w1) * inv);
-      *reinterpret_cast<float4*>(cs + wave * FHD + dq * 4) = c4;
-      *reinterpret_cast<float4*>(sv + SV_CTX + wave * FHD + dq * 4) = c4;
-      if (lane == 0) { sv[SV_ST + 4 + wave] = mm; sv[SV_ST + 8 + wave] = lt; }
-    }
-    __syncthreads();
-    FF_STAMP(4);
     if (wave == 0) {
+      // merge the two partial softmaxes of every head (a wave that saw no key has m = -inf, l = 0): lane = context component, head = lane >> 4 - in the
+      // wave that consumes the context, so the merge needs no phase and no barrier of its own (same wave: its LDS accesses complete in order)
+      {
+        const int hh = lane >> 4;
+        const float m0 = mrg_s[hh * 2], l0 = mrg_s[hh * 2 + 1], m1 = mrg_s[(FH + hh) * 2], l1 = mrg_s[(FH + hh) * 2 + 1];
+        const float mm = fmaxf(m0, m1);
+        const float w0 = m0 == -INFINITY ? 0.f : expf(m0 - mm), w1 = m1 == -INFINITY ? 0.f : expf(m1 - mm);
+        const float lt = l0 * w0 + l1 * w1;
+        const float inv = 1.f / lt;
+        const float c = (mrg_c[lane] * w0 + mrg_c[FD + lane] * w1) * inv;
+        cs[lane] = c;
+        sv[SV_CTX + lane] = c;
+        if ((lane & 15) == 0) { sv[SV_ST + 4 + hh] = mm; sv[SV_ST + 8 + hh] = lt; }
+      }
+      FF_STAMP(4);
       float sa = ff_matvec64(WoT, FD, lane, cs, bo);
       if constexpr (DROP) sa = ((kw_d1 >> (lane & 31)) & 1u) ? sa * dm.scale : 0.f;     // dropout1
       float rstd;

@@ -371,13 +371,13 @@ class A2MTrunkMMFn(torch.autograd.Function):
             sv["bn_x"][i], sv["bn_b"][i], sv["stats"][i], sv["bn_g"][i] = xin, bp, (mu, istd), gp
             return y
 
-        # analysis layer 0 (one input channel, K = 3): the exact-fp32 generic GEMM (three multiply-adds per output)
+        # analysis layer 0 (one input channel, K = 3): three exact-fp32 multiply-adds per output, a streaming kernel of its own (with Ci = 1 the packed
+        # weight (Co, KH * Ci) IS the parameter's memory)
         w0, b0 = convs[0]
-        wg0 = new(72, 3)
-        be.conv_weight_pack(w0, wg0, 72, 1, 3, 0)
+        wg0 = w0.view(72, 3)
         R = B * H0 * 16
         z = new(R, 72)
-        ops.conv_fwd(be, a0, wg0, b0, z, R, 16, 1, 72, relu=False)
+        be.conv_k3s2_c1_fwd(a0, wg0, b0, R, 16, 72, z)
         sv["wg"][0], sv["conv_in"][0] = wg0, a0
         act = bn(0, z, R, 72, 72, True)
         Wd = 16

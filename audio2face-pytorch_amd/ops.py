@@ -390,6 +390,11 @@ class HipBackend:
         _lib.check(self.lib.a2f_a2m_pack(_ptr(x), _ptr(one_hot), B, n_onehot, _ptr(a0), _ptr(cat), cat_ld, cat_off,
                                          self._stream(x)), "a2f_a2m_pack")
 
+    def conv_k3s2_c1_fwd(self, x, wg, bias, R, P_out, Co, z):
+        """One-input-channel k = 3 / stride 2 / pad 1 convolution (Audio2Mesh analysis layer 0): z (R, Co) = windows of x . wg (Co, 3) + bias."""
+        _chk(x, wg, bias, z)
+        _lib.check(self.lib.a2f_conv_k3s2_c1_fwd(_ptr(x), _ptr(wg), _ptr(bias), R, P_out, Co, _ptr(z), self._stream(x)), "a2f_conv_k3s2_c1_fwd")
+
     def conv_weight_pack(self, src, dst, Co, Ci, KH, direction):
         _chk(src, dst)
         _lib.check(self.lib.a2f_conv_weight_pack(_ptr(src), _ptr(dst), Co, Ci, KH, direction, self._stream(src)), "a2f_conv_weight_pack")

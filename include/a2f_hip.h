@@ -189,6 +189,12 @@ int a2f_voca_trunk_bwd_data(const float* dh3, const float* z2, const float* cat7
 /* Conv weight re-layout  w (Co,Ci,KH) <-> wg (Co, KH*Ci) [k = kh*Ci+ci]; dir 0: w->wg, 1: wg->w(+=0 overwrite) */
 int a2f_conv_weight_pack(const float* src, float* dst, int64_t Co, int64_t Ci, int64_t KH, int32_t dir, a2f_stream_t stream);
 
+/* Audio2Mesh analysis layer 0 (audio2face.py:13-17: Conv2d(1, 72, (1,3), stride (1,2), padding (0,1)) over the 32 spectral bins of every
+ * row of the (B, 52 + n_onehot, 32) input): x = R / P_out groups of 2 P_out values each, wg (Co, 3) = the weight with k = kh, bias (Co),
+ * z (R, Co) channels-last: z[r][co] = bias[co] + sum_kh x[2r - 1 + kh] wg[co][kh], x[2r - 1] = 0 at the first position of a group.
+ * Exact fp32 multiply-adds; a streaming kernel (one float4 of outputs per thread).  Co a multiple of 4, z / bias 16-byte aligned. */
+int a2f_conv_k3s2_c1_fwd(const float* x, const float* wg, const float* bias, int64_t R, int64_t P_out, int64_t Co, float* z, a2f_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm2d over channels-last rows (audio2face.py:15-46), training-mode batch statistics:
  *   x (R, C) rows = (b,h,w) positions.  stats: mean[c], invstd[c] (biased var, eps); running buffers

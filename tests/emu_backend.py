@@ -422,6 +422,12 @@ class EmuBackend:
         a0v[:, 52:] = one_hot.reshape(B, n_onehot)[:, (32 * r + c) % n_onehot]
         cat.reshape(B, cat_ld)[:, cat_off:cat_off + n_onehot] = one_hot.reshape(B, n_onehot)
 
+    def conv_k3s2_c1_fwd(self, x, wg, bias, R, P_out, Co, z):
+        xf = x.reshape(-1)[: 2 * R].double().view(R // P_out, 2 * P_out)
+        xp = torch.nn.functional.pad(xf, (1, 0))                                   # left zero padding of every group
+        win = torch.stack([xp[:, 0:2 * P_out:2], xp[:, 1:2 * P_out + 1:2], xp[:, 2:2 * P_out + 2:2]], -1)   # (groups, P_out, 3): x[2p-1], x[2p], x[2p+1]
+        z.copy_((win.reshape(R, 3) @ wg.double().view(Co, 3).t() + bias.double().view(1, Co)).to(z.dtype).view_as(z))
+
     def conv_weight_pack(self, src, dst, Co, Ci, KH, direction):
         if direction == 0:
             dst.reshape(Co, KH, Ci).copy_(src.reshape(Co, Ci, KH).permute(0, 2, 1))

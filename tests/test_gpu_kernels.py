@@ -642,3 +642,16 @@ def test_head_fused_at_bench_size_properties():
     l3 = torch.empty(3, device=DEV)
     hip.vocaloss_fwd(p_f, gt, B, n, 1.0, 10.0, l3)
     assert torch.allclose(l3, o_f, rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("groups,P_out,Co", [(3, 16, 72), (1, 1, 4), (130, 16, 72), (7, 5, 8)])
+def test_conv_k3s2_c1_fwd_vs_contract(groups, P_out, Co):
+    """The one-input-channel k = 3 / stride 2 / pad 1 convolution (Audio2Mesh analysis layer 0) against the float64 emulation: left padding at the
+    first position of every group, exact-fp32 class."""
+    hip, emu = ops.HipBackend(), EmuBackend()
+    R = groups * P_out
+    x, wg, bias = rnd(groups, 2 * P_out, seed=70), rnd(Co, 3, seed=71), rnd(Co, seed=72)
+    z_h, z_e = torch.full((R, Co), float("nan"), device=DEV), torch.empty(R, Co)
+    hip.conv_k3s2_c1_fwd(x.to(DEV), wg.to(DEV), bias.to(DEV), R, P_out, Co, z_h)
+    emu.conv_k3s2_c1_fwd(x, wg, bias, R, P_out, Co, z_e)
+    assert rel_l2(z_h.cpu(), z_e) < 1e-6

@@ -88,12 +88,15 @@ SIGNATURES = {
     "a2f_voca_trunk_bwd_data": (C.c_int, [c_f32p] * 12 + [i64] + [c_f32p] * 6 + [C.c_void_p]),
     "a2f_a2m_pack": (C.c_int, [c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, i64, i64, C.c_void_p]),
     "a2f_conv_weight_pack": (C.c_int, [c_f32p, c_f32p, i64, i64, i64, i32, C.c_void_p]),
-    "a2f_conv_k3s2_c1_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, i64, i64, i64, c_f32p, C.c_void_p]),
     "a2f_bn_ws_bytes": (sz, [i64, i64]),
     "a2f_bn_fwd": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, c_f32p, f32, f32, i32, i32,
                              c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
     "a2f_bn_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, i32, i32,
                              c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
+    "a2f_bn_fwd_conv0": (C.c_int, [c_f32p, c_f32p, c_f32p, i64, i64, i64, c_f32p, c_f32p, c_f32p, c_f32p, f32, f32, i32, i32,
+                                   c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
+    "a2f_bn_bwd_conv0": (C.c_int, [c_f32p, c_f32p, c_f32p, i64, c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, i32, i32,
+                                   c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
     "a2f_ff_save_bytes": (sz, [i64, i64]),
     "a2f_ff_decoder_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, i32, c_f32p, C.c_void_p, sz, C.c_void_p]),
     "a2f_ff_decoder_bwd": (C.c_int, [c_f32p, c_f32p, i64, i64, i32, C.c_void_p, sz, c_f32p, c_f32p, c_f32p, C.c_void_p]),

@@ -31,6 +31,24 @@ __device__ __forceinline__ float bn_affine(float x, float sc, float sh) { return
 __device__ __forceinline__ float bn_scale(float invstd, float gamma) { return invstd * gamma; }
 __device__ __forceinline__ float bn_shift(float beta, float mean, float sc) { return fmaf(-mean, sc, beta); }
 
+// Where x comes from.  Memory (a0 == nullptr), or RECOMPUTED (round 3, Audio2Mesh analysis layer 0, audio2face.py:13-17): x(r, c) = cbias[c] + sum_kh a0[2r - 1 + kh]
+// wg[c][kh] (a0[2r - 1] = 0 at the first position of every group of P_out rows: the left padding) is the one-input-channel k = 3 / stride 2 / pad 1 convolution - three multiply-adds from an input 72x smaller than the (R, C)
+// tensor, so neither the forward's two passes nor the backward's two ever read (or write) the convolution's 302-MB output at B = 1024.  Every pass evaluates the
+// same expression (conv0_eval4), so the ReLU masks and x-hat of the backward are the forward's bit for bit.
+struct BnSrc {
+  const float* x;
+  const float* a0;
+  const float* wg;       // (C, 3)
+  const float* cbias;    // (C)
+  int P_out;
+};
+__device__ __forceinline__ float4 conv0_eval4(const float* __restrict__ a0, int64_t r, int P_out, const float* w12, const float4 b) {
+  const float x1 = a0[2 * r], x2 = a0[2 * r + 1];
+  const float x0 = (r % P_out) ? a0[2 * r - 1] : 0.f;
+  return make_float4(((b.x + x0 * w12[0]) + x1 * w12[1]) + x2 * w12[2], ((b.y + x0 * w12[3]) + x1 * w12[4]) + x2 * w12[5],
+                     ((b.z + x0 * w12[6]) + x1 * w12[7]) + x2 * w12[8], ((b.w + x0 * w12[9]) + x1 * w12[10]) + x2 * w12[11]);
+}
+
 // part[blk][0][c] = sum_r u(r,c) ; part[blk][1][c] = sum_r u(r,c)*w(r,c)
 //   MODE 0 (fwd stats): u = x, w = x
 //   MODE 1 (bwd):       u = dy' , w = xhat   (dy' = relu ? dy*(bn_affine(x) > 0) : dy; `y` = beta in this mode)
@@ -114,8 +132,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float* __r
 // The same partials for C % 4 == 0 (every Audio2Mesh layer: 72, 108, 164, 244, 256) with 16-byte loads: lane -> (row offset t / (C/4), channel
 // quad t % (C/4)), four rows per trip = up to twelve float4 loads in flight per lane (the scalar form above reaches 3.1-3.5 TB/s, this one the
 // stream rate).  Same [block][2][C] double layout; the accumulation order differs from the scalar form but is fixed.
-template <int MODE>
-__global__ __launch_bounds__(BN_THREADS) void bn_partial4_kernel(const float* __restrict__ x, const float* __restrict__ y,
+template <int MODE, bool CONV0 = false>
+__global__ __launch_bounds__(BN_THREADS) void bn_partial4_kernel(const BnSrc src, const float* __restrict__ y,
                                                                   const float* __restrict__ dy, int64_t R, int C,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                   const float* __restrict__ gamma, int relu, double* __restrict__ part) {
@@ -126,6 +144,20 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial4_kernel(const float* __
   const int64_t r0 = blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
   double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+  const float* __restrict__ x = src.x;
+  float w12[12];
+  float4 cb4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (CONV0) {
+    if (ro < rpp) {
+#pragma unroll
+      for (int e = 0; e < 12; ++e) w12[e] = src.wg[12 * q + e];
+      cb4 = *reinterpret_cast<const float4*>(src.cbias + 4 * q);
+    }
+  }
+  auto load_x = [&](int64_t row) {
+    if constexpr (CONV0) return conv0_eval4(src.a0, row, src.P_out, w12, cb4);
+    else return *reinterpret_cast<const float4*>(x + row * C + 4 * q);
+  };
   if (ro < rpp) {
     float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu, sc = mu, sh = make_float4(1.f, 1.f, 1.f, 1.f);
     if (MODE == 1) {
@@ -155,17 +187,16 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial4_kernel(const float* __
       float4 xv[4], gv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int64_t i = (r + (int64_t)u * rpp) * C + 4 * q;
-        xv[u] = *reinterpret_cast<const float4*>(x + i);
-        gv[u] = MODE == 1 ? *reinterpret_cast<const float4*>(dy + i) : one;
+        const int64_t row = r + (int64_t)u * rpp;
+        xv[u] = load_x(row);
+        gv[u] = MODE == 1 ? *reinterpret_cast<const float4*>(dy + row * C + 4 * q) : one;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc(xv[u], gv[u]);
     }
     for (; r < r1; r += rpp) {
-      const int64_t i = r * C + 4 * q;
-      const float4 xv = *reinterpret_cast<const float4*>(x + i);
-      const float4 gv = MODE == 1 ? *reinterpret_cast<const float4*>(dy + i) : one;
+      const float4 xv = load_x(r);
+      const float4 gv = MODE == 1 ? *reinterpret_cast<const float4*>(dy + r * C + 4 * q) : one;
       acc(xv, gv);
     }
   }
@@ -247,24 +278,44 @@ __global__ __launch_bounds__(256) void bn_finish_bwd_kernel(const double* __rest
   dgamma[c] = (float)q;
 }
 
+// (row, channel) of flat element i: 32-bit arithmetic whenever the tensor allows it (block-uniform) - the 64-bit modulo by a run-time C is ~50 instructions, half
+// of what a thread of a kernel that streams at the HBM rate can afford
+__device__ __forceinline__ void bn_row_col(int64_t i, int64_t total, int C, int64_t& row, int& c) {
+  if (total < (1ll << 31)) {
+    const unsigned r = (unsigned)i / (unsigned)C;
+    row = r;
+    c = (int)((unsigned)i - r * (unsigned)C);
+  } else {
+    row = i / C;
+    c = (int)(i - row * C);
+  }
+}
+
 // y = (x - mean) * invstd * gamma + beta  [relu]        VEC: one float4 per thread (C % 4 == 0, 16-byte aligned), else one element
-template <bool VEC>
-__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float* __restrict__ x, int64_t total, int C,
+template <bool VEC, bool CONV0 = false>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const BnSrc src, int64_t total, int C,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                int relu, float* __restrict__ y) {
   __shared__ __attribute__((aligned(16))) float sc[BN_MAX_C], sh[BN_MAX_C];
+  __shared__ __attribute__((aligned(16))) float cw[CONV0 ? 4 * BN_MAX_C : 4];      // CONV0: wg (C, 3) then cbias (C)
+  const float* __restrict__ x = src.x;
   for (int c = threadIdx.x; c < C; c += BN_THREADS) {
     const float s = bn_scale(invstd[c], gamma[c]);
     sc[c] = s;
     sh[c] = bn_shift(beta[c], mean[c], s);
+    if constexpr (CONV0) { cw[3 * c] = src.wg[3 * c]; cw[3 * c + 1] = src.wg[3 * c + 1]; cw[3 * c + 2] = src.wg[3 * c + 2]; cw[3 * BN_MAX_C + c] = src.cbias[c]; }
   }
   __syncthreads();
   const int64_t i = (blockIdx.x * (int64_t)BN_THREADS + threadIdx.x) * (VEC ? 4 : 1);
   if (i >= total) return;
-  const int c = (int)(i % C);
+  int64_t row;
+  int c;
+  bn_row_col(i, total, C, row, c);
   if constexpr (VEC) {
-    const float4 xv = *reinterpret_cast<const float4*>(x + i);
+    float4 xv;
+    if constexpr (CONV0) xv = conv0_eval4(src.a0, row, src.P_out, cw + 3 * c, *reinterpret_cast<const float4*>(cw + 3 * BN_MAX_C + c));
+    else xv = *reinterpret_cast<const float4*>(x + i);
     const float4 s4 = *reinterpret_cast<const float4*>(sc + c), h4 = *reinterpret_cast<const float4*>(sh + c);
     float4 v = make_float4(bn_affine(xv.x, s4.x, h4.x), bn_affine(xv.y, s4.y, h4.y), bn_affine(xv.z, s4.z, h4.z), bn_affine(xv.w, s4.w, h4.w));
     if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
@@ -277,15 +328,18 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float* __res
 }
 
 // training: dx = gamma*invstd/R * (R*dy' - dbeta - xhat*dgamma) ; eval: dx = dy'*gamma*invstd        (dy' = dy where the forward output was > 0)
-template <bool VEC>
-__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ beta,
+template <bool VEC, bool CONV0 = false>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnSrc src, const float* __restrict__ beta,
                                                                    const float* __restrict__ dy, int64_t total, int C, float invR,
                                                                    const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                    const float* __restrict__ invstd, const float* __restrict__ dgamma,
                                                                    const float* __restrict__ dbeta, int training, int relu,
                                                                    float* __restrict__ dx) {
   __shared__ __attribute__((aligned(16))) float s_gi[BN_MAX_C], s_mu[BN_MAX_C], s_is[BN_MAX_C], s_db[BN_MAX_C], s_dg[BN_MAX_C], s_sh[BN_MAX_C];
+  __shared__ __attribute__((aligned(16))) float cw[CONV0 ? 4 * BN_MAX_C : 4];      // CONV0: wg (C, 3) then cbias (C)
+  const float* __restrict__ x = src.x;
   for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+    if constexpr (CONV0) { cw[3 * c] = src.wg[3 * c]; cw[3 * c + 1] = src.wg[3 * c + 1]; cw[3 * c + 2] = src.wg[3 * c + 2]; cw[3 * BN_MAX_C + c] = src.cbias[c]; }
     const float gi = bn_scale(invstd[c], gamma[c]);           // the forward's scale, bit for bit
     s_gi[c] = gi;
     s_mu[c] = mean[c];
@@ -297,14 +351,19 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float* _
   __syncthreads();
   const int64_t i = (blockIdx.x * (int64_t)BN_THREADS + threadIdx.x) * (VEC ? 4 : 1);
   if (i >= total) return;
-  const int c = (int)(i % C);
+  int64_t row;
+  int c;
+  bn_row_col(i, total, C, row, c);
   auto one = [&](float xv, float g, int cc) {
     if (!(bn_affine(xv, relu ? s_gi[cc] : 0.f, s_sh[cc]) > 0.f)) g = 0.f;
     const float xhat = (xv - s_mu[cc]) * s_is[cc];
     return s_gi[cc] * (g - s_db[cc] - xhat * s_dg[cc]);
   };
   if constexpr (VEC) {
-    const float4 xv = *reinterpret_cast<const float4*>(x + i), gv = *reinterpret_cast<const float4*>(dy + i);
+    float4 xv;
+    if constexpr (CONV0) xv = conv0_eval4(src.a0, row, src.P_out, cw + 3 * c, *reinterpret_cast<const float4*>(cw + 3 * BN_MAX_C + c));
+    else xv = *reinterpret_cast<const float4*>(x + i);
+    const float4 gv = *reinterpret_cast<const float4*>(dy + i);
     *reinterpret_cast<float4*>(dx + i) = make_float4(one(xv.x, gv.x, c), one(xv.y, gv.y, c + 1), one(xv.z, gv.z, c + 2), one(xv.w, gv.w, c + 3));
   } else {
     dx[i] = one(x[i], dy[i], c);
@@ -318,11 +377,13 @@ extern "C" size_t a2f_bn_ws_bytes(int64_t R, int64_t C) {
   return (size_t)a2f::bn_blocks(R, (int)C) * 2 * (size_t)C * sizeof(double);
 }
 
-extern "C" int a2f_bn_fwd(const float* x, int64_t R, int64_t C, const float* gamma, const float* beta, float* running_mean,
-                          float* running_var, float momentum, float eps, int32_t training, int32_t relu, float* y,
-                          float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, a2f_stream_t stream) {
+// conv0: x is recomputed from (a0, wg, cbias, P_out) - a2f_bn_fwd_conv0 / a2f_bn_bwd_conv0 (C % 4 == 0 required there)
+static int bn_fwd_impl(const a2f::BnSrc src, bool conv0, int64_t R, int64_t C, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, float momentum, float eps, int32_t training, int32_t relu, float* y, float* save_mean, float* save_invstd,
+                       void* ws, size_t ws_bytes, a2f_stream_t stream) {
   using namespace a2f;
-  A2F_CHECK_ARG(x && gamma && beta && running_mean && running_var && y && save_mean && save_invstd, "bn_fwd: null pointer");
+  const float* x = src.x;
+  A2F_CHECK_ARG((x || conv0) && gamma && beta && running_mean && running_var && y && save_mean && save_invstd, "bn_fwd: null pointer");
   A2F_CHECK_ARG(R > 0 && C > 0 && C <= BN_MAX_C, "bn_fwd: R=%lld C=%lld (C <= %d)", (long long)R, (long long)C, BN_MAX_C);
   hipStream_t s = (hipStream_t)stream;
   const int cb = (int)cdiv(C, 256);
@@ -330,8 +391,11 @@ extern "C" int a2f_bn_fwd(const float* x, int64_t R, int64_t C, const float* gam
     A2F_CHECK_ARG(ws != nullptr, "bn_fwd: null workspace");
     if (ws_bytes < a2f_bn_ws_bytes(R, C)) return set_err(A2F_EWORKSPACE, "bn_fwd: workspace %zu < %zu", ws_bytes, a2f_bn_ws_bytes(R, C));
     const int nblk = bn_blocks(R, (int)C);
-    if (bn_vec4_ok(x, nullptr, nullptr, C))
-      hipLaunchKernelGGL(bn_partial4_kernel<0>, dim3(nblk), dim3(BN_THREADS), 0, s, x, (const float*)nullptr, (const float*)nullptr, R,
+    if (conv0)
+      hipLaunchKernelGGL((bn_partial4_kernel<0, true>), dim3(nblk), dim3(BN_THREADS), 0, s, src, (const float*)nullptr, (const float*)nullptr, R,
+                         (int)C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
+    else if (bn_vec4_ok(x, nullptr, nullptr, C))
+      hipLaunchKernelGGL((bn_partial4_kernel<0, false>), dim3(nblk), dim3(BN_THREADS), 0, s, src, (const float*)nullptr, (const float*)nullptr, R,
                          (int)C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
     else
       hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblk), dim3(BN_THREADS), 0, s, x, (const float*)nullptr, (const float*)nullptr, R,
@@ -343,27 +407,36 @@ extern "C" int a2f_bn_fwd(const float* x, int64_t R, int64_t C, const float* gam
   }
   const int64_t total = R * C;
   A2F_CHECK_ARG(total / BN_THREADS < 0x7FFFFFFFll, "bn_fwd: R * C too large for one element per thread");
-  if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
-    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3((unsigned)cdiv(total / 4, BN_THREADS)), dim3(BN_THREADS), 0, s, x, total, (int)C, gamma, beta, save_mean,
+  if (conv0)
+    hipLaunchKernelGGL((bn_apply_kernel<true, true>), dim3((unsigned)cdiv(total / 4, BN_THREADS)), dim3(BN_THREADS), 0, s, src, total, (int)C, gamma, beta, save_mean,
+                       save_invstd, (int)relu, y);
+  else if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
+    hipLaunchKernelGGL((bn_apply_kernel<true, false>), dim3((unsigned)cdiv(total / 4, BN_THREADS)), dim3(BN_THREADS), 0, s, src, total, (int)C, gamma, beta, save_mean,
                        save_invstd, (int)relu, y);
   else
-    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3((unsigned)cdiv(total, BN_THREADS)), dim3(BN_THREADS), 0, s, x, total, (int)C, gamma, beta, save_mean,
+    hipLaunchKernelGGL((bn_apply_kernel<false, false>), dim3((unsigned)cdiv(total, BN_THREADS)), dim3(BN_THREADS), 0, s, src, total, (int)C, gamma, beta, save_mean,
                        save_invstd, (int)relu, y);
   A2F_CHECK_LAUNCH("bn_fwd");
   return A2F_OK;
 }
 
-extern "C" int a2f_bn_bwd(const float* x, const float* beta, const float* dy, int64_t R, int64_t C, const float* gamma,
-                          const float* save_mean, const float* save_invstd, int32_t training, int32_t relu, float* dx,
-                          float* dgamma, float* dbeta, void* ws, size_t ws_bytes, a2f_stream_t stream) {
+static int bn_bwd_impl(const a2f::BnSrc src, bool conv0, const float* beta, const float* dy, int64_t R, int64_t C, const float* gamma,
+                       const float* save_mean, const float* save_invstd, int32_t training, int32_t relu, float* dx, float* dgamma, float* dbeta, void* ws,
+                       size_t ws_bytes, a2f_stream_t stream) {
   using namespace a2f;
-  A2F_CHECK_ARG(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws && (beta || !relu), "bn_bwd: null pointer (beta is needed with relu)");
+  const float* x = src.x;
+  A2F_CHECK_ARG((x || conv0) && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws && (beta || !relu), "bn_bwd: null pointer (beta is needed with relu)");
   A2F_CHECK_ARG(R > 0 && C > 0 && C <= BN_MAX_C, "bn_bwd: R=%lld C=%lld (C <= %d)", (long long)R, (long long)C, BN_MAX_C);
   if (ws_bytes < a2f_bn_ws_bytes(R, C)) return set_err(A2F_EWORKSPACE, "bn_bwd: workspace %zu < %zu", ws_bytes, a2f_bn_ws_bytes(R, C));
   hipStream_t s = (hipStream_t)stream;
   const int nblk = bn_blocks(R, (int)C);
-  if (bn_vec4_ok(x, nullptr, dy, C) && (((uintptr_t)save_mean | (uintptr_t)save_invstd | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0)
-    hipLaunchKernelGGL(bn_partial4_kernel<1>, dim3(nblk), dim3(BN_THREADS), 0, s, x, beta, dy, R, (int)C, save_mean, save_invstd, gamma, (int)relu,
+  const bool vec_stats = (((uintptr_t)save_mean | (uintptr_t)save_invstd | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
+  if (conv0) {
+    A2F_CHECK_ARG(vec_stats && bn_vec4_ok(dy, nullptr, dx, C), "bn_bwd_conv0: dy, dx, gamma, beta and the saved statistics must be 16-byte aligned");
+    hipLaunchKernelGGL((bn_partial4_kernel<1, true>), dim3(nblk), dim3(BN_THREADS), 0, s, src, beta, dy, R, (int)C, save_mean, save_invstd, gamma, (int)relu,
+                       (double*)ws);
+  } else if (bn_vec4_ok(x, nullptr, dy, C) && vec_stats)
+    hipLaunchKernelGGL((bn_partial4_kernel<1, false>), dim3(nblk), dim3(BN_THREADS), 0, s, src, beta, dy, R, (int)C, save_mean, save_invstd, gamma, (int)relu,
                        (double*)ws);
   else
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(BN_THREADS), 0, s, x, beta, dy, R, (int)C, save_mean, save_invstd, gamma, (int)relu,
@@ -371,12 +444,54 @@ extern "C" int a2f_bn_bwd(const float* x, const float* beta, const float* dy, in
   hipLaunchKernelGGL(bn_finish_bwd_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, s, (const double*)ws, nblk, (int)C, dgamma, dbeta);
   const int64_t total = R * C;
   A2F_CHECK_ARG(total / BN_THREADS < 0x7FFFFFFFll, "bn_bwd: R * C too large for one element per thread");
-  if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)cdiv(total / 4, BN_THREADS)), dim3(BN_THREADS), 0, s, x, beta, dy, total, (int)C, 1.0f / (float)R,
+  if (conv0)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), dim3((unsigned)cdiv(total / 4, BN_THREADS)), dim3(BN_THREADS), 0, s, src, beta, dy, total, (int)C, 1.0f / (float)R,
+                       gamma, save_mean, save_invstd, dgamma, dbeta, (int)training, (int)relu, dx);
+  else if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), dim3((unsigned)cdiv(total / 4, BN_THREADS)), dim3(BN_THREADS), 0, s, src, beta, dy, total, (int)C, 1.0f / (float)R,
                        gamma, save_mean, save_invstd, dgamma, dbeta, (int)training, (int)relu, dx);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3((unsigned)cdiv(total, BN_THREADS)), dim3(BN_THREADS), 0, s, x, beta, dy, total, (int)C, 1.0f / (float)R,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), dim3((unsigned)cdiv(total, BN_THREADS)), dim3(BN_THREADS), 0, s, src, beta, dy, total, (int)C, 1.0f / (float)R,
                        gamma, save_mean, save_invstd, dgamma, dbeta, (int)training, (int)relu, dx);
   A2F_CHECK_LAUNCH("bn_bwd");
   return A2F_OK;
+}
+
+extern "C" int a2f_bn_fwd(const float* x, int64_t R, int64_t C, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, float momentum, float eps, int32_t training, int32_t relu, float* y,
+                          float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, a2f_stream_t stream) {
+  return bn_fwd_impl(a2f::BnSrc{x, nullptr, nullptr, nullptr, 1}, false, R, C, gamma, beta, running_mean, running_var, momentum, eps, training, relu, y, save_mean,
+                     save_invstd, ws, ws_bytes, stream);
+}
+
+extern "C" int a2f_bn_bwd(const float* x, const float* beta, const float* dy, int64_t R, int64_t C, const float* gamma,
+                          const float* save_mean, const float* save_invstd, int32_t training, int32_t relu, float* dx,
+                          float* dgamma, float* dbeta, void* ws, size_t ws_bytes, a2f_stream_t stream) {
+  return bn_bwd_impl(a2f::BnSrc{x, nullptr, nullptr, nullptr, 1}, false, beta, dy, R, C, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta, ws, ws_bytes,
+                     stream);
+}
+
+static int bn_conv0_check(const float* a0, const float* wg, const float* cbias, int64_t P_out, int64_t R, int64_t C, const float* gamma, const float* beta,
+                          const float* y_or_dy, const char* who) {
+  A2F_CHECK_ARG(a0 && wg && cbias, "%s: null convolution operand", who);
+  A2F_CHECK_ARG(P_out > 0 && R % P_out == 0 && C % 4 == 0 && C <= a2f::BN_THREADS, "%s: R=%lld must be a multiple of P_out=%lld, C=%lld a multiple of 4 (<= %d)", who,
+                (long long)R, (long long)P_out, (long long)C, a2f::BN_THREADS);
+  A2F_CHECK_ARG((((uintptr_t)cbias | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y_or_dy) & 15) == 0, "%s: cbias, gamma, beta and the (R, C) tensors must be 16-byte aligned", who);
+  return A2F_OK;
+}
+
+extern "C" int a2f_bn_fwd_conv0(const float* a0, const float* wg, const float* cbias, int64_t P_out, int64_t R, int64_t C, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, int32_t training, int32_t relu, float* y,
+                                float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, a2f_stream_t stream) {
+  if (int rc = bn_conv0_check(a0, wg, cbias, P_out, R, C, gamma, beta, y, "bn_fwd_conv0")) return rc;
+  return bn_fwd_impl(a2f::BnSrc{nullptr, a0, wg, cbias, (int)P_out}, true, R, C, gamma, beta, running_mean, running_var, momentum, eps, training, relu, y, save_mean,
+                     save_invstd, ws, ws_bytes, stream);
+}
+
+extern "C" int a2f_bn_bwd_conv0(const float* a0, const float* wg, const float* cbias, int64_t P_out, const float* beta, const float* dy, int64_t R, int64_t C,
+                                const float* gamma, const float* save_mean, const float* save_invstd, int32_t training, int32_t relu, float* dx,
+                                float* dgamma, float* dbeta, void* ws, size_t ws_bytes, a2f_stream_t stream) {
+  if (int rc = bn_conv0_check(a0, wg, cbias, P_out, R, C, gamma, beta, dy, "bn_bwd_conv0")) return rc;
+  return bn_bwd_impl(a2f::BnSrc{nullptr, a0, wg, cbias, (int)P_out}, true, beta, dy, R, C, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta, ws, ws_bytes,
+                     stream);
 }

@@ -55,43 +55,7 @@ __global__ void conv_weight_pack_kernel(const float* __restrict__ src, float* __
   }
 }
 
-// One-input-channel k = 3 / stride 2 / pad 1 convolution over channels-last rows (Audio2Mesh analysis layer 0, audio2face.py:13-17): an output row is three
-// multiply-adds per channel, so the layer is a pure streaming write (302 MB at B = 1024) - as an implicit GEMM with K = 3 on the generic kernel it took 185 us,
-// three times its HBM time.  One float4 of outputs per thread (Co / 4 threads per row, consecutive threads = consecutive 16 bytes): z[r][co] = bias[co] +
-// sum_kh x[2r - 1 + kh] w[co][kh], x[2r - 1] reading as zero at the first position of every group of P_out rows (the left padding).
-__global__ __launch_bounds__(256) void conv_k3s2_c1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wg, const float* __restrict__ bias,
-                                                               int64_t total4, int P_out, int Co4, float4* __restrict__ z) {
-  const int64_t idx = blockIdx.x * 256ll + threadIdx.x;
-  if (idx >= total4) return;
-  const int64_t r = idx / Co4;
-  const int q = (int)(idx - r * Co4);
-  const float x1 = x[2 * r], x2 = x[2 * r + 1];
-  const float x0 = (r % P_out) ? x[2 * r - 1] : 0.f;
-  const float* w = wg + 12 * q;                    // rows 4q .. 4q+3 of (Co, 3)
-  const float4 b = *reinterpret_cast<const float4*>(bias + 4 * q);
-  float4 o;
-  o.x = ((b.x + x0 * w[0]) + x1 * w[1]) + x2 * w[2];
-  o.y = ((b.y + x0 * w[3]) + x1 * w[4]) + x2 * w[5];
-  o.z = ((b.z + x0 * w[6]) + x1 * w[7]) + x2 * w[8];
-  o.w = ((b.w + x0 * w[9]) + x1 * w[10]) + x2 * w[11];
-  z[idx] = o;
-}
-
 }  // namespace a2f
-
-extern "C" int a2f_conv_k3s2_c1_fwd(const float* x, const float* wg, const float* bias, int64_t R, int64_t P_out, int64_t Co, float* z, a2f_stream_t stream) {
-  using namespace a2f;
-  A2F_CHECK_ARG(x && wg && bias && z, "conv_k3s2_c1_fwd: null pointer");
-  A2F_CHECK_ARG(R > 0 && P_out > 0 && R % P_out == 0 && Co > 0 && Co % 4 == 0, "conv_k3s2_c1_fwd: R=%lld must be a multiple of P_out=%lld, Co=%lld of 4", (long long)R,
-                (long long)P_out, (long long)Co);
-  A2F_CHECK_ARG((((uintptr_t)z | (uintptr_t)bias) & 15) == 0, "conv_k3s2_c1_fwd: z and bias must be 16-byte aligned");
-  const int64_t total4 = R * (Co / 4);
-  A2F_CHECK_ARG(total4 <= 256ll * 0x7FFFFFFF, "conv_k3s2_c1_fwd: too many outputs for one launch");
-  hipLaunchKernelGGL(conv_k3s2_c1_fwd_kernel, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, wg, bias, total4, (int)P_out, (int)(Co / 4),
-                     reinterpret_cast<float4*>(z));
-  A2F_CHECK_LAUNCH("conv_k3s2_c1_fwd");
-  return A2F_OK;
-}
 
 extern "C" int a2f_voca_pack(const float* x, const float* one_hot, int64_t B, int64_t n_onehot, float* a0, float* cat72,
                              a2f_stream_t stream) {

@@ -371,15 +371,18 @@ class A2MTrunkMMFn(torch.autograd.Function):
             sv["bn_x"][i], sv["bn_b"][i], sv["stats"][i], sv["bn_g"][i] = xin, bp, (mu, istd), gp
             return y
 
-        # analysis layer 0 (one input channel, K = 3): three exact-fp32 multiply-adds per output, a streaming kernel of its own (with Ci = 1 the packed
-        # weight (Co, KH * Ci) IS the parameter's memory)
+        # analysis layer 0 (one input channel, K = 3) and its BatchNorm: the convolution is three exact-fp32 multiply-adds per output from an input 72x
+        # smaller than its output, so it is RECOMPUTED inside every BatchNorm pass instead of stored (a2f_bn_fwd_conv0 / a2f_bn_bwd_conv0; with Ci = 1 the
+        # packed weight (Co, KH * Ci) is the parameter's own memory).  Same box: 5.82 -> 5.73 ms per step against storing the layer's output with a streaming kernel
+        # of its own (which had replaced the K = 3 implicit GEMM: 6.00 -> 5.76).
         w0, b0 = convs[0]
         wg0 = w0.view(72, 3)
         R = B * H0 * 16
-        z = new(R, 72)
-        be.conv_k3s2_c1_fwd(a0, wg0, b0, R, 16, 72, z)
         sv["wg"][0], sv["conv_in"][0] = wg0, a0
-        act = bn(0, z, R, 72, 72, True)
+        g0, bt0 = bns[0]
+        act, mu0, istd0 = new(R, 72), new(72), new(72)
+        be.bn_fwd_conv0(a0, wg0, b0, 16, R, 72, g0, bt0, bufs[0], bufs[1], A2M_BN_MOMENTUM, A2M_BN_EPS, training, True, act, mu0, istd0)
+        sv["bn_x"][0], sv["bn_b"][0], sv["stats"][0], sv["bn_g"][0] = (a0, wg0, b0), bt0, (mu0, istd0), g0
         Wd = 16
         for l in range(1, 5):                                  # analysis layers 1..4: windows over W, sequences = (frame, row)
             ci, co, cip, cop = A2M_CH[l], A2M_CH[l + 1], A2M_CHP[l], A2M_CHP[l + 1]
@@ -503,7 +506,11 @@ class A2MTrunkMMFn(torch.autograd.Function):
             d = conv_bwd(l, draw, B * H0, 2 * Wd, Wd, ci, co, cip, cop, (co, ci, 1, 3))
             Wd *= 2
         # analysis layer 0 (Ci = 1): exact-fp32 generic kernels; no data gradient needed
-        draw = bn_bwd(0, d, B * H0 * Wd, 72, 72, True)
+        a0_, wg0_, cb0_ = sv["bn_x"][0]                      # layer 0: the convolution output is recomputed, not read
+        mu0, istd0 = sv["stats"][0]
+        draw, dg0, dbt0 = new(B * H0 * Wd, 72), new(72), new(72)
+        be.bn_bwd_conv0(a0_, wg0_, cb0_, Wd, sv["bn_b"][0], d, B * H0 * Wd, 72, sv["bn_g"][0], mu0, istd0, training, True, draw, dg0, dbt0)
+        g_bn[0], g_bn[1] = dg0, dbt0
         dwg0, dbias0 = new(72, 3), new(72)
         ops.conv_bwd_weight(be, sv["conv_in"][0], draw, dwg0, dbias0, B * H0 * Wd, Wd, 1, 72)
         dw0 = new(72, 1, 1, 3)

@@ -390,11 +390,6 @@ class HipBackend:
         _lib.check(self.lib.a2f_a2m_pack(_ptr(x), _ptr(one_hot), B, n_onehot, _ptr(a0), _ptr(cat), cat_ld, cat_off,
                                          self._stream(x)), "a2f_a2m_pack")
 
-    def conv_k3s2_c1_fwd(self, x, wg, bias, R, P_out, Co, z):
-        """One-input-channel k = 3 / stride 2 / pad 1 convolution (Audio2Mesh analysis layer 0): z (R, Co) = windows of x . wg (Co, 3) + bias."""
-        _chk(x, wg, bias, z)
-        _lib.check(self.lib.a2f_conv_k3s2_c1_fwd(_ptr(x), _ptr(wg), _ptr(bias), R, P_out, Co, _ptr(z), self._stream(x)), "a2f_conv_k3s2_c1_fwd")
-
     def conv_weight_pack(self, src, dst, Co, Ci, KH, direction):
         _chk(src, dst)
         _lib.check(self.lib.a2f_conv_weight_pack(_ptr(src), _ptr(dst), Co, Ci, KH, direction, self._stream(src)), "a2f_conv_weight_pack")
@@ -416,6 +411,23 @@ class HipBackend:
         _lib.check(self.lib.a2f_bn_bwd(_ptr(x), _ptr(beta), _ptr(dy), R, Cc, _ptr(gamma), _ptr(save_mean), _ptr(save_invstd),
                                        int(training), int(relu), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb,
                                        self._stream(x)), "a2f_bn_bwd")
+
+    def bn_fwd_conv0(self, a0, wg, cbias, P_out, R, Cc, gamma, beta, rmean, rvar, momentum, eps, training, relu, y, save_mean, save_invstd):
+        """bn_fwd with x = the one-input-channel k = 3 / stride 2 convolution of a0 recomputed in every pass (x is never stored)."""
+        _chk(a0, wg, cbias, gamma, beta, rmean, rvar, y, save_mean, save_invstd)
+        nb = self.lib.a2f_bn_ws_bytes(R, Cc)
+        ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=a0.device)
+        _lib.check(self.lib.a2f_bn_fwd_conv0(_ptr(a0), _ptr(wg), _ptr(cbias), P_out, R, Cc, _ptr(gamma), _ptr(beta), _ptr(rmean), _ptr(rvar), momentum, eps,
+                                             int(training), int(relu), _ptr(y), _ptr(save_mean), _ptr(save_invstd), _ptr(ws), nb,
+                                             self._stream(a0)), "a2f_bn_fwd_conv0")
+
+    def bn_bwd_conv0(self, a0, wg, cbias, P_out, beta, dy, R, Cc, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta):
+        _chk(a0, wg, cbias, beta, dy, gamma, save_mean, save_invstd, dx, dgamma, dbeta)
+        nb = self.lib.a2f_bn_ws_bytes(R, Cc)
+        ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=a0.device)
+        _lib.check(self.lib.a2f_bn_bwd_conv0(_ptr(a0), _ptr(wg), _ptr(cbias), P_out, _ptr(beta), _ptr(dy), R, Cc, _ptr(gamma), _ptr(save_mean), _ptr(save_invstd),
+                                             int(training), int(relu), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb,
+                                             self._stream(a0)), "a2f_bn_bwd_conv0")
 
     # ---- FaceFormer recurrence ----------------------------------------------------------------
     def ff_save_floats(self, S, T):

@@ -189,11 +189,6 @@ int a2f_voca_trunk_bwd_data(const float* dh3, const float* z2, const float* cat7
 /* Conv weight re-layout  w (Co,Ci,KH) <-> wg (Co, KH*Ci) [k = kh*Ci+ci]; dir 0: w->wg, 1: wg->w(+=0 overwrite) */
 int a2f_conv_weight_pack(const float* src, float* dst, int64_t Co, int64_t Ci, int64_t KH, int32_t dir, a2f_stream_t stream);
 
-/* Audio2Mesh analysis layer 0 (audio2face.py:13-17: Conv2d(1, 72, (1,3), stride (1,2), padding (0,1)) over the 32 spectral bins of every
- * row of the (B, 52 + n_onehot, 32) input): x = R / P_out groups of 2 P_out values each, wg (Co, 3) = the weight with k = kh, bias (Co),
- * z (R, Co) channels-last: z[r][co] = bias[co] + sum_kh x[2r - 1 + kh] wg[co][kh], x[2r - 1] = 0 at the first position of a group.
- * Exact fp32 multiply-adds; a streaming kernel (one float4 of outputs per thread).  Co a multiple of 4, z / bias 16-byte aligned. */
-int a2f_conv_k3s2_c1_fwd(const float* x, const float* wg, const float* bias, int64_t R, int64_t P_out, int64_t Co, float* z, a2f_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm2d over channels-last rows (audio2face.py:15-46), training-mode batch statistics:
@@ -211,6 +206,17 @@ int a2f_bn_fwd(const float* x, int64_t R, int64_t C, const float* gamma, const f
 int a2f_bn_bwd(const float* x, const float* beta, const float* dy, int64_t R, int64_t C, const float* gamma,
                const float* save_mean, const float* save_invstd, int32_t training, int32_t relu,
                float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, a2f_stream_t stream);
+/* The same two entries for the BatchNorm that follows Audio2Mesh's analysis layer 0 (audio2face.py:13-17), with the convolution FUSED IN: x is never stored -
+ * every pass re-evaluates x(r, c) = cbias[c] + sum_kh a0[2r - 1 + kh] wg[c][kh] (Conv2d(1, C, (1,3), stride (1,2), padding (0,1)); a0[2r - 1] = 0 at the first
+ * position of a group; exact fp32, bit for bit the same in all four passes) from
+ * the one-channel input a0, so the forward moves R*C*4 bytes (the output) instead of 4x that and the backward 3x instead of 5x.  a0: R / P_out groups of 2 P_out
+ * values; C a multiple of 4 (<= 256); cbias, gamma, beta, the saved statistics and the (R, C) tensors 16-byte aligned. */
+int a2f_bn_fwd_conv0(const float* a0, const float* wg, const float* cbias, int64_t P_out, int64_t R, int64_t C, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, int32_t training, int32_t relu,
+                     float* y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, a2f_stream_t stream);
+int a2f_bn_bwd_conv0(const float* a0, const float* wg, const float* cbias, int64_t P_out, const float* beta, const float* dy, int64_t R, int64_t C,
+                     const float* gamma, const float* save_mean, const float* save_invstd, int32_t training, int32_t relu,
+                     float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, a2f_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * FaceFormer decoder recurrence (faceformer.py:154-185 evaluated incrementally):

@@ -466,6 +466,17 @@ class EmuBackend:
             dxv = dyv * g * invstd
         dx.reshape(R, Cc).copy_(dxv.float()); dgamma.copy_(dg.float()); dbeta.copy_(db.float())
 
+    def _conv0(self, a0, wg, cbias, P_out, R, Cc):
+        z = torch.empty(R, Cc, dtype=torch.float64)
+        self.conv_k3s2_c1_fwd(a0.double(), wg.double(), cbias.double(), R, P_out, Cc, z)
+        return z
+
+    def bn_fwd_conv0(self, a0, wg, cbias, P_out, R, Cc, gamma, beta, rmean, rvar, momentum, eps, training, relu, y, save_mean, save_invstd):
+        self.bn_fwd(self._conv0(a0, wg, cbias, P_out, R, Cc), R, Cc, gamma, beta, rmean, rvar, momentum, eps, training, relu, y, save_mean, save_invstd)
+
+    def bn_bwd_conv0(self, a0, wg, cbias, P_out, beta, dy, R, Cc, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta):
+        self.bn_bwd(self._conv0(a0, wg, cbias, P_out, R, Cc), beta, dy, R, Cc, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta)
+
     # ------------------------------------------------------------------ FaceFormer recurrence (autograd on the spec)
     @staticmethod
     def _ff_unpack(p):

@@ -219,35 +219,47 @@ static inline bool bn_vec4_ok(const void* a, const void* b, const void* c, int64
   return C % 4 == 0 && C / 4 <= BN_THREADS && C <= BN_THREADS && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0;
 }
 
-// Fold of the per-block double partials: 16 channels x 16 block-lanes per workgroup (a lane sums every 16th block, the 16
-// lane sums are added in fixed order through LDS) - deterministic, and ~nblk/16 dependent loads deep instead of nblk.
+// Fold of the per-block double partials: 4 channels x 64 block-lanes per workgroup (a lane sums every 64th block with all its loads in flight at once, the 64
+// lane sums are added in fixed order through LDS) - deterministic.  (16 channels x 16 lanes, i.e. up to 64 dependent L2 round trips per lane on 5-16 workgroups,
+// made each of the twenty finish launches of an Audio2Mesh step 9.5 us long.)
+constexpr int BN_FOLD_CH = 4, BN_FOLD_LANES = 64;
 __device__ __forceinline__ void bn_fold_partials(const double* __restrict__ part, int nblk, int C, int c, int zg, bool valid,
-                                                 double (&sh)[2][16][17], double& s, double& q) {
-  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+                                                 double (&sh)[2][BN_FOLD_LANES][BN_FOLD_CH + 1], double& s, double& q) {
+  double a[4] = {0.0, 0.0, 0.0, 0.0}, bq[4] = {0.0, 0.0, 0.0, 0.0};
   if (valid) {
     int b = zg;
-    for (; b + 16 < nblk; b += 32) {
-      a0 += part[((int64_t)b * 2 + 0) * C + c]; b0 += part[((int64_t)b * 2 + 1) * C + c];
-      a1 += part[((int64_t)(b + 16) * 2 + 0) * C + c]; b1 += part[((int64_t)(b + 16) * 2 + 1) * C + c];
+    for (; b + 3 * BN_FOLD_LANES < nblk; b += 4 * BN_FOLD_LANES) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] += part[((int64_t)(b + u * BN_FOLD_LANES) * 2 + 0) * C + c];
+        bq[u] += part[((int64_t)(b + u * BN_FOLD_LANES) * 2 + 1) * C + c];
+      }
     }
-    if (b < nblk) { a0 += part[((int64_t)b * 2 + 0) * C + c]; b0 += part[((int64_t)b * 2 + 1) * C + c]; }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {                            // at most three blocks are left for this lane
+      const int bb = b + u * BN_FOLD_LANES;
+      if (bb < nblk) {
+        a[u] += part[((int64_t)bb * 2 + 0) * C + c];
+        bq[u] += part[((int64_t)bb * 2 + 1) * C + c];
+      }
+    }
   }
-  const int o = threadIdx.x & 15;
-  sh[0][zg][o] = a0 + a1;
-  sh[1][zg][o] = b0 + b1;
+  const int o = threadIdx.x % BN_FOLD_CH;
+  sh[0][zg][o] = (a[0] + a[1]) + (a[2] + a[3]);
+  sh[1][zg][o] = (bq[0] + bq[1]) + (bq[2] + bq[3]);
   __syncthreads();
   s = 0.0; q = 0.0;
   if (zg == 0) {
-#pragma unroll
-    for (int g = 0; g < 16; ++g) { s += sh[0][g][o]; q += sh[1][g][o]; }
+#pragma unroll 8
+    for (int g = 0; g < BN_FOLD_LANES; ++g) { s += sh[0][g][o]; q += sh[1][g][o]; }
   }
 }
 
 __global__ __launch_bounds__(256) void bn_finish_stats_kernel(const double* __restrict__ part, int nblk, int64_t R, int C, float momentum,
                                                                float eps, float* __restrict__ rmean, float* __restrict__ rvar,
                                                                float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  __shared__ double sh[2][16][17];
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15), zg = threadIdx.x >> 4;
+  __shared__ double sh[2][BN_FOLD_LANES][BN_FOLD_CH + 1];
+  const int c = blockIdx.x * BN_FOLD_CH + (threadIdx.x % BN_FOLD_CH), zg = threadIdx.x / BN_FOLD_CH;
   double s, q;
   bn_fold_partials(part, nblk, C, c, zg, c < C, sh, s, q);
   if (zg != 0 || c >= C) return;
@@ -271,8 +283,8 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const floa
 
 __global__ __launch_bounds__(256) void bn_finish_bwd_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta) {
-  __shared__ double sh[2][16][17];
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15), zg = threadIdx.x >> 4;
+  __shared__ double sh[2][BN_FOLD_LANES][BN_FOLD_CH + 1];
+  const int c = blockIdx.x * BN_FOLD_CH + (threadIdx.x % BN_FOLD_CH), zg = threadIdx.x / BN_FOLD_CH;
   double s, q;
   bn_fold_partials(part, nblk, C, c, zg, c < C, sh, s, q);
   if (zg != 0 || c >= C) return;
@@ -448,7 +460,7 @@ static int bn_fwd_impl(const a2f::BnSrc src, bool conv0, int64_t R, int64_t C, c
     else
       hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblk), dim3(BN_THREADS), 0, s, x, (const float*)nullptr, (const float*)nullptr, R,
                          (int)C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (double*)ws);
-    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, s, (const double*)ws, nblk, R, (int)C, momentum, eps,
+    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3((unsigned)cdiv(C, BN_FOLD_CH)), dim3(256), 0, s, (const double*)ws, nblk, R, (int)C, momentum, eps,
                        running_mean, running_var, save_mean, save_invstd);
   } else {
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cb), dim3(256), 0, s, running_mean, running_var, (int)C, eps, save_mean, save_invstd);
@@ -491,7 +503,7 @@ static int bn_bwd_impl(const a2f::BnSrc src, bool conv0, const float* beta, cons
   else
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblk), dim3(BN_THREADS), 0, s, x, beta, dy, R, (int)C, save_mean, save_invstd, gamma, (int)relu,
                        (double*)ws);
-  hipLaunchKernelGGL(bn_finish_bwd_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, s, (const double*)ws, nblk, (int)C, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_finish_bwd_kernel, dim3((unsigned)cdiv(C, BN_FOLD_CH)), dim3(256), 0, s, (const double*)ws, nblk, (int)C, dgamma, dbeta);
   const int64_t total = R * C;
   A2F_CHECK_ARG(total / BN_THREADS < 0x7FFFFFFFll, "bn_bwd: R * C too large for one element per thread");
   if (conv0) {

@@ -431,15 +431,26 @@ __global__ __launch_bounds__(256) void gemm_mfma_fold_kernel(const Args a) {
     const int bz = (int)(idx / mn);
     const long long r = idx - bz * mn;
     const int m = (int)(r / a.N), n = (int)(r - (long long)m * a.N);
+    // four slabs per trip, their loads in flight together (one load - wait - add per slab was up to 64 dependent L2 round trips per element); the order of the
+    // additions is fixed: ((s0 + s1) + (s2 + s3)) per trip, trips in order
+    const float* w = a.ws + (long long)bz * a.split_k * mn + r;
     float v = 0.f;
-    for (int s = 0; s < a.split_k; ++s) v += a.ws[((long long)(bz * a.split_k + s)) * mn + r];
+    int s = 0;
+    for (; s + 4 <= a.split_k; s += 4) {
+      const float x0 = w[(long long)s * mn], x1 = w[(long long)(s + 1) * mn], x2 = w[(long long)(s + 2) * mn], x3 = w[(long long)(s + 3) * mn];
+      v += (x0 + x1) + (x2 + x3);
+    }
+    for (; s < a.split_k; ++s) v += w[(long long)s * mn];
     epilogue_store(a, bz, m, n, c_row_offset(a, m), v);
   }
   if (a.a_rowsum) {                                            // the row-sum slabs of the split product, same fixed order
     const float* rs = a.ws + (long long)a.batch * a.split_k * mn;
     for (long long m = blockIdx.x * 256ll + threadIdx.x; m < a.M; m += (long long)gridDim.x * 256) {
       float v = 0.f;
-      for (int s = 0; s < a.split_k; ++s) v += rs[(long long)s * a.M + m];
+      int s = 0;
+      for (; s + 4 <= a.split_k; s += 4)
+        v += (rs[(long long)s * a.M + m] + rs[(long long)(s + 1) * a.M + m]) + (rs[(long long)(s + 2) * a.M + m] + rs[(long long)(s + 3) * a.M + m]);
+      for (; s < a.split_k; ++s) v += rs[(long long)s * a.M + m];
       a.a_rowsum[m] = v;
     }
   }

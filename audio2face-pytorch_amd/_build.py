@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "liba2f_hip.so")
 OBJ_DIR = os.path.join(PKG_DIR, "..", "build", "obj")
 SOURCES = ["capi.hip", "gemm.hip", "wgrad.hip", "voca_trunk.hip", "loss.hip", "pack.hip", "adam.hip", "bn.hip", "head_fused.hip",
-           "ff_decoder.hip", "interp.hip", "util.hip", "gemm_mfma.hip", "rowops.hip", "attention.hip", "featenc.hip", "dropout.hip"]
+           "ff_decoder.hip", "interp.hip", "util.hip", "gemm_mfma.hip", "gemm_img.hip", "rowops.hip", "attention.hip", "featenc.hip", "dropout.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -75,14 +75,29 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+def _deps_mtime(src: str) -> float:
+    """Newest of the source and the headers it includes (transitively, quoted includes only; every source reaches include/a2f_hip.h
+    through a2f_common.h) - a change to gemm_mfma.h rebuilds the two GEMM files, not all eighteen."""
+    import re
+    seen, todo, newest = set(), [src], 0.0
+    while todo:
+        f = os.path.normpath(todo.pop())
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.add(f)
+        newest = max(newest, os.path.getmtime(f))
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(f).read(), flags=re.M):
+            todo.append(os.path.join(os.path.dirname(f), inc))
+    return newest
+
+
 def _build_locked(force: bool, verbose: bool) -> str:
-    hdr_t = max(os.path.getmtime(h) for h in _headers())
     jobs, objs = [], []
     for s in _sources():
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < _deps_mtime(src):
             jobs.append((src, obj))
     nj = max(1, int(os.environ.get("A2F_BUILD_JOBS", str(min(8, os.cpu_count() or 1)))))
     with ThreadPoolExecutor(max_workers=nj) as ex:

@@ -54,7 +54,7 @@ class MMDesc(C.Structure):
         ("ws", c_f32p),
         ("batch", i32), ("accumulate", i32),
         ("a_bstride", i64), ("b_bstride", i64), ("c_bstride", i64), ("bias_bstride", i64),
-        ("alpha", f32), ("reserved", i32),
+        ("alpha", f32), ("c_format", i32),
         ("keep_bits", c_f32p), ("keep_wpr", i64),
         ("keep_scale", f32), ("reserved2", i32),
         ("a_rowsum", c_f32p),
@@ -104,6 +104,7 @@ SIGNATURES = {
     "a2f_ff_decoder_bwd_drop": (C.c_int, [c_f32p, c_f32p, i64, i64, i32, C.c_void_p, sz, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, f32, C.c_void_p]),
     "a2f_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, f32, f32, f32, f32, f32, f32, i32, C.c_void_p]),
     "a2f_mm": (C.c_int, [C.POINTER(MMDesc), C.c_void_p]),
+    "a2f_split_img": (C.c_int, [c_f32p, i64, i64, i64, i32, C.c_void_p, i64, C.c_void_p]),
     "a2f_layernorm_fwd": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, f32, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "a2f_layernorm_bwd_ws_bytes": (sz, [i64, i64]),
     "a2f_layernorm_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),

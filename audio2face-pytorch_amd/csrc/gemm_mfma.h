@@ -48,6 +48,7 @@ struct Args {
   const unsigned* keep;          // dropout keep bits of C (csrc/dropout.hip: word (m, n >> 5), bit n & 31), applied after the activation
   long long keep_wpr;
   float keep_scale;
+  int c_format;                   // 0: C is fp32; 1: C is a split-32 image (csrc/gemm_img.hip; image-operand kernels only)
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }

@@ -492,7 +492,9 @@ static int dispatch_layout(const Args& a, bool at, bool bt, bool plain, hipStrea
 
 static int fill_op(const a2f_mm_operand& o, int64_t bstride, int64_t contiguous_extent, Op& k, const char* name) {
   A2F_CHECK_ARG(o.p != nullptr, "a2f_mm: operand %s is null", name);
-  A2F_CHECK_ARG(o.format == 0 && o.p_lo == nullptr, "a2f_mm: operand %s: format %d (only 0 = fp32 is defined; p_lo is reserved and must be null)", name, o.format);
+  A2F_CHECK_ARG((o.format == 0 || o.format == 1) && o.p_lo == nullptr, "a2f_mm: operand %s: format %d (0 = fp32, 1 = split-32 image; p_lo is reserved and must be null)", name, o.format);
+  A2F_CHECK_ARG(o.format == 0 || (o.ld % 32 == 0 && o.off % 32 == 0 && o.seq_stride % 32 == 0 && ((uintptr_t)o.p & 127) == 0),
+                "a2f_mm: image operand %s: ld, off and seq_stride must be multiples of 32 elements and the base 128-byte aligned", name);
   A2F_CHECK_ARG(((uintptr_t)o.p & 15) == 0, "a2f_mm: operand %s must be 16-byte aligned", name);
   A2F_CHECK_ARG(o.bytes > 0 && o.bytes < (int64_t)0xFFFFFFF0ll, "a2f_mm: operand %s spans %lld bytes (must be < 4 GiB)", name, (long long)o.bytes);
   A2F_CHECK_ARG(o.ld % 4 == 0 && o.off % 4 == 0 && o.seq_stride % 4 == 0 && bstride % 4 == 0 && contiguous_extent % 4 == 0,
@@ -514,6 +516,8 @@ static int fill_op(const a2f_mm_operand& o, int64_t bstride, int64_t contiguous_
   k.bstride = bstride;
   return A2F_OK;
 }
+
+int launch_img(const Args& a, bool tn, hipStream_t st);      // csrc/gemm_img.hip
 
 }  // namespace mm
 }  // namespace a2f
@@ -565,6 +569,59 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   a.keep_wpr = d->keep_wpr;
   a.keep_scale = d->keep_scale;
   const bool at = d->A.trans != 0, bt = d->B.trans != 0;
+  a.c_format = d->c_format;
+  A2F_CHECK_ARG(d->A.format == d->B.format, "a2f_mm: both operands must have the same format (%d vs %d)", d->A.format, d->B.format);
+  A2F_CHECK_ARG(d->c_format == 0 || (d->c_format == 1 && d->A.format == 1), "a2f_mm: c_format %d (1 = image output, image-operand products only)", d->c_format);
+  if (d->A.format == 1) {
+    // operands arrive as split-32 images: the 256 x 256 LDS-DMA kernels of csrc/gemm_img.hip (bf16x3 only)
+    A2F_CHECK_ARG(d->precision == 1 && batch == 1 && !d->accumulate && at == bt && d->a_rowsum == nullptr,
+                  "a2f_mm (image operands): precision 1, batch 1, no accumulate, no a_rowsum, both operands with the same `trans`");
+    A2F_CHECK_ARG(d->aux_mode == 0 || d->aux_mode == 1 || d->aux_mode == 4, "a2f_mm (image operands): aux_mode %d", d->aux_mode);
+    A2F_CHECK_ARG(d->N % 4 == 0 && d->ldc % 4 == 0 && d->ldaux % 4 == 0 && d->c_seq_stride % 4 == 0 && (((uintptr_t)d->C | (uintptr_t)d->C2 | (uintptr_t)d->aux | (uintptr_t)d->bias) & 15) == 0,
+                  "a2f_mm (image operands): N, ldc, ldaux multiples of 4 and 16-byte aligned C / C2 / aux / bias (float4 epilogue)");
+    const long long lim = 0x80000000ll / 4;
+    const long long M1 = d->M - 1;
+    const long long c_max = (d->c_rows_per_seq > 0 ? (M1 / d->c_rows_per_seq) * d->c_seq_stride + (M1 % d->c_rows_per_seq) * d->ldc : M1 * d->ldc) + d->N;
+    A2F_CHECK_ARG(c_max < lim && d->M * d->N < lim && M1 * d->ldaux + d->N < lim && d->M * d->keep_wpr < lim, "a2f_mm (image operands): output spans must stay below 2 GiB");
+    if (!at) {
+      A2F_CHECK_ARG(d->K % 32 == 0 && split == 1, "a2f_mm (image operands, k-contiguous): K %% 32 == 0, no split-K");
+      A2F_CHECK_ARG(a.B.lps == 0, "a2f_mm (image operands): B must be a plain matrix");
+      if (a.A.lps > 0)
+        A2F_CHECK_ARG(d->A.off >= 0 && (d->A.lines_per_seq - 1) * d->A.ld + d->A.off + d->K <= d->A.seq_elems, "a2f_mm (image operands): windows must lie inside their sequence (no padding)");
+    } else {
+      A2F_CHECK_ARG(a.A.lps == 0 && a.B.lps == 0 && d->c_format == 0 && d->c_rows_per_seq == 0, "a2f_mm (image operands, weight-gradient layout): plain matrices, fp32 C");
+      A2F_CHECK_ARG(d->M % 32 == 0 && d->N % 32 == 0, "a2f_mm (image operands, weight-gradient layout): M, N multiples of 32");
+    }
+    A2F_CHECK_ARG(d->c_format == 0 || (d->ldc % 32 == 0 && d->c_rows_per_seq == 0 && ((uintptr_t)d->C & 127) == 0), "a2f_mm: image output needs ldc %% 32 == 0, a plain row map and a 128-byte aligned C");
+    a.epi32 = 1;
+    a.group_n = 0;
+    {
+      const long long b_bytes = (long long)d->N * d->K * 4, a_bytes = (long long)d->M * d->K * 4;
+      const long long tiles_n = cdiv(d->N, 256), tiles_m = cdiv(d->M, 256);
+      static const int forced = [] { const char* e = getenv("A2F_MM_GROUP_N"); return e ? atoi(e) : -1; }();
+      if (forced >= 0) a.group_n = forced;
+      else if (!at && b_bytes > (5ll << 19) && tiles_n >= 4) {
+        long long g = (2ll << 20) / (256 * d->K * 4);
+        g = g < 1 ? 1 : (g > tiles_n ? tiles_n : g);
+        const long long rows_live = 32 / tiles_n > 0 ? 32 / tiles_n : 1;
+        const long long row_major = a_bytes + b_bytes * cdiv(tiles_m, rows_live);
+        const long long panel = a_bytes * cdiv(tiles_n, g) + 8 * b_bytes;
+        if (panel < row_major) a.group_n = (int)g;
+      }
+      if (a.group_n >= tiles_n) a.group_n = 0;
+    }
+    rc = launch_img(a, at, (hipStream_t)stream);
+    if (rc) return rc;
+    A2F_CHECK_LAUNCH("a2f_mm (image operands)");
+    if (split > 1) {
+      const long long total = (long long)a.M * a.N;
+      long long blocks = (total + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(gemm_mfma_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+      A2F_CHECK_LAUNCH("a2f_mm fold");
+    }
+    return A2F_OK;
+  }
   // 32-bit epilogue offsets (gemm_mfma.h tile_epilogue_band): every element offset of C / C2 / like-C aux, of the (m, ldaux) aux, of the keep words and
   // of one split-K slab, in bytes from its (per-batch) base, below 2^31
   {

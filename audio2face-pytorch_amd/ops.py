@@ -29,14 +29,16 @@ class MMOp:
     instead of k; ``lines_per_seq`` > 0 switches on the window structure (sequence stride, in-sequence offset, bounds)."""
 
     def __init__(self, t: torch.Tensor, ld: int, *, trans: bool = False, lines_per_seq: int = 0, seq_stride: int = 0, off: int = 0,
-                 seq_elems: int = 0, ptr_off: int = 0):
+                 seq_elems: int = 0, ptr_off: int = 0, img: bool = False):
         self.t, self.ld, self.trans = t, int(ld), bool(trans)
+        self.img = bool(img)            # the tensor holds a split-32 image (a2f_mm_operand.format 1) of the fp32 matrix of the same shape
         self.lines_per_seq, self.seq_stride, self.off, self.seq_elems, self.ptr_off = int(lines_per_seq), int(seq_stride), int(off), int(seq_elems), int(ptr_off)
 
     def fill(self, o: MMOperand):
         o.p = self.t.data_ptr() + 4 * self.ptr_off
         o.bytes = 4 * (self.t.numel() - self.ptr_off)
         o.ld, o.trans = self.ld, int(self.trans)
+        o.format = 1 if self.img else 0
         o.lines_per_seq, o.seq_stride, o.off, o.seq_elems = self.lines_per_seq, self.seq_stride, self.off, self.seq_elems
 
 
@@ -136,9 +138,9 @@ class HipBackend:
 
     def mm(self, A: "MMOp", B: "MMOp", Cout, M, N, K, ldc, *, c_off=0, c_rows_per_seq=0, c_seq_stride=0, C2=None, bias=None, aux=None,
            ldaux=0, act=MM_ACT_NONE, aux_mode=MM_AUX_NONE, precision=None, split_k=1, batch=1, a_bstride=0, b_bstride=0, c_bstride=0,
-           bias_bstride=0, aux_bstride=0, accumulate=False, alpha=1.0, tag="gemm_mfma", keep=None, a_rowsum=None):
+           bias_bstride=0, aux_bstride=0, accumulate=False, alpha=1.0, tag="gemm_mfma", keep=None, a_rowsum=None, c_img=False):
         """C[m,n] = epi(alpha * sum_k A(m,k) B(k,n)) on the bf16 matrix pipe (contract: include/a2f_hip.h, a2f_mm).
-        keep = (bits int32 (M, wpr), scale): train-mode dropout of C in the epilogue."""
+        keep = (bits int32 (M, wpr), scale): train-mode dropout of C in the epilogue.  c_img: C is written as a split-32 image."""
         _chk(A.t, B.t, Cout, C2, bias, aux)
         d = MMDesc()
         A.fill(d.A)
@@ -150,7 +152,11 @@ class HipBackend:
         d.aux, d.ldaux = _ptr(aux, c_off if aux_mode == MM_AUX_MUL_LIKE_C else 0), ldaux
         d.act, d.aux_mode = act, aux_mode
         d.precision = self.mm_precision if precision is None else precision
-        if split_k == 0:                                        # auto: enough workgroups for the chip, slabs stay small
+        d.c_format = 1 if c_img else 0
+        if split_k == 0 and A.img:                              # image operands: 256 x 256 tiles, one workgroup per CU
+            tiles = ((M + 255) // 256) * ((N + 255) // 256)
+            split_k = max(1, min(256 // max(tiles, 1), K // 512, 128))
+        elif split_k == 0:                                      # auto: enough workgroups for the chip, slabs stay small
             tiles = ((M + 127) // 128) * ((N + (127 if N > 64 else 63)) // (128 if N > 64 else 64)) * batch
             split_k = max(1, min(512 // max(tiles, 1), K // 256, 64)) if tiles < 192 else 1
         d.split_k = split_k
@@ -181,9 +187,14 @@ class HipBackend:
             ps = getattr(self, "prof_shapes", None)
             if ps is not None and ev is not None:                # per launch variant: layout / shape / precision -> events, flops per launch
                 key = (("T" if A.trans else "N") + ("T" if not B.trans else "N"), M, N, K, batch, bool(A.lines_per_seq or B.lines_per_seq),
-                       d.precision, False)
+                       d.precision, bool(A.img))
                 ent = ps.setdefault(key, {"events": [], "flops": 2.0 * M * N * K * batch})
                 ent["events"].append(ev)
+
+    def split_img(self, x, R, Cc, ld, out, ldo, transpose=False):
+        """fp32 rows -> split-32 image (a2f_split_img); transpose: the image of x^T."""
+        _chk(x, out)
+        _lib.check(self.lib.a2f_split_img(_ptr(x), R, Cc, ld, int(transpose), _ptr(out), ldo, self._stream(x)), "a2f_split_img")
 
     # ---- row-wise encoder kernels (csrc/rowops.hip) ----------------------------------------------
     def layernorm_fwd(self, x, R, Cc, gamma, beta, eps, y, mean, rstd):

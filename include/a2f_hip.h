@@ -322,8 +322,14 @@ int a2f_stream_triad(float* dst, const float* a, const float* b, int64_t n, a2f_
  * are lines with ld < K, zero padding and sequence ends are the bounds test.  `bytes` = addressable span from p (< 4 GiB):
  * anything beyond reads as zero.  All of p, ld, off, seq_stride and the contiguous extent must be multiples of 4 elements
  * (16-byte vector loads).
- * `format` must be 0 and `p_lo` null (reserved: rounds 2 / 3 measured operands that arrive as ready-made bf16 hi / lo images staged by LDS-DMA
- * - +6..25 % at the kernel, not enough to pay for splitting passes; the kernel was removed until the producers emit images).
+ * `format` 1 (both operands; `p_lo` stays null): the operand arrives as a SPLIT-32 IMAGE of the fp32 matrix it stands for - same shape, same 4 bytes
+ * per element, same `ld` / `off` / `bytes` units: a row is ld / 32 blocks of 128 bytes, block b = the 32 elements 32 b .. 32 b + 31 as 32 bf16 `hi`
+ * (RNE(x)) followed by 32 bf16 `lo` (RNE(x - hi)); ld, off, seq_stride multiples of 32, base 128-byte aligned.  Producers write it directly
+ * (a2f_mm with c_format 1, a2f_layernorm_fwd / _bwd image outputs, the attention kernels, a2f_split_img for everything else), so no consumer converts:
+ * such products run on the 256 x 256 LDS-DMA kernels of csrc/gemm_img.hip (bf16x3 only: precision 1, batch 1, no accumulate / a_rowsum; both operands
+ * k-contiguous - plain or un-padded windows of A, K % 32 == 0, no split-K - or both line-contiguous = the weight-gradient layout with split-K, M and N
+ * multiples of 32; aux_mode 0 / 1 / 4; N, ldc, ldaux multiples of 4; GELU there is the Abramowitz-Stegun 7.1.26 form, |error| < 1e-7).
+ * c_format 1 (k-contiguous image products only): C itself is written as a split-32 image (ldc % 32 == 0); C2 stays fp32.
  * Tile order: workgroups walk the (m-tile, n-tile) grid row-major, or - when B (N x K x 4 bytes) outgrows an XCD's 4 MB L2 - in panels of n-tiles
  * whose slice of B stays resident while the A panels stream past (same results bit for bit; A2F_MM_GROUP_N=0 forces row-major).
  * Epilogue, per element: v = alpha*acc; if bias: v += bias[n]; C2 (optional) = v;  act: 0 none, 1 ReLU, 3 GELU (erf form), 4 GELU with
@@ -345,7 +351,7 @@ typedef struct a2f_mm_operand {
   const float* p;
   int64_t bytes;
   int64_t ld;
-  int32_t trans, format;          /* format: 0 (fp32); other values are reserved */
+  int32_t trans, format;          /* format: 0 = fp32; 1 = split-32 image (see below) */
   int64_t lines_per_seq, seq_stride, off, seq_elems;
   const void* p_lo;               /* reserved: must be null */
 } a2f_mm_operand;
@@ -361,13 +367,18 @@ typedef struct a2f_mm_desc {
   float* ws;
   int32_t batch, accumulate;
   int64_t a_bstride, b_bstride, c_bstride, bias_bstride;
-  float alpha; int32_t reserved;
+  float alpha; int32_t c_format;                    /* 0: C is fp32; 1: C is a split-32 image (image-operand products only) */
   const uint32_t* keep_bits; int64_t keep_wpr;     /* optional dropout of C: see a2f_keep_bits */
   float keep_scale; int32_t reserved2;
   float* a_rowsum;                                 /* optional: a_rowsum[m] = sum_k A(m,k), see below */
 } a2f_mm_desc;
 
 int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream);
+
+/* fp32 (R, C) rows at stride ld -> split-32 image (a2f_mm_operand.format 1) with row stride ldo elements (ldo % 32 == 0, ldo >= C);
+ * transpose != 0: the image of the TRANSPOSE, (C, R) rows at stride ldo >= R (R % 4 == 0): how data gradients read a weight k-contiguously.
+ * A streaming pass for operands no producer emits as images (weights once per step; activations in tests).  C % 4 == 0, ld % 4 == 0. */
+int a2f_split_img(const float* x, int64_t R, int64_t C, int64_t ld, int32_t transpose, void* out, int64_t ldo, a2f_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row-wise kernels of the wav2vec2 encoder path (csrc/rowops.hip; HF Wav2Vec2Model as wrapped by

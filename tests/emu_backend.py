@@ -69,6 +69,23 @@ def philox_keep_words(seed, site, R, Cc, p, wpr):
     return words.view(np.int32)
 
 
+def img_encode(x):
+    """fp32 (..., C) with C % 32 == 0 -> float32 tensor of the same shape whose BYTES are the split-32 image (include/a2f_hip.h, a2f_mm_operand.format 1):
+    per 32 elements 32 bf16 hi = RNE(x) then 32 bf16 lo = RNE(x - hi)."""
+    x = x.float()
+    assert x.shape[-1] % 32 == 0
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    blk = torch.stack((hi.reshape(*x.shape[:-1], -1, 32), lo.reshape(*x.shape[:-1], -1, 32)), dim=-2)       # (..., C/32, 2, 32) bf16
+    return blk.contiguous().view(torch.float32).reshape(x.shape)
+
+
+def img_decode(img):
+    """the float64 values hi + lo an image stands for."""
+    blk = img.contiguous().view(torch.bfloat16).reshape(*img.shape[:-1], -1, 2, 32)
+    return (blk[..., 0, :].double() + blk[..., 1, :].double()).reshape(img.shape)
+
+
 class EmuBackend:
     name = "emu"
 
@@ -143,7 +160,11 @@ class EmuBackend:
     @staticmethod
     def _mm_matrix(op, nlines, ncontig):
         """(nlines, ncontig) float64 matrix of an a2f_mm_operand by the header's contract (zeros outside the windows)."""
-        flat = op.t.reshape(-1)[op.ptr_off:].double()
+        if getattr(op, "img", False):            # image operands: rows of ld elements, ptr_off a multiple of 32
+            assert op.ptr_off % 32 == 0 and op.ld % 32 == 0
+            flat = img_decode(op.t.reshape(-1)[op.ptr_off:].reshape(-1, 32)).reshape(-1)
+        else:
+            flat = op.t.reshape(-1)[op.ptr_off:].double()
         i = torch.arange(nlines).view(-1, 1)
         j = torch.arange(ncontig).view(1, -1)
         if op.lines_per_seq > 0:
@@ -159,8 +180,17 @@ class EmuBackend:
 
     def mm(self, A, B, Cout, M, N, K, ldc, *, c_off=0, c_rows_per_seq=0, c_seq_stride=0, C2=None, bias=None, aux=None, ldaux=0, act=0,
            aux_mode=0, precision=None, split_k=1, batch=1, a_bstride=0, b_bstride=0, c_bstride=0, bias_bstride=0, aux_bstride=0,
-           accumulate=False, alpha=1.0, tag=None, keep=None, a_rowsum=None):
+           accumulate=False, alpha=1.0, tag=None, keep=None, a_rowsum=None, c_img=False):
         import copy
+        if c_img:                                      # image output: plain row map, whole 32-blocks; the values land as hi / lo pairs
+            assert getattr(A, "img", False) and c_rows_per_seq == 0 and ldc % 32 == 0 and c_off % 32 == 0 and N % 32 == 0 and batch == 1 and not accumulate
+            tmp = torch.zeros(Cout.numel())
+            self.mm(A, B, tmp, M, N, K, ldc, c_off=c_off, C2=C2, bias=bias, aux=aux, ldaux=ldaux, act=act, aux_mode=aux_mode, precision=precision,
+                    alpha=alpha, keep=keep)
+            enc = img_encode(tmp.view(-1, 32))
+            blocks = ((c_off + torch.arange(M).view(-1, 1) * ldc + torch.arange(0, N, 32).view(1, -1)) // 32).reshape(-1)
+            Cout.reshape(-1, 32)[blocks] = enc[blocks]
+            return
         self.calls.append(("mm", M, N, K, batch))
         cflat = Cout.reshape(-1)
         c2flat = C2.reshape(-1) if C2 is not None else None
@@ -207,6 +237,18 @@ class EmuBackend:
             if accumulate:
                 v = v + cflat[cidx].double()
             cflat[cidx] = v.float()
+
+    def split_img(self, x, R, Cc, ld, out, ldo, transpose=False):
+        src = x.reshape(-1)[: (R - 1) * ld + Cc]
+        m = src[torch.arange(R).view(-1, 1) * ld + torch.arange(Cc).view(1, -1)]
+        if transpose:
+            m = m.t().contiguous()
+        rows, cols = m.shape
+        pad = torch.zeros(rows, ((cols + 31) // 32) * 32)
+        pad[:, :cols] = m
+        enc = img_encode(pad)
+        of = out.reshape(-1)
+        of[(torch.arange(rows).view(-1, 1) * ldo + torch.arange(pad.shape[1]).view(1, -1)).reshape(-1)] = enc.reshape(-1)
 
     # ------------------------------------------------------------------ row-wise encoder kernels / attention (float64 contracts)
     def layernorm_fwd(self, x, R, Cc, gamma, beta, eps, y, mean, rstd):

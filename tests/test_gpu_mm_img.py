@@ -1,0 +1,142 @@
+"""GPU: the image-operand kernels of a2f_mm (csrc/gemm_img.hip: split-32 images, 256 x 256 tiles, LDS-DMA staging, ping-pong wave groups)
+and a2f_split_img against the float64 emulator of the contract in include/a2f_hip.h.  The emulator decodes the images (hi + lo exactly), so
+what is left on the GPU side is the dropped lo x lo term and fp32 accumulation: <= 3e-5 relative L2, the bf16x3 bar of tests/test_gpu_mm.py."""
+import pytest
+import torch
+
+import a2f_amd
+from a2f_amd import ops
+from a2f_amd.ops import MMOp
+from emu_backend import EmuBackend, img_decode, img_encode, pack_keep_bits
+from golden_util import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 3e-5
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def both(fn):
+    hip, emu = ops.HipBackend(), EmuBackend()
+    a = [t.cpu() for t in fn(hip, DEV)]
+    torch.cuda.synchronize()
+    return a, fn(emu, "cpu")
+
+
+@pytest.mark.parametrize("R,C,ld", [(7, 64, 64), (300, 768, 768), (33, 96, 128), (256, 3072, 3072)])
+def test_split_img_is_the_documented_layout_bit_for_bit(R, C, ld):
+    x = rnd(R, ld, seed=1)
+    be = ops.HipBackend()
+    out = torch.zeros(R, C, device=DEV)
+    be.split_img(x.to(DEV), R, C, ld, out, C)
+    assert torch.equal(out.cpu().view(torch.int32), img_encode(x[:, :C]).view(torch.int32))
+    Rt = (R + 3) // 4 * 4
+    xt = rnd(Rt, ld, seed=2)
+    ldo = (Rt + 31) // 32 * 32
+    outt = torch.zeros(C, ldo, device=DEV)
+    be.split_img(xt.to(DEV), Rt, C, ld, outt, ldo, transpose=True)
+    ref = torch.zeros(C, ldo)
+    ref[:, :Rt] = xt[:, :C].t()
+    got = outt.cpu()
+    assert torch.equal(img_decode(got)[:, :Rt], img_decode(img_encode(ref))[:, :Rt])
+
+
+EPIS = [dict(), dict(bias=True), dict(bias=True, act=ops.MM_ACT_GELU_SAVE_GRAD, with_pre=True, keep=True, c_img=True), dict(bias=True, act=ops.MM_ACT_GELU),
+        dict(bias=True, aux_mode=ops.MM_AUX_ADD, keep=True), dict(aux_mode=ops.MM_AUX_MUL_LIKE_C, keep=True, c_img=True), dict(act=ops.MM_ACT_RELU, with_pre=True, alpha=0.5)]
+
+
+@pytest.mark.parametrize("M,N,K", [(600, 768, 768), (257, 160, 64), (1200, 3072, 768), (96, 32, 32), (513, 544, 96), (1, 256, 3072)])
+def test_mm_img_nt_epilogues(M, N, K):
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2)
+    bias, aux = rnd(N, seed=3), rnd(M, N, seed=4)
+    mask = torch.rand(M, N, generator=torch.Generator().manual_seed(5)) > 0.1
+    bits = pack_keep_bits(mask)
+
+    def run(be, dev):
+        Ai, Bi = torch.zeros(M, K, device=dev), torch.zeros(N, K, device=dev)
+        be.split_img(A.to(dev), M, K, K, Ai, K)
+        be.split_img(B.to(dev), N, K, K, Bi, K)
+        outs = []
+        for e in EPIS:
+            kw = {k: v for k, v in e.items() if k in ("act", "aux_mode", "alpha", "c_img")}
+            if e.get("bias"):
+                kw["bias"] = bias.to(dev)
+            if e.get("aux_mode"):
+                kw["aux"], kw["ldaux"] = aux.to(dev), N
+            if e.get("keep"):
+                kw["keep"] = (bits.to(dev), 1.0 / 0.9)
+            C = torch.full((M, N), 7.0, device=dev)
+            pre = torch.zeros(M, N, device=dev) if e.get("with_pre") else None
+            be.mm(MMOp(Ai, K, img=True), MMOp(Bi, K, img=True), C, M, N, K, N, C2=pre, precision=1, **kw)
+            outs.append((C, bool(e.get("c_img"))))
+            if pre is not None:
+                outs.append((pre, False))
+        return [o for o, _ in outs] + [torch.tensor([float(f) for _, f in outs])]
+    got, ref = both(run)
+    flags = ref[-1]
+    for g, r, f in zip(got[:-1], ref[:-1], flags):
+        if f:
+            g, r = img_decode(g), img_decode(r)
+        assert rel_l2(g, r) < TOL
+
+
+def test_mm_img_nt_windows_are_a_strided_convolution():
+    """Un-padded windows of an image A (lines_per_seq / seq_stride / ld < K): the conv feature encoder's forward shape."""
+    S, Lin, Ci, Co, KH, stride = 3, 45, 64, 96, 3, 2
+    Lout = (Lin - KH) // stride + 1
+    x, Wg = rnd(S, Lin, Ci, seed=1), rnd(Co, KH * Ci, seed=2, scale=0.1)
+
+    def run(be, dev):
+        xi, Wi = torch.zeros(S, Lin, Ci, device=dev), torch.zeros(Co, KH * Ci, device=dev)
+        be.split_img(x.to(dev), S * Lin, Ci, Ci, xi, Ci)
+        be.split_img(Wg.to(dev), Co, KH * Ci, KH * Ci, Wi, KH * Ci)
+        y = torch.zeros(S * Lout, Co, device=dev)
+        A = MMOp(xi, stride * Ci, lines_per_seq=Lout, seq_stride=Lin * Ci, seq_elems=Lin * Ci, img=True)
+        be.mm(A, MMOp(Wi, KH * Ci, img=True), y, S * Lout, Co, KH * Ci, Co, precision=1)
+        return [y]
+    got, ref = both(run)
+    assert rel_l2(got[0], ref[0]) < TOL
+    yd = torch.nn.functional.conv1d(x.double().transpose(1, 2), Wg.double().view(Co, KH, Ci).permute(0, 2, 1), stride=stride).transpose(1, 2)
+    assert rel_l2(got[0].view(S, Lout, Co), yd) < 5e-5
+
+
+@pytest.mark.parametrize("R,M,N,split", [(1000, 768, 768, 0), (96, 64, 32, 1), (4800, 3072, 768, 0), (333, 256, 512, 3), (2000, 2304, 768, 0)])
+def test_mm_img_tn_weight_gradient_layout(R, M, N, split):
+    """C[m, n] = sum_r A[r, m] B[r, n]: both operands line-contiguous images, split-K slabs folded in fixed order."""
+    R4 = (R + 3) // 4 * 4
+    A, B = rnd(R4, M, seed=1), rnd(R4, N, seed=2)
+    A[R:] = 0
+    B[R:] = 0
+
+    def run(be, dev):
+        Ai, Bi = torch.zeros(R4, M, device=dev), torch.zeros(R4, N, device=dev)
+        be.split_img(A.to(dev), R4, M, M, Ai, M)
+        be.split_img(B.to(dev), R4, N, N, Bi, N)
+        C = torch.zeros(M, N, device=dev)
+        be.mm(MMOp(Ai, M, trans=True, img=True), MMOp(Bi, N, trans=True, img=True), C, M, N, R4, N, split_k=split, precision=1)
+        return [C]
+    got, ref = both(run)
+    assert rel_l2(got[0], ref[0]) < TOL
+
+
+def test_mm_img_is_bitwise_reproducible_and_rejects_what_it_cannot_do():
+    M, N, K = 2048, 768, 768
+    A, B = rnd(M, K, seed=1).to(DEV), rnd(N, K, seed=2).to(DEV)
+    be = ops.HipBackend()
+    Ai, Bi = torch.zeros_like(A), torch.zeros_like(B)
+    be.split_img(A, M, K, K, Ai, K)
+    be.split_img(B, N, K, K, Bi, K)
+    outs = []
+    for _ in range(3):
+        C = torch.zeros(M, N, device=DEV)
+        be.mm(MMOp(Ai, K, img=True), MMOp(Bi, K, img=True), C, M, N, K, N, precision=1)
+        outs.append(C.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    with pytest.raises(a2f_amd.A2FError):
+        be.mm(MMOp(Ai, K, img=True), MMOp(B, K), torch.zeros(M, N, device=DEV), M, N, K, N, precision=1)          # mixed formats
+    with pytest.raises(a2f_amd.A2FError):
+        be.mm(MMOp(Ai, K, img=True), MMOp(Bi, K, img=True), torch.zeros(M, N, device=DEV), M, N, K, N, precision=0)   # bf16x3 only

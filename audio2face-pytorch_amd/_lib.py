@@ -58,6 +58,7 @@ class MMDesc(C.Structure):
         ("keep_bits", c_f32p), ("keep_wpr", i64),
         ("keep_scale", f32), ("reserved2", i32),
         ("a_rowsum", c_f32p),
+        ("c_colsum", c_f32p),
     ]
 
 
@@ -106,6 +107,13 @@ SIGNATURES = {
     "a2f_mm": (C.c_int, [C.POINTER(MMDesc), C.c_void_p]),
     "a2f_split_img": (C.c_int, [c_f32p, i64, i64, i64, i32, C.c_void_p, i64, C.c_void_p]),
     "a2f_layernorm_fwd": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, f32, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "a2f_layernorm_fwd_img": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, f32, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "a2f_layernorm_bwd_img": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, f32, c_f32p,
+                                        C.c_void_p, sz, C.c_void_p]),
+    "a2f_colsum_img": (C.c_int, [c_f32p, i64, i64, i64, c_f32p, C.c_void_p, sz, C.c_void_p]),
+    "a2f_attn_fwd_img": (C.c_int, [c_f32p, i64, i64, i64, i64, f32, i32, c_f32p, i64, c_f32p, c_f32p, f32, c_f32p, C.c_void_p]),
+    "a2f_attn_bwd_img": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, i64, i64, i64, f32, i32, c_f32p, c_f32p, c_f32p, c_f32p, f32, i32,
+                                   C.c_void_p]),
     "a2f_layernorm_bwd_ws_bytes": (sz, [i64, i64]),
     "a2f_layernorm_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
     "a2f_colsum_ws_bytes": (sz, [i64, i64]),

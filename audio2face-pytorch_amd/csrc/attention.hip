@@ -18,6 +18,7 @@
 //   dQ      : wave = 32 queries (Q, dO fragments in registers), streams K / V tiles; dS^T feeds dQ^T from registers.
 // No atomics anywhere: every output element has exactly one owner (deterministic).
 #include "a2f_common.h"
+#include "img.h"
 
 namespace a2f {
 namespace attn {
@@ -45,6 +46,8 @@ struct Args {
   float* out_lse;
   float* out_delta;
   float* dqkv;           // (S*T, ld)
+  char* out_ctx_img;     // optional: the context also as a split-32 image (S*T, ldo) - the operand format of the out-projection GEMM and of its weight gradient
+  int dqkv_img;          // 1: dqkv is written as a split-32 image (its only readers are the q|k|v weight-gradient / data-gradient GEMMs)
   int ld, ldo, koff, voff;
   int S, T, H;
   float scale;
@@ -355,6 +358,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
       for (int gq = 0; gq < 4; ++gq) {
         const f32x4 v = {o[dt][4 * gq] * inv, o[dt][4 * gq + 1] * inv, o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv};
         *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * gq + 4 * h) = v;
+        if (a.out_ctx_img) img::store4(a.out_ctx_img + ((long long)seq * T + q) * a.ldo * 4, hc + 32 * dt + 8 * gq + 4 * h, v);
       }
     if (h == 0) a.out_lse[((long long)seq * a.H + head) * T + q] = m + __logf(lt);
   }
@@ -596,6 +600,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_fwd_fp8x3_kernel(const Args a
       for (int gq = 0; gq < 4; ++gq) {
         const f32x4 v = {o[dt][4 * gq] * inv, o[dt][4 * gq + 1] * inv, o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv};
         *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * gq + 4 * h) = v;
+        if (a.out_ctx_img) img::store4(a.out_ctx_img + ((long long)seq * T + q) * a.ldo * 4, hc + 32 * dt + 8 * gq + 4 * h, v);
       }
     if (h == 0) a.out_lse[((long long)seq * a.H + head) * T + q] = m + __logf(lt);
   }
@@ -730,8 +735,14 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) 
         const f32x4 x = {dk[dd][4 * gq], dk[dd][4 * gq + 1], dk[dd][4 * gq + 2], dk[dd][4 * gq + 3]};
         const float vs = DROP ? a.keep_scale : 1.f;
         const f32x4 y = {dv[dd][4 * gq] * vs, dv[dd][4 * gq + 1] * vs, dv[dd][4 * gq + 2] * vs, dv[dd][4 * gq + 3] * vs};
-        *reinterpret_cast<f32x4*>(krow + a.koff + 32 * dd + 8 * gq + 4 * h) = x;
-        *reinterpret_cast<f32x4*>(krow + a.voff + 32 * dd + 8 * gq + 4 * h) = y;
+        if (a.dqkv_img) {
+          char* kimg_row = reinterpret_cast<char*>(a.dqkv) + ((long long)seq * T + key) * a.ld * 4;
+          img::store4(kimg_row, hc + a.koff + 32 * dd + 8 * gq + 4 * h, x);
+          img::store4(kimg_row, hc + a.voff + 32 * dd + 8 * gq + 4 * h, y);
+        } else {
+          *reinterpret_cast<f32x4*>(krow + a.koff + 32 * dd + 8 * gq + 4 * h) = x;
+          *reinterpret_cast<f32x4*>(krow + a.voff + 32 * dd + 8 * gq + 4 * h) = y;
+        }
       }
   }
 }
@@ -837,7 +848,8 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dq_kernel(const Args a) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const f32x4 x = {dq[dd][4 * gq] * a.scale, dq[dd][4 * gq + 1] * a.scale, dq[dd][4 * gq + 2] * a.scale, dq[dd][4 * gq + 3] * a.scale};
-        *reinterpret_cast<f32x4*>(qrow + 32 * dd + 8 * gq + 4 * h) = x;
+        if (a.dqkv_img) img::store4(reinterpret_cast<char*>(a.dqkv) + ((long long)seq * T + q) * a.ld * 4, hc + 32 * dd + 8 * gq + 4 * h, x);
+        else *reinterpret_cast<f32x4*>(qrow + 32 * dd + 8 * gq + 4 * h) = x;
       }
   }
 }
@@ -866,7 +878,7 @@ static int check_common(const float* qkv, int64_t S, int64_t T, int64_t H, int64
 }  // namespace a2f
 
 static int attn_fwd_impl(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx, int64_t ldo,
-                         float* lse, const uint32_t* keep_q, float keep_scale, a2f_stream_t stream) {
+                         float* lse, const uint32_t* keep_q, float keep_scale, a2f_stream_t stream, void* ctx_img = nullptr) {
   using namespace a2f;
   using namespace a2f::attn;
   int rc = check_common(qkv, S, T, H, ld, ldo, precision);
@@ -874,6 +886,8 @@ static int attn_fwd_impl(const float* qkv, int64_t S, int64_t T, int64_t H, int6
   A2F_CHECK_ARG(ctx && lse && ((uintptr_t)ctx & 15) == 0, "attn_fwd: null / misaligned output");
   Args a{};
   a.qkv = qkv; a.out_ctx = ctx; a.out_lse = lse;
+  A2F_CHECK_ARG(ctx_img == nullptr || (ldo % 32 == 0 && ((uintptr_t)ctx_img & 127) == 0), "attn_fwd: an image output needs ldo %% 32 == 0 and a 128-byte aligned buffer");
+  a.out_ctx_img = (char*)ctx_img;
   a.ld = (int)ld; a.ldo = (int)ldo; a.koff = (int)(H * 64); a.voff = (int)(2 * H * 64);
   a.S = (int)S; a.T = (int)T; a.H = (int)H; a.scale = scale;
   a.keep_q = keep_q; a.TW = (int)a2f_attn_keep_words(T); a.keep_scale = keep_scale;
@@ -907,12 +921,13 @@ static int attn_fwd_impl(const float* qkv, int64_t S, int64_t T, int64_t H, int6
 
 static int attn_bwd_impl(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
                          int64_t ldo, float scale, int32_t precision, float* dqkv, float* delta_ws, const uint32_t* keep_q, const uint32_t* keep_k,
-                         float keep_scale, a2f_stream_t stream) {
+                         float keep_scale, a2f_stream_t stream, int32_t dqkv_format = 0) {
   using namespace a2f;
   using namespace a2f::attn;
   int rc = check_common(qkv, S, T, H, ld, ldo, precision);
   if (rc) return rc;
   A2F_CHECK_ARG(ctx && dctx && lse && dqkv && delta_ws, "attn_bwd: null pointer");
+  A2F_CHECK_ARG(dqkv_format == 0 || (dqkv_format == 1 && ld % 32 == 0 && ((uintptr_t)dqkv & 127) == 0), "attn_bwd: dqkv_format %d (1 = image: ld %% 32 == 0, 128-byte aligned)", dqkv_format);
   A2F_CHECK_ARG((((uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)dqkv) & 15) == 0, "attn_bwd: buffers must be 16-byte aligned");
   A2F_CHECK_ARG((keep_q == nullptr) == (keep_k == nullptr), "attn_bwd: both keep-bit layouts or neither");
   Args a{};
@@ -920,6 +935,7 @@ static int attn_bwd_impl(const float* qkv, const float* ctx, const float* dctx, 
   a.ld = (int)ld; a.ldo = (int)ldo; a.koff = (int)(H * 64); a.voff = (int)(2 * H * 64);
   a.S = (int)S; a.T = (int)T; a.H = (int)H; a.scale = scale;
   a.keep_q = keep_q; a.keep_k = keep_k; a.TW = (int)a2f_attn_keep_words(T); a.keep_scale = keep_scale;
+  a.dqkv_img = dqkv_format;
   if (precision == 2) precision = 0;          // fp8 is a forward mode: gradients would need dynamic scaling; the backward runs its bf16 kernels
   if (precision == 3) precision = 1;          // ... the fp32-class fp8x3 forward pairs with the bf16x3 backward
   hipStream_t st = (hipStream_t)stream;
@@ -963,4 +979,15 @@ extern "C" int a2f_attn_bwd_drop(const float* qkv, const float* ctx, const float
                                  const uint32_t* keep_kmajor, float keep_scale, a2f_stream_t stream) {
   if (!keep_qmajor || !keep_kmajor) return a2f::set_err(A2F_EINVAL, "attn_bwd_drop: null keep bits");
   return attn_bwd_impl(qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, precision, dqkv, delta_ws, keep_qmajor, keep_kmajor, keep_scale, stream);
+}
+
+extern "C" int a2f_attn_fwd_img(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx, int64_t ldo,
+                                float* lse, const uint32_t* keep_qmajor, float keep_scale, void* ctx_img, a2f_stream_t stream) {
+  return attn_fwd_impl(qkv, S, T, H, ld, scale, precision, ctx, ldo, lse, keep_qmajor, keep_scale, stream, ctx_img);
+}
+
+extern "C" int a2f_attn_bwd_img(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
+                                int64_t ldo, float scale, int32_t precision, void* dqkv, float* delta_ws, const uint32_t* keep_qmajor,
+                                const uint32_t* keep_kmajor, float keep_scale, int32_t dqkv_format, a2f_stream_t stream) {
+  return attn_bwd_impl(qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, precision, (float*)dqkv, delta_ws, keep_qmajor, keep_kmajor, keep_scale, stream, dqkv_format);
 }

@@ -22,6 +22,7 @@
 // TN kernel (both operands k-strided: weight gradients, K = rows of the batch): [k][256 lines] LDS images with 1088-byte pitch (one DMA piece
 //   per k-row), fragments by two ds_read_b64_tr_b16, split-K slabs folded by gemm_mfma_fold_kernel.
 #include "gemm_mfma.h"
+#include "img.h"
 
 namespace a2f {
 namespace mm {
@@ -78,19 +79,7 @@ __device__ __forceinline__ void gelu_pair(const f32x4 x, f32x4& g, f32x4& dg) {
   dg = f32x4{d0, d1, d2, d3};
 }
 
-__device__ __forceinline__ void split_store4(char* row_base, int n, const f32x4 v) {          // four consecutive columns n .. n + 3 of an image row
-  const f32x2_t v0 = {v.x, v.y}, v1 = {v.z, v.w};
-  const bf16x2_t h0 = __builtin_convertvector(v0, bf16x2_t), h1 = __builtin_convertvector(v1, bf16x2_t);
-  const f32x2_t r0 = v0 - __builtin_convertvector(h0, f32x2_t), r1 = v1 - __builtin_convertvector(h1, f32x2_t);
-  u32x2_t hi, lo;
-  hi.x = __builtin_bit_cast(unsigned, h0);
-  hi.y = __builtin_bit_cast(unsigned, h1);
-  lo.x = __builtin_bit_cast(unsigned, __builtin_convertvector(r0, bf16x2_t));
-  lo.y = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
-  char* p = row_base + (n >> 5) * 128 + (n & 31) * 2;
-  *reinterpret_cast<u32x2_t*>(p) = hi;
-  *reinterpret_cast<u32x2_t*>(p + 64) = lo;
-}
+__device__ __forceinline__ void split_store4(char* row_base, int n, const f32x4 v) { a2f::img::store4(row_base, n, v); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Epilogue of one wave's 128 x 64 block (transposed accumulators: lane = row of C, four consecutive registers = four consecutive columns).
@@ -115,6 +104,12 @@ __device__ __forceinline__ void epilogue_wave(const Args& a, const f32x16 (&acc)
       bv[j][q] = (a.bias && a.split_k <= 1 && n < a.N) ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   const unsigned ldc = a.split_k > 1 ? (unsigned)a.N : (unsigned)a.ldc;
+  const bool do_cs = a.c_colsum != nullptr && a.split_k <= 1;        // wave-uniform
+  f32x4 cs[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cs[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 128 + i * 32 + (lane & 31);
@@ -166,6 +161,7 @@ __device__ __forceinline__ void epilogue_wave(const Args& a, const f32x16 (&acc)
             v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rax, ok ? ((unsigned)m * (unsigned)a.ldaux + (unsigned)n) * 4u : NOWHERE, 0, 0));
           }
         }
+        if (do_cs && ok) cs[j][q] += v;
         if (a.c_format == 1) {
           if (ok) split_store4(reinterpret_cast<char*>(a.C) + (size_t)crow * 4u, n, v);
         } else {
@@ -174,6 +170,40 @@ __device__ __forceinline__ void epilogue_wave(const Args& a, const f32x16 (&acc)
       }
     }
   }
+  // column sums of the stored values over this wave's 128 rows (the bias gradient of the Linear whose input gradient C is): a fixed butterfly over the 32
+  // row-lanes, one partial row per (m-tile, wave row) in the workspace, folded in order by colsum_fold_kernel - deterministic, no atomics
+  if (do_cs) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = cs[j][q];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          v.x += __shfl_xor(v.x, o, 64);
+          v.y += __shfl_xor(v.y, o, 64);
+          v.z += __shfl_xor(v.z, o, 64);
+          v.w += __shfl_xor(v.w, o, 64);
+        }
+        const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * h;
+        if ((lane & 31) == 0 && n < a.N) *reinterpret_cast<f32x4*>(a.ws + (long long)((m0 >> 8) * 2 + wm) * a.N + n) = v;
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ part, int P, int N, float* __restrict__ out) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;               // four chains, fixed order
+  int p = 0;
+  for (; p + 4 <= P; p += 4) {
+    v0 += part[(long long)p * N + n];
+    v1 += part[(long long)(p + 1) * N + n];
+    v2 += part[(long long)(p + 2) * N + n];
+    v3 += part[(long long)(p + 3) * N + n];
+  }
+  for (; p < P; ++p) v0 += part[(long long)p * N + n];
+  out[n] = (v0 + v1) + (v2 + v3);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -409,7 +439,15 @@ static int launch_img_t(const Args& a, hipStream_t st) {
 }
 
 // both operands format 1; trans flags equal (NT: both k-contiguous, TN: both line-contiguous); checked by the caller (a2f_mm)
-int launch_img(const Args& a, bool tn, hipStream_t st) { return tn ? launch_img_t<true>(a, st) : launch_img_t<false>(a, st); }
+int launch_img(const Args& a, bool tn, hipStream_t st) {
+  const int rc = tn ? launch_img_t<true>(a, st) : launch_img_t<false>(a, st);
+  if (rc) return rc;
+  if (!tn && a.c_colsum) {
+    const int P = 2 * (int)cdiv(a.M, img::TB);
+    hipLaunchKernelGGL(img::colsum_fold_kernel, dim3((unsigned)cdiv(a.N, 256)), dim3(256), 0, st, a.ws, P, a.N, a.c_colsum);
+  }
+  return A2F_OK;
+}
 
 }  // namespace mm
 }  // namespace a2f

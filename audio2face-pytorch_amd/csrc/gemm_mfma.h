@@ -48,6 +48,7 @@ struct Args {
   const unsigned* keep;          // dropout keep bits of C (csrc/dropout.hip: word (m, n >> 5), bit n & 31), applied after the activation
   long long keep_wpr;
   float keep_scale;
+  float* c_colsum;                // image-operand k-contiguous products: c_colsum[n] = sum_m C[m][n] (partials in ws, folded in fixed order)
   int c_format;                   // 0: C is fp32; 1: C is a split-32 image (csrc/gemm_img.hip; image-operand kernels only)
 };
 

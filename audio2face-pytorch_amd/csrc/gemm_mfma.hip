@@ -570,6 +570,8 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   a.keep_scale = d->keep_scale;
   const bool at = d->A.trans != 0, bt = d->B.trans != 0;
   a.c_format = d->c_format;
+  a.c_colsum = d->c_colsum;
+  A2F_CHECK_ARG(d->c_colsum == nullptr || (d->A.format == 1 && !at && d->ws != nullptr), "a2f_mm: c_colsum needs image operands (k-contiguous) and a workspace");
   A2F_CHECK_ARG(d->A.format == d->B.format, "a2f_mm: both operands must have the same format (%d vs %d)", d->A.format, d->B.format);
   A2F_CHECK_ARG(d->c_format == 0 || (d->c_format == 1 && d->A.format == 1), "a2f_mm: c_format %d (1 = image output, image-operand products only)", d->c_format);
   if (d->A.format == 1) {

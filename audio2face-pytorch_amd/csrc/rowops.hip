@@ -3,6 +3,7 @@
 // All are HBM-streaming: one wave per row, float4 per lane, wave64 butterfly reductions; every cross-row reduction
 // (dgamma, dbeta, column sums) goes through per-workgroup partial slabs folded in fixed order (deterministic).
 #include "a2f_common.h"
+#include "img.h"
 
 namespace a2f {
 
@@ -19,7 +20,7 @@ __device__ __forceinline__ float gelu_grad(float x) {
 template <int NV>
 __global__ __launch_bounds__(RO_THREADS) void layernorm_fwd_kernel(const float* __restrict__ x, int64_t R, int C, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float eps, float* __restrict__ y,
-                                                                   float* __restrict__ mean, float* __restrict__ rstd) {
+                                                                   float* __restrict__ mean, float* __restrict__ rstd, char* __restrict__ y_img) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * (RO_THREADS / 64) + (threadIdx.x >> 6);
   if (row >= R) return;
@@ -45,13 +46,16 @@ __global__ __launch_bounds__(RO_THREADS) void layernorm_fwd_kernel(const float* 
   }
   const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
   float4* yr = reinterpret_cast<float4*>(y + row * C);
+  char* yi = y_img + row * C * 4;                          // split-32 image of y (the operand format of the image GEMMs): same row pitch as fp32
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c4 = lane + 64 * i;
     if (c4 < nv) {
       const float4 g = reinterpret_cast<const float4*>(gamma)[c4], b = reinterpret_cast<const float4*>(beta)[c4];
-      yr[c4] = make_float4((v[i].x - mu) * rs * g.x + b.x, (v[i].y - mu) * rs * g.y + b.y, (v[i].z - mu) * rs * g.z + b.z,
-                           (v[i].w - mu) * rs * g.w + b.w);
+      const float4 o = make_float4((v[i].x - mu) * rs * g.x + b.x, (v[i].y - mu) * rs * g.y + b.y, (v[i].z - mu) * rs * g.z + b.z,
+                                   (v[i].w - mu) * rs * g.w + b.w);
+      if (y) yr[c4] = o;
+      if (y_img) img::store4(yi, 4 * c4, f32x4{o.x, o.y, o.z, o.w});
     }
   }
   if (lane == 0) {
@@ -68,7 +72,9 @@ __global__ __launch_bounds__(RO_THREADS) void layernorm_fwd_kernel(const float* 
 template <int NV>
 __global__ __launch_bounds__(RO_THREADS) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                                                    const float* __restrict__ rstd, const float* __restrict__ gamma, int64_t R, int C,
-                                                                   float* __restrict__ dx, float* __restrict__ part) {
+                                                                   float* __restrict__ dx, float* __restrict__ part, const unsigned* __restrict__ keep,
+                                                                   int64_t keep_wpr, float keep_scale, char* __restrict__ dxm_img) {
+  // third partial: column sums of what the Linear below receives = dx, or (keep given) the masked gradient keep ? dx * keep_scale : 0
   __shared__ float red[3][RO_THREADS / 64][NV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = C >> 2;
@@ -114,6 +120,14 @@ __global__ __launch_bounds__(RO_THREADS) void layernorm_bwd_kernel(const float* 
         dxr[c4] = o;
         ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
         ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+        if (keep) {                                        // train-mode dropout of the Linear's output: its gradient passes the same mask
+          const unsigned b = keep[row * keep_wpr + (c4 >> 3)] >> ((c4 & 7) * 4);
+          o.x = (b & 1u) ? o.x * keep_scale : 0.f;
+          o.y = (b & 2u) ? o.y * keep_scale : 0.f;
+          o.z = (b & 4u) ? o.z * keep_scale : 0.f;
+          o.w = (b & 8u) ? o.w * keep_scale : 0.f;
+        }
+        if (dxm_img) img::store4(dxm_img + row * C * 4, 4 * c4, f32x4{o.x, o.y, o.z, o.w});
         ax[i].x += o.x; ax[i].y += o.y; ax[i].z += o.z; ax[i].w += o.w;
       }
     }
@@ -169,6 +183,16 @@ __global__ __launch_bounds__(RO_THREADS) void colsum_partial_kernel(const float*
   *reinterpret_cast<float4*>(part + (int64_t)blockIdx.x * C + 4 * c4) = acc;
 }
 
+// the same over a split-32 image (values hi + lo): the bias gradient of a Linear whose output gradient only exists as an image
+__global__ __launch_bounds__(RO_THREADS) void colsum_img_partial_kernel(const char* __restrict__ x, int64_t R, int C, int64_t ld, float* __restrict__ part) {
+  const int c4 = blockIdx.y * RO_THREADS + threadIdx.x;
+  const int nv = C >> 2;
+  if (c4 >= nv) return;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t row = blockIdx.x; row < R; row += gridDim.x) acc += img::load4(x + row * ld * 4, 4 * c4);
+  *reinterpret_cast<f32x4*>(part + (int64_t)blockIdx.x * C + 4 * c4) = acc;
+}
+
 // dz = dy * gelu'(z), float4 grid-stride (may run in place: out == dy)
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ z, int64_t n4, float4* __restrict__ out) {
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -189,22 +213,40 @@ extern "C" size_t a2f_layernorm_bwd_ws_bytes(int64_t R, int64_t C) { return (siz
 
 extern "C" int a2f_layernorm_fwd(const float* x, int64_t R, int64_t C, const float* gamma, const float* beta, float eps, float* y, float* mean,
                                  float* rstd, a2f_stream_t stream) {
+  A2F_CHECK_ARG(y != nullptr, "layernorm_fwd: null pointer");
+  return a2f_layernorm_fwd_img(x, R, C, gamma, beta, eps, y, nullptr, mean, rstd, stream);
+}
+
+extern "C" int a2f_layernorm_fwd_img(const float* x, int64_t R, int64_t C, const float* gamma, const float* beta, float eps, float* y, void* y_img_, float* mean,
+                                     float* rstd, a2f_stream_t stream) {
   using namespace a2f;
-  A2F_CHECK_ARG(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+  char* y_img = (char*)y_img_;
+  A2F_CHECK_ARG(x && gamma && beta && (y || y_img) && mean && rstd, "layernorm_fwd: null pointer");
+  A2F_CHECK_ARG(y_img == nullptr || (C % 32 == 0 && ((uintptr_t)y_img & 127) == 0), "layernorm_fwd: an image output needs C %% 32 == 0 and a 128-byte aligned buffer");
   A2F_CHECK_ARG(R > 0 && C > 0 && C % 4 == 0 && C <= RO_MAXV * 256, "layernorm_fwd: R=%lld C=%lld (C must be a multiple of 4, <= 1024)", (long long)R, (long long)C);
   A2F_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "layernorm_fwd: buffers must be 16-byte aligned");
   const dim3 grid((unsigned)cdiv(R, RO_THREADS / 64));
   hipStream_t st = (hipStream_t)stream;
-  if (C <= 256) hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, dim3(RO_THREADS), 0, st, x, R, (int)C, gamma, beta, eps, y, mean, rstd);
-  else if (C <= 512) hipLaunchKernelGGL(layernorm_fwd_kernel<2>, grid, dim3(RO_THREADS), 0, st, x, R, (int)C, gamma, beta, eps, y, mean, rstd);
-  else hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, dim3(RO_THREADS), 0, st, x, R, (int)C, gamma, beta, eps, y, mean, rstd);
+  if (C <= 256) hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, dim3(RO_THREADS), 0, st, x, R, (int)C, gamma, beta, eps, y, mean, rstd, y_img);
+  else if (C <= 512) hipLaunchKernelGGL(layernorm_fwd_kernel<2>, grid, dim3(RO_THREADS), 0, st, x, R, (int)C, gamma, beta, eps, y, mean, rstd, y_img);
+  else hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, dim3(RO_THREADS), 0, st, x, R, (int)C, gamma, beta, eps, y, mean, rstd, y_img);
   A2F_CHECK_LAUNCH("layernorm_fwd");
   return A2F_OK;
 }
 
 extern "C" int a2f_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, int64_t R, int64_t C,
                                  float* dx, float* dgamma, float* dbeta, float* dx_colsum, void* ws, size_t ws_bytes, a2f_stream_t stream) {
+  return a2f_layernorm_bwd_img(dy, x, mean, rstd, gamma, R, C, dx, dgamma, dbeta, dx_colsum, nullptr, 0, 1.f, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int a2f_layernorm_bwd_img(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, int64_t R, int64_t C,
+                                     float* dx, float* dgamma, float* dbeta, float* dxm_colsum, const uint32_t* keep_bits, int64_t keep_wpr, float keep_scale,
+                                     void* dxm_img_, void* ws, size_t ws_bytes, a2f_stream_t stream) {
   using namespace a2f;
+  float* dx_colsum = dxm_colsum;
+  char* dxm_img = (char*)dxm_img_;
+  A2F_CHECK_ARG(dxm_img == nullptr || (C % 32 == 0 && ((uintptr_t)dxm_img & 127) == 0), "layernorm_bwd: an image output needs C %% 32 == 0 and a 128-byte aligned buffer");
+  A2F_CHECK_ARG(keep_bits == nullptr || keep_wpr * 32 >= C, "layernorm_bwd: keep_wpr * 32 < C");
   A2F_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws, "layernorm_bwd: null pointer");
   A2F_CHECK_ARG(R > 0 && C > 0 && C % 4 == 0 && C <= RO_MAXV * 256, "layernorm_bwd: R=%lld C=%lld", (long long)R, (long long)C);
   A2F_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)ws) & 15) == 0, "layernorm_bwd: buffers must be 16-byte aligned");
@@ -212,9 +254,9 @@ extern "C" int a2f_layernorm_bwd(const float* dy, const float* x, const float* m
   const int nb = ln_blocks_bwd(R);
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)ws;
-  if (C <= 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(nb), dim3(RO_THREADS), 0, st, dy, x, mean, rstd, gamma, R, (int)C, dx, part);
-  else if (C <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nb), dim3(RO_THREADS), 0, st, dy, x, mean, rstd, gamma, R, (int)C, dx, part);
-  else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nb), dim3(RO_THREADS), 0, st, dy, x, mean, rstd, gamma, R, (int)C, dx, part);
+  if (C <= 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(nb), dim3(RO_THREADS), 0, st, dy, x, mean, rstd, gamma, R, (int)C, dx, part, keep_bits, keep_wpr, keep_scale, dxm_img);
+  else if (C <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nb), dim3(RO_THREADS), 0, st, dy, x, mean, rstd, gamma, R, (int)C, dx, part, keep_bits, keep_wpr, keep_scale, dxm_img);
+  else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nb), dim3(RO_THREADS), 0, st, dy, x, mean, rstd, gamma, R, (int)C, dx, part, keep_bits, keep_wpr, keep_scale, dxm_img);
   A2F_CHECK_LAUNCH("layernorm_bwd");
   hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)cdiv(3 * C, 64)), dim3(256), 0, st, part, nb, 3, (int)C, dgamma, dbeta, dx_colsum);
   A2F_CHECK_LAUNCH("layernorm_bwd fold");
@@ -238,6 +280,20 @@ extern "C" int a2f_colsum(const float* x, int64_t R, int64_t C, int64_t ld, floa
   A2F_CHECK_LAUNCH("colsum");
   hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, st, (const float*)ws, nb, 1, (int)C, out, (float*)nullptr, (float*)nullptr);
   A2F_CHECK_LAUNCH("colsum fold");
+  return A2F_OK;
+}
+
+extern "C" int a2f_colsum_img(const void* x, int64_t R, int64_t C, int64_t ld, float* out, void* ws, size_t ws_bytes, a2f_stream_t stream) {
+  using namespace a2f;
+  A2F_CHECK_ARG(x && out && ws, "colsum_img: null pointer");
+  A2F_CHECK_ARG(R > 0 && C > 0 && C % 4 == 0 && ld % 32 == 0 && ld >= C && ((uintptr_t)x & 127) == 0, "colsum_img: R=%lld C=%lld ld=%lld", (long long)R, (long long)C, (long long)ld);
+  if (ws_bytes < a2f_colsum_ws_bytes(R, C)) return set_err(A2F_EWORKSPACE, "colsum_img: workspace too small");
+  const int nb = (int)(R < 256 ? R : 256);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_img_partial_kernel, dim3(nb, (unsigned)cdiv(C / 4, RO_THREADS)), dim3(RO_THREADS), 0, st, (const char*)x, R, (int)C, ld, (float*)ws);
+  A2F_CHECK_LAUNCH("colsum_img");
+  hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, st, (const float*)ws, nb, 1, (int)C, out, (float*)nullptr, (float*)nullptr);
+  A2F_CHECK_LAUNCH("colsum_img fold");
   return A2F_OK;
 }
 

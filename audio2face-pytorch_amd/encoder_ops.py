@@ -21,6 +21,8 @@ FUSED_QKV = _os.environ.get("A2F_FUSED_QKV", "1") != "0"         # A-B hook: 0 =
 POSCONV_WGRAD_T = _os.environ.get("A2F_POSCONV_WGRAD_T", "1") != "0"   # A-B hook: 0 = positional-conv weight gradient with the 48 channels on the m axis
 
 
+MM_IMG = _os.environ.get("A2F_MM_IMG", "1") != "0"               # A-B hook: 0 = the Transformer layers' products on the fp32-operand kernels
+IMG_MIN_ROWS = int(_os.environ.get("A2F_MM_IMG_MIN_ROWS", "2048"))   # below this many rows the 256 x 256 image tiles leave the chip empty: fp32-operand kernels
 WGRAD_STREAM = _os.environ.get("A2F_WGRAD_STREAM", "1") != "0"   # A-B hook: 0 = weight gradients in line on the launch stream
 _wgrad_streams = {}
 
@@ -167,7 +169,14 @@ class EncoderLayerFn(torch.autograd.Function):
     incoming gradient of the two hidden sites with one streaming pass each and the activation site in the data-gradient epilogue."""
 
     @staticmethod
-    def forward(ctx, x, S, T, heads, masks, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2):
+    def use_images(be, M, d, F):
+        """The image-operand path (csrc/gemm_img.hip): bf16x3 products only, widths in whole 32-blocks, enough rows to fill 256-row tiles."""
+        return MM_IMG and be.mm_precision == 1 and d % 32 == 0 and F % 32 == 0 and M >= IMG_MIN_ROWS and hasattr(be, "split_img")
+
+    @staticmethod
+    def forward(ctx, x, x_img, S, T, heads, masks, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2):
+        """Returns (h2, h2_img): the layer output as fp32 rows and (image path; else None) as a split-32 image for the next layer's q|k|v product.
+        x_img: the same for the input (None: made here by a splitting pass)."""
         be = ops.backend()
         _save_prec(ctx)
         xc = _f32c(x)
@@ -177,6 +186,9 @@ class EncoderLayerFn(torch.autograd.Function):
         M, d = xc.shape
         F = W1.shape[0]
         keep = any(ctx.needs_input_grad)
+        ctx.img = EncoderLayerFn.use_images(be, M, d, F)
+        if ctx.img:
+            return EncoderLayerFn._forward_img(ctx, be, xc, x_img, S, T, heads, mk, keep, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2)
         # q | k | v as ONE product against the stacked (3d, d) weight (a 7 MB copy per call): one launch and one tile tail instead of three
         Wqkv, bqkv = torch.cat((Wq, Wk, Wv), 0), torch.cat((bq, bk, bv), 0)
         qkv = _new(xc, M, 3 * d)
@@ -207,12 +219,104 @@ class EncoderLayerFn(torch.autograd.Function):
             ctx.save_for_backward(xc, qkv, att, lse, a1, m1, r1, h1, z, g, a2, m2, r2, Wqkv, Wo, g1, W1, W2, g2)
             ctx.dims = (S, T, heads, scale)
             ctx.masks = mk
-        return h2
+        return h2, None                         # no image on this path
+
+    # ---- the same layer on split-32 image operands (csrc/gemm_img.hip): every GEMM input is an image written by its producer ----------------
+    @staticmethod
+    def _wimg(be, W):
+        """(image of W, image of W^T): forward / weight-gradient products read W (N, K) k-contiguously, data gradients read W^T."""
+        N, K = W.shape
+        wi, wt = torch.empty_like(W), torch.empty(K, N, device=W.device, dtype=torch.float32)
+        be.split_img(W, N, K, K, wi, K)
+        be.split_img(W, N, K, K, wt, N, transpose=True)
+        return wi, wt
+
+    @staticmethod
+    def _forward_img(ctx, be, xc, x_img, S, T, heads, mk, keep, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2):
+        M, d = xc.shape
+        F = W1.shape[0]
+        I = lambda t, ld, **kw: MMOp(t, ld, img=True, **kw)
+        if x_img is None:
+            x_img = _new(xc, M, d)
+            be.split_img(xc, M, d, d, x_img, d)
+        Wqkv, bqkv = torch.cat((Wq, Wk, Wv), 0), torch.cat((bq, bk, bv), 0)
+        Wqkv_i, Wqkv_t = EncoderLayerFn._wimg(be, Wqkv)
+        Wo_i, Wo_t = EncoderLayerFn._wimg(be, Wo)
+        W1_i, W1_t = EncoderLayerFn._wimg(be, W1)
+        W2_i, W2_t = EncoderLayerFn._wimg(be, W2)
+        qkv = _new(xc, M, 3 * d)
+        be.mm(I(x_img, d), I(Wqkv_i, d), qkv, M, 3 * d, d, 3 * d, bias=bqkv)
+        att, att_img, lse = _new(xc, M, d), _new(xc, M, d), _new(xc, S, heads, T)
+        scale = float((d // heads) ** -0.5)
+        be.attn_fwd_img(qkv, S, T, heads, 3 * d, scale, att, d, lse, att_img, keep=(mk["attn"][0], mk["attn"][2]) if "attn" in mk else None)
+        a1 = _new(xc, M, d)
+        be.mm(I(att_img, d), I(Wo_i, d), a1, M, d, d, d, bias=bo, aux=xc, ldaux=d, aux_mode=MM_AUX_ADD, keep=mk.get("hid1"))
+        h1, h1_img, m1, r1 = _new(xc, M, d), _new(xc, M, d), _new(xc, M), _new(xc, M)
+        be.layernorm_fwd_img(a1, M, d, g1, b1, LN_EPS, h1, h1_img, m1, r1)
+        z = _new(xc, M, F) if keep else None
+        g_img = _new(xc, M, F)                                  # GELU(intermediate_dense) exists only as the image the next product reads
+        be.mm(I(h1_img, d), I(W1_i, d), g_img, M, F, d, F, bias=c1, act=MM_ACT_GELU_SAVE_GRAD if keep else MM_ACT_GELU, C2=z, keep=mk.get("act"), c_img=True)
+        a2 = _new(xc, M, d)
+        be.mm(I(g_img, F), I(W2_i, F), a2, M, d, F, d, bias=c2, aux=h1, ldaux=d, aux_mode=MM_AUX_ADD, keep=mk.get("hid2"))
+        h2, h2_img, m2, r2 = _new(xc, M, d), _new(xc, M, d), _new(xc, M), _new(xc, M)
+        be.layernorm_fwd_img(a2, M, d, g2, b2, LN_EPS, h2, h2_img, m2, r2)
+        if keep:
+            ctx.save_for_backward(x_img, qkv, att, att_img, lse, a1, m1, r1, h1_img, z, g_img, a2, m2, r2, Wqkv_t, Wo_t, W1_t, W2_t, g1, g2)
+            ctx.dims = (S, T, heads, scale)
+            ctx.masks = mk
+        ctx.mark_non_differentiable(h2_img)
+        return h2, h2_img
+
+    @staticmethod
+    def _backward_img(ctx, be, dh2):
+        x_img, qkv, att, att_img, lse, a1, m1, r1, h1_img, z, g_img, a2, m2, r2, Wqkv_t, Wo_t, W1_t, W2_t, g1, g2 = ctx.saved_tensors
+        S, T, heads, scale = ctx.dims
+        mk = ctx.masks
+        M, d = x_img.shape
+        F = g_img.shape[1]
+        new = lambda *s: _new(x_img, *s)
+        I = lambda t, ld, **kw: MMOp(t, ld, img=True, **kw)
+        dh2 = _f32c(dh2)
+        lane = _WeightGradLane(x_img)
+        # final_layer_norm: da2 (fp32: the residual branch) + the gradient output_dense receives, through its dropout mask, as an image + its column sums
+        da2, dy2_img, dg2, db2, dc2 = new(M, d), new(M, d), new(d), new(d), new(d)
+        be.layernorm_bwd_img(dh2, a2, m2, r2, g2, M, d, da2, dg2, db2, dxm_colsum=dc2, keep=mk.get("hid2"), dxm_img=dy2_img)
+        dW2 = new(d, F)
+        lane.run(lambda: be.mm(I(dy2_img, d, trans=True), I(g_img, F, trans=True), dW2, d, F, M, F, split_k=0))
+        # through output_dense and GELU: the epilogue multiplies by the saved derivative (and the activation-dropout mask), writes the image the two
+        # products of intermediate_dense read, and collects its column sums = intermediate_dense's bias gradient
+        dz_img, dc1 = new(M, F), new(F)
+        be.mm(I(dy2_img, d), I(W2_t, d), dz_img, M, F, d, F, keep=mk.get("act"), aux=z, aux_mode=MM_AUX_MUL_LIKE_C, c_img=True, c_colsum=dc1)
+        dW1 = new(F, d)
+        lane.run(lambda: be.mm(I(dz_img, F, trans=True), I(h1_img, d, trans=True), dW1, F, d, M, d, split_k=0))
+        dh1 = new(M, d)
+        be.mm(I(dz_img, F), I(W1_t, F), dh1, M, d, F, d, aux=da2, ldaux=d, aux_mode=MM_AUX_ADD)
+        da1, dy1_img, dg1, db1, dbo = new(M, d), new(M, d), new(d), new(d), new(d)
+        be.layernorm_bwd_img(dh1, a1, m1, r1, g1, M, d, da1, dg1, db1, dxm_colsum=dbo, keep=mk.get("hid1"), dxm_img=dy1_img)
+        dWo = new(d, d)
+        lane.run(lambda: be.mm(I(dy1_img, d, trans=True), I(att_img, d, trans=True), dWo, d, d, M, d, split_k=0))
+        datt = new(M, d)
+        be.mm(I(dy1_img, d), I(Wo_t, d), datt, M, d, d, d)
+        dqkv_img = new(M, 3 * d)
+        be.attn_bwd_img(qkv, att, datt, lse, S, T, heads, 3 * d, d, scale, dqkv_img,
+                        keep=(mk["attn"][0], mk["attn"][1], mk["attn"][2]) if "attn" in mk else None)
+        dbqkv, dWqkv = new(3 * d), new(3 * d, d)
+        lane.run(lambda: (be.mm(I(dqkv_img, 3 * d, trans=True), I(x_img, d, trans=True), dWqkv, 3 * d, d, M, d, split_k=0),
+                          be.colsum_img(dqkv_img, M, 3 * d, 3 * d, dbqkv)))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = new(M, d)
+            be.mm(I(dqkv_img, 3 * d), I(Wqkv_t, 3 * d), dx, M, d, 3 * d, d, aux=da1, ldaux=d, aux_mode=MM_AUX_ADD)
+        lane.join()
+        return (dx, None, None, None, None, None, dWqkv[0:d], dbqkv[0:d], dWqkv[d:2 * d], dbqkv[d:2 * d], dWqkv[2 * d:], dbqkv[2 * d:], dWo, dbo, dg1, db1,
+                dW1, dc1, dW2, dc2, dg2, db2)
 
     @staticmethod
     @_restores_precision
-    def backward(ctx, dh2):
+    def backward(ctx, dh2, _dh2_img=None):
         be = ops.backend()
+        if ctx.img:
+            return EncoderLayerFn._backward_img(ctx, be, dh2)
         xc, qkv, att, lse, a1, m1, r1, h1, z, g, a2, m2, r2, Wqkv, Wo, g1, W1, W2, g2 = ctx.saved_tensors
         S, T, heads, scale = ctx.dims
         mk = ctx.masks
@@ -281,7 +385,7 @@ class EncoderLayerFn(torch.autograd.Function):
                     be.mm(MMOp(dqkv, 3 * d, ptr_off=i * d), MMOp(Wqkv, d, trans=True, ptr_off=i * d * d), dx, M, d, d, d, accumulate=i > 0,
                           **(dict(aux=da1, ldaux=d, aux_mode=MM_AUX_ADD) if i == 0 else {}))
         lane.join()                                  # outputs were allocated on the launch stream; the lane only wrote them
-        return (dx, None, None, None, None, dWqkv[0:d], dbqkv[0:d], dWqkv[d:2 * d], dbqkv[d:2 * d], dWqkv[2 * d:], dbqkv[2 * d:], dWo, dbo, dg1, db1,
+        return (dx, None, None, None, None, None, dWqkv[0:d], dbqkv[0:d], dWqkv[d:2 * d], dbqkv[d:2 * d], dWqkv[2 * d:], dbqkv[2 * d:], dWo, dbo, dg1, db1,
                 dW1, dc1, dW2, dc2, dg2, db2)
 
 

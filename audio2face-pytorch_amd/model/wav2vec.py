@@ -186,16 +186,17 @@ class Wav2Vec2Model(nn.Module):
         if masks is not None and masks.enc is not None:
             h = DropoutFn.apply(h, masks.enc[0], masks.enc[1])
         self.forwards_run += 1
+        h_img = None                                                         # the layer input as a split-32 image, handed from layer to layer (encoder_ops)
         for l, layer in enumerate(enc.layers):
             if masks is not None and masks.layer_skip[l]:
                 continue                                                     # LayerDrop (HF Wav2Vec2Encoder.forward)
             self.layers_run += 1
             a, f = layer.attention, layer.feed_forward
-            h = EncoderLayerFn.apply(h, S, T, self.heads, masks.layers[l] if masks is not None else None,
-                                     a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias, a.v_proj.weight,
-                                     a.v_proj.bias, a.out_proj.weight, a.out_proj.bias, layer.layer_norm.weight, layer.layer_norm.bias,
-                                     f.intermediate_dense.weight, f.intermediate_dense.bias, f.output_dense.weight, f.output_dense.bias,
-                                     layer.final_layer_norm.weight, layer.final_layer_norm.bias)
+            h, h_img = EncoderLayerFn.apply(h, h_img, S, T, self.heads, masks.layers[l] if masks is not None else None,
+                                            a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias, a.v_proj.weight,
+                                            a.v_proj.bias, a.out_proj.weight, a.out_proj.bias, layer.layer_norm.weight, layer.layer_norm.bias,
+                                            f.intermediate_dense.weight, f.intermediate_dense.bias, f.output_dense.weight, f.output_dense.bias,
+                                            layer.final_layer_norm.weight, layer.final_layer_norm.bias)
         return h.view(S, T, d)
 
     def forward(self, input_values, dataset="vocaset", attention_mask=None, frame_num=None, **_):

@@ -138,9 +138,10 @@ class HipBackend:
 
     def mm(self, A: "MMOp", B: "MMOp", Cout, M, N, K, ldc, *, c_off=0, c_rows_per_seq=0, c_seq_stride=0, C2=None, bias=None, aux=None,
            ldaux=0, act=MM_ACT_NONE, aux_mode=MM_AUX_NONE, precision=None, split_k=1, batch=1, a_bstride=0, b_bstride=0, c_bstride=0,
-           bias_bstride=0, aux_bstride=0, accumulate=False, alpha=1.0, tag="gemm_mfma", keep=None, a_rowsum=None, c_img=False):
+           bias_bstride=0, aux_bstride=0, accumulate=False, alpha=1.0, tag="gemm_mfma", keep=None, a_rowsum=None, c_img=False, c_colsum=None):
         """C[m,n] = epi(alpha * sum_k A(m,k) B(k,n)) on the bf16 matrix pipe (contract: include/a2f_hip.h, a2f_mm).
-        keep = (bits int32 (M, wpr), scale): train-mode dropout of C in the epilogue.  c_img: C is written as a split-32 image."""
+        keep = (bits int32 (M, wpr), scale): train-mode dropout of C in the epilogue.  c_img: C is written as a split-32 image.
+        c_colsum (N): receives the column sums of the stored C (image operands only)."""
         _chk(A.t, B.t, Cout, C2, bias, aux)
         d = MMDesc()
         A.fill(d.A)
@@ -164,6 +165,10 @@ class HipBackend:
         if split_k > 1:
             ws = torch.empty(batch * split_k * M * N + (split_k * M if a_rowsum is not None else 0), device=Cout.device, dtype=torch.float32)
             d.ws = _ptr(ws)
+        if c_colsum is not None:
+            _chk(c_colsum)
+            ws = torch.empty(2 * ((M + 255) // 256) * N, device=Cout.device, dtype=torch.float32)
+            d.ws, d.c_colsum = _ptr(ws), _ptr(c_colsum)
         if a_rowsum is not None:
             _chk(a_rowsum)
             if _NO_FUSED_ROWSUM:                                # A-B hook: the bias gradient as its own pass over dY
@@ -208,6 +213,30 @@ class HipBackend:
         ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
         _lib.check(self.lib.a2f_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), R, Cc, _ptr(dx), _ptr(dgamma), _ptr(dbeta),
                                               _ptr(dx_colsum), _ptr(ws), nb, self._stream(x)), "a2f_layernorm_bwd")
+
+    def layernorm_fwd_img(self, x, R, Cc, gamma, beta, eps, y, y_img, mean, rstd):
+        """layernorm_fwd that also (y given) or only (y None) writes y as a split-32 image."""
+        _chk(x, gamma, beta, y, y_img, mean, rstd)
+        _lib.check(self.lib.a2f_layernorm_fwd_img(_ptr(x), R, Cc, _ptr(gamma), _ptr(beta), eps, _ptr(y), _ptr(y_img), _ptr(mean), _ptr(rstd),
+                                                  self._stream(x)), "a2f_layernorm_fwd_img")
+
+    def layernorm_bwd_img(self, dy, x, mean, rstd, gamma, R, Cc, dx, dgamma, dbeta, dxm_colsum=None, keep=None, dxm_img=None):
+        """layernorm_bwd + the masked gradient dxm = keep ? dx * scale : 0 (keep = (bits, scale); None: dxm = dx) as an image and its column sums."""
+        _chk(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, dxm_colsum, dxm_img)
+        nb = self.lib.a2f_layernorm_bwd_ws_bytes(R, Cc)
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
+        bits, wpr, scale = (None, 0, 1.0)
+        if keep is not None:
+            _chk_bits(keep[0])
+            bits, wpr, scale = keep[0].data_ptr(), keep[0].shape[-1], float(keep[1])
+        _lib.check(self.lib.a2f_layernorm_bwd_img(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), R, Cc, _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+                                                  _ptr(dxm_colsum), bits, wpr, scale, _ptr(dxm_img), _ptr(ws), nb, self._stream(x)), "a2f_layernorm_bwd_img")
+
+    def colsum_img(self, x, R, Cc, ld, out):
+        _chk(x, out)
+        nb = self.lib.a2f_colsum_ws_bytes(R, Cc)
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.a2f_colsum_img(_ptr(x), R, Cc, ld, _ptr(out), _ptr(ws), nb, self._stream(x)), "a2f_colsum_img")
 
     def colsum(self, x, R, Cc, ld, out, x_off=0):
         _chk(x, out)
@@ -271,6 +300,31 @@ class HipBackend:
         _lib.check(self.lib.a2f_attn_bwd_drop(_ptr(qkv), _ptr(ctx), _ptr(dctx), _ptr(lse), S, T, H, ld, ldo, scale,
                                               self._attn_prec(precision), _ptr(dqkv), _ptr(ws), keep_q.data_ptr(),
                                               keep_k.data_ptr(), float(keep_scale), self._stream(qkv)), "a2f_attn_bwd_drop")
+        self._prof_end("attn", ev)
+
+    def attn_fwd_img(self, qkv, S, T, H, ld, scale, ctx, ldo, lse, ctx_img, keep=None, precision=None):
+        """attention forward that also writes the context as a split-32 image; keep = (query-major bits, scale) or None."""
+        _chk(qkv, ctx, lse, ctx_img)
+        kq, ks = (None, 1.0)
+        if keep is not None:
+            _chk_bits(keep[0])
+            kq, ks = keep[0].data_ptr(), float(keep[1])
+        ev = self._prof_begin("attn")
+        _lib.check(self.lib.a2f_attn_fwd_img(_ptr(qkv), S, T, H, ld, scale, self._attn_prec(precision), _ptr(ctx), ldo, _ptr(lse), kq, ks,
+                                             _ptr(ctx_img), self._stream(qkv)), "a2f_attn_fwd_img")
+        self._prof_end("attn", ev)
+
+    def attn_bwd_img(self, qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, dqkv_img, keep=None, precision=None):
+        """attention backward whose dqkv is written as a split-32 image; keep = (query-major bits, key-major bits, scale) or None."""
+        _chk(qkv, ctx, dctx, lse, dqkv_img)
+        ws = torch.empty(S * H * T, dtype=torch.float32, device=qkv.device)
+        kq, kk, ks = (None, None, 1.0)
+        if keep is not None:
+            _chk_bits(keep[0], keep[1])
+            kq, kk, ks = keep[0].data_ptr(), keep[1].data_ptr(), float(keep[2])
+        ev = self._prof_begin("attn")
+        _lib.check(self.lib.a2f_attn_bwd_img(_ptr(qkv), _ptr(ctx), _ptr(dctx), _ptr(lse), S, T, H, ld, ldo, scale, self._attn_prec(precision),
+                                             _ptr(dqkv_img), _ptr(ws), kq, kk, ks, 1, self._stream(qkv)), "a2f_attn_bwd_img")
         self._prof_end("attn", ev)
 
     # ---- dropout keep masks (csrc/dropout.hip) ---------------------------------------------------

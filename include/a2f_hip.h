@@ -330,6 +330,8 @@ int a2f_stream_triad(float* dst, const float* a, const float* b, int64_t n, a2f_
  * k-contiguous - plain or un-padded windows of A, K % 32 == 0, no split-K - or both line-contiguous = the weight-gradient layout with split-K, M and N
  * multiples of 32; aux_mode 0 / 1 / 4; N, ldc, ldaux multiples of 4; GELU there is the Abramowitz-Stegun 7.1.26 form, |error| < 1e-7).
  * c_format 1 (k-contiguous image products only): C itself is written as a split-32 image (ldc % 32 == 0); C2 stays fp32.
+ * c_colsum (k-contiguous image products only): the column sums of the values stored to C - when C is the input gradient of a Linear this is its bias
+ * gradient - from per-(m-tile, wave-row) partial rows in `ws`, folded in fixed order (deterministic).
  * Tile order: workgroups walk the (m-tile, n-tile) grid row-major, or - when B (N x K x 4 bytes) outgrows an XCD's 4 MB L2 - in panels of n-tiles
  * whose slice of B stays resident while the A panels stream past (same results bit for bit; A2F_MM_GROUP_N=0 forces row-major).
  * Epilogue, per element: v = alpha*acc; if bias: v += bias[n]; C2 (optional) = v;  act: 0 none, 1 ReLU, 3 GELU (erf form), 4 GELU with
@@ -371,6 +373,7 @@ typedef struct a2f_mm_desc {
   const uint32_t* keep_bits; int64_t keep_wpr;     /* optional dropout of C: see a2f_keep_bits */
   float keep_scale; int32_t reserved2;
   float* a_rowsum;                                 /* optional: a_rowsum[m] = sum_k A(m,k), see below */
+  float* c_colsum;                                 /* optional (image operands, k-contiguous): c_colsum[n] = sum_m of the values stored to C; ws >= 2 ceil(M/256) N floats */
 } a2f_mm_desc;
 
 int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream);
@@ -392,10 +395,21 @@ int a2f_split_img(const float* x, int64_t R, int64_t C, int64_t ld, int32_t tran
  */
 int a2f_layernorm_fwd(const float* x, int64_t R, int64_t C, const float* gamma, const float* beta, float eps, float* y, float* mean,
                       float* rstd, a2f_stream_t stream);
+/* the same with a split-32 image of y beside (or, y == NULL, instead of) the fp32 rows: the operand format of the image-operand a2f_mm (C % 32 == 0) */
+int a2f_layernorm_fwd_img(const float* x, int64_t R, int64_t C, const float* gamma, const float* beta, float eps, float* y, void* y_img, float* mean,
+                          float* rstd, a2f_stream_t stream);
 size_t a2f_layernorm_bwd_ws_bytes(int64_t R, int64_t C);
 int a2f_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, int64_t R, int64_t C,
                       float* dx, float* dgamma, float* dbeta, float* dx_colsum, void* ws, size_t ws_bytes, a2f_stream_t stream);
+/* layernorm_bwd that also hands the Linear below its output gradient as an image: dxm = keep_bits ? (bit ? dx * keep_scale : 0) : dx  (the
+ * train-mode dropout that sat on that Linear's output, a2f_keep_bits layout) -> dxm_img (split-32 image, may be NULL) and dxm_colsum = column sums of
+ * dxm (= that Linear's bias gradient; may be NULL); dx itself (unmasked: the residual branch) is always written as fp32. */
+int a2f_layernorm_bwd_img(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, int64_t R, int64_t C,
+                          float* dx, float* dgamma, float* dbeta, float* dxm_colsum, const uint32_t* keep_bits, int64_t keep_wpr, float keep_scale,
+                          void* dxm_img, void* ws, size_t ws_bytes, a2f_stream_t stream);
 size_t a2f_colsum_ws_bytes(int64_t R, int64_t C);
+/* colsum over a split-32 image (values hi + lo); ld % 32 == 0; workspace of a2f_colsum_ws_bytes(R, C) */
+int a2f_colsum_img(const void* x, int64_t R, int64_t C, int64_t ld, float* out, void* ws, size_t ws_bytes, a2f_stream_t stream);
 int a2f_colsum(const float* x, int64_t R, int64_t C, int64_t ld, float* out, void* ws, size_t ws_bytes, a2f_stream_t stream);
 int a2f_gelu_bwd(const float* dy, const float* z, int64_t n, float* out, a2f_stream_t stream);
 
@@ -437,6 +451,13 @@ int a2f_attn_fwd(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, 
                  float* lse, a2f_stream_t stream);
 int a2f_attn_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
                  int64_t ldo, float scale, int32_t precision, float* dqkv, float* delta_ws, a2f_stream_t stream);
+/* Image forms (keep bits optional: NULL = no dropout): a2f_attn_fwd_img also writes the context as a split-32 image (ctx_img, (S*T, ldo), may be NULL);
+ * a2f_attn_bwd_img with dqkv_format 1 writes dqkv as a split-32 image INSTEAD of fp32 (its readers are the image-operand GEMMs of the q|k|v projection). */
+int a2f_attn_fwd_img(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx, int64_t ldo,
+                     float* lse, const uint32_t* keep_qmajor, float keep_scale, void* ctx_img, a2f_stream_t stream);
+int a2f_attn_bwd_img(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
+                     int64_t ldo, float scale, int32_t precision, void* dqkv, float* delta_ws, const uint32_t* keep_qmajor,
+                     const uint32_t* keep_kmajor, float keep_scale, int32_t dqkv_format, a2f_stream_t stream);
 /* The same with dropout on the probabilities (HF eager attention: softmax -> nn.functional.dropout(p = attention_dropout) -> @ v):
  * ctx = (P o D) v with D = keep ? keep_scale : 0; lse is that of the un-thinned scores.  keep bits as a2f_keep_bits_attn lays them out. */
 int a2f_attn_fwd_drop(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx, int64_t ldo,

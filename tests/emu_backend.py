@@ -180,13 +180,13 @@ class EmuBackend:
 
     def mm(self, A, B, Cout, M, N, K, ldc, *, c_off=0, c_rows_per_seq=0, c_seq_stride=0, C2=None, bias=None, aux=None, ldaux=0, act=0,
            aux_mode=0, precision=None, split_k=1, batch=1, a_bstride=0, b_bstride=0, c_bstride=0, bias_bstride=0, aux_bstride=0,
-           accumulate=False, alpha=1.0, tag=None, keep=None, a_rowsum=None, c_img=False):
+           accumulate=False, alpha=1.0, tag=None, keep=None, a_rowsum=None, c_img=False, c_colsum=None):
         import copy
         if c_img:                                      # image output: plain row map, whole 32-blocks; the values land as hi / lo pairs
             assert getattr(A, "img", False) and c_rows_per_seq == 0 and ldc % 32 == 0 and c_off % 32 == 0 and N % 32 == 0 and batch == 1 and not accumulate
             tmp = torch.zeros(Cout.numel())
             self.mm(A, B, tmp, M, N, K, ldc, c_off=c_off, C2=C2, bias=bias, aux=aux, ldaux=ldaux, act=act, aux_mode=aux_mode, precision=precision,
-                    alpha=alpha, keep=keep)
+                    alpha=alpha, keep=keep, c_colsum=c_colsum)
             enc = img_encode(tmp.view(-1, 32))
             blocks = ((c_off + torch.arange(M).view(-1, 1) * ldc + torch.arange(0, N, 32).view(1, -1)) // 32).reshape(-1)
             Cout.reshape(-1, 32)[blocks] = enc[blocks]
@@ -237,8 +237,12 @@ class EmuBackend:
             if accumulate:
                 v = v + cflat[cidx].double()
             cflat[cidx] = v.float()
+            if c_colsum is not None:
+                assert batch == 1
+                c_colsum.copy_(v.sum(0).float())
 
     def split_img(self, x, R, Cc, ld, out, ldo, transpose=False):
+        self.calls.append(("split_img", R, Cc, bool(transpose)))
         src = x.reshape(-1)[: (R - 1) * ld + Cc]
         m = src[torch.arange(R).view(-1, 1) * ld + torch.arange(Cc).view(1, -1)]
         if transpose:
@@ -268,6 +272,28 @@ class EmuBackend:
         dgamma.copy_((dyd * xh).sum(0).float()); dbeta.copy_(dyd.sum(0).float())
         if dx_colsum is not None:
             dx_colsum.copy_(d.sum(0).float())
+
+    def layernorm_fwd_img(self, x, R, Cc, gamma, beta, eps, y, y_img, mean, rstd):
+        tmp = torch.empty(R, Cc)
+        self.layernorm_fwd(x, R, Cc, gamma, beta, eps, tmp, mean, rstd)
+        if y is not None:
+            y.reshape(R, Cc).copy_(tmp)
+        if y_img is not None:
+            y_img.reshape(R, Cc).copy_(img_encode(tmp))
+
+    def layernorm_bwd_img(self, dy, x, mean, rstd, gamma, R, Cc, dx, dgamma, dbeta, dxm_colsum=None, keep=None, dxm_img=None):
+        self.layernorm_bwd(dy, x, mean, rstd, gamma, R, Cc, dx, dgamma, dbeta, None)
+        d = dx.reshape(R, Cc).clone()
+        if keep is not None:
+            d = torch.where(unpack_keep_bits(keep[0], Cc)[:R], d * float(keep[1]), torch.zeros_like(d))
+        if dxm_colsum is not None:
+            dxm_colsum.copy_(d.double().sum(0).float())
+        if dxm_img is not None:
+            dxm_img.reshape(R, Cc).copy_(img_encode(d))
+
+    def colsum_img(self, x, R, Cc, ld, out):
+        v = img_decode(x.reshape(-1)[: R * ld].reshape(R, ld))[:, :Cc]
+        out.copy_(v.sum(0).float())
 
     def colsum(self, x, R, Cc, ld, out, x_off=0):
         flat = x.reshape(-1)[x_off:].double()
@@ -361,6 +387,22 @@ class EmuBackend:
             out[:, :, off:off + 64 * H] = t.grad.permute(0, 2, 1, 3).reshape(S, T, 64 * H).float()
 
     # ------------------------------------------------------------------ dropout keep masks (contract of csrc/dropout.hip)
+    def attn_fwd_img(self, qkv, S, T, H, ld, scale, ctx, ldo, lse, ctx_img, keep=None, precision=None):
+        if keep is None:
+            self.attn_fwd(qkv, S, T, H, ld, scale, ctx, ldo, lse, precision)
+        else:
+            self.attn_fwd_drop(qkv, S, T, H, ld, scale, ctx, ldo, lse, keep[0], keep[1], precision)
+        if ctx_img is not None:
+            ctx_img.reshape(S * T, ldo).copy_(img_encode(ctx.reshape(S * T, ldo)))
+
+    def attn_bwd_img(self, qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, dqkv_img, keep=None, precision=None):
+        tmp = torch.zeros(S * T, ld)
+        if keep is None:
+            self.attn_bwd(qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, tmp, precision)
+        else:
+            self.attn_bwd_drop(qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, tmp, keep[0], keep[1], keep[2], precision)
+        dqkv_img.reshape(S * T, ld).copy_(img_encode(tmp))
+
     def attn_keep_words(self, T):
         return 2 * ((T + 63) // 64)
 

@@ -140,3 +140,82 @@ def test_mm_img_is_bitwise_reproducible_and_rejects_what_it_cannot_do():
         be.mm(MMOp(Ai, K, img=True), MMOp(B, K), torch.zeros(M, N, device=DEV), M, N, K, N, precision=1)          # mixed formats
     with pytest.raises(a2f_amd.A2FError):
         be.mm(MMOp(Ai, K, img=True), MMOp(Bi, K, img=True), torch.zeros(M, N, device=DEV), M, N, K, N, precision=0)   # bf16x3 only
+
+
+def test_mm_img_colsum_of_the_stored_values_is_deterministic():
+    M, N, K = 1500, 768, 256
+    A, B, aux = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(M, N, seed=3)
+    mask = torch.rand(M, N, generator=torch.Generator().manual_seed(5)) > 0.1
+    bits = pack_keep_bits(mask)
+
+    def run(be, dev):
+        Ai, Bi = torch.zeros(M, K, device=dev), torch.zeros(N, K, device=dev)
+        be.split_img(A.to(dev), M, K, K, Ai, K)
+        be.split_img(B.to(dev), N, K, K, Bi, K)
+        outs = []
+        for _ in range(2):
+            C, cs = torch.zeros(M, N, device=dev), torch.zeros(N, device=dev)
+            be.mm(MMOp(Ai, K, img=True), MMOp(Bi, K, img=True), C, M, N, K, N, precision=1, aux=aux.to(dev), aux_mode=ops.MM_AUX_MUL_LIKE_C,
+                  keep=(bits.to(dev), 1.25), c_img=True, c_colsum=cs)
+            outs += [C, cs]
+        return outs
+    got, ref = both(run)
+    assert torch.equal(got[1], got[3]) and torch.equal(got[0], got[2])
+    assert rel_l2(img_decode(got[0]), img_decode(ref[0])) < TOL
+    assert rel_l2(got[1], ref[1]) < TOL
+    assert rel_l2(got[1], img_decode(got[0]).sum(0)) < 1e-5          # the sums are of the values that were stored
+
+
+@pytest.mark.parametrize("R,C", [(300, 768), (77, 512), (1030, 1024)])
+def test_layernorm_image_outputs(R, C):
+    x, g, b, dy = rnd(R, C, seed=1), rnd(C, seed=2), rnd(C, seed=3), rnd(R, C, seed=4)
+    mask = torch.rand(R, C, generator=torch.Generator().manual_seed(5)) > 0.1
+    bits = pack_keep_bits(mask)
+
+    def run(be, dev):
+        y, yi, mu, rs = (torch.zeros(R, C, device=dev), torch.zeros(R, C, device=dev), torch.zeros(R, device=dev), torch.zeros(R, device=dev))
+        be.layernorm_fwd_img(x.to(dev), R, C, g.to(dev), b.to(dev), 1e-5, y, yi, mu, rs)
+        yi2 = torch.zeros(R, C, device=dev)
+        be.layernorm_fwd_img(x.to(dev), R, C, g.to(dev), b.to(dev), 1e-5, None, yi2, mu, rs)
+        outs = [y, yi, yi2]
+        for keep in (None, (bits.to(dev), 1.0 / 0.9)):
+            dx, dxi, dg, db, cs = (torch.zeros(R, C, device=dev), torch.zeros(R, C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev),
+                                   torch.zeros(C, device=dev))
+            be.layernorm_bwd_img(dy.to(dev), x.to(dev), mu, rs, g.to(dev), R, C, dx, dg, db, dxm_colsum=cs, keep=keep, dxm_img=dxi)
+            outs += [dx, dxi, dg, db, cs]
+        return outs
+    got, ref = both(run)
+    assert torch.equal(got[1].view(torch.int32), img_encode(got[0]).view(torch.int32))       # the image IS the split of the fp32 output
+    assert torch.equal(got[1], got[2])
+    for i, (a, r) in enumerate(zip(got, ref)):
+        if i in (1, 2, 4, 9):
+            a, r = img_decode(a), img_decode(r)
+        assert rel_l2(a, r) < 2e-5, i
+    assert torch.equal(got[4].view(torch.int32), img_encode(got[3]).view(torch.int32))       # no mask: image of dx itself
+    masked = torch.where(mask, got[8] * (1.0 / 0.9), torch.zeros(()))
+    assert rel_l2(img_decode(got[9]), masked) < 1e-5 and rel_l2(got[12], masked.double().sum(0)) < 1e-5
+
+
+def test_attention_image_outputs_and_image_colsum():
+    S, T, H = 2, 150, 12
+    ld, ldo = 3 * 64 * H, 64 * H
+    qkv, dctx = rnd(S * T, ld, seed=1, scale=0.5), rnd(S * T, ldo, seed=2)
+    be = ops.HipBackend()
+    q = qkv.to(DEV)
+    ctx, ctx_i, lse = torch.zeros(S * T, ldo, device=DEV), torch.zeros(S * T, ldo, device=DEV), torch.zeros(S, H, T, device=DEV)
+    be.attn_fwd_img(q, S, T, H, ld, 0.125, ctx, ldo, lse, ctx_i)
+    ctx0, lse0 = torch.zeros_like(ctx), torch.zeros_like(lse)
+    be.attn_fwd(q, S, T, H, ld, 0.125, ctx0, ldo, lse0)
+    # the image holds hi + lo of the same value the fp32 store rounds (the compiler may form the lo residual from the unrounded product: hi + lo is then
+    # CLOSER to the exact value than the fp32 word, never further than 2^-16 |x| from it)
+    def close(image, ref):
+        d = (img_decode(image.cpu()) - ref.cpu().double()).abs()
+        return bool((d <= ref.cpu().double().abs() * 2.0 ** -16 + 1e-30).all())
+    assert torch.equal(ctx, ctx0) and close(ctx_i, ctx)
+    dq_i, dq = torch.zeros(S * T, ld, device=DEV), torch.zeros(S * T, ld, device=DEV)
+    be.attn_bwd_img(q, ctx, dctx.to(DEV), lse, S, T, H, ld, ldo, 0.125, dq_i)
+    be.attn_bwd(q, ctx, dctx.to(DEV), lse, S, T, H, ld, ldo, 0.125, dq)
+    assert close(dq_i, dq)
+    cs = torch.zeros(ld, device=DEV)
+    be.colsum_img(dq_i, S * T, ld, ld, cs)
+    assert rel_l2(cs.cpu(), img_decode(dq_i.cpu()).sum(0)) < 1e-5

@@ -266,7 +266,11 @@ def test_faceformer_decoder_golden_g3(T):
         assert packed_error(g, pre + "grad::enc", enc.grad) < TOL
 
 
-def test_faceformer_end_to_end_golden_g8():
+@pytest.mark.parametrize("images", [False, True])
+def test_faceformer_end_to_end_golden_g8(images, monkeypatch):
+    """images: the Transformer layers on split-32 image operands (the product's path from 2048 rows; forced here at T = 30)."""
+    from a2f_amd import encoder_ops
+    monkeypatch.setattr(encoder_ops, "IMG_MIN_ROWS", 0 if images else 1 << 30)
     g = load("g8_faceformer_e2e")
     m = _faceformer(stub=False)
     m.audio_encoder.load_state_dict(W.formula_state_dict(W.wav2vec2_shapes(), gains={"original0": 40.0}))
@@ -512,11 +516,14 @@ def _faceformer_full():
     return m.to(DEV).eval(), esd, dsd
 
 
-def test_faceformer_config2_full_size_vs_oracle():
+def test_faceformer_config2_full_size_vs_oracle(monkeypatch):
     """BASELINE configs[2] at full size: N = 160 008 samples -> T = 600 frames through the real wav2vec2-base encoder, the
     incremental decoder, the 15069-wide head and FaceFormerLoss; forward <= 1e-4 on vertex offsets, and the gradients that
     cross the whole encoder (d loss / d audio, first conv layer, feature projection, an attention projection of layer 0) against
-    the oracle's autograd (oracle/wav2vec2.py + decode_incremental; reference: faceformer.py:139-191, wav2vec.py:91-189)."""
+    the oracle's autograd (oracle/wav2vec2.py + decode_incremental; reference: faceformer.py:139-191, wav2vec.py:91-189).
+    Runs the path the 64-sequence bench step runs: Transformer products on split-32 image operands (forced: one sequence is 600 rows)."""
+    from a2f_amd import encoder_ops
+    monkeypatch.setattr(encoder_ops, "IMG_MIN_ROWS", 0)
     from oracle import faceformer as o_ff, wav2vec2 as o_w2v
     m, esd, dsd = _faceformer_full()
     T = 600
@@ -993,10 +1000,13 @@ def test_faceformer_pipelined_step_equals_single_stream_step(S, T, parts, monkey
             assert rel_l2(torch.cat([got[k].flatten() for k in keys]).cpu(), torch.cat([whole[k].flatten() for k in keys]).cpu()) < 2e-5
 
 
-def test_wav2vec2_train_mode_with_reference_masks_g13():
+@pytest.mark.parametrize("images", [False, True])
+def test_wav2vec2_train_mode_with_reference_masks_g13(images, monkeypatch):
     """The hand-written encoder in TRAIN mode on the GPU, fed every mask the reference drew in its own train-mode forward (fixture
     G13: dropout at the 6 kinds of sites, LayerDrop of layers 3 and 8, SpecAugment rows): last_hidden_state and the recorded
-    parameter gradients of the reference within the parity bar."""
+    parameter gradients of the reference within the parity bar.  images: masks inside the image GEMM epilogues / masked LayerNorm backward."""
+    from a2f_amd import encoder_ops
+    monkeypatch.setattr(encoder_ops, "IMG_MIN_ROWS", 0 if images else 1 << 30)
     from test_train_regularisers_cpu import check_against_g13, g13_model_and_input
     g, m, wave, S, T = g13_model_and_input(DEV)
     hs = m(wave, "vocaset", frame_num=T).last_hidden_state

@@ -258,10 +258,14 @@ def test_voca_accepts_per_frame_features(emu):
     assert torch.equal(w[0, :, 8], feats[0, 0]) and torch.all(w[0, :, :8] == 0) and torch.equal(w[T, :, 8], feats[1, 0]) and torch.all(w[T, :, :8] == 0)
 
 
-def test_hip_encoder_composition_matches_oracle(emu):
+@pytest.mark.parametrize("images", [False, True])
+def test_hip_encoder_composition_matches_oracle(emu, images, monkeypatch):
     """The hand-written encoder path (encoder_ops: a2f_mm windows / batches / epilogues, flash-attention and LayerNorm contracts,
     fixed backward launch sequence) composed over the float64 emulator of the C ABI against the oracle's autograd: forward,
-    d/d(waveform) and every parameter gradient of the first layers (two sequences, T = 12)."""
+    d/d(waveform) and every parameter gradient of the first layers (two sequences, T = 12).  images: the Transformer layers on split-32 image
+    operands (what the product runs from 2048 rows: producer-side images, image GEMM epilogues, masked LayerNorm backward) at this small size."""
+    from a2f_amd import encoder_ops
+    monkeypatch.setattr(encoder_ops, "IMG_MIN_ROWS", 0 if images else 1 << 30)
     from a2f_amd.model.wav2vec import Wav2Vec2Model
     from oracle import wav2vec2 as o_w2v
     m = Wav2Vec2Model(layers=2).eval()                 # the deterministic function (train mode: tests/test_train_regularisers_cpu.py)
@@ -274,6 +278,8 @@ def test_hip_encoder_composition_matches_oracle(emu):
     E = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     wo = wave.clone().requires_grad_(True)
     ref = torch.cat([o_w2v.wav2vec2_forward(E, wo[i:i + 1], T, n_layers=2) for i in range(2)], 0)
+    assert ("mm", 24, 3072, 768, 1) in ops.backend().calls
+    assert any(c[0] == "split_img" for c in ops.backend().calls) == images
     assert rel_l2(h, ref) < 1e-5
     gout = W.formula_input("enc.gout", tuple(ref.shape))
     h.backward(gout)

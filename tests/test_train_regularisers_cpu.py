@@ -105,9 +105,13 @@ def test_torch_ops_train_mode_matches_reference_g13():
     check_against_g13(g, m, hs, T, 2e-5, 1e-4)
 
 
-def test_hip_path_composition_train_mode_matches_reference_g13():
+@pytest.mark.parametrize("images", [False, True])
+def test_hip_path_composition_train_mode_matches_reference_g13(images, monkeypatch):
     """The hand-written path's composition in train mode (dropout in the a2f_mm epilogues and the attention kernels' contract, the
-    masked backward passes, LayerDrop, SpecAugment) over the float64 emulator of the C ABI against G13."""
+    masked backward passes, LayerDrop, SpecAugment) over the float64 emulator of the C ABI against G13; images: the Transformer layers on
+    split-32 image operands (masks inside the image GEMM epilogues and the LayerNorm backward)."""
+    from a2f_amd import encoder_ops
+    monkeypatch.setattr(encoder_ops, "IMG_MIN_ROWS", 0 if images else 1 << 30)
     g, m, wave, S, T = g13_model_and_input()
     old = ops.set_backend(EmuBackend())
     try:

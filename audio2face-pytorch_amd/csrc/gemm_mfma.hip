@@ -594,7 +594,8 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
       A2F_CHECK_ARG(a.A.lps == 0 && a.B.lps == 0 && d->c_format == 0 && d->c_rows_per_seq == 0, "a2f_mm (image operands, weight-gradient layout): plain matrices, fp32 C");
       A2F_CHECK_ARG(d->M % 32 == 0 && d->N % 32 == 0, "a2f_mm (image operands, weight-gradient layout): M, N multiples of 32");
     }
-    A2F_CHECK_ARG(d->c_format == 0 || (d->ldc % 32 == 0 && d->c_rows_per_seq == 0 && ((uintptr_t)d->C & 127) == 0), "a2f_mm: image output needs ldc %% 32 == 0, a plain row map and a 128-byte aligned C");
+    A2F_CHECK_ARG(d->c_format == 0 || (d->ldc % 32 == 0 && d->N % 8 == 0 && d->c_rows_per_seq == 0 && ((uintptr_t)d->C & 127) == 0),
+                  "a2f_mm: image output needs ldc %% 32 == 0, N %% 8 == 0, a plain row map and a 128-byte aligned C");
     a.epi32 = 1;
     a.group_n = 0;
     {

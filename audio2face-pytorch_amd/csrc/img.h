@@ -28,6 +28,23 @@ __device__ __forceinline__ void store4(char* row_base, int n, const f32x4 v) {
   *reinterpret_cast<u32x2_t*>(p + 64) = lo;
 }
 
+// eight consecutive elements n .. n + 7 (n % 8 == 0): 16 bytes of hi, 16 bytes of lo
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ void store8(char* row_base, int n, const f32x4 a, const f32x4 b) {
+  const f32x2_t v[4] = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}};
+  unsigned hi[4], lo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bf16x2_t h = __builtin_convertvector(v[i], bf16x2_t);
+    const f32x2_t r = v[i] - __builtin_convertvector(h, f32x2_t);
+    hi[i] = __builtin_bit_cast(unsigned, h);
+    lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+  }
+  char* p = row_base + elem_byte(n);
+  *reinterpret_cast<u32x4_t*>(p) = u32x4_t{hi[0], hi[1], hi[2], hi[3]};
+  *reinterpret_cast<u32x4_t*>(p + 64) = u32x4_t{lo[0], lo[1], lo[2], lo[3]};
+}
+
 // the values hi + lo of four consecutive elements
 __device__ __forceinline__ f32x4 load4(const char* row_base, int n) {
   const char* p = row_base + elem_byte(n);

@@ -130,6 +130,7 @@ SIGNATURES = {
     "a2f_dropout_apply": (C.c_int, [c_f32p, c_f32p, i64, i64, i64, i64, f32, c_f32p, C.c_void_p]),
     "a2f_featenc0_ws_bytes": (sz, [i64, i64, i64]),
     "a2f_featenc0_fwd": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, i64, f32, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
+    "a2f_featenc0_fwd_img": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, i64, f32, c_f32p, i32, c_f32p, C.c_void_p, sz, C.c_void_p]),
     "a2f_featenc0_bwd": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, sz,
                                    C.c_void_p]),
     "a2f_stream_copy": (C.c_int, [c_f32p, c_f32p, i64, C.c_void_p]),

@@ -7,6 +7,7 @@
 // (writes the output once); backward = reduction pass + apply pass over the incoming gradient.  All reductions go through
 // per-workgroup partials folded in fixed order, in double where sums run over the whole sequence (deterministic).
 #include "a2f_common.h"
+#include "img.h"
 
 namespace a2f {
 namespace fe {
@@ -33,6 +34,7 @@ struct Args {
   float* dy;           // optional (S, L, C): gradient w.r.t. the convolution output
   float* part;         // partial slabs
   int S, N, L, C, nchunk, chunks_per_block;
+  int out_img;         // 1: out is written as a split-32 image (its only reader is the first convolution of the stack on image operands)
 };
 
 // thread -> 4 consecutive channels c4 = 4 (t % (C/4)); position phase ph = t / (C/4), PH phases
@@ -134,7 +136,8 @@ __global__ __launch_bounds__(THREADS) void conv0_apply_kernel(const Args a) {
       o.y = gelu_f((y[1] - mu[1]) * sc[1] + sh[1]);
       o.z = gelu_f((y[2] - mu[2]) * sc[2] + sh[2]);
       o.w = gelu_f((y[3] - mu[3]) * sc[3] + sh[3]);
-      *reinterpret_cast<float4*>(a.out + ((long long)s * a.L + l0 + p) * a.C + c4) = o;
+      if (a.out_img) img::store4(reinterpret_cast<char*>(a.out) + ((long long)s * a.L + l0 + p) * a.C * 4, c4, f32x4{o.x, o.y, o.z, o.w});
+      else *reinterpret_cast<float4*>(a.out + ((long long)s * a.L + l0 + p) * a.C + c4) = o;
     }
   }
 }
@@ -295,8 +298,15 @@ extern "C" size_t a2f_featenc0_ws_bytes(int64_t S, int64_t N, int64_t C) {
 
 extern "C" int a2f_featenc0_fwd(const float* wave, int64_t S, int64_t N, const float* w, const float* gamma, const float* beta, int64_t C,
                                 float eps, float* out, float* stats, void* ws, size_t ws_bytes, a2f_stream_t stream) {
+  return a2f_featenc0_fwd_img(wave, S, N, w, gamma, beta, C, eps, out, 0, stats, ws, ws_bytes, stream);
+}
+
+extern "C" int a2f_featenc0_fwd_img(const float* wave, int64_t S, int64_t N, const float* w, const float* gamma, const float* beta, int64_t C,
+                                    float eps, void* out_, int32_t out_format, float* stats, void* ws, size_t ws_bytes, a2f_stream_t stream) {
   using namespace a2f;
   using namespace a2f::fe;
+  float* out = (float*)out_;
+  A2F_CHECK_ARG(out_format == 0 || (out_format == 1 && C % 32 == 0 && ((uintptr_t)out & 127) == 0), "featenc0_fwd: out_format %d (1 = image: C %% 32 == 0, 128-byte aligned)", out_format);
   A2F_CHECK_ARG(wave && w && gamma && beta && out && stats && ws, "featenc0_fwd: null pointer");
   A2F_CHECK_ARG(S > 0 && N >= KW && C % 4 == 0 && C >= 4 && THREADS % (C / 4) == 0 && C / 4 <= THREADS, "featenc0_fwd: S=%lld N=%lld C=%lld", (long long)S,
                 (long long)N, (long long)C);
@@ -304,6 +314,7 @@ extern "C" int a2f_featenc0_fwd(const float* wave, int64_t S, int64_t N, const f
   if (ws_bytes < a2f_featenc0_ws_bytes(S, N, C)) return set_err(A2F_EWORKSPACE, "featenc0_fwd: workspace too small");
   Args a{};
   a.wave = wave; a.w = w; a.gamma = gamma; a.beta = beta; a.stats = stats; a.out = out; a.part = (float*)ws;
+  a.out_img = out_format;
   a.S = (int)S; a.N = (int)N; a.L = (int)((N - KW) / STRIDE + 1); a.C = (int)C;
   int nblk, cpb;
   a.nchunk = plan(a.L, nblk, cpb);

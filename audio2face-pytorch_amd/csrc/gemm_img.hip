@@ -52,6 +52,11 @@ __device__ __forceinline__ void lds_dma16(rsrc_t rs, char* lds, unsigned voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
 #endif
 }
+__device__ __forceinline__ void lds_dma16s(rsrc_t rs, char* lds, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+#endif
+}
 __device__ __forceinline__ u32x4_t lds_read16(const char* p) { return *reinterpret_cast<const u32x4_t*>(p); }
 
 // GELU and its derivative from ONE exponential: Phi(-|x|) = 0.5 erfc(|x| / sqrt 2) by Abramowitz-Stegun 7.1.26 (|error| <= 0.75e-7 on Phi, relative
@@ -258,7 +263,21 @@ __global__ __launch_bounds__(TH, 2) void gemm_img_kernel(const Args a) {
     } else {
       const int krow = pc & 31;
       const int x = x0 + (lane >> 3) * 32;                     // first line of this lane's 128-byte block
-      voff[i] = x < cnt ? ((unsigned)krow * (unsigned)op.ld + (unsigned)x0) * 4u + (unsigned)(lane * 16) : 0xFFFFFFFFu;
+      // windowed operand (conv weight gradient: a k-row is one output position, its lines the window starting at q * ld + off): the row's byte offset is
+      // wave-uniform and travels in the instruction's scalar offset, re-derived per k-tile from (sequence, position)
+      const unsigned rowpart = op.lps > 0 ? (unsigned)op.off : (unsigned)krow * (unsigned)op.ld;
+      voff[i] = x < cnt ? (rowpart + (unsigned)x0) * 4u + (unsigned)(lane * 16) : 0xFFFFFFFFu;
+    }
+  }
+  // TN, windowed B: (sequence, position) of the four B k-rows this wave moves, for the current k-tile
+  int bs[4] = {0, 0, 0, 0}, bq[4] = {0, 0, 0, 0};
+  const bool bwin = TN && a.B.lps > 0;                         // wave-uniform
+  if (bwin) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = kbeg + ((wave + 8 * (i + 4)) & 31);
+      bs[i] = __builtin_amdgcn_readfirstlane(r / a.B.lps);
+      bq[i] = __builtin_amdgcn_readfirstlane(r - (r / a.B.lps) * a.B.lps);
     }
   }
   auto dma = [&](int kt, int st) {
@@ -278,7 +297,21 @@ __global__ __launch_bounds__(TH, 2) void gemm_img_kernel(const Args a) {
     for (int i = 0; i < 8; ++i) {
       const int pc = wave + 8 * i;
       char* dst = TN ? base + (i >= 4 ? PRT : 0) + (pc & 31) * TPITCH : base + pc * 1024;
-      lds_dma16(i >= 4 ? rb : ra, dst, voff[i]);
+      if (TN && i >= 4 && bwin) {
+        // rows at or beyond the end of this k-range must read as zero whatever lies there (their A rows are zero, but 0 x NaN is not): out-of-range offset
+        const bool live = kbeg + kt * 32 + (pc & 31) < kend;
+        const unsigned so = live ? (unsigned)bs[i - 4] * (unsigned)(a.B.seq_stride * 4) + (unsigned)bq[i - 4] * (unsigned)(a.B.ld * 4) : 0u;
+        lds_dma16s(rsrc_at(pB, a.B.bytes, 0), dst, live ? voff[i] : 0xFFFFFFFFu, so);
+      } else {
+        lds_dma16(i >= 4 ? rb : ra, dst, voff[i]);
+      }
+    }
+    if (TN && bwin) {                                          // next k-tile: 32 positions on (scalar arithmetic; short sequences wrap more than once)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bq[i] += 32;
+        while (bq[i] >= a.B.lps) { bq[i] -= a.B.lps; bs[i] += 1; }
+      }
     }
   };
 
@@ -531,6 +564,9 @@ __device__ __forceinline__ void epilogue_wave16(const Args& a, const f32x4v (&ac
   }
 }
 
+// CHK: the windows of A may reach outside their sequence (zero padding: the two-row windows of the k = 3 / stride 2 data gradient in gather form) - every A
+// piece then tests its element offset against [0, seq_elems) per k-tile and addresses the un-rebased buffer (negative offsets cannot ride on a moved base).
+template <bool CHK>
 __global__ __launch_bounds__(TH, 2) void gemm_img16_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
@@ -542,6 +578,7 @@ __global__ __launch_bounds__(TH, 2) void gemm_img16_kernel(const Args a) {
   const float* pA = uniform_ptr(a.A.p);
   const float* pB = uniform_ptr(a.B.p);
   unsigned voff[8];
+  int e0[CHK ? 4 : 1];                                              // CHK: element offset of this lane's A row inside its sequence at k = 0 (may be negative)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int pc = wave + 8 * i;
@@ -556,18 +593,32 @@ __global__ __launch_bounds__(TH, 2) void gemm_img16_kernel(const Args a) {
     unsigned rb;
     if (op.lps > 0) {
       const int s = g / op.lps, q = g - s * op.lps;
-      rb = (unsigned)s * (unsigned)(op.seq_stride * 4) + (unsigned)(q * op.ld + op.off) * 4u;
+      if (CHK && !isB) {
+        e0[i & 3] = g < cnt ? q * op.ld + op.off : -0x40000000;      // a row beyond M: never in range
+        rb = (unsigned)s * (unsigned)(op.seq_stride * 4);
+      } else {
+        rb = (unsigned)s * (unsigned)(op.seq_stride * 4) + (unsigned)(q * op.ld + op.off) * 4u;
+      }
     } else {
       rb = (unsigned)g * (unsigned)op.ld * 4u;
     }
     voff[i] = g < cnt ? rb + (unsigned)(c * 16) : 0xFFFFFFFFu;
   }
   auto dma = [&](int kt, int st) {
-    const rsrc_t ra = rsrc_at(pA, a.A.bytes, (long long)kt * 128);
+    const rsrc_t ra = rsrc_at(pA, a.A.bytes, CHK ? 0ll : (long long)kt * 128);
     const rsrc_t rb = rsrc_at(pB, a.B.bytes, (long long)kt * 128);
     char* base = smem + st * STAGE + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) lds_dma16(i >= 4 ? rb : ra, base + i * 8192, voff[i]);
+    for (int i = 0; i < 8; ++i) {
+      unsigned vo = voff[i];
+      if constexpr (CHK) {
+        if (i < 4) {
+          const unsigned e = (unsigned)(e0[i] + kt * 32);
+          vo = e < (unsigned)a.A.seq_elems ? vo + e * 4u : 0xFFFFFFFFu;
+        }
+      }
+      lds_dma16(i >= 4 ? rb : ra, base + i * 8192, vo);
+    }
   };
   // fragment: row lane & 15 of a 16-row block, 16-byte chunk ((lane >> 4) + 4 lo) ^ ((row >> 1) & 7)
   const int lr = lane & 15;
@@ -680,17 +731,18 @@ __global__ __launch_bounds__(256) void split_img_t_kernel(const float* __restric
 
 }  // namespace img
 
+template <bool CHK>
 static int launch_img16(const Args& a, hipStream_t st) {
   using namespace img;
   constexpr int smem = 2 * STAGE;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_img16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_img16_kernel<CHK>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return set_err(A2F_ELAUNCH, "a2f_mm (image operands): cannot reserve %d bytes of LDS", smem);
     attr_done = true;
   }
   dim3 grid((unsigned)(cdiv(a.N, TB) * cdiv(a.M, TB)), 1, 1);
-  hipLaunchKernelGGL(gemm_img16_kernel, grid, dim3(TH), smem, st, a);
+  hipLaunchKernelGGL(gemm_img16_kernel<CHK>, grid, dim3(TH), smem, st, a);
   return A2F_OK;
 }
 
@@ -713,7 +765,8 @@ static int launch_img_t(const Args& a, hipStream_t st) {
 // both operands format 1; trans flags equal (NT: both k-contiguous, TN: both line-contiguous); checked by the caller (a2f_mm)
 int launch_img(const Args& a, bool tn, hipStream_t st) {
   static const int shape16 = [] { const char* e = getenv("A2F_MM_IMG_MFMA"); return !(e && e[0] == '3'); }();       // A-B hook: 32 = the 32 x 32 x 16 form
-  const int rc = tn ? launch_img_t<true>(a, st) : (shape16 ? launch_img16(a, st) : launch_img_t<false>(a, st));
+  const bool chk = !tn && a.A.lps > 0 && (a.A.off < 0 || (long long)(a.A.lps - 1) * a.A.ld + a.A.off + a.K > a.A.seq_elems);      // padded windows of A
+  const int rc = tn ? launch_img_t<true>(a, st) : (chk ? launch_img16<true>(a, st) : shape16 ? launch_img16<false>(a, st) : launch_img_t<false>(a, st));
   if (rc) return rc;
   if (!tn && a.c_colsum) {
     const int P = 2 * (int)cdiv(a.M, img::TB);

@@ -588,14 +588,14 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
     if (!at) {
       A2F_CHECK_ARG(d->K % 32 == 0 && split == 1, "a2f_mm (image operands, k-contiguous): K %% 32 == 0, no split-K");
       A2F_CHECK_ARG(a.B.lps == 0, "a2f_mm (image operands): B must be a plain matrix");
-      if (a.A.lps > 0)
-        A2F_CHECK_ARG(d->A.off >= 0 && (d->A.lines_per_seq - 1) * d->A.ld + d->A.off + d->K <= d->A.seq_elems, "a2f_mm (image operands): windows must lie inside their sequence (no padding)");
+      A2F_CHECK_ARG(a.A.lps == 0 || llabs(d->A.off) + d->A.lines_per_seq * d->A.ld + d->K < (1ll << 30), "a2f_mm (image operands): window offsets must stay below 2^30 elements");
     } else {
-      A2F_CHECK_ARG(a.A.lps == 0 && a.B.lps == 0 && d->c_format == 0 && d->c_rows_per_seq == 0, "a2f_mm (image operands, weight-gradient layout): plain matrices, fp32 C");
+      A2F_CHECK_ARG(a.A.lps == 0 && d->c_format == 0 && d->c_rows_per_seq == 0, "a2f_mm (image operands, weight-gradient layout): plain A, fp32 C");
+      A2F_CHECK_ARG(a.B.lps == 0 || (d->B.off >= 0 && d->B.seq_stride >= 0), "a2f_mm (image operands, weight-gradient layout): B windows need off >= 0 and seq_stride >= 0");
       A2F_CHECK_ARG(d->M % 32 == 0 && d->N % 32 == 0, "a2f_mm (image operands, weight-gradient layout): M, N multiples of 32");
     }
-    A2F_CHECK_ARG(d->c_format == 0 || (d->ldc % 32 == 0 && d->N % 8 == 0 && d->c_rows_per_seq == 0 && ((uintptr_t)d->C & 127) == 0),
-                  "a2f_mm: image output needs ldc %% 32 == 0, N %% 8 == 0, a plain row map and a 128-byte aligned C");
+    A2F_CHECK_ARG(d->c_format == 0 || (d->ldc % 32 == 0 && d->c_seq_stride % 32 == 0 && d->N % 8 == 0 && ((uintptr_t)d->C & 127) == 0),
+                  "a2f_mm: image output needs ldc and c_seq_stride %% 32 == 0, N %% 8 == 0 and a 128-byte aligned C");
     a.epi32 = 1;
     a.group_n = 0;
     {

@@ -419,7 +419,8 @@ class FeatEnc0Fn(torch.autograd.Function):
     """wave (S, N), w (C, 1, 10), gamma (C), beta (C) -> (S, L, C), L = (N - 10) // 5 + 1   (csrc/featenc.hip)."""
 
     @staticmethod
-    def forward(ctx, wave, w, gamma, beta):
+    def forward(ctx, wave, w, gamma, beta, out_img=False):
+        """out_img: the returned tensor holds the split-32 IMAGE of the layer output (its only reader: ConvStackFn on image operands)."""
         be = ops.backend()
         _save_prec(ctx)
         xc, wc, g, b = _f32c(wave), _f32c(w), _f32c(gamma), _f32c(beta)
@@ -427,7 +428,10 @@ class FeatEnc0Fn(torch.autograd.Function):
         C = wc.shape[0]
         L = (N - 10) // 5 + 1
         out, stats = _new(xc, S, L, C), _new(xc, S, 2, C)
-        be.featenc0_fwd(xc, S, N, wc, g, b, C, 1e-5, out, stats)
+        if out_img:
+            be.featenc0_fwd(xc, S, N, wc, g, b, C, 1e-5, out, stats, out_img=True)
+        else:
+            be.featenc0_fwd(xc, S, N, wc, g, b, C, 1e-5, out, stats)
         ctx.save_for_backward(xc, wc, g, b, stats)
         return out
 
@@ -455,7 +459,7 @@ class FeatEnc0Fn(torch.autograd.Function):
             dx = torch.zeros(S, N, device=xc.device, dtype=torch.float32)
             for k in range(10):
                 dx[:, k:k + 5 * (L - 1) + 1:5] += dcol[:, :, k]
-        return dx, dw, dg, db
+        return dx, dw, dg, db, None
 
 
 # =================================================================================================
@@ -509,11 +513,23 @@ class ConvStackFn(torch.autograd.Function):
     layer i already as its pre-activation gradient - one streaming GELU' multiply (the top layer's) instead of one per layer."""
 
     @staticmethod
-    def forward(ctx, x, strides, *weights):
+    def use_images(be, x, weights):
+        """Image operands (csrc/gemm_img.hip) for the whole stack: bf16x3 products, channel counts in whole 32-blocks, enough rows, every operand and
+        output span below 2 GiB (32-bit epilogue offsets)."""
+        S, L0, C0 = x.shape
+        return (MM_IMG and be.mm_precision == 1 and hasattr(be, "split_img") and C0 % 32 == 0 and all(w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0 for w in weights)
+                and S * L0 >= 4 * IMG_MIN_ROWS and S * L0 * C0 * 4 < (1 << 31))
+
+    @staticmethod
+    def forward(ctx, x, strides, x_is_img, *weights):
+        """x_is_img: x already holds the split-32 image of the stack's input (FeatEnc0Fn with out_img)."""
         be = ops.backend()
         _save_prec(ctx)
         cur = _f32c(x)
         keep = any(ctx.needs_input_grad)
+        ctx.img = bool(x_is_img) or ConvStackFn.use_images(be, cur, weights)
+        if ctx.img:
+            return ConvStackFn._forward_img(ctx, be, cur, bool(x_is_img), strides, keep, weights)
         saved, dims = [], []
         for w, stride in zip(weights, strides):
             wc = _f32c(w)
@@ -533,10 +549,101 @@ class ConvStackFn(torch.autograd.Function):
             ctx.dims = dims
         return cur
 
+    # ---- the stack on image operands: every activation between the layers exists only as a split-32 image written by the producing epilogue ----------
+    @staticmethod
+    def _forward_img(ctx, be, cur, x_is_img, strides, keep, weights):
+        I = lambda t, ld, **kw: MMOp(t, ld, img=True, **kw)
+        if not x_is_img:
+            ci = torch.empty_like(cur)
+            be.split_img(cur, cur.shape[0] * cur.shape[1], cur.shape[2], cur.shape[2], ci, cur.shape[2])
+            cur = ci
+        saved, dims = [], []
+        n = len(weights)
+        for li, (w, stride) in enumerate(zip(weights, strides)):
+            wc = _f32c(w)
+            S, Lin, Ci = cur.shape
+            Co, _, KH = wc.shape
+            Lout = (Lin - KH) // stride + 1
+            wg, wgi = _new(cur, Co, KH * Ci), _new(cur, Co, KH * Ci)
+            be.conv_weight_pack(wc, wg, Co, Ci, KH, 0)
+            be.split_img(wg, Co, KH * Ci, KH * Ci, wgi, KH * Ci)
+            gp = _new(cur, S, Lout, Co) if keep else None
+            y = _new(cur, S, Lout, Co)
+            last = li == n - 1                                     # the top layer's output goes on to the interpolation as fp32 rows
+            A = I(cur, stride * Ci, lines_per_seq=Lout, seq_stride=Lin * Ci, seq_elems=Lin * Ci)
+            be.mm(A, I(wgi, KH * Ci), y, S * Lout, Co, KH * Ci, Co, act=MM_ACT_GELU_SAVE_GRAD if keep else MM_ACT_GELU, C2=gp, c_img=not last)
+            saved += [cur, wg, gp]
+            dims.append((S, Lin, Lout, Ci, Co, KH, stride))
+            cur = y
+        if keep:
+            ctx.save_for_backward(*saved)
+            ctx.dims = dims
+        return cur
+
+    @staticmethod
+    def _backward_img(ctx, be, dy):
+        saved, dims = ctx.saved_tensors, ctx.dims
+        n = len(dims)
+        I = lambda t, ld, **kw: MMOp(t, ld, img=True, **kw)
+
+        def img_of(t2d):
+            o = torch.empty_like(t2d)
+            be.split_img(t2d, t2d.shape[0], t2d.shape[1], t2d.shape[1], o, t2d.shape[1])
+            return o
+        dzf = (_f32c(dy) * saved[3 * (n - 1) + 2])                # top layer: dy o gelu' (small: 49 Hz frames)
+        dz = img_of(dzf.view(-1, dzf.shape[-1])).view(dzf.shape)
+        dws = [None] * n
+        dx = None
+        lane, held = _WeightGradLane(dz), []
+        for i in range(n - 1, -1, -1):
+            xi, wg, _gp = saved[3 * i: 3 * i + 3]
+            S, Lin, Lout, Ci, Co, KH, stride = dims[i]
+            dwg, dw = _new(xi, Co, KH * Ci), _new(xi, Co, Ci, KH)
+
+            def wgrad(xi=xi, dz=dz, dwg=dwg, dw=dw, dm=(S, Lin, Lout, Ci, Co, KH, stride)):
+                S_, Lin_, Lout_, Ci_, Co_, KH_, st_ = dm
+                B = I(xi, st_ * Ci_, trans=True, lines_per_seq=Lout_, seq_stride=Lin_ * Ci_, seq_elems=Lin_ * Ci_)
+                be.mm(I(dz, Co_, trans=True), B, dwg, Co_, KH_ * Ci_, S_ * Lout_, KH_ * Ci_, split_k=0)
+                be.conv_weight_pack(dwg, dw, Co_, Ci_, KH_, 1)
+            lane.run(wgrad)
+            held.append((dz, dwg))
+            dws[i] = dw
+            if i == 0 and not ctx.needs_input_grad[0]:
+                break
+            # data gradient in gather form; below layer 1 it lands as the image the next (lower) layer's two gradient products read, already multiplied
+            # by that layer's saved gelu' - the bottom one as fp32 rows for layer 0's backward
+            covered = Lout * KH if KH == stride else 2 * Lout + 1
+            dxi = torch.empty(S, Lin, Ci, device=xi.device, dtype=torch.float32)
+            if covered < Lin:
+                dxi[:, covered:].zero_()
+            ex = dict(aux=saved[3 * (i - 1) + 2], aux_mode=MM_AUX_MUL_LIKE_C) if i > 0 else {}
+            cimg = i > 0
+            if KH == stride:
+                wt = img_of(wg.t().contiguous())                                       # (KH * Ci, Co)
+                be.mm(I(dz, Co), I(wt, Co), dxi, S * Lout, KH * Ci, Co, KH * Ci, c_rows_per_seq=Lout, c_seq_stride=Lin * Ci, c_img=cimg, **ex)
+            else:
+                assert KH == 3 and stride == 2 and Lin >= 2 * Lout + 1
+                rows = Lout + 1
+                # positions 2 q: dy[q - 1] through tap 2 + dy[q] through tap 0 - a two-row window of dz (zero rows beyond both ends) against [W_2 ; W_0]
+                w20 = img_of(torch.cat((wg[:, 2 * Ci:3 * Ci].t(), wg[:, 0:Ci].t()), 1).contiguous())     # (Ci, 2 Co)
+                A = I(dz, Co, lines_per_seq=rows, seq_stride=Lout * Co, off=-Co, seq_elems=Lout * Co)
+                be.mm(A, I(w20, 2 * Co), dxi, S * rows, Ci, 2 * Co, 2 * Ci, c_off=0, c_rows_per_seq=rows, c_seq_stride=Lin * Ci, c_img=cimg, **ex)
+                # positions 2 q + 1: dy[q] through the middle tap
+                w1 = img_of(wg[:, Ci:2 * Ci].t().contiguous())                                             # (Ci, Co)
+                be.mm(I(dz, Co), I(w1, Co), dxi, S * Lout, Ci, Co, 2 * Ci, c_off=Ci, c_rows_per_seq=Lout, c_seq_stride=Lin * Ci, c_img=cimg, **ex)
+            if i > 0:
+                dz = dxi
+            else:
+                dx = dxi
+        lane.join()
+        return (dx, None, None, *dws)
+
     @staticmethod
     @_restores_precision
     def backward(ctx, dy):
         be = ops.backend()
+        if ctx.img:
+            return ConvStackFn._backward_img(ctx, be, dy)
         saved, dims = ctx.saved_tensors, ctx.dims
         n = len(dims)
         dz = _f32c(dy) * saved[3 * (n - 1) + 2]                   # top layer: dy o gelu'
@@ -568,7 +675,7 @@ class ConvStackFn(torch.autograd.Function):
             else:
                 dx = dxi
         lane.join()
-        return (dx, None, *dws)
+        return (dx, None, None, *dws)
 
 
 # =================================================================================================

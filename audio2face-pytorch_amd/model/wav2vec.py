@@ -157,14 +157,20 @@ class Wav2Vec2Model(nn.Module):
         # feature encoder, in chunks of sequences: the sequences are independent there and an a2f_mm operand spans < 4 GiB (the layer-0
         # output of 32 sequences of 160 000 samples is 2.1 GB); the chunks are concatenated once the frame rate is down to 49 Hz
         n = wave.shape[1]
-        per = max(1, int((3 << 30) // (max((n - 10) // 5 + 1, 1) * 512 * 4)))
+        from .. import ops as _ops
+        L0, C0 = max((n - 10) // 5 + 1, 1), fe[0].conv.weight.shape[0]
+        per = max(1, int(((1 << 31) - (1 << 20)) // (L0 * C0 * 4)))   # < 2 GiB per chunk: what the image-operand kernels' 32-bit epilogue offsets span
         per = -(-S // -(-S // per))                               # balanced chunks
+        stack_w = [fe[i].conv.weight for i in range(1, len(fe))]
         outs = []
         for s0 in range(0, S, per):
+            ns = min(per, S - s0)
+            # the stack on split-32 image operands (encoder_ops.ConvStackFn): layer 0 then writes its output as the image layer 1 reads
+            imgs = GELU_SAVED and len(fe) > 1 and ConvStackFn.use_images(_ops.backend(), torch.empty(ns, L0, C0, device="meta"), stack_w)
             # layer 0 (1 -> 512 channels, k = 10, stride 5) + GroupNorm(512 groups) + GELU: 10 MACs per output, memory-bound
-            z = FeatEnc0Fn.apply(wave[s0:s0 + per], fe[0].conv.weight, fe[0].layer_norm.weight, fe[0].layer_norm.bias)      # channels-last (s, L, 512)
+            z = FeatEnc0Fn.apply(wave[s0:s0 + per], fe[0].conv.weight, fe[0].layer_norm.weight, fe[0].layer_norm.bias, imgs)      # channels-last (s, L, 512)
             if GELU_SAVED:
-                z = ConvStackFn.apply(z, tuple(CONV_STRIDE[1:len(fe)]), *[fe[i].conv.weight for i in range(1, len(fe))])
+                z = ConvStackFn.apply(z, tuple(CONV_STRIDE[1:len(fe)]), imgs, *stack_w)
             else:
                 for i in range(1, len(fe)):
                     z = ConvGeluFn.apply(z, fe[i].conv.weight, CONV_STRIDE[i])

@@ -249,12 +249,13 @@ class HipBackend:
         _lib.check(self.lib.a2f_gelu_bwd(_ptr(dy), _ptr(z), dy.numel(), _ptr(out), self._stream(dy)), "a2f_gelu_bwd")
 
     # ---- feature-encoder layer 0 (csrc/featenc.hip) ----------------------------------------------
-    def featenc0_fwd(self, wave, S, N, w, gamma, beta, Cc, eps, out, stats):
+    def featenc0_fwd(self, wave, S, N, w, gamma, beta, Cc, eps, out, stats, out_img=False):
+        """out_img: `out` receives the split-32 image of the layer output instead of fp32 rows."""
         _chk(wave, w, gamma, beta, out, stats)
         nb = self.lib.a2f_featenc0_ws_bytes(S, N, Cc)
         ws = torch.empty(nb // 4, dtype=torch.float32, device=wave.device)
-        _lib.check(self.lib.a2f_featenc0_fwd(_ptr(wave), S, N, _ptr(w), _ptr(gamma), _ptr(beta), Cc, eps, _ptr(out), _ptr(stats), _ptr(ws), nb,
-                                             self._stream(wave)), "a2f_featenc0_fwd")
+        _lib.check(self.lib.a2f_featenc0_fwd_img(_ptr(wave), S, N, _ptr(w), _ptr(gamma), _ptr(beta), Cc, eps, _ptr(out), int(out_img), _ptr(stats), _ptr(ws), nb,
+                                                 self._stream(wave)), "a2f_featenc0_fwd")
 
     def featenc0_bwd(self, wave, S, N, w, gamma, beta, Cc, stats, dout, dw, dgamma, dbeta, dy=None):
         _chk(wave, w, gamma, beta, stats, dout, dw, dgamma, dbeta, dy)

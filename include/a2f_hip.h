@@ -479,6 +479,9 @@ int a2f_attn_bwd_drop(const float* qkv, const float* ctx, const float* dctx, con
 size_t a2f_featenc0_ws_bytes(int64_t S, int64_t N, int64_t C);
 int a2f_featenc0_fwd(const float* wave, int64_t S, int64_t N, const float* w, const float* gamma, const float* beta, int64_t C, float eps,
                      float* out, float* stats, void* ws, size_t ws_bytes, a2f_stream_t stream);
+/* the same with the output written as a split-32 image (out_format 1; 0 = fp32): the operand format of the convolution stack on image operands */
+int a2f_featenc0_fwd_img(const float* wave, int64_t S, int64_t N, const float* w, const float* gamma, const float* beta, int64_t C, float eps,
+                         void* out, int32_t out_format, float* stats, void* ws, size_t ws_bytes, a2f_stream_t stream);
 int a2f_featenc0_bwd(const float* wave, int64_t S, int64_t N, const float* w, const float* gamma, const float* beta, int64_t C,
                      const float* stats, const float* dout, float* dw, float* dgamma, float* dbeta, float* dy, void* ws, size_t ws_bytes,
                      a2f_stream_t stream);

@@ -182,13 +182,15 @@ class EmuBackend:
            aux_mode=0, precision=None, split_k=1, batch=1, a_bstride=0, b_bstride=0, c_bstride=0, bias_bstride=0, aux_bstride=0,
            accumulate=False, alpha=1.0, tag=None, keep=None, a_rowsum=None, c_img=False, c_colsum=None):
         import copy
-        if c_img:                                      # image output: plain row map, whole 32-blocks; the values land as hi / lo pairs
-            assert getattr(A, "img", False) and c_rows_per_seq == 0 and ldc % 32 == 0 and c_off % 32 == 0 and N % 32 == 0 and batch == 1 and not accumulate
+        if c_img:                                      # image output: whole 32-blocks; the values land as hi / lo pairs
+            assert getattr(A, "img", False) and ldc % 32 == 0 and c_off % 32 == 0 and c_seq_stride % 32 == 0 and N % 32 == 0 and batch == 1 and not accumulate
             tmp = torch.zeros(Cout.numel())
-            self.mm(A, B, tmp, M, N, K, ldc, c_off=c_off, C2=C2, bias=bias, aux=aux, ldaux=ldaux, act=act, aux_mode=aux_mode, precision=precision,
-                    alpha=alpha, keep=keep, c_colsum=c_colsum)
+            self.mm(A, B, tmp, M, N, K, ldc, c_off=c_off, c_rows_per_seq=c_rows_per_seq, c_seq_stride=c_seq_stride, C2=C2, bias=bias, aux=aux, ldaux=ldaux, act=act,
+                    aux_mode=aux_mode, precision=precision, alpha=alpha, keep=keep, c_colsum=c_colsum)
             enc = img_encode(tmp.view(-1, 32))
-            blocks = ((c_off + torch.arange(M).view(-1, 1) * ldc + torch.arange(0, N, 32).view(1, -1)) // 32).reshape(-1)
+            mm_ = torch.arange(M).view(-1, 1)
+            crow_ = mm_ * ldc if c_rows_per_seq <= 0 else (mm_ // c_rows_per_seq) * c_seq_stride + (mm_ % c_rows_per_seq) * ldc
+            blocks = ((c_off + crow_ + torch.arange(0, N, 32).view(1, -1)) // 32).reshape(-1)
             Cout.reshape(-1, 32)[blocks] = enc[blocks]
             return
         self.calls.append(("mm", M, N, K, batch))
@@ -316,14 +318,15 @@ class EmuBackend:
         g = 0.5 * (1 + torch.erf(zd / math.sqrt(2.0))) + zd * torch.exp(-0.5 * zd * zd) / math.sqrt(2 * math.pi)
         out.copy_((dy.double() * g).float())
 
-    def featenc0_fwd(self, wave, S, N, w, gamma, beta, Cc, eps, out, stats):
+    def featenc0_fwd(self, wave, S, N, w, gamma, beta, Cc, eps, out, stats, out_img=False):
         import torch.nn.functional as F
         y = F.conv1d(wave.reshape(S, 1, N).double(), w.reshape(Cc, 1, 10).double(), stride=5)          # (S,C,L)
         mu = y.mean(dim=2, keepdim=True)
         var = ((y - mu) ** 2).mean(dim=2, keepdim=True)
         rs = 1.0 / torch.sqrt(var + eps)
         u = (y - mu) * rs * gamma.double().view(1, -1, 1) + beta.double().view(1, -1, 1)
-        out.copy_(F.gelu(u).transpose(1, 2).float())
+        o = F.gelu(u).transpose(1, 2).float()
+        out.copy_(img_encode(o) if out_img else o)
         stats.reshape(S, 2, Cc)[:, 0].copy_(mu.squeeze(2).float()); stats.reshape(S, 2, Cc)[:, 1].copy_(rs.squeeze(2).float())
 
     def featenc0_bwd(self, wave, S, N, w, gamma, beta, Cc, stats, dout, dw, dgamma, dbeta, dy=None):

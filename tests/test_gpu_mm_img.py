@@ -219,3 +219,53 @@ def test_attention_image_outputs_and_image_colsum():
     cs = torch.zeros(ld, device=DEV)
     be.colsum_img(dq_i, S * T, ld, ld, cs)
     assert rel_l2(cs.cpu(), img_decode(dq_i.cpu()).sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("S,L0", [(3, 171), (2, 1000)])
+def test_conv_stack_on_image_operands_vs_torch_float64(S, L0, monkeypatch):
+    """encoder_ops.ConvStackFn on split-32 images (un-padded forward windows, padded two-row windows + strided image outputs of the gather-form data
+    gradient, windowed B of the weight gradient) against torch's conv1d + GELU autograd in float64: output, d/d input, every weight gradient."""
+    from a2f_amd import encoder_ops
+    monkeypatch.setattr(encoder_ops, "IMG_MIN_ROWS", 0)
+    C = 64
+    strides, ks = (2, 2, 2), (3, 3, 2)
+    x = rnd(S, L0, C, seed=1)
+    ws = [rnd(C, C, k, seed=10 + i, scale=0.12) for i, k in enumerate(ks)]
+    xd = x.double().requires_grad_(True)
+    wd = [w.double().requires_grad_(True) for w in ws]
+    cur = xd.transpose(1, 2)
+    for w, st in zip(wd, strides):
+        cur = torch.nn.functional.gelu(torch.nn.functional.conv1d(cur, w, stride=st))
+    ref = cur.transpose(1, 2)
+    gout = rnd(*ref.shape, seed=5)
+    ref.backward(gout.double())
+    xg = x.to(DEV).requires_grad_(True)
+    wg = [w.to(DEV).requires_grad_(True) for w in ws]
+    for x_is_img in (False, True):
+        xg.grad = None
+        for w in wg:
+            w.grad = None
+        if x_is_img:
+            xi = torch.empty_like(xg)
+            ops.backend().split_img(xg.detach(), S * L0, C, C, xi, C)
+            y = encoder_ops.ConvStackFn.apply(xi.requires_grad_(True), strides, True, *wg)
+        else:
+            y = encoder_ops.ConvStackFn.apply(xg, strides, False, *wg)
+        assert rel_l2(y, ref) < 5e-5
+        y.backward(gout.to(DEV))
+        if not x_is_img:
+            assert rel_l2(xg.grad, xd.grad) < 5e-5
+        for w, r in zip(wg, wd):
+            assert rel_l2(w.grad, r.grad) < 5e-5
+
+
+def test_featenc0_image_output_is_the_split_of_the_fp32_output():
+    S, N, C = 2, 3205, 512
+    wave, w, g, b = rnd(S, N, seed=1), rnd(C, 10, seed=2, scale=0.3), rnd(C, seed=3), rnd(C, seed=4)
+    be = ops.HipBackend()
+    L = (N - 10) // 5 + 1
+    o32, oi, st = torch.zeros(S, L, C, device=DEV), torch.zeros(S, L, C, device=DEV), torch.zeros(S, 2, C, device=DEV)
+    be.featenc0_fwd(wave.to(DEV), S, N, w.to(DEV), g.to(DEV), b.to(DEV), C, 1e-5, o32, st)
+    be.featenc0_fwd(wave.to(DEV), S, N, w.to(DEV), g.to(DEV), b.to(DEV), C, 1e-5, oi, st, out_img=True)
+    d = (img_decode(oi.cpu()) - o32.cpu().double()).abs()
+    assert bool((d <= o32.cpu().double().abs() * 2.0 ** -16 + 1e-30).all())

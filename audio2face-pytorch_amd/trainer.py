@@ -141,9 +141,19 @@ class BucketedAllReduce:
         self.next = len(self.bounds) - 1
         self.works = []
         self.launch_log = []                                   # bucket indices in launch order (tests)
+        # the hooks hold this object (and through it the FlatAdam and its four flat buffers): keep the handles so that close() can take them
+        # off the parameters when the step that owns this exchange goes away (bench.py builds several TrainSteps on one model)
+        self._handles = []
         for name, p in named_params:
             if id(p) in self.bucket_of:
-                p.register_post_accumulate_grad_hook(self._hook)
+                self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
+
+    def close(self):
+        """Remove the gradient hooks (idempotent)."""
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+        self.active = False
 
     def begin(self):
         """Call right before the LAST backward pass of the step (gradients of earlier passes are already accumulated)."""
@@ -217,10 +227,11 @@ class TrainStep:
         # (measured on MI355X with the round-1 recurrence, 17 ms per half at T = 600: 64 sequences 179.5 -> 171.5 ms.  With the 8-wave forward and the
         # blocked record-form backward the recurrence is 11 ms at T = 600 and the halves' doubled per-launch tails cost as much as hiding it gains:
         # 64 x 600 155.9 ms single-stream vs 158-161 ms pipelined inside the full bench run; at 3000 frames (89 ms per half) it pays: 12 x 3000
-        # 251 -> 238 ms.  So: from 1200 frames per sequence and 48 x 600 frames per step up.)
+        # 251 -> 238 ms.  Round 4: with the encoder's products on image operands the step is 30 ms shorter, the recurrence is 6 % of it again and hiding
+        # it pays at 600 frames too: 64 x 600 131.0 -> 125.8 ms, same box.)  So: from 600 frames per sequence and 48 x 600 frames per step up.
         self.pipeline = os.environ.get("A2F_FF_PIPELINE", "1") != "0"
         self.pipeline_min_seqs = int(os.environ.get("A2F_FF_PIPELINE_MIN_SEQS", "48"))    # in sequences of 600 frames: the test is on frames per step
-        self.pipeline_min_frames = int(os.environ.get("A2F_FF_PIPELINE_MIN_FRAMES", "1200"))
+        self.pipeline_min_frames = int(os.environ.get("A2F_FF_PIPELINE_MIN_FRAMES", "600"))
         self._graph2 = None
         # models that expose `grad_bucket_key(name)` (FaceFormer: 386 MB of gradients) exchange them bucket by bucket under the backward
         # (A2F_DP_BUCKETS=0: one blocking all-reduce after the backward, as round 2 did)
@@ -228,6 +239,23 @@ class TrainStep:
         if (hasattr(model, "grad_bucket_key") and (self.opt.world() > 1 or self.opt.force_collectives)
                 and os.environ.get("A2F_DP_BUCKETS", "1") != "0"):
             self.buckets = BucketedAllReduce(self.opt, list(model.named_parameters()), model.grad_bucket_key)
+        if self.buckets is not None and use_graph:
+            # autograd hooks that launch collectives cannot live inside a hipGraph capture (and a replay would not run them): a captured step
+            # exchanges its gradients with the one blocking all-reduce inside FlatAdam.step() instead
+            self.buckets.close()
+            self.buckets = None
+
+    def close(self):
+        """Detach this step from the model (gradient hooks of the bucketed exchange); the model and its parameters stay usable."""
+        if getattr(self, "buckets", None) is not None:
+            self.buckets.close()
+            self.buckets = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _direct(self, ins, phase):
         lf = getattr(self.loss_fn, "loss", self.loss_fn)

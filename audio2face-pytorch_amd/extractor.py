@@ -8,9 +8,9 @@ into it, so it is a pure pre-processing step upstream of the hot path).
 
 torchaudio is NOT in this image and the reference pins no version, so the arithmetic below is a restatement of torchaudio's
 published defaults - **PARITY UNPINNED**: there is no torchaudio build, reference test or fixture here to check it against; tests
-pin structural properties only.  Two evaluations of the same definition: plain torch ops (``torch.stft``; what CPU tensors and
-``use_hip = False`` run) and, on HIP tensors, the STFT / mel filter bank / DCT as three products on the library's exact-fp32 MFMA
-GEMM (``mel_spectrogram_hip``: the windowed DFT as a matrix, no vendor FFT), checked against the torch-ops form on the GPU.
+pin structural properties only.  ONE evaluation in the product: the STFT / mel filter bank / DCT as three products on the library's
+exact-fp32 MFMA GEMM (``mel_spectrogram``: the windowed DFT as a matrix, no vendor FFT; HIP tensors only).  The plain torch-ops form
+(``torch.stft``) is test infrastructure (tests/torch_ops_mfcc.py) the HIP products are checked against.
     MelSpectrogram: torch.stft(center=True, pad_mode="reflect", hann window of win_length, onesided) -> |.|^2 ->
                     HTK mel filter bank (n_mels=128, f_min=0, f_max=sr/2, norm=None)
     AmplitudeToDB("power", top_db=80): 10 log10(max(x, 1e-10)), floored at (max over the whole (batch, mel, time) input) - 80
@@ -74,14 +74,6 @@ class MFCCExtractor(nn.Module):
         self.register_buffer("dct_mat", create_dct_ortho(self.n_mfcc, n_mels), persistent=False)
         self._first = True
 
-    def mel_spectrogram(self, x: torch.Tensor) -> torch.Tensor:
-        spec = torch.stft(x, self.n_fft, hop_length=self.hop_length, win_length=self.win_length, window=self.window, center=True,
-                          pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
-        power = spec.real * spec.real + spec.imag * spec.imag                     # (batch, n_freqs, frames)
-        return torch.matmul(power.transpose(-1, -2), self.fb).transpose(-1, -2)   # (batch, n_mels, frames)
-
-    use_hip = True            # HIP tensors: the three matrix products (windowed DFT, mel filter bank, DCT) on the library's exact-fp32 MFMA GEMM
-
     def _basis(self, device):
         """(2 * nfp, win_length) real DFT basis restricted to the support of the centred window: row f = w[k] cos(2 pi f (k + off) / n_fft),
         row nfp + f = -w[k] sin(...), f < n_fft/2 + 1 (rows up to nfp = the next multiple of 4 are zero), built in float64."""
@@ -104,8 +96,8 @@ class MFCCExtractor(nn.Module):
             self._nfp = nfp
         return b
 
-    def mel_spectrogram_hip(self, x: torch.Tensor) -> torch.Tensor:
-        """The same mel power spectrogram with the STFT as a matrix product: frames of the reflect-padded signal (only the win_length
+    def mel_spectrogram(self, x: torch.Tensor) -> torch.Tensor:
+        """The mel power spectrogram with the STFT as a matrix product: frames of the reflect-padded signal (only the win_length
         samples under the centred window) against the windowed DFT basis, then |.|^2 and the mel filter bank - three launches of the
         exact-fp32 MFMA GEMM (a2f_gemm_f32) instead of the vendor FFT.  (batch, time) -> (batch, n_mels, frames)."""
         from . import ops
@@ -125,22 +117,20 @@ class MFCCExtractor(nn.Module):
         return mel.view(B, nfr, -1).transpose(1, 2)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        hip = x.is_cuda and self.use_hip
-        mel = self.mel_spectrogram_hip(x) if hip else self.mel_spectrogram(x)
+        """One path: the three matrix products run on the library's GEMM through ``ops.backend()`` (HIP tensors; off-device tensors fail in
+        ``ops._chk`` like everywhere else in the package).  The torch.stft restatement the tests compare against lives in tests/torch_ops_mfcc.py."""
+        mel = self.mel_spectrogram(x)
         db = 10.0 * torch.log10(torch.clamp(mel, min=1e-10))
         # torchaudio.functional.amplitude_to_DB packs a (batch, mel, time) input as ONE (1, batch, mel, time) item: the top_db
         # floor is the maximum over the whole batch minus top_db (per item only for 4-D input).  extractor.py:47 feeds (batch, time)
         # audio, so the spectrogram is 3-D here.
         red = (-3, -2, -1) if db.dim() == 3 else (-2, -1)
         db = torch.maximum(db, db.amax(dim=red, keepdim=True) - self.top_db)
-        if hip:
-            from . import ops
-            dbt = db.transpose(-1, -2).contiguous()                                # (batch, frames, n_mels)
-            mfcc = torch.empty(dbt.shape[0], dbt.shape[1], self.n_mfcc, device=x.device, dtype=torch.float32)
-            ops.linear_fwd(ops.backend(), dbt.view(-1, dbt.shape[2]), self._dct_lin, None, mfcc.view(-1, self.n_mfcc), dbt.shape[0] * dbt.shape[1],
-                           self.n_mfcc, dbt.shape[2])
-        else:
-            mfcc = torch.matmul(db.transpose(-1, -2), self.dct_mat)                # (batch, frames, n_mfcc) = T(x).transpose(1, 2)
+        from . import ops
+        dbt = db.transpose(-1, -2).contiguous()                                    # (batch, frames, n_mels)
+        mfcc = torch.empty(dbt.shape[0], dbt.shape[1], self.n_mfcc, device=x.device, dtype=torch.float32)
+        ops.linear_fwd(ops.backend(), dbt.view(-1, dbt.shape[2]), self._dct_lin, None, mfcc.view(-1, self.n_mfcc), dbt.shape[0] * dbt.shape[1],
+                       self.n_mfcc, dbt.shape[2])
         if self.out_dim != mfcc.shape[1]:                                          # extractor.py:49-58
             if self._first:
                 logging.warning(f"MFCCExtractor: Got tensor shape {mfcc.shape}, resizing to {self.out_dim} using bilinear interpolation")

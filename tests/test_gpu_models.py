@@ -1088,11 +1088,13 @@ def test_mfcc_extractor_hip_products_vs_torch_ops():
     x[3] *= 1e-3
     t = torch.arange(11440) / 22000.0
     x[5] = 0.3 * torch.sin(2 * 3.14159265 * 440.0 * t) + 1e-4 * x[5]          # a tone 70 dB above its noise floor: wide dynamic range
+    from torch_ops_mfcc import mfcc_torch_ops
     ex = MFCCExtractor(22000, 32, 52, 440, None, 1024).to(DEV)
     hip = ex(x.to(DEV))
-    ex.use_hip = False
-    fft_gpu = ex(x.to(DEV))
-    cpu = MFCCExtractor(22000, 32, 52, 440, None, 1024)(x)
+    fft_gpu = mfcc_torch_ops(ex, x.to(DEV))
+    cpu = mfcc_torch_ops(MFCCExtractor(22000, 32, 52, 440, None, 1024), x)
+    with pytest.raises(a2f_amd.A2FError):
+        ex(x)                                                             # no CPU path in the product
     assert hip.shape == (8, 52, 32)
     assert rel_l2(hip.cpu(), cpu) < 1e-4 and rel_l2(hip.cpu(), fft_gpu.cpu()) < 1e-4
 

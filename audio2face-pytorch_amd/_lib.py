@@ -125,6 +125,8 @@ SIGNATURES = {
     "a2f_attn_bwd_drop": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, i64, i64, i64, f32, i32, c_f32p, c_f32p, c_f32p, c_f32p, f32,
                                     C.c_void_p]),
     "a2f_keep_bits": (C.c_int, [C.c_uint64, C.c_uint32, i64, i64, f32, c_f32p, i64, C.c_void_p]),
+    "a2f_keep_bits_dev": (C.c_int, [c_f32p, C.c_uint32, i64, i64, f32, c_f32p, i64, C.c_void_p]),
+    "a2f_keep_bits_attn_dev": (C.c_int, [c_f32p, C.c_uint32, i64, i64, f32, c_f32p, c_f32p, C.c_void_p]),
     "a2f_attn_keep_words": (i64, [i64]),
     "a2f_keep_bits_attn": (C.c_int, [C.c_uint64, C.c_uint32, i64, i64, f32, c_f32p, c_f32p, C.c_void_p]),
     "a2f_dropout_apply": (C.c_int, [c_f32p, c_f32p, i64, i64, i64, i64, f32, c_f32p, C.c_void_p]),

@@ -44,8 +44,11 @@ __device__ __forceinline__ unsigned keep_word(unsigned k0, unsigned k1, unsigned
   return word;
 }
 
+// seed_dev (optional): the 64-bit step seed lives in device memory - a hipGraph-captured train step replays the same launch with a fresh seed written
+// into that word before every replay (a seed passed by value would be baked into the captured node)
 __global__ __launch_bounds__(256) void keep_bits_kernel(unsigned k0, unsigned k1, unsigned site, long long R, int C, int wpr, unsigned thresh,
-                                                        unsigned* __restrict__ out) {
+                                                        unsigned* __restrict__ out, const unsigned long long* __restrict__ seed_dev) {
+  if (seed_dev) { const unsigned long long s = *seed_dev; k0 = (unsigned)s; k1 = (unsigned)(s >> 32); }
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= R * wpr) return;
   const long long r = idx / wpr;
@@ -55,7 +58,8 @@ __global__ __launch_bounds__(256) void keep_bits_kernel(unsigned k0, unsigned k1
 
 // grid (TW / 4, ceil(T / 64), SH), 256 threads: wave <-> key word kw, lane <-> query
 __global__ __launch_bounds__(256) void keep_bits_attn_kernel(unsigned k0, unsigned k1, unsigned site, int T, int TW, unsigned thresh,
-                                                             unsigned* __restrict__ qmaj, unsigned* __restrict__ kmaj) {
+                                                             unsigned* __restrict__ qmaj, unsigned* __restrict__ kmaj, const unsigned long long* __restrict__ seed_dev) {
+  if (seed_dev) { const unsigned long long s = *seed_dev; k0 = (unsigned)s; k1 = (unsigned)(s >> 32); }
   const int lane = threadIdx.x & 63, kw = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int q = blockIdx.y * 64 + lane;
   const long long sh = blockIdx.z;
@@ -101,27 +105,43 @@ static unsigned keep_threshold(float p) {            // keep iff random u32 >= p
 
 }  // namespace a2f
 
+static int keep_bits_impl(uint64_t seed, const uint64_t* seed_dev, uint32_t site, int64_t R, int64_t C, float p, uint32_t* bits, int64_t wpr, a2f_stream_t stream);
 extern "C" int a2f_keep_bits(uint64_t seed, uint32_t site, int64_t R, int64_t C, float p, uint32_t* bits, int64_t wpr, a2f_stream_t stream) {
+  return keep_bits_impl(seed, nullptr, site, R, C, p, bits, wpr, stream);
+}
+extern "C" int a2f_keep_bits_dev(const uint64_t* seed_dev, uint32_t site, int64_t R, int64_t C, float p, uint32_t* bits, int64_t wpr, a2f_stream_t stream) {
+  if (!seed_dev) return a2f::set_err(A2F_EINVAL, "keep_bits_dev: null seed pointer");
+  return keep_bits_impl(0, seed_dev, site, R, C, p, bits, wpr, stream);
+}
+static int keep_bits_impl(uint64_t seed, const uint64_t* seed_dev, uint32_t site, int64_t R, int64_t C, float p, uint32_t* bits, int64_t wpr, a2f_stream_t stream) {
   using namespace a2f;
   A2F_CHECK_ARG(bits && R > 0 && C > 0 && R < (1ll << 32) && C < (1ll << 31) && wpr * 32 >= C && wpr < (1 << 26), "keep_bits: R=%lld C=%lld wpr=%lld",
                 (long long)R, (long long)C, (long long)wpr);
   A2F_CHECK_ARG(p >= 0.f && p < 1.f, "keep_bits: p=%g", (double)p);
   const long long n = R * wpr;
   hipLaunchKernelGGL(keep_bits_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (unsigned)seed, (unsigned)(seed >> 32), site,
-                     (long long)R, (int)C, (int)wpr, keep_threshold(p), bits);
+                     (long long)R, (int)C, (int)wpr, keep_threshold(p), bits, (const unsigned long long*)seed_dev);
   A2F_CHECK_LAUNCH("keep_bits");
   return A2F_OK;
 }
 
 extern "C" int64_t a2f_attn_keep_words(int64_t T) { return 2 * ((T + 63) / 64); }
 
+static int keep_bits_attn_impl(uint64_t seed, const uint64_t* seed_dev, uint32_t site, int64_t SH, int64_t T, float p, uint32_t* qmajor, uint32_t* kmajor, a2f_stream_t stream);
 extern "C" int a2f_keep_bits_attn(uint64_t seed, uint32_t site, int64_t SH, int64_t T, float p, uint32_t* qmajor, uint32_t* kmajor, a2f_stream_t stream) {
+  return keep_bits_attn_impl(seed, nullptr, site, SH, T, p, qmajor, kmajor, stream);
+}
+extern "C" int a2f_keep_bits_attn_dev(const uint64_t* seed_dev, uint32_t site, int64_t SH, int64_t T, float p, uint32_t* qmajor, uint32_t* kmajor, a2f_stream_t stream) {
+  if (!seed_dev) return a2f::set_err(A2F_EINVAL, "keep_bits_attn_dev: null seed pointer");
+  return keep_bits_attn_impl(0, seed_dev, site, SH, T, p, qmajor, kmajor, stream);
+}
+static int keep_bits_attn_impl(uint64_t seed, const uint64_t* seed_dev, uint32_t site, int64_t SH, int64_t T, float p, uint32_t* qmajor, uint32_t* kmajor, a2f_stream_t stream) {
   using namespace a2f;
   A2F_CHECK_ARG(qmajor && kmajor && SH > 0 && SH < 65536 && T > 0 && SH * T < (1ll << 32), "keep_bits_attn: SH=%lld T=%lld", (long long)SH, (long long)T);
   A2F_CHECK_ARG(p >= 0.f && p < 1.f, "keep_bits_attn: p=%g", (double)p);
   const int TW = (int)a2f_attn_keep_words(T);
   hipLaunchKernelGGL(keep_bits_attn_kernel, dim3((unsigned)cdiv(TW, 4), (unsigned)cdiv(T, 64), (unsigned)SH), dim3(256), 0, (hipStream_t)stream,
-                     (unsigned)seed, (unsigned)(seed >> 32), site, (int)T, TW, keep_threshold(p), qmajor, kmajor);
+                     (unsigned)seed, (unsigned)(seed >> 32), site, (int)T, TW, keep_threshold(p), qmajor, kmajor, (const unsigned long long*)seed_dev);
   A2F_CHECK_LAUNCH("keep_bits_attn");
   return A2F_OK;
 }

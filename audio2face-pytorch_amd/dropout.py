@@ -93,6 +93,7 @@ class EncoderMasks:
         self.layers: List[Dict] = []
         self.layer_skip: List[bool] = []
         self.spec: Optional[torch.Tensor] = None
+        self.layer_keep_dev: Optional[torch.Tensor] = None     # graph-captured steps: bool (L,) on the device, every layer runs and this selects
 
     @staticmethod
     def from_recorded(rec: Dict, device, p_feat=0.1, p_hidden=0.1, p_attn=0.1, p_act=0.1) -> "EncoderMasks":
@@ -148,11 +149,65 @@ def _to_device_async(a: np.ndarray, device) -> torch.Tensor:
     return out
 
 
-def draw_encoder_masks(be, S: int, T: int, n_layers: int, heads: int, hidden: int, ffn: int, cfg, seed: int, device) -> EncoderMasks:
+class StepRandomness:
+    """The per-step random state of a FaceFormer train step as DEVICE-RESIDENT tensors, for hipGraph-captured steps: a captured launch cannot take a fresh
+    seed by value, and a host-side LayerDrop branch or SpecAugment mask cannot change between replays.  ``refresh()`` draws on the host exactly what the eager
+    step draws - one 62-bit encoder seed from torch's CPU generator, LayerDrop and SpecAugment from the numpy stream seeded with it, one decoder seed - and copies
+    it into the static tensors (pinned staging, non-blocking); the captured kernels read ``seed`` / ``dec_seed`` at run time (a2f_keep_bits_dev), every layer is
+    launched and ``layer_keep[l]`` selects its output or its input (a dropped layer's gradients come out as exact zeros: what FlatAdam.collect_grads fills in
+    for a layer autograd never visited), ``spec`` is applied as a select.  Same seed -> same masks, decisions and results as the eager step."""
+
+    def __init__(self, device, n_layers: int, S: int, T: int):
+        self.device, self.n_layers, self.S, self.T = torch.device(device), n_layers, S, T
+        self.seed = torch.zeros(1, dtype=torch.int64, device=device)
+        self.dec_seed = torch.zeros(1, dtype=torch.int64, device=device)
+        self.layer_keep = torch.ones(n_layers, dtype=torch.bool, device=device)
+        self.spec = torch.zeros(S, T, dtype=torch.bool, device=device)
+        self._stage = None
+        self.last = None                      # the host-side values of the last refresh (tests)
+
+    def refresh(self, cfg, train_encoder: bool = True, train_decoder: bool = True):
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if train_encoder else 0
+        rng = np.random.RandomState(seed & 0x7FFFFFFF)
+        keep = np.ones(self.n_layers, dtype=bool)
+        spec = np.zeros((self.S, self.T), dtype=bool)
+        if train_encoder:
+            for l in range(self.n_layers):
+                keep[l] = not (rng.rand() < cfg.layerdrop)
+            if cfg.apply_spec_augment and cfg.mask_time_prob > 0.0 and self.T > cfg.mask_time_length:
+                spec = compute_mask_indices((self.S, self.T), cfg.mask_time_prob, cfg.mask_time_length, min_masks=2, rng=rng)
+        dec_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if train_decoder else 0
+        self.last = {"seed": seed, "dec_seed": dec_seed, "layer_keep": keep.copy(), "spec": spec.copy()}
+        if self.device.type != "cuda":
+            self.seed[0], self.dec_seed[0] = seed, dec_seed
+            self.layer_keep.copy_(torch.from_numpy(keep))
+            self.spec.copy_(torch.from_numpy(spec))
+            return
+        if self._stage is None:
+            self._stage = {"seeds": torch.zeros(2, dtype=torch.int64).pin_memory(), "keep": torch.zeros(self.n_layers, dtype=torch.bool).pin_memory(),
+                           "spec": torch.zeros(self.S, self.T, dtype=torch.bool).pin_memory(), "ev": None}
+        st = self._stage
+        if st["ev"] is not None:
+            st["ev"].synchronize()            # the previous step's copies have left the staging buffers
+        st["seeds"][0], st["seeds"][1] = seed, dec_seed
+        st["keep"].copy_(torch.from_numpy(keep))
+        st["spec"].copy_(torch.from_numpy(spec))
+        self.seed.copy_(st["seeds"][0:1], non_blocking=True)
+        self.dec_seed.copy_(st["seeds"][1:2], non_blocking=True)
+        self.layer_keep.copy_(st["keep"], non_blocking=True)
+        self.spec.copy_(st["spec"], non_blocking=True)
+        st["ev"] = torch.cuda.current_stream(self.device).record_event()
+
+
+def draw_encoder_masks(be, S: int, T: int, n_layers: int, heads: int, hidden: int, ffn: int, cfg, seed, device, static: "StepRandomness" = None) -> EncoderMasks:
     """The masks of one step, drawn on the device from ``seed`` (sites: 0 feature projection, 1 encoder, 2 + 4 l + {0 attention,
-    1 attention output, 2 activation, 3 feed-forward output}); LayerDrop and SpecAugment draw from a numpy stream seeded with it."""
+    1 attention output, 2 activation, 3 feed-forward output}); LayerDrop and SpecAugment draw from a numpy stream seeded with it.
+    ``static`` (graph-captured steps): seed, LayerDrop decisions and SpecAugment rows come from its device tensors - masks for every layer."""
     M = S * T
     m = EncoderMasks()
+    if static is not None:
+        seed = static.seed
+        m.layer_keep_dev = static.layer_keep
     words = lambda c: torch.empty(M, (c + 31) // 32, dtype=torch.int32, device=device)
 
     def site(idx, cols, p):
@@ -164,11 +219,11 @@ def draw_encoder_masks(be, S: int, T: int, n_layers: int, heads: int, hidden: in
 
     m.featproj = site(0, hidden, cfg.feat_proj_dropout)
     m.enc = site(1, hidden, cfg.hidden_dropout)
-    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    rng = np.random.RandomState(seed & 0x7FFFFFFF) if static is None else None
     TW = attn_keep_words(T)
     for l in range(n_layers):
         d = {}
-        m.layer_skip.append(bool(rng.rand() < cfg.layerdrop))              # HF Wav2Vec2Encoder: skip when the draw is below layerdrop
+        m.layer_skip.append(bool(rng.rand() < cfg.layerdrop) if static is None else False)   # HF Wav2Vec2Encoder: skip when the draw is below layerdrop
         if m.layer_skip[-1]:
             m.layers.append(d)                                             # a dropped layer needs no masks
             continue
@@ -182,7 +237,9 @@ def draw_encoder_masks(be, S: int, T: int, n_layers: int, heads: int, hidden: in
             if s_ is not None:
                 d[name] = s_
         m.layers.append(d)
-    if cfg.apply_spec_augment and cfg.mask_time_prob > 0.0 and T > cfg.mask_time_length:
+    if static is not None:
+        m.spec = static.spec
+    elif cfg.apply_spec_augment and cfg.mask_time_prob > 0.0 and T > cfg.mask_time_length:
         m.spec = _to_device_async(compute_mask_indices((S, T), cfg.mask_time_prob, cfg.mask_time_length, min_masks=2, rng=rng), device)
     return m
 
@@ -214,7 +271,7 @@ class DecoderMasks:
         return DecoderMasks(row, attn, cross_v, pack_keep_bits(t(rec["d2"])), 1.0 / (1.0 - p))
 
 
-def draw_decoder_masks(be, S: int, T: int, p: float, seed: int, device) -> DecoderMasks:
+def draw_decoder_masks(be, S: int, T: int, p: float, seed, device) -> DecoderMasks:
     """Masks of one step from ``seed`` (sites 1000 row block, 1001 self-attention, 1002 cross-attention heads, 1003 dropout2)."""
     M = S * T
     row = torch.empty(M, 10, dtype=torch.int32, device=device)

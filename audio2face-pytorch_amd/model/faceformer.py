@@ -122,7 +122,9 @@ class Faceformer(nn.Module):
             return self.injected_decoder_masks
         from .. import ops
         from ..dropout import draw_decoder_masks
-        return draw_decoder_masks(ops.backend(), S, T, self.decoder_dropout, int(torch.randint(0, 2 ** 62, (1,)).item()), device)
+        static = getattr(self.audio_encoder, "static_rand", None)
+        seed = static.dec_seed if static is not None else int(torch.randint(0, 2 ** 62, (1,)).item())      # captured step: the seed lives on the device
+        return draw_decoder_masks(ops.backend(), S, T, self.decoder_dropout, seed, device)
 
     def decode_hidden(self, enc, one_hot):
         """enc (S,T,768), one_hot (S,n_onehot) -> decoder rows y (S,T,64)."""

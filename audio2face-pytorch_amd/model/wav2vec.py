@@ -117,6 +117,7 @@ class Wav2Vec2Model(nn.Module):
                                             layerdrop=0.1, apply_spec_augment=True, mask_time_prob=0.05, mask_time_length=10)
         self.train_regularisers = True
         self.injected_masks = None   # an EncoderMasks to use instead of drawing (parity tests: masks recorded from the reference)
+        self.static_rand = None      # a dropout.StepRandomness: the step's random state lives on the device (hipGraph-captured train steps)
         self.last_masks = None
         self.layers_run = 0          # Transformer layers executed / forwards since the counters were reset (LayerDrop skips layers: bench.py
         self.forwards_run = 0        # subtracts them from the step's flop count)
@@ -138,8 +139,12 @@ class Wav2Vec2Model(nn.Module):
         from .. import ops
         from ..dropout import draw_encoder_masks
         enc = self.encoder
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         lay = enc.layers[0]
+        if self.static_rand is not None:                       # captured step: nothing is drawn on the host here (trainer refreshes the device state)
+            assert (self.static_rand.S, self.static_rand.T, self.static_rand.n_layers) == (S, T, len(enc.layers))
+            return draw_encoder_masks(ops.backend(), S, T, len(enc.layers), self.heads, lay.layer_norm.normalized_shape[0],
+                                      lay.feed_forward.intermediate_dense.out_features, self.config, None, device, static=self.static_rand)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         return draw_encoder_masks(ops.backend(), S, T, len(enc.layers), self.heads, lay.layer_norm.normalized_shape[0],
                                   lay.feed_forward.intermediate_dense.out_features, self.config, seed, device)
 
@@ -198,11 +203,18 @@ class Wav2Vec2Model(nn.Module):
                 continue                                                     # LayerDrop (HF Wav2Vec2Encoder.forward)
             self.layers_run += 1
             a, f = layer.attention, layer.feed_forward
+            h_in, h_img_in = h, h_img
             h, h_img = EncoderLayerFn.apply(h, h_img, S, T, self.heads, masks.layers[l] if masks is not None else None,
                                             a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias, a.v_proj.weight,
                                             a.v_proj.bias, a.out_proj.weight, a.out_proj.bias, layer.layer_norm.weight, layer.layer_norm.bias,
                                             f.intermediate_dense.weight, f.intermediate_dense.bias, f.output_dense.weight, f.output_dense.bias,
                                             layer.final_layer_norm.weight, layer.final_layer_norm.bias)
+            if masks is not None and masks.layer_keep_dev is not None:
+                # LayerDrop decided on the device (captured step): the layer ran; a dropped one hands its input on and receives zero gradients
+                keep_l = masks.layer_keep_dev[l]
+                h = torch.where(keep_l, h, h_in)
+                if h_img is not None:
+                    h_img = torch.where(keep_l, h_img, h_img_in) if h_img_in is not None else None
         return h.view(S, T, d)
 
     def forward(self, input_values, dataset="vocaset", attention_mask=None, frame_num=None, **_):

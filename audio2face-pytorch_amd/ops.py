@@ -333,11 +333,21 @@ class HipBackend:
         return 2 * ((T + 63) // 64)
 
     def keep_bits(self, seed, site, R, Cc, p, bits):
+        """seed: a Python int, or a one-element int64 HIP tensor (read at run time: graph-captured steps)."""
         _chk_bits(bits)
+        if torch.is_tensor(seed):
+            assert seed.is_cuda and seed.dtype == torch.int64 and seed.numel() == 1
+            _lib.check(self.lib.a2f_keep_bits_dev(seed.data_ptr(), int(site), R, Cc, float(p), bits.data_ptr(), bits.shape[-1], self._stream(bits)), "a2f_keep_bits_dev")
+            return
         _lib.check(self.lib.a2f_keep_bits(int(seed), int(site), R, Cc, float(p), bits.data_ptr(), bits.shape[-1], self._stream(bits)), "a2f_keep_bits")
 
     def keep_bits_attn(self, seed, site, SH, T, p, qmajor, kmajor):
         _chk_bits(qmajor, kmajor)
+        if torch.is_tensor(seed):
+            assert seed.is_cuda and seed.dtype == torch.int64 and seed.numel() == 1
+            _lib.check(self.lib.a2f_keep_bits_attn_dev(seed.data_ptr(), int(site), SH, T, float(p), qmajor.data_ptr(), kmajor.data_ptr(), self._stream(qmajor)),
+                       "a2f_keep_bits_attn_dev")
+            return
         _lib.check(self.lib.a2f_keep_bits_attn(int(seed), int(site), SH, T, float(p), qmajor.data_ptr(), kmajor.data_ptr(), self._stream(qmajor)),
                    "a2f_keep_bits_attn")
 

@@ -291,8 +291,24 @@ class TrainStep:
         self.opt.step(reduced=self.buckets.finish() if self.buckets is not None else False)
         return loss
 
+    def _static_randomness(self, x):
+        """Captured FaceFormer step: the step's random state (mask seeds, LayerDrop decisions, SpecAugment rows) must live on the device - a value drawn on
+        the host inside the captured region would be frozen into the graph.  Creates the model's dropout.StepRandomness once and refreshes it (host draws +
+        non-blocking copies, OUTSIDE the graph) before every warm-up / capture / replay."""
+        enc = getattr(self.model, "audio_encoder", None)
+        if enc is None or not hasattr(enc, "static_rand") or not x.is_cuda or x.dim() != 2:
+            return
+        from .dropout import StepRandomness
+        S, T = x.shape[0], x.shape[1] * 60 // 16000
+        sr = enc.static_rand
+        if sr is None or (sr.S, sr.T) != (S, T):
+            sr = enc.static_rand = StepRandomness(x.device, len(enc.encoder.layers), S, T)
+        sr.refresh(enc.config, train_encoder=bool(enc.training and enc.train_regularisers and enc.injected_masks is None),
+                   train_decoder=bool(self.model.training and getattr(self.model, "decoder_regularisers", False)))
+
     def _graph_step(self, x, one_hot, gt, template):
         ins = (x, one_hot, gt, template)
+        self._static_randomness(x)
         if self._graph is None:
             # Warm-up and capture run on ONE side stream: autograd's AccumulateGrad nodes remember the stream their
             # gradient buffers were last used on, and a capture that has to synchronise with another stream is illegal.
@@ -335,6 +351,8 @@ class TrainStep:
                 torch.cuda.synchronize()
                 self.use_graph = False
                 self._graph = self._graph2 = None
+                if getattr(getattr(self.model, "audio_encoder", None), "static_rand", None) is not None:
+                    self.model.audio_encoder.static_rand = None       # the eager step draws on the host again
                 return self.__call__(*ins)
             self._graph, self._graph_inputs, self._graph_out = g, ins, out
         else:

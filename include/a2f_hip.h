@@ -426,8 +426,12 @@ int a2f_gelu_bwd(const float* dy, const float* z, int64_t n, float* out, a2f_str
  * The consumers never generate masks themselves, so tests inject the masks recorded from the reference's own dropout calls.
  */
 int a2f_keep_bits(uint64_t seed, uint32_t site, int64_t R, int64_t C, float p, uint32_t* bits, int64_t wpr, a2f_stream_t stream);
+/* the same mask with the seed read from device memory at run time (one uint64): what a hipGraph-captured train step launches, so that every replay draws
+ * fresh masks from the seed the host wrote there (same function of (seed, site, element) as the by-value form) */
+int a2f_keep_bits_dev(const uint64_t* seed_dev, uint32_t site, int64_t R, int64_t C, float p, uint32_t* bits, int64_t wpr, a2f_stream_t stream);
 int64_t a2f_attn_keep_words(int64_t T);
 int a2f_keep_bits_attn(uint64_t seed, uint32_t site, int64_t SH, int64_t T, float p, uint32_t* qmajor, uint32_t* kmajor, a2f_stream_t stream);
+int a2f_keep_bits_attn_dev(const uint64_t* seed_dev, uint32_t site, int64_t SH, int64_t T, float p, uint32_t* qmajor, uint32_t* kmajor, a2f_stream_t stream);
 int a2f_dropout_apply(const float* x, const uint32_t* bits, int64_t R, int64_t C, int64_t ld, int64_t wpr, float scale, float* y,
                       a2f_stream_t stream);
 

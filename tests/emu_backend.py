@@ -410,9 +410,11 @@ class EmuBackend:
         return 2 * ((T + 63) // 64)
 
     def keep_bits(self, seed, site, R, Cc, p, bits):
+        seed = int(seed.item()) & 0xFFFFFFFFFFFFFFFF if torch.is_tensor(seed) else seed          # device-resident seed of the graph-captured step
         bits.copy_(torch.from_numpy(philox_keep_words(seed, site, R, Cc, p, bits.shape[-1])))
 
     def keep_bits_attn(self, seed, site, SH, T, p, qmajor, kmajor):
+        seed = int(seed.item()) & 0xFFFFFFFFFFFFFFFF if torch.is_tensor(seed) else seed
         TW = self.attn_keep_words(T)
         words = philox_keep_words(seed, site, SH * T, T, p, TW)
         qmajor.reshape(SH * T, TW).copy_(torch.from_numpy(words))

@@ -9,6 +9,7 @@ import torch
 
 import a2f_amd
 from golden_util import load, packed_error, rel_l2
+from a2f_amd import ops
 from oracle import losses as o_loss
 from oracle import voca as o_voca
 from oracle import weights as W
@@ -508,9 +509,17 @@ def test_voca_train_step_bench_size_features_equal_windows_and_graph_equals_eage
 # ------------------------------------------------------------------------------------------------------------------------
 # Full-size configurations with the REAL encoder (BASELINE configs[2] and configs[4]) against the CPU oracle
 # ------------------------------------------------------------------------------------------------------------------------
-def _faceformer_full():
+# A second encoder weight set for the every-gradient check: the plain formula weights let the token representations collapse onto a common direction in the
+# deep layers (every residual branch adds the same large vector to every frame), so dP - delta in the attention backward cancels and the q / k gradients of layers
+# 8-11 are ill-conditioned - the reference's own fp32 arithmetic misses float64 by 2e-4 .. 2e-2 there.  With the two residual-branch output projections scaled
+# to a quarter the frames stay diverse and the fp32 reference resolves EVERY gradient to <= 2.5e-5 of float64 at T = 600 (tools/grad_conditioning.py; larger
+# q / k gains instead make the whole network chaotic: gain 2 puts every gradient at 1e-3, gain 4 at O(1)) - there the 1e-4 bar applies with no floor at all.
+WELL_CONDITIONED_GAINS = {"original0": 40.0, "attention.out_proj": 0.25, "feed_forward.output_dense": 0.25}
+
+
+def _faceformer_full(gains=None):
     m = _faceformer(stub=False)
-    esd = W.formula_state_dict(W.wav2vec2_shapes(), gains={"original0": 40.0})
+    esd = W.formula_state_dict(W.wav2vec2_shapes(), gains=gains or {"original0": 40.0})
     m.audio_encoder.load_state_dict(esd)
     dsd = W.formula_state_dict(W.faceformer_decoder_shapes(NV, 12, 64), gains=FF_GAINS)
     return m.to(DEV).eval(), esd, dsd
@@ -543,7 +552,37 @@ def test_faceformer_config2_full_size_vs_oracle(monkeypatch):
     assert abs(float(loss["loss"].detach()) - o32["loss"]) <= 1e-4 * abs(o32["loss"])
     loss["loss"].backward()
     assert rel_l2(a_gpu.grad, o32["grads"]["audio"]) < TOL
-    _assert_all_grads(m, o32["grads"], o64["grads"])
+    floored = _assert_all_grads(m, o32["grads"], o64["grads"])
+    # the ill-conditioned set is pinned: a gradient that needs the float64 floor and is not on the committed list fails (the list cannot silently grow)
+    allowed = {l.strip() for l in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ill_conditioned_gradients_T600.txt")) if l.strip() and not l.startswith("#")}
+    assert set(floored) <= allowed, sorted(set(floored) - allowed)
+
+
+def test_faceformer_config2_full_size_every_gradient_without_a_floor(monkeypatch):
+    """The same full-size step (N = 160 008 samples -> T = 600, real encoder, image-operand path forced) on the WELL-CONDITIONED weight set: all 223 parameter
+    gradients and d loss / d audio <= 1e-4 against the fp32 oracle, max_floor_share = 0 - no gradient is excused."""
+    from a2f_amd import encoder_ops
+    monkeypatch.setattr(encoder_ops, "IMG_MIN_ROWS", 0)
+    m, esd, dsd = _faceformer_full(WELL_CONDITIONED_GAINS)
+    T = 600
+    # the inputs of the formula-weight test above (tools/grad_parity_probe.py: worst gradient 3.8e-5, median 1.0e-5 on this set; another draw - seed 601,
+    # subject 2 - lands every gradient upstream of the decoder's feed-forward at 2e-4: one ReLU unit of the recurrence sits on its kink there, the same
+    # discontinuity the large-batch VOCA tests meet in the fp32 oracle itself)
+    gen = torch.Generator().manual_seed(600)
+    audio = torch.randn(1, T * 16000 // 60 + 8, generator=gen) * 0.1
+    oh = torch.zeros(1, 12); oh[0, 5] = 1
+    template = torch.randn(1, 5023, 3, generator=gen) * 5
+    gt = template.view(1, 1, 5023, 3) + torch.randn(1, T, 5023, 3, generator=gen) * 0.5
+    o32 = _oracle_ff_run(esd, dsd, audio, oh, template, gt, T, torch.float32)
+    o64 = _oracle_ff_run(esd, dsd, audio, oh, template, gt, T, torch.float64)
+    a_gpu = audio.to(DEV).requires_grad_(True)
+    pred, loss = m.forward_with_loss(a_gpu, oh.to(DEV), template.to(DEV), gt.to(DEV))
+    assert rel_l2(pred.detach().cpu() - template.view(1, 1, 5023, 3), o32["pred"] - template.view(1, 1, 5023, 3)) < TOL
+    loss["loss"].backward()
+    print("d loss / d audio vs fp32 oracle:", rel_l2(a_gpu.grad, o32["grads"]["audio"]), "vs float64:", rel_l2(a_gpu.grad, o64["grads"]["audio"]),
+          "fp32 oracle vs float64:", rel_l2(o32["grads"]["audio"], o64["grads"]["audio"]))
+    assert _assert_all_grads(m, o32["grads"], o64["grads"], max_floor_share=0.0) == []
+    assert rel_l2(a_gpu.grad, o32["grads"]["audio"]) < TOL
 
 
 def _oracle_ff_run(esd, dsd, audio, oh, template, gt, T, dtype, enc_states=None, checkpoint=False):
@@ -601,9 +640,10 @@ def _assert_all_grads(m, g32, g64, tol=TOL, max_floor_share=0.15):
         floored.append((k, f"hip {e64:.2e}", f"fp32 oracle {eref:.2e}"))
         assert e64 <= max(tol, _ILL_CONDITIONED_FLOOR * eref), (k, e64, eref)
     rows.sort(reverse=True)
-    print("gradients compared:", len(rows) + len(floored), "worst well-conditioned:", [(f"{e:.2e}", k) for e, k in rows[:3]])
+    print("gradients compared:", len(rows) + len(floored), "worst well-conditioned:", [(f"{e:.2e}", k) for e, k in rows[:8]])
     print("ill-conditioned (judged against float64):", floored)
     assert len(rows) + len(floored) >= 10 and len(floored) <= max_floor_share * (len(rows) + len(floored))
+    return [k for k, _h, _r in floored]
 
 
 def _ff_long_inputs(T, seed):
@@ -1127,3 +1167,58 @@ def test_faceformer_full_size_pipelined_step_is_bitwise_reproducible(S, T):
         del step, m
     assert finals[0][1] == finals[1][1]
     assert torch.equal(finals[0][0], finals[1][0])
+
+
+def test_keep_bits_with_a_device_resident_seed_is_the_same_mask():
+    """a2f_keep_bits_dev / a2f_keep_bits_attn_dev (seed read from device memory at run time: hipGraph-captured steps) against the by-value entry points."""
+    be = ops.backend()
+    seed = 0x1234_5678_9ABC_DEF1 & (2 ** 62 - 1)
+    sd = torch.tensor([seed], dtype=torch.int64, device=DEV)
+    a, b = torch.zeros(77, 24, dtype=torch.int32, device=DEV), torch.zeros(77, 24, dtype=torch.int32, device=DEV)
+    be.keep_bits(seed, 5, 77, 768, 0.1, a)
+    be.keep_bits(sd, 5, 77, 768, 0.1, b)
+    assert torch.equal(a, b) and int(a.abs().sum()) != 0
+    T, SH = 70, 6
+    TW = be.attn_keep_words(T)
+    q1, k1 = torch.zeros(SH * T, TW, dtype=torch.int32, device=DEV), torch.zeros(SH, TW, 32 * TW, dtype=torch.int32, device=DEV)
+    q2, k2 = torch.zeros_like(q1), torch.zeros_like(k1)
+    be.keep_bits_attn(seed, 9, SH, T, 0.1, q1, k1)
+    be.keep_bits_attn(sd, 9, SH, T, 0.1, q2, k2)
+    assert torch.equal(q1, q2) and torch.equal(k1, k2)
+
+
+def test_faceformer_batch1_step_as_one_hipgraph_equals_the_eager_step():
+    """The reference's own step (train.py:33: ONE sequence per optimizer step) captured as one hipGraph - device-resident mask seeds, LayerDrop as a
+    device-side select, SpecAugment as a select - against the eager step with the same torch seeds: identical parameters after three train-mode steps, and
+    the replays draw fresh masks (the loss changes from step to step although the inputs do not)."""
+    from a2f_amd.trainer import TrainStep
+    T = 48
+    esd = W.formula_state_dict(W.wav2vec2_shapes(), gains={"original0": 40.0})
+    dsd = W.formula_state_dict(W.faceformer_decoder_shapes(NV, 12, 64), gains=FF_GAINS)
+    gen = torch.Generator().manual_seed(48)
+    audio = (torch.randn(1, T * 16000 // 60 + 8, generator=gen) * 0.1).to(DEV)
+    oh = torch.zeros(1, 12, device=DEV); oh[0, 3] = 1
+    template = (torch.randn(1, 5023, 3, generator=gen) * 5).to(DEV)
+    gt = template.view(1, 1, 5023, 3) + (torch.randn(1, T, 5023, 3, generator=gen) * 0.5).to(DEV)
+    finals, losses = {}, {}
+    for mode in ("eager", "graph"):
+        m = a2f_amd.Faceformer(n_verts=NV, n_onehot=12)
+        m.audio_encoder.load_state_dict(esd)
+        m.load_state_dict(dsd, strict=False)
+        m.audio_encoder.config.layerdrop = 0.3                       # several dropped layers in three steps
+        m.to(DEV).train()
+        step = TrainStep(m, a2f_amd.FaceFormerLoss(), lr=1e-4, use_graph=(mode == "graph"))
+        torch.manual_seed(77)
+        ls = []
+        for _ in range(5):                                           # graph mode: two eager warm-ups, the capture step, two replays
+            out = step(audio, oh, gt, template)
+            ls.append(float(out["loss"].detach()))
+        torch.cuda.synchronize()
+        if mode == "graph":
+            assert step.use_graph and step._graph is not None, "the capture failed"
+        finals[mode], losses[mode] = step.opt.flat_p.clone(), ls
+        step.close()
+        del step, m
+    assert len(set(losses["graph"])) == 5                            # fresh masks every replay
+    assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(losses["eager"], losses["graph"])), (losses["eager"], losses["graph"])
+    assert rel_l2(finals["graph"], finals["eager"]) < 1e-6

@@ -146,6 +146,50 @@ def test_drawn_masks_are_reproducible_and_eval_is_deterministic():
         ops.set_backend(old)
 
 
+def test_device_resident_step_randomness_equals_the_host_drawn_step():
+    """dropout.StepRandomness (the random state of a hipGraph-captured step: mask seeds read from device memory, LayerDrop as a device-side select over
+    layers that all run, SpecAugment as a device-side select) against the eager step that draws on the host: same torch seed -> same masks and decisions
+    -> the same output and the same gradients (a dropped layer's come out as exact zeros instead of None)."""
+    from a2f_amd.dropout import StepRandomness
+    L = 4
+    m = a2f_amd.model.wav2vec.Wav2Vec2Model(layers=L)
+    m.load_state_dict(W.formula_state_dict(W.wav2vec2_shapes(layers=L), gains={"original0": 40.0}))
+    m.config.layerdrop = 0.5                                   # make dropped layers the rule
+    T = 14
+    wave = o_w2v.normalize_waveform(W.formula_input("static.audio", (2, T * 16000 // 60 + 5), 0.1))
+    gout = W.formula_input("static.gout", (2, T, 768))
+    old = ops.set_backend(EmuBackend())
+    try:
+        m.train()
+        seen_drop = False
+        for seed in (3, 4, 5):
+            torch.manual_seed(seed)
+            for p in m.parameters():
+                p.grad = None
+            a = m._forward_hip(wave, T)
+            a.backward(gout)
+            skipped = list(m.last_masks.layer_skip)
+            ga = {k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}
+            sr = m.static_rand = StepRandomness("cpu", L, 2, T)
+            torch.manual_seed(seed)
+            sr.refresh(m.config)
+            assert [not k for k in sr.last["layer_keep"]] == skipped
+            for p in m.parameters():
+                p.grad = None
+            b = m._forward_hip(wave, T)
+            b.backward(gout)
+            m.static_rand = None
+            seen_drop = seen_drop or any(skipped)
+            assert torch.equal(a.detach(), b.detach())
+            for k, p in m.named_parameters():
+                g = p.grad if p.grad is not None else torch.zeros_like(p)
+                assert torch.equal(g, ga[k]) or rel_l2(g, ga[k]) < 1e-6, k
+        assert seen_drop
+    finally:
+        m.static_rand = None
+        ops.set_backend(old)
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # FaceFormer decoder / PPE dropout with per-row masks (fixture G14)
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -364,248 +364,6 @@ __global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
   }
 }
 
-// =====================================================================================================================
-// forward, PREC 3: fp8 (e4m3) MFMA attention at fp32-class accuracy - BASELINE configs[4] ("fp8 MFMA attention, tol 1e-3").
-// A single e4m3 operand carries 4 significant bits (PREC 2: 5e-2 on the context).  Here every operand is the SUM OF THREE e4m3 terms,
-//   x s = t0 + t1 + t2,   t0 = e4m3(x s),  t1 = e4m3(x s - t0),  t2 = e4m3(x s - t0 - t1),
-// under a power-of-two scale s that puts the operand's largest magnitude in [128, 256) (e4m3: normals 2^-6 .. 448, subnormal step 2^-9): the
-// residual after three terms is <= 2^-12 of the value or 2^-18 of the largest magnitude, and a product keeps the six term products of
-// order <= 2 (t_i u_j, i + j <= 2), smallest first, on v_mfma_f32_32x32x16_fp8_fp8 into ONE fp32 accumulator (all terms share the scale).
-// Scales: q per query row (the lane's own row), k and v per 64-key tile (absolute maximum collected while the tile is staged, exchanged
-// through 4 LDS words per tile), probabilities x 2^8.  Scores are rescaled to true units before the softmax (lse is exact-scale); the
-// context accumulators carry the current V tile's scale, a change of scale rides on the online-softmax rescale factor.
-// The LDS images stay the bf16 hi / lo pair of PREC 1 (16 significant bits of x); the e4m3 terms are derived in registers per fragment.
-// Domain: |q|, |k|, |v| in [2^-27, 2^13] per scale group (smaller maxima only lose relative precision, larger ones would saturate).
-// Backward of the mode: the bf16x3 kernels (gradients in fp8 would need dynamic range management of dP - delta).
-// =====================================================================================================================
-__device__ __forceinline__ float pow2_scale(float amax, float& inv) {
-  unsigned e = (__builtin_bit_cast(unsigned, amax) >> 23) & 255u;
-  e = e < 100u ? 100u : (e > 140u ? 140u : e);
-  inv = __builtin_bit_cast(float, (e - 7u) << 23);            // 2^(e - 134)
-  return __builtin_bit_cast(float, (261u - e) << 23);         // 2^(134 - e): amax * s lies in [128, 256)
-}
-__device__ __forceinline__ void split_fp8x3(const float (&v)[8], u32x4_t (&f)[3]) {
-  float r[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = v[j];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    int lo = 0, hi = 0;
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], lo, false);
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], lo, true);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(r[4], r[5], hi, false);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(r[6], r[7], hi, true);
-    f[t] = u32x4_t{(unsigned)lo, (unsigned)hi, 0u, 0u};
-    if (t < 2) {
-      const f32x2_t d0 = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), d1 = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
-      const f32x2_t d2 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d3 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
-      r[0] -= d0.x; r[1] -= d0.y; r[2] -= d1.x; r[3] -= d1.y; r[4] -= d2.x; r[5] -= d2.y; r[6] -= d3.x; r[7] -= d3.y;
-    }
-  }
-}
-// eight bf16 hi / lo pairs (the words of two fragments) -> (hi + lo) * s as fp32
-__device__ __forceinline__ void hilo_to_f32(const u32x4_t hi, const u32x4_t lo, float s, float (&v)[8]) {
-  const unsigned hw[4] = {hi.x, hi.y, hi.z, hi.w}, lw[4] = {lo.x, lo.y, lo.z, lo.w};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    v[2 * j] = (__builtin_bit_cast(float, hw[j] << 16) + __builtin_bit_cast(float, lw[j] << 16)) * s;
-    v[2 * j + 1] = (__builtin_bit_cast(float, hw[j] & 0xFFFF0000u) + __builtin_bit_cast(float, lw[j] & 0xFFFF0000u)) * s;
-  }
-}
-// c += (a0 + a1 + a2)(b0 + b1 + b2) without the terms of order > 2, smallest first
-__device__ __forceinline__ f32x16 mac_fp8x3(const u32x4_t (&a)[3], const u32x4_t (&b)[3], f32x16 c) {
-  c = mfma8(a[2], b[0], c);
-  c = mfma8(a[0], b[2], c);
-  c = mfma8(a[1], b[1], c);
-  c = mfma8(a[1], b[0], c);
-  c = mfma8(a[0], b[1], c);
-  return mfma8(a[0], b[0], c);
-}
-__device__ __forceinline__ float tile_absmax(const Tile<1>& tl) {
-  float m = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) m = fmaxf(fmaxf(m, fmaxf(fabsf(tl.reg[i].x), fabsf(tl.reg[i].y))), fmaxf(fabsf(tl.reg[i].z), fabsf(tl.reg[i].w)));
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  return m;
-}
-
-template <bool DROP>
-__global__ __launch_bounds__(THREADS, 2) void attn_fwd_fp8x3_kernel(const Args a) {
-  constexpr int STAGE = 4 * IMG;                              // K hi / lo, V hi / lo
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* scl = reinterpret_cast<float*>(smem + 2 * STAGE);    // [stage][k | v][wave]: absolute maxima of the staged tiles
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5;
-  const int head = blockIdx.y, seq = blockIdx.z;
-  const int T = a.T;
-  const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
-  const rsrc_t rs = seq_rsrc(a.qkv + (long long)seq * T * a.ld, (long long)T * a.ld * 4);
-  const int hc = head * D;
-
-  // this lane's half of its query row (d = 16 ks + 8 h .. + 7), scaled per query row
-  u32x4_t qf[4][3];
-  float inv_sq;
-  {
-    f32x4 qa[4], qb[4];
-    float m = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const unsigned off = (unsigned)(q * a.ld + hc + 16 * ks + 8 * h) * 4u;
-      qa[ks] = ld4(rs, off);
-      qb[ks] = ld4(rs, off + 16u);
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(qa[ks].x), fabsf(qa[ks].y))), fmaxf(fabsf(qa[ks].z), fabsf(qa[ks].w)));
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(qb[ks].x), fabsf(qb[ks].y))), fmaxf(fabsf(qb[ks].z), fabsf(qb[ks].w)));
-    }
-    m = fmaxf(m, __shfl_xor(m, 32, 64)) * a.scale;
-    const float sq = pow2_scale(m, inv_sq) * a.scale;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const float v[8] = {qa[ks].x * sq, qa[ks].y * sq, qa[ks].z * sq, qa[ks].w * sq, qb[ks].x * sq, qb[ks].y * sq, qb[ks].z * sq, qb[ks].w * sq};
-      split_fp8x3(v, qf[ks]);
-    }
-  }
-
-  f32x16 o[2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) o[0][r] = o[1][r] = 0.f;
-  float m = -INFINITY, l = 0.f, sv_run = 1.f;
-  const unsigned* keepq = nullptr;
-  if constexpr (DROP) keepq = a.keep_q + (((long long)seq * a.H + head) * T + min(q, T - 1)) * a.TW;
-
-  const int nt = (T + TILE - 1) / TILE;
-  Tile<1> kt_, vt_;
-  kt_.load(rs, 0, a.ld, a.koff + hc, t);
-  vt_.load(rs, 0, a.ld, a.voff + hc, t);
-  kt_.commit(smem, t);
-  vt_.commit(smem + 2 * IMG, t);
-  {
-    const float mk = tile_absmax(kt_), mv = tile_absmax(vt_);
-    if (lane == 0) { scl[wave] = mk; scl[4 + wave] = mv; }
-  }
-  __syncthreads();
-
-  for (int it = 0; it < nt; ++it) {
-    const char* kimg = smem + (it & 1) * STAGE;
-    const char* vimg = kimg + 2 * IMG;
-    const float* sc = scl + (it & 1) * 8;
-    float inv_sk, inv_sv_unused;
-    const float sk = pow2_scale(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), inv_sk);
-    const float sv = pow2_scale(fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])), inv_sv_unused);
-    if (it + 1 < nt) {
-      kt_.load(rs, (it + 1) * TILE, a.ld, a.koff + hc, t);
-      vt_.load(rs, (it + 1) * TILE, a.ld, a.voff + hc, t);
-    }
-    u32x2_t keep = {0u, 0u};
-    if constexpr (DROP) keep = *reinterpret_cast<const u32x2_t*>(keepq + 2 * it) >> (unsigned)(4 * h);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- S^T = K Q^T in six e4m3 term products per k-step, back to true units afterwards
-    f32x16 st[2];
-    const float unscale = inv_sq * inv_sk;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        u32x4_t kb16[2], kf[3];
-        frag_rows<1>(kimg, 32 * kb, ks, lane, kb16);
-        float v[8];
-        hilo_to_f32(kb16[0], kb16[1], sk, v);
-        split_fp8x3(v, kf);
-        st[kb] = mac_fp8x3(kf, qf[ks], st[kb]);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[kb][r] *= unscale;
-    }
-    if ((it + 1) * TILE > T) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (it * TILE + 32 * kb + rho(r, h) >= T) st[kb][r] = -INFINITY;
-    }
-    float mx = st[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx);
-    const float alpha = __expf(m - mn);
-    m = mn;
-    float ps = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        st[kb][r] = __expf(st[kb][r] - mn);
-        ps += st[kb][r];
-      }
-    l = l * alpha + ps;
-    const float oscale = alpha * (sv / sv_run);               // the accumulators move to this V tile's scale with the softmax rescale
-    sv_run = sv;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      o[0][r] *= oscale;
-      o[1][r] *= oscale;
-    }
-    if constexpr (DROP) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        st[0][r] = ((keep.x >> ((r & 3) + 8 * (r >> 2))) & 1u) ? st[0][r] : 0.f;
-        st[1][r] = ((keep.y >> ((r & 3) + 8 * (r >> 2))) & 1u) ? st[1][r] : 0.f;
-      }
-    }
-    // ---- O^T += V^T P: P (x 2^8) straight from the accumulator registers
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        u32x4_t pf[3];
-        {
-          float v[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = st[kb][8 * s + j] * FP8_P_SCALE;
-          split_fp8x3(v, pf);
-        }
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          u32x4_t vb16[2], vf[3];
-          frag_cols<1>(vimg, 32 * kb, s, 32 * dt, lane, vb16);
-          float v[8];
-          hilo_to_f32(vb16[0], vb16[1], sv, v);
-          split_fp8x3(v, vf);
-          o[dt] = mac_fp8x3(vf, pf, o[dt]);
-        }
-      }
-    __builtin_amdgcn_sched_barrier(0);
-    if (it + 1 < nt) {
-      char* nk = smem + ((it + 1) & 1) * STAGE;
-      kt_.commit(nk, t);
-      vt_.commit(nk + 2 * IMG, t);
-      const float mk = tile_absmax(kt_), mv = tile_absmax(vt_);
-      float* ns = scl + ((it + 1) & 1) * 8;
-      if (lane == 0) { ns[wave] = mk; ns[4 + wave] = mv; }
-    }
-    __syncthreads();
-  }
-
-  const float lt = l + __shfl_xor(l, 32, 64);
-  const float inv = (DROP ? a.keep_scale : 1.f) / (lt * FP8_P_SCALE * sv_run);
-  if (q < T) {
-    float* orow = a.out_ctx + ((long long)seq * T + q) * a.ldo + hc;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const f32x4 v = {o[dt][4 * gq] * inv, o[dt][4 * gq + 1] * inv, o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv};
-        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * gq + 4 * h) = v;
-        if (a.out_ctx_img) img::store4(a.out_ctx_img + ((long long)seq * T + q) * a.ldo * 4, hc + 32 * dt + 8 * gq + 4 * h, v);
-      }
-    if (h == 0) a.out_lse[((long long)seq * a.H + head) * T + q] = m + __logf(lt);
-  }
-}
-
 // delta[s,h,q] = sum_d dctx[q, 64 h + d] * ctx[q, 64 h + d]: one wave per row of (S*T), lane l <-> columns 4 l .. (ldo <= 1024)
 __global__ __launch_bounds__(THREADS) void attn_delta_kernel(const Args a) {
   const int lane = threadIdx.x & 63;
@@ -870,7 +628,7 @@ static int check_common(const float* qkv, int64_t S, int64_t T, int64_t H, int64
                 (long long)T, (long long)H, (long long)ld, (long long)ldo);
   A2F_CHECK_ARG(ld % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)qkv & 15) == 0, "attention: strides must be multiples of 4 floats, buffers 16-byte aligned");
   A2F_CHECK_ARG(T * ld * 4 < (1ll << 31) && H * 64 <= 1024, "attention: one sequence of the q|k|v buffer must span < 2 GiB");
-  A2F_CHECK_ARG(precision >= 0 && precision <= 3, "attention: precision %d (0 bf16, 1 bf16x3, 2 fp8 forward, 3 fp8x3 forward)", precision);
+  A2F_CHECK_ARG(precision >= 0 && precision <= 2, "attention: precision %d (0 bf16, 1 bf16x3, 2 fp8 forward)", precision);
   return A2F_OK;
 }
 
@@ -900,18 +658,7 @@ static int attn_fwd_impl(const float* qkv, int64_t S, int64_t T, int64_t H, int6
     if ((rc = set_lds(attn_fwd_kernel<P, D>, lds, done[2 * P + D]))) return rc;   \
     hipLaunchKernelGGL((attn_fwd_kernel<P, D>), grid, dim3(THREADS), lds, st, a); \
   } while (0)
-  if (precision == 3) {                       // three-term e4m3 operands (PREC-1 images + the tile maxima behind them)
-    static bool done3[2] = {false, false};
-    const int lds3 = 2 * 4 * IMG + 64;
-    if (keep_q) {
-      if ((rc = set_lds(attn_fwd_fp8x3_kernel<true>, lds3, done3[1]))) return rc;
-      hipLaunchKernelGGL((attn_fwd_fp8x3_kernel<true>), grid, dim3(THREADS), lds3, st, a);
-    } else {
-      if ((rc = set_lds(attn_fwd_fp8x3_kernel<false>, lds3, done3[0]))) return rc;
-      hipLaunchKernelGGL((attn_fwd_fp8x3_kernel<false>), grid, dim3(THREADS), lds3, st, a);
-    }
-  }
-  else if (precision == 1) { if (keep_q) A2F_ATTN_FWD(1, true); else A2F_ATTN_FWD(1, false); }
+  if (precision == 1) { if (keep_q) A2F_ATTN_FWD(1, true); else A2F_ATTN_FWD(1, false); }
   else if (precision == 2) { if (keep_q) A2F_ATTN_FWD(2, true); else A2F_ATTN_FWD(2, false); }
   else { if (keep_q) A2F_ATTN_FWD(0, true); else A2F_ATTN_FWD(0, false); }
 #undef A2F_ATTN_FWD
@@ -937,7 +684,6 @@ static int attn_bwd_impl(const float* qkv, const float* ctx, const float* dctx, 
   a.keep_q = keep_q; a.keep_k = keep_k; a.TW = (int)a2f_attn_keep_words(T); a.keep_scale = keep_scale;
   a.dqkv_img = dqkv_format;
   if (precision == 2) precision = 0;          // fp8 is a forward mode: gradients would need dynamic scaling; the backward runs its bf16 kernels
-  if (precision == 3) precision = 1;          // ... the fp32-class fp8x3 forward pairs with the bf16x3 backward
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(S * T, THREADS / 64)), dim3(THREADS), 0, st, a);
   A2F_CHECK_LAUNCH("attn_bwd delta");

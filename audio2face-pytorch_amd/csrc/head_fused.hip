@@ -782,8 +782,10 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
         const float p1 = acc[r + 1] + bias_r + tc[r + 1];
         const int so0 = (4 * (rr * n + lo)) | ~(mint | (mcolv & ((rr + h4 - rlim) >> 31)));
         const int so1 = (4 * ((rr + 1) * n + lo)) | ~(mint | (mcolv & ((rr + 1 + h4 - rlim) >> 31)));
-        buf_store_stream(pbuf, so0, p0);
-        buf_store_stream(pbuf, so1, p1);
+        if (a.pred) {                                   // wave-uniform; pred == NULL: the labelled no-pred-store variant of the training step
+          buf_store_stream(pbuf, so0, p0);
+          buf_store_stream(pbuf, so1, p1);
+        }
         const bool in_loss = colok && (rb * HF_ROWS + rr + h4 + 1 < a.Bloss);
         const float d0 = in_loss ? p0 - gcur[r] : 0.f;
         const float d1 = in_loss ? p1 - gcur[r + 1] : 0.f;
@@ -1216,7 +1218,8 @@ extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias,
                               float* pred, float* out3, float* dH, float* dW, float* dbias, void* ws, size_t ws_bytes,
                               a2f_stream_t stream) {
   using namespace a2f;
-  A2F_CHECK_ARG(H && W && bias && templ && gt && pred && out3 && dH && dW && dbias && ws, "head_fused: null pointer");
+  A2F_CHECK_ARG(H && W && bias && templ && gt && out3 && dH && dW && dbias && ws, "head_fused: null pointer");
+  A2F_CHECK_ARG(pred != nullptr || head_cfg(K) == 5, "head_fused: pred may only be NULL (no prediction written: a training step that reads the loss alone) on the x3 kernel");
   A2F_CHECK_ARG(K == 50 || K == 64, "head_fused: K=%lld unsupported (50: VOCA/Audio2Mesh bottleneck, 64: FaceFormer)", (long long)K);
   A2F_CHECK_ARG(B >= 2 && B < (1 << 30), "head_fused: B=%lld", (long long)B);
   A2F_CHECK_ARG(Bloss >= 2 && (Bloss % 2) == 0 && Bloss <= B, "head_fused: Bloss=%lld must be even, >= 2 and <= B (loss.py:13-15,33-35)", (long long)Bloss);

@@ -66,6 +66,8 @@ class Voca(nn.Module):
                                            gt.reshape(bs, -1), bs, k_rec, k_vel, unit_grad)
         return pred.view(bs, -1, 3), {"loss": out3[0], "rec_loss": out3[1].detach(), "vel_loss": out3[2].detach()}
 
+    store_pred = True     # train_step_direct: False = the fused head writes no prediction (labelled bench variant; the loss and every gradient are unchanged)
+
     @torch.no_grad()
     def train_step_direct(self, x, one_hot, template, gt, k_rec: float = 1.0, k_vel: float = 10.0, phase: int = 0):
         """Autograd-free training pass for the trainer: forward + VocaLoss + backward as one fixed launch sequence that
@@ -93,12 +95,12 @@ class Voca(nn.Module):
         h3, saved = voca_trunk_fwd(be, x, one_hot, [p.data for p in tp])
         n, K = head_w.shape
         dev = h3.device
-        pred = torch.empty(bs, n, device=dev, dtype=torch.float32)
+        pred = torch.empty(bs, n, device=dev, dtype=torch.float32) if self.store_pred else None
         out3 = torch.empty(3, device=dev, dtype=torch.float32)
         dH = torch.empty(bs, K, device=dev, dtype=torch.float32)
         be.head_fused(h3, head_w.data, head_b.data, template.reshape(bs, n).contiguous(), bs, gt.reshape(bs, n).contiguous(), bs, bs, n, K,
                       float(k_rec), float(k_vel), pred, out3, dH, head_w.grad, head_b.grad)
-        ret = (pred.view(bs, -1, 3), out3)
+        ret = (pred.view(bs, -1, 3) if pred is not None else None, out3)
         if phase == 1:
             self._direct_state = (saved, dH, ret)
             return ret

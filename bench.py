@@ -433,6 +433,22 @@ def main():
                                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(head_ms, 4), "launches_timed": nl,
                                "measured_stream_GBs": stream_rates,
                                "whole_step_frac": round(B * steps / elapsed * 182732 / 1e9 / HBM_PEAK_GBS, 4)}
+        if rank == 0 and world == 1 and not args.no_secondary:
+            # LABELLED VARIANT, not the headline: the same step with no prediction written (Voca.store_pred = False).  The reference's training_step never
+            # reads pred (mse_error = rec_loss / 3 comes from the loss sums), so a trainer may drop the store; the Module API (forward returns pred) is what
+            # the headline keeps.  Own algorithmic bytes: 182 732 - 60 276 = 122 456 per frame.
+            try:
+                model.store_pred = False
+                vstep = TrainStep(model, a2f_amd.VocaLoss(), lr=1e-4, use_graph=not args.no_graph)
+                el, _lv, _ti = timed(lambda: vstep(x, one_hot, gt, templ), steps, 3, barrier, world, device, budget_s=3.0)
+                res["variants"] = [{"variant": "store_pred=False (training step that reads the loss only; pred is not materialised)", "ms_per_step": round(1e3 * el / steps, 4),
+                                    "value": round(B * steps / el, 1), "algorithmic_bytes_per_frame": 122456,
+                                    "whole_step_frac": round(B * steps / el * 122456 / 1e9 / HBM_PEAK_GBS, 4)}]
+                del vstep
+            except Exception as e:
+                res["variants"] = [{"variant": "store_pred=False", "error": repr(e)[:200]}]
+            finally:
+                model.store_pred = True
         if want_cpu:
             res["cpu_baseline"] = cpu_baseline_voca()
         del step, model
@@ -624,13 +640,14 @@ def main():
         S, T = args.ff_long_seqs, args.ff_long_frames
         res, model, (audio, one_hot, templ) = run_faceformer(min(steps, 3), 2, S=S, T=T, config_name="BASELINE configs[4] (long context; per GPU)", cpu=False,
                                                              batch_points=(), long=True)
-        res["parity_setting"] = {"attention": "bf16x3 split MFMA (forward and backward)", "tolerance": 1e-3,
+        res["parity_setting"] = {"attention": "bf16x3 split MFMA (forward and backward) - THE attention setting of this configuration: an fp8 form that meets 1e-3 "
+                                              "needs three e4m3 terms per operand = six term products per k-step, the MFMA work of bf16x3 at best (block-scaled K = 64 "
+                                              "instruction: 2x rate) plus conversions; measured +3 % per step in round 3 and removed", "tolerance": 1e-3,
                                  "pinned_by": "tests/test_gpu_models.py::test_faceformer_config5_T3000_encoder_vs_oracle (<= 1e-4 vs the CPU oracle)"}
         variants = []
         was_training = model.training
         specs = [(name, ap, label) for name, ap, label in
-                 (("fp8x3_attention_forward", 3, "three-term e4m3 split operands on v_mfma_f32_32x32x16_fp8_fp8 (power-of-two scales per query row / key tile / value tile)"),
-                  ("fp8_attention_forward", 2, "single e4m3 operands on v_mfma_f32_32x32x16_fp8_fp8"))
+                 (("fp8_attention_forward", 2, "single e4m3 operands on v_mfma_f32_32x32x16_fp8_fp8"),)
                  if ap in getattr(be, "attn_precisions", (0, 1, 2))]
         # errors first, on the weights the reference output was computed with (the timed steps below update them)
         model.eval()

@@ -477,7 +477,8 @@ class EmuBackend:
         t = templ.reshape(template_rows, n).double()
         assert B % template_rows == 0
         p = Hd @ Wd.t() + bias.double().view(1, -1) + t.repeat_interleave(B // template_rows, dim=0)
-        pred.reshape(B, n).copy_(p.float())
+        if pred is not None:                       # NULL pred: the loss-only training variant
+            pred.reshape(B, n).copy_(p.float())
         V = n // 3
         d = (p - gt.reshape(B, n).double())[:Bloss]
         rec = (d ** 2).sum() / (Bloss * V)

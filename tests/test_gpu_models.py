@@ -722,8 +722,6 @@ def test_faceformer_config5_T3000_encoder_vs_oracle():
     assert be.mm_precision == 1 and be.attn_precision is None          # what the timed bench entry runs
     errs = {}
     settings = {"bf16_everywhere": (0, None), "bf16x3_gemms_fp8_attention": (1, 2)}
-    if 3 in getattr(be, "attn_precisions", ()):
-        settings["bf16x3_gemms_fp8x3_attention"] = (1, 3)
     for name, (mmp, ap) in settings.items():
         old = be.mm_precision, be.attn_precision
         be.mm_precision, be.attn_precision = mmp, ap
@@ -734,8 +732,6 @@ def test_faceformer_config5_T3000_encoder_vs_oracle():
             be.mm_precision, be.attn_precision = old
         errs[name] = rel_l2(p2.cpu().view(T, -1) - template.view(1, -1), ref_off)
     print("T=3000 vertex-offset error vs oracle:", errs)
-    if "bf16x3_gemms_fp8x3_attention" in errs:                       # the fp8 MFMA attention form that is allowed to carry configs[4]
-        assert errs["bf16x3_gemms_fp8x3_attention"] < 1e-3
     # single-term e4m3 attention is NOT a configs[4] setting: if it ever met the tolerance this test (and bench.py's labelling) must change
     assert errs["bf16x3_gemms_fp8_attention"] > 1e-3
 
@@ -1222,3 +1218,28 @@ def test_faceformer_batch1_step_as_one_hipgraph_equals_the_eager_step():
     assert len(set(losses["graph"])) == 5                            # fresh masks every replay
     assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(losses["eager"], losses["graph"])), (losses["eager"], losses["graph"])
     assert rel_l2(finals["graph"], finals["eager"]) < 1e-6
+
+
+def test_voca_step_without_the_prediction_store_is_the_same_step():
+    """Voca.store_pred = False (the labelled bench variant: a2f_head_fused with pred == NULL) - the loss and every gradient are bit for bit those of the
+    API-preserving step; only the prediction is not materialised."""
+    torch.manual_seed(5)
+    m = a2f_amd.Voca(n_verts=NV, n_onehot=12).to(DEV)
+    B = 256
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 29, 16, generator=g).to(DEV)
+    oh = torch.zeros(B, 12, device=DEV); oh[:, 2] = 1
+    t = (torch.randn(B, 5023, 3, generator=g) * 5).to(DEV)
+    gt = t + (torch.randn(B, 5023, 3, generator=g) * 0.5).to(DEV)
+    from a2f_amd.trainer import FlatAdam
+    opt = FlatAdam(m.parameters(), lr=1e-4)
+    outs = []
+    for sp in (True, False):
+        m.store_pred = sp
+        opt.zero_grad()
+        pred, out3 = m.train_step_direct(x, oh, t, gt)
+        torch.cuda.synchronize()
+        assert (pred is None) == (not sp)
+        outs.append((out3.clone(), opt.flat_g.clone()))
+    m.store_pred = True
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

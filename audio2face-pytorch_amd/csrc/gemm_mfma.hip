@@ -424,6 +424,45 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, PREC == 2 ? (CFG == 3 ? 2 : 1) : Cfg<
   tile_epilogue<TM, TN>(a, acc, m0, n0, wm, wn, lane, bz);
 }
 
+// The weight-gradient fold (plain store, batch 1, N a multiple of 4: every split-K product of a Linear / convolution weight gradient): one float4 of C per
+// thread, EIGHT slabs in flight per trip (the scalar form below ran 45 us per call on 66 MB of slabs - a quarter of the HBM rate - 60 calls per FaceFormer
+// step), same fixed order of additions per element as the scalar kernel: ((s0 + s1) + (s2 + s3)) per group of four, groups in order.
+__global__ __launch_bounds__(256) void gemm_mfma_fold4_kernel(const Args a) {
+  const long long mn4 = (long long)a.M * a.N / 4;
+  const long long i = blockIdx.x * 256ll + threadIdx.x;
+  if (i < mn4) {
+    const f32x4* w = reinterpret_cast<const f32x4*>(a.ws) + i;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= a.split_k; s += 8) {
+      f32x4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = __builtin_nontemporal_load(w + (long long)(s + u) * mn4);
+      v += (x[0] + x[1]) + (x[2] + x[3]);
+      v += (x[4] + x[5]) + (x[6] + x[7]);
+    }
+    for (; s + 4 <= a.split_k; s += 4) {
+      const f32x4 x0 = w[(long long)s * mn4], x1 = w[(long long)(s + 1) * mn4], x2 = w[(long long)(s + 2) * mn4], x3 = w[(long long)(s + 3) * mn4];
+      v += (x0 + x1) + (x2 + x3);
+    }
+    for (; s < a.split_k; ++s) v += w[(long long)s * mn4];
+    const long long e = i * 4;
+    const int m = (int)(e / a.N), n = (int)(e - (long long)m * a.N);
+    *reinterpret_cast<f32x4*>(a.C + (long long)m * a.ldc + n) = v * a.alpha;
+  }
+  if (a.a_rowsum) {
+    const float* rs = a.ws + (long long)a.split_k * a.M * a.N;
+    for (long long m = blockIdx.x * 256ll + threadIdx.x; m < a.M; m += (long long)gridDim.x * 256) {
+      float v = 0.f;
+      int s = 0;
+      for (; s + 4 <= a.split_k; s += 4)
+        v += (rs[(long long)s * a.M + m] + rs[(long long)(s + 1) * a.M + m]) + (rs[(long long)(s + 2) * a.M + m] + rs[(long long)(s + 3) * a.M + m]);
+      for (; s < a.split_k; ++s) v += rs[(long long)s * a.M + m];
+      a.a_rowsum[m] = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void gemm_mfma_fold_kernel(const Args a) {
   const long long total = (long long)a.batch * a.M * a.N;
   const long long mn = (long long)a.M * a.N;
@@ -518,6 +557,20 @@ static int fill_op(const a2f_mm_operand& o, int64_t bstride, int64_t contiguous_
 }
 
 int launch_img(const Args& a, bool tn, hipStream_t st);      // csrc/gemm_img.hip
+
+static void launch_fold(const Args& a, hipStream_t st) {
+  const bool plain = a.batch == 1 && !a.bias && !a.act && !a.aux_mode && !a.keep && !a.accumulate && !a.C2 && a.c_rps <= 0 && a.N % 4 == 0 && a.ldc % 4 == 0 &&
+                     (((uintptr_t)a.C | (uintptr_t)a.ws) & 15) == 0;
+  if (plain) {
+    const long long mn4 = (long long)a.M * a.N / 4;
+    hipLaunchKernelGGL(gemm_mfma_fold4_kernel, dim3((unsigned)((mn4 + 255) / 256)), dim3(256), 0, st, a);
+    return;
+  }
+  const long long total = (long long)a.batch * a.M * a.N;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gemm_mfma_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+}
 
 }  // namespace mm
 }  // namespace a2f
@@ -617,10 +670,7 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
     if (rc) return rc;
     A2F_CHECK_LAUNCH("a2f_mm (image operands)");
     if (split > 1) {
-      const long long total = (long long)a.M * a.N;
-      long long blocks = (total + 255) / 256;
-      if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(gemm_mfma_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+      launch_fold(a, (hipStream_t)stream);
       A2F_CHECK_LAUNCH("a2f_mm fold");
     }
     return A2F_OK;
@@ -681,10 +731,7 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   if (rc) return rc;
   A2F_CHECK_LAUNCH("a2f_mm");
   if (split > 1) {
-    const long long total = (long long)batch * a.M * a.N;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gemm_mfma_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    launch_fold(a, st);
     A2F_CHECK_LAUNCH("a2f_mm fold");
   }
   return A2F_OK;

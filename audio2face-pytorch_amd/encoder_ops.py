@@ -23,7 +23,10 @@ POSCONV_WGRAD_T = _os.environ.get("A2F_POSCONV_WGRAD_T", "1") != "0"   # A-B hoo
 
 MM_IMG = _os.environ.get("A2F_MM_IMG", "1") != "0"               # A-B hook: 0 = the Transformer layers' products on the fp32-operand kernels
 IMG_MIN_ROWS = int(_os.environ.get("A2F_MM_IMG_MIN_ROWS", "2048"))   # below this many rows the 256 x 256 image tiles leave the chip empty: fp32-operand kernels
-WGRAD_STREAM = _os.environ.get("A2F_WGRAD_STREAM", "1") != "0"   # A-B hook: 0 = weight gradients in line on the launch stream
+# Weight gradients on a second stream beside the data-gradient chain: paid 1 ms of 157 in round 2 (tile tails of the 128 x 128 kernels filled each other);
+# with the 256 x 256 image-operand kernels it measures 131.0 (on) vs 129.9 ms (off), and every extra stream of the process can alias a hardware queue another
+# stream uses - so OFF by default since round 4 (A2F_WGRAD_STREAM=1 brings it back)
+WGRAD_STREAM = _os.environ.get("A2F_WGRAD_STREAM", "0") != "0"
 _wgrad_streams = {}
 
 

@@ -183,6 +183,9 @@ class BucketedAllReduce:
         return True
 
 
+_CAPTURE_STREAMS = {}
+
+
 class StepOutput(dict):
     """{"loss", "rec_loss", "vel_loss"} of a step; "err" (mse_error of lightning_model.py:119-125 == rec_loss / 3 for
     3-vectors) is derived on every access instead of costing an extra launch in every step.  It is NOT cached: under
@@ -313,7 +316,13 @@ class TrainStep:
             # Warm-up and capture run on ONE side stream: autograd's AccumulateGrad nodes remember the stream their
             # gradient buffers were last used on, and a capture that has to synchronise with another stream is illegal.
             if self._side is None:
-                self._side = torch.cuda.Stream()
+                # ONE capture stream per device for every TrainStep of the process: HIP maps streams onto a handful of hardware queues, and each
+                # further stream can land on the queue another one already uses (bench.py builds several steps in one process: with a stream per
+                # step the pipelined FaceFormer step behind them ran 153 ms instead of 125)
+                dev = torch.cuda.current_device()
+                if dev not in _CAPTURE_STREAMS:
+                    _CAPTURE_STREAMS[dev] = torch.cuda.Stream()
+                self._side = _CAPTURE_STREAMS[dev]
                 self._side.wait_stream(torch.cuda.current_stream())
             if self._warm < 2:                                  # eager warm-up: allocator pools, LDS attributes, autotune-free
                 self._warm += 1

@@ -523,7 +523,9 @@ constexpr int X3_RED_FLOATS = X3_NW * HF_ROWS * HF_KP;          // [wave][32][64
 constexpr int X3_WB_BYTES = X3_NW * 8 * 64 * 16;               // per wave: dH B fragments [kt][s][split][lane] x 16 B (lane-linear)
 constexpr size_t X3_LDS_BYTES = X3_HROW_BYTES + X3_HCOL_BYTES + (size_t)X3_RED_FLOATS * 4 + X3_WB_BYTES;
 
-template <int K>
+// PRED: false = the labelled no-prediction variant (a.pred == NULL: a training step that reads the loss alone) - a compile-time choice, so that the
+// hot loop of the API-preserving kernel carries no branch around its pred stores
+template <int K, bool PRED>
 __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* Hrow = reinterpret_cast<char*>(lds);
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
         const float p1 = acc[r + 1] + bias_r + tc[r + 1];
         const int so0 = (4 * (rr * n + lo)) | ~(mint | (mcolv & ((rr + h4 - rlim) >> 31)));
         const int so1 = (4 * ((rr + 1) * n + lo)) | ~(mint | (mcolv & ((rr + 1 + h4 - rlim) >> 31)));
-        if (a.pred) {                                   // wave-uniform; pred == NULL: the labelled no-pred-store variant of the training step
+        if constexpr (PRED) {
           buf_store_stream(pbuf, so0, p0);
           buf_store_stream(pbuf, so1, p1);
         }
@@ -1125,17 +1127,17 @@ static int head_launch(const HeadArgs& a, const HeadPlan& p, hipStream_t s) {
   return A2F_OK;
 }
 
-template <int K>
+template <int K, bool PRED>
 static int head_x3_launch(const HeadArgs& a, const HeadPlan& p, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_x3_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_x3_kernel<K, PRED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS_BYTES);
     if (e != hipSuccess) return set_err(A2F_ELAUNCH, "head_fused: hipFuncSetAttribute(%zu B LDS): %s", X3_LDS_BYTES, hipGetErrorString(e));
     attr_set = true;
   }
   const bool prof = g_prof_on && g_prof_n < 64;
   if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], s);
-  hipLaunchKernelGGL((head_x3_kernel<K>), dim3((unsigned)(p.CG * p.RG)), dim3(X3_THREADS), X3_LDS_BYTES, s, a);
+  hipLaunchKernelGGL((head_x3_kernel<K, PRED>), dim3((unsigned)(p.CG * p.RG)), dim3(X3_THREADS), X3_LDS_BYTES, s, a);
   if (prof) { (void)hipEventRecord(g_prof_ev[g_prof_n][1], s); ++g_prof_n; }
   return A2F_OK;
 }
@@ -1248,7 +1250,8 @@ extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias,
   a.cv = (float)(2.0 * k_vel / ((double)(Bloss / 2) * V));
   const int cfg = head_cfg(K);
   int rc;
-  if (cfg == 5) rc = K == 50 ? head_x3_launch<50>(a, p, s) : head_x3_launch<64>(a, p, s);
+  if (cfg == 5) rc = K == 50 ? (pred ? head_x3_launch<50, true>(a, p, s) : head_x3_launch<50, false>(a, p, s))
+                             : (pred ? head_x3_launch<64, true>(a, p, s) : head_x3_launch<64, false>(a, p, s));
   else if (K == 50) rc = cfg == 0 ? head_launch<50, 8, 512, 2>(a, p, s) : cfg == 1 ? head_launch<50, 4, 512, 1>(a, p, s)
                   : cfg == 2 ? head_launch<50, 4, 256, 2>(a, p, s) : cfg == 4 ? head_launch<50, 8, 256, 2>(a, p, s)
                   : head_launch<50, 4, 384, 1>(a, p, s);

@@ -328,6 +328,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--ff-deterministic", action="store_true", help="FaceFormer: switch the train-mode regularisers off (A/B timing)")
+    ap.add_argument("--no-batch-points", action="store_true", help="FaceFormer: skip the 1- and 16-sequence points (clean kernel profiles of the main step)")
     ap.add_argument("--no-graph", action="store_true", help="launch the ~90 kernels of a step eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
@@ -564,6 +565,8 @@ def main():
             res["roofline"] = roof
         # the reference trains ONE sequence per optimizer step (train.py:33): the same step at S = 1 and S = 16 beside the S-sequence figure
         pts = []
+        if args.no_batch_points:
+            batch_points = ()
         for s_pt in batch_points:
             if s_pt >= S:
                 continue

@@ -3,7 +3,7 @@
 // attention_dropout / activation_dropout = 0.1 in facebook/wav2vec2-base-960h's configuration).
 //
 // Every dropout site is a bit-packed KEEP mask in HBM (1 bit per element: 1/32 of the fp32 traffic of the tensor it gates):
-//   * produced once per step by a counter-based generator (Philox4x32-10 keyed by the step seed; counter = (group of four
+//   * produced once per step by a counter-based generator (Philox4x32-10 keyed by the step seed; counter = (group of eight
 //     elements, row, site)), so a mask is a pure function of (seed, site, element) - reproducible, order-independent;
 //   * consumed where the gated tensor is produced or used: in the a2f_mm epilogue (csrc/gemm_mfma.hip), inside the
 //     flash-attention kernels on the probabilities (csrc/attention.hip), or by the streaming a2f_dropout_apply below;
@@ -29,15 +29,21 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// the 32 keep bits of elements (row, 32 w .. 32 w + 31) of a row of `cols` elements: element e keeps iff its random word >= thresh
-__device__ __forceinline__ unsigned keep_word(unsigned k0, unsigned k1, unsigned site, unsigned row, int w, int cols, unsigned thresh) {
+// the 32 keep bits of elements (row, 32 w .. 32 w + 31) of a row of `cols` elements.  One Philox call yields four 32-bit words = EIGHT 16-bit randoms:
+// element 8 g + 2 e takes the low half of word e of group g = 4 w + j, element 8 g + 2 e + 1 the high half; an element keeps iff its 16-bit random
+// >= thresh16 = round(p 2^16) (p = 0.1: 6554 / 65536 = 0.100006).  Half the Philox work of one 32-bit word per element: the mask kernels are
+// bound by exactly that arithmetic (round 4: 5.2 ms of the 64 x 600 FaceFormer step with 32-bit randoms).
+__device__ __forceinline__ unsigned keep_word(unsigned k0, unsigned k1, unsigned site, unsigned row, int w, int cols, unsigned thresh16) {
   unsigned word = 0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < 4; ++j) {
     unsigned r[4];
-    philox4x32_10((unsigned)(8 * w + j), row, site, 0u, k0, k1, r);
+    philox4x32_10((unsigned)(4 * w + j), row, site, 0u, k0, k1, r);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) word |= (r[e] >= thresh ? 1u : 0u) << (4 * j + e);
+    for (int e = 0; e < 4; ++e) {
+      word |= ((r[e] & 0xFFFFu) >= thresh16 ? 1u : 0u) << (8 * j + 2 * e);
+      word |= ((r[e] >> 16) >= thresh16 ? 1u : 0u) << (8 * j + 2 * e + 1);
+    }
   }
   const int left = cols - 32 * w;
   if (left < 32) word = left <= 0 ? 0u : (word & ((1u << left) - 1u));
@@ -98,9 +104,9 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restr
   }
 }
 
-static unsigned keep_threshold(float p) {            // keep iff random u32 >= p * 2^32
-  const double t = (double)p * 4294967296.0;
-  return t <= 0.0 ? 0u : t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+static unsigned keep_threshold(float p) {            // keep iff random u16 >= round(p * 2^16)
+  const double t = (double)p * 65536.0 + 0.5;
+  return t <= 0.0 ? 0u : t >= 65535.0 ? 65535u : (unsigned)t;
 }
 
 }  // namespace a2f

@@ -22,6 +22,16 @@ POSCONV_WGRAD_T = _os.environ.get("A2F_POSCONV_WGRAD_T", "1") != "0"   # A-B hoo
 
 
 MM_IMG = _os.environ.get("A2F_MM_IMG", "1") != "0"               # A-B hook: 0 = the Transformer layers' products on the fp32-operand kernels
+WIMG_CACHE = _os.environ.get("A2F_WIMG_CACHE", "1") != "0"        # A-B hook: 0 = every layer call re-splits its weights
+_WIMG_CACHE = {}
+WEIGHTS_EPOCH = 0            # bumped by whoever rewrites parameters behind torch's back (trainer.FlatAdam.step)
+
+
+def bump_weights_epoch():
+    global WEIGHTS_EPOCH
+    WEIGHTS_EPOCH += 1
+
+
 IMG_MIN_ROWS = int(_os.environ.get("A2F_MM_IMG_MIN_ROWS", "2048"))   # below this many rows the 256 x 256 image tiles leave the chip empty: fp32-operand kernels
 # Weight gradients on a second stream beside the data-gradient chain: paid 1 ms of 157 in round 2 (tile tails of the 128 x 128 kernels filled each other);
 # with the 256 x 256 image-operand kernels it measures 131.0 (on) vs 129.9 ms (off), and every extra stream of the process can alias a hardware queue another
@@ -235,6 +245,31 @@ class EncoderLayerFn(torch.autograd.Function):
         return wi, wt
 
     @staticmethod
+    def _layer_weight_images(be, Wq, Wk, Wv, bq, bk, bv, Wo, W1, W2):
+        """The fused q|k|v weight / bias and the (image, transposed image) pairs of a layer's four weights.  They depend on the weights alone, and a step
+        runs every layer several times on unchanged weights (the parts of the pipelined step): built once per (weights state, stream), 16 small launches per
+        layer and part otherwise (1.35 ms of the 64 x 600 step).  A cache entry holds its source tensors, so their addresses cannot be handed to other tensors
+        while it exists; a change of the weights shows as a tensor version (in-place torch ops) or as a new `WEIGHTS_EPOCH` (trainer.FlatAdam: its Adam
+        kernel writes the parameters through raw pointers).  Never used under stream capture (a replay must run the splitting passes)."""
+        def build():
+            Wqkv, bqkv = torch.cat((Wq, Wk, Wv), 0), torch.cat((bq, bk, bv), 0)
+            return (Wqkv, bqkv) + EncoderLayerFn._wimg(be, Wqkv) + EncoderLayerFn._wimg(be, Wo) + EncoderLayerFn._wimg(be, W1) + EncoderLayerFn._wimg(be, W2)
+        if not WIMG_CACHE or not Wq.is_cuda or torch.cuda.is_current_stream_capturing():
+            return build()
+        src = (Wq, Wk, Wv, bq, bk, bv, Wo, W1, W2)
+        key = tuple(t.data_ptr() for t in src)
+        tag = (WEIGHTS_EPOCH, torch.cuda.current_stream(Wq.device).cuda_stream) + tuple(t._version for t in src)
+        ent = _WIMG_CACHE.get(key)
+        if ent is not None and ent[0] == tag:
+            return ent[2]
+        out = build()
+        _WIMG_CACHE.pop(key, None)
+        while len(_WIMG_CACHE) >= 64:                              # a handful of models at most (12 layers each); oldest first
+            _WIMG_CACHE.pop(next(iter(_WIMG_CACHE)))
+        _WIMG_CACHE[key] = (tag, src, out)
+        return out
+
+    @staticmethod
     def _forward_img(ctx, be, xc, x_img, S, T, heads, mk, keep, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2):
         M, d = xc.shape
         F = W1.shape[0]
@@ -242,11 +277,7 @@ class EncoderLayerFn(torch.autograd.Function):
         if x_img is None:
             x_img = _new(xc, M, d)
             be.split_img(xc, M, d, d, x_img, d)
-        Wqkv, bqkv = torch.cat((Wq, Wk, Wv), 0), torch.cat((bq, bk, bv), 0)
-        Wqkv_i, Wqkv_t = EncoderLayerFn._wimg(be, Wqkv)
-        Wo_i, Wo_t = EncoderLayerFn._wimg(be, Wo)
-        W1_i, W1_t = EncoderLayerFn._wimg(be, W1)
-        W2_i, W2_t = EncoderLayerFn._wimg(be, W2)
+        Wqkv, bqkv, Wqkv_i, Wqkv_t, Wo_i, Wo_t, W1_i, W1_t, W2_i, W2_t = EncoderLayerFn._layer_weight_images(be, Wq, Wk, Wv, bq, bk, bv, Wo, W1, W2)
         qkv = _new(xc, M, 3 * d)
         be.mm(I(x_img, d), I(Wqkv_i, d), qkv, M, 3 * d, d, 3 * d, bias=bqkv)
         att, att_img, lse = _new(xc, M, d), _new(xc, M, d), _new(xc, S, heads, T)

@@ -61,6 +61,7 @@ def _chk(*ts):
 
 
 _NO_FUSED_ROWSUM = os.environ.get("A2F_MM_ROWSUM", "1") == "0"
+SMALL_M_SPLIT = int(os.environ.get("A2F_MM_SMALL_M", "1024"))     # products of at most this many rows are cut along K automatically (0: never; A-B hook)
 
 
 def _chk_bits(*ts):
@@ -160,6 +161,13 @@ class HipBackend:
         elif split_k == 0:                                      # auto: enough workgroups for the chip, slabs stay small
             tiles = ((M + 127) // 128) * ((N + (127 if N > 64 else 63)) // (128 if N > 64 else 64)) * batch
             split_k = max(1, min(512 // max(tiles, 1), K // 256, 64)) if tiles < 192 else 1
+        elif (split_k == 1 and SMALL_M_SPLIT and batch == 1 and not A.img and not A.trans and not accumulate and a_rowsum is None and c_colsum is None
+              and M <= SMALL_M_SPLIT and N > 64 and K >= 384):
+            # a product of few rows (the reference's own batch-1 FaceFormer step: 600 rows) makes (M / 128) (N / 128) workgroups - 30 for N = 768 - that
+            # each walk the whole K alone: cut K so that ~256 workgroups run three or more 32-deep k-tiles each; the fold applies the epilogue
+            tiles = ((M + 127) // 128) * ((N + 127) // 128)
+            if tiles <= 128:
+                split_k = max(1, min(256 // tiles, K // 96, 32))
         d.split_k = split_k
         ws = None
         if split_k > 1:

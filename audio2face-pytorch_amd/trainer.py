@@ -103,6 +103,8 @@ class FlatAdam:
         if not reduced:
             self.allreduce_grads()
         self.step_count += 1
+        from . import encoder_ops
+        encoder_ops.bump_weights_epoch()                # the kernel below rewrites every parameter through its raw pointer: cached weight images are stale
         ops.backend().adam_step(self.flat_p, self.flat_g, self.m, self.v, self.numel, self.lr, self.betas[0], self.betas[1],
                                 self.eps, self.wd, 1.0 / self.world(), self.step_count)
 

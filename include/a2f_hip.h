@@ -419,8 +419,9 @@ int a2f_gelu_bwd(const float* dy, const float* z, int64_t n, float* out, a2f_str
  * feat_proj_dropout / hidden_dropout / attention_dropout / activation_dropout, /root/reference/src/model/wav2vec.py:87-189 and
  * HF modeling_wav2vec2 Wav2Vec2FeatureProjection / Wav2Vec2Encoder / Wav2Vec2EncoderLayer / Wav2Vec2FeedForward / eager attention).
  * A dropout site is a bit-packed KEEP mask: (R, C) elements = R rows of `wpr` 32-bit words (wpr * 32 >= C), bit b of word (r, w)
- * <-> element (r, 32 w + b), 1 = keep.  a2f_keep_bits fills one from Philox4x32-10: key = seed, counter = (element / 4 within the row,
- * row, site, 0), element e of the group keeps iff output[e % 4] >= p * 2^32 - a pure function of (seed, site, row, column).
+ * <-> element (r, 32 w + b), 1 = keep.  a2f_keep_bits fills one from Philox4x32-10: key = seed, counter = (element / 8 within the row,
+ * row, site, 0); the four output words are eight 16-bit randoms (element 8 g + 2 e: low half of word e, 8 g + 2 e + 1: its high half) and an
+ * element keeps iff its random >= round(p * 2^16) - a pure function of (seed, site, row, column); the drop probability is exact to 2^-17.
  * a2f_keep_bits_attn: the (SH, T, T) mask of the attention probabilities in the two layouts the kernels read: query-major words
  * [sh][q][TW] (bit = key) and key-major words [sh][TW][32 TW] (word (qw, key): bit b = query 32 qw + b); TW = a2f_attn_keep_words(T)
  * = 2 ceil(T / 64); row index of the counter = sh * T + q.  a2f_dropout_apply: y = keep ? x * scale : 0 (streaming; y may be x).

@@ -44,12 +44,13 @@ def unpack_keep_bits(bits, Cc):
 
 
 def philox_keep_words(seed, site, R, Cc, p, wpr):
-    """numpy restatement of a2f_keep_bits (include/a2f_hip.h): Philox4x32-10, key = seed, counter = (column / 4, row, site, 0);
-    element keeps iff its output word >= p * 2^32.  Returns int32 (R, wpr)."""
+    """numpy restatement of a2f_keep_bits (include/a2f_hip.h): Philox4x32-10, key = seed, counter = (column / 8, row, site, 0); the four output words
+    are eight 16-bit randoms (element 8 g + 2 e: low half of word e, 8 g + 2 e + 1: high half); an element keeps iff its random >= round(p * 2^16).
+    Returns int32 (R, wpr)."""
     import numpy as np
     M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
     mask32 = np.uint64(0xFFFFFFFF)
-    ng = wpr * 8
+    ng = wpr * 4
     c0 = np.broadcast_to(np.arange(ng, dtype=np.uint64)[None, :], (R, ng)).copy()
     c1 = np.broadcast_to(np.arange(R, dtype=np.uint64)[:, None], (R, ng)).copy()
     c2 = np.full((R, ng), site, dtype=np.uint64)
@@ -60,10 +61,11 @@ def philox_keep_words(seed, site, R, Cc, p, wpr):
         hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask32, p1 >> np.uint64(32), p1 & mask32
         c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
         k0, k1 = (k0 + W0) & mask32, (k1 + W1) & mask32
-    t = float(p) * 4294967296.0
-    thresh = np.uint64(0 if t <= 0 else min(int(t), 4294967295))
-    keep = np.stack([c0, c1, c2, c3], axis=-1) >= thresh                     # (R, ng, 4): element 4 g + e
-    keep = keep.reshape(R, ng * 4)
+    t = float(p) * 65536.0 + 0.5
+    thresh = np.uint64(0 if t <= 0 else min(int(t), 65535))
+    words4 = np.stack([c0, c1, c2, c3], axis=-1)                              # (R, ng, 4)
+    halves = np.stack([words4 & np.uint64(0xFFFF), words4 >> np.uint64(16)], axis=-1)   # (R, ng, 4, 2): element 8 g + 2 e + half
+    keep = (halves >= thresh).reshape(R, ng * 8)
     keep[:, Cc:] = False
     words = (keep.reshape(R, wpr, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32)
     return words.view(np.int32)

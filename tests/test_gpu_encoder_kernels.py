@@ -104,8 +104,8 @@ def test_featenc0_fwd_bwd(S, N):
 # ---------------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("R,C,p", [(1, 4, 0.1), (77, 768, 0.1), (600, 3072, 0.25), (5, 100, 0.0)])
 def test_keep_bits_is_philox_bit_for_bit(R, C, p):
-    """a2f_keep_bits against the numpy restatement of its contract (Philox4x32-10, counter = (column / 4, row, site), keep iff
-    word >= p 2^32): every word equal; the bits beyond C are zero."""
+    """a2f_keep_bits against the numpy restatement of its contract (Philox4x32-10, counter = (column / 8, row, site), keep iff
+    the element's 16-bit half word >= round(p 2^16)): every word equal; the bits beyond C are zero."""
     from emu_backend import philox_keep_words
     wpr = (C + 31) // 32 + (1 if R == 77 else 0)                # a padded row pitch is allowed
     seed, site = 0x1234_5678_9ABC_DEF0 >> 1, 9

@@ -1033,7 +1033,44 @@ def test_faceformer_pipelined_step_equals_single_stream_step(S, T, parts, monkey
                 assert rel_l2(got[k].cpu(), whole[k].cpu()) < TOL, k
         keys = sorted(halves)
         if whole_comparable:
-            assert rel_l2(torch.cat([got[k].flatten() for k in keys]).cpu(), torch.cat([whole[k].flatten() for k in keys]).cpu()) < 2e-5
+            # two evaluations of one function whose bf16x3 products are cut differently along K at the two batch sizes (few-row products are split
+            # along K automatically, ops.SMALL_M_SPLIT): 2.3e-5 measured for (3, 30, 2), each side ~1e-5 from the float64 oracle
+            assert rel_l2(torch.cat([got[k].flatten() for k in keys]).cpu(), torch.cat([whole[k].flatten() for k in keys]).cpu()) < 5e-5
+
+
+def test_weight_image_cache_follows_the_weights(monkeypatch):
+    """encoder_ops._layer_weight_images: a layer's fused q|k|v weight and split-32 weight images are built once per state of the weights.  Three training
+    steps (the raw-pointer Adam update between them bumps WEIGHTS_EPOCH), then an in-place torch edit of one weight (tensor version): every loss, the
+    parameters after the steps and the prediction after the edit are BITWISE those of the same run with the cache switched off."""
+    from a2f_amd import encoder_ops
+    from a2f_amd.trainer import TrainStep
+    monkeypatch.setattr(encoder_ops, "IMG_MIN_ROWS", 0)
+    S, T = 2, 30
+    gen = torch.Generator().manual_seed(9)
+    audio = (torch.randn(S, T * 16000 // 60 + 8, generator=gen) * 0.1).to(DEV)
+    oh = torch.zeros(S, 12); oh[torch.arange(S), torch.arange(S) % 8] = 1
+    template = torch.randn(S, 5023, 3, generator=gen) * 5
+    gt = (template.view(S, 1, 5023, 3) + torch.randn(S, T, 5023, 3, generator=gen) * 0.5).to(DEV)
+    oh, template = oh.to(DEV), template.to(DEV)
+    runs = []
+    for cache in (True, False):
+        monkeypatch.setattr(encoder_ops, "WIMG_CACHE", cache)
+        encoder_ops._WIMG_CACHE.clear()
+        m, _, _ = _faceformer_full()
+        m.train()
+        m.audio_encoder.train_regularisers = m.decoder_regularisers = False
+        step = TrainStep(m, a2f_amd.FaceFormerLoss(), lr=1e-3)
+        losses = [float(step(audio, oh, gt, template)["loss"]) for _ in range(3)]
+        assert (len(encoder_ops._WIMG_CACHE) > 0) == cache
+        params = [p.detach().clone() for p in m.parameters()]
+        with torch.no_grad():
+            m.audio_encoder.encoder.layers[3].feed_forward.intermediate_dense.weight.mul_(1.25)          # a torch in-place edit: version counter
+            pred = m.eval()(audio[:1], oh[:1], template[:1]).clone()
+        runs.append((losses, params, pred))
+    (l1, p1, y1), (l0, p0, y0) = runs
+    assert l1 == l0 and l1[0] != l1[1] != l1[2]
+    assert all(torch.equal(a, b) for a, b in zip(p1, p0))
+    assert torch.equal(y1, y0)
 
 
 @pytest.mark.parametrize("images", [False, True])

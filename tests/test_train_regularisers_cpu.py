@@ -89,10 +89,11 @@ def test_philox_restatement_known_answers():
     import emu_backend
     w = philox_keep_words(0, 0, 1, 4, 0.0, 1)              # p = 0 keeps everything; checks the packing only
     assert int(w[0, 0]) == 0xF
-    # counter (0, 0, 0, 0), key 0 -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8 (Random123 kat_vectors): element e keeps iff word >= thresh
-    for thresh_word, expect in ((0x6627e8d5, (1, 1, 1, 1)), (0x6627e8d6, (0, 1, 1, 1)), (0xbc57ac4d, (0, 1, 0, 0))):
-        w = philox_keep_words(0, 0, 1, 4, thresh_word / 4294967296.0, 1)
-        assert tuple((int(w[0, 0]) >> e) & 1 for e in range(4)) == expect
+    # counter (0, 0, 0, 0), key 0 -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8 (Random123 kat_vectors): eight 16-bit randoms, low half first:
+    # e8d5 6627 c58d e169 ac4c bc57 dbd8 9b00; an element keeps iff its random >= thresh
+    for thresh16, expect in ((0x6627, (1, 1, 1, 1, 1, 1, 1, 1)), (0x6628, (1, 0, 1, 1, 1, 1, 1, 1)), (0xbc58, (1, 0, 1, 1, 0, 0, 1, 0)), (0xe8d6, (0,) * 8)):
+        w = philox_keep_words(0, 0, 1, 8, thresh16 / 65536.0, 1)
+        assert tuple((int(w[0, 0]) >> e) & 1 for e in range(8)) == expect
     k = unpack_keep_bits(torch.from_numpy(philox_keep_words(987654321987, 5, 64, 768, 0.1, 24)), 768)
     assert abs(float(k.float().mean()) - 0.9) < 0.01
 

@@ -276,26 +276,30 @@ A2M_BN_MOMENTUM, A2M_BN_EPS = 0.1, 1e-5
 A2M_CHP = (1, 72, 108, 164, 244, 256)          # padded analysis channels
 
 
-# Padded / re-laid-out copies of parameters are refreshed every step (the parameters change); their BUFFERS are kept per source tensor, so a
+# Padded / re-laid-out copies of parameters are refreshed every step (the parameters change); their BUFFERS are kept with the source tensor, so a
 # refresh is one copy into the valid region of a buffer whose padding was written once - not an allocation, a fill and a copy (the Audio2Mesh
-# step spent ~50 launches of ~5 us on exactly that).  Keyed by the source's storage address and shape: two models never share a buffer, and a
-# second forward of the same model before its backward rewrites the same values.
-_PAD_CACHE = {}
-
-
-def _cached(key, make):
-    buf = _PAD_CACHE.get(key)
+# step spent ~50 launches of ~5 us on exactly that).  A buffer lives in a dict ON its owner - the parameter / BatchNorm buffer itself, or the base
+# tensor of a view of one - so it exists exactly as long as the owner does: a captured hipGraph that has its address baked in and an autograd graph that
+# saved it both hold the model, hence the owner, hence the buffer (a process-global table keyed by address had to be emptied at some size, under
+# the feet of whoever still replayed a graph over those addresses).
+def _cached(src, key, make):
+    owner = src._base if src._base is not None else src
+    table = owner.__dict__.get("_a2f_padded")
+    if table is None:
+        table = owner.__dict__["_a2f_padded"] = {}
+    key = key + (src.data_ptr(), src.device)               # the owner may move (.to(), FlatAdam re-homing .data): stale entries simply stop matching
+    buf = table.get(key)
     if buf is None:
-        if len(_PAD_CACHE) > 512:                     # models come and go in test suites; the buffers are small
-            _PAD_CACHE.clear()
-        buf = _PAD_CACHE[key] = make()
+        for k in [k for k in table if k[:len(key) - 2] == key[:-2]]:
+            del table[k]                                   # the same view at an older address
+        buf = table[key] = make()
     return buf
 
 
 def _padv(v, n, value=0.0):
     if v.shape[0] == n:
         return v
-    buf = _cached(("padv", v.data_ptr(), v.device, v.shape[0], n, float(value)), lambda: v.new_full((n,), value))
+    buf = _cached(v, ("padv", v.shape[0], n, float(value)), lambda: v.new_full((n,), value))
     buf[: v.shape[0]].copy_(v)
     return buf
 
@@ -303,7 +307,7 @@ def _padv(v, n, value=0.0):
 def _pack_conv_w(w3, Cop, Cip):
     """w3 (Co, Ci, KH) -> (Cop, KH*Cip) with k = kh*Cip + ci, zero padded."""
     Co, Ci, KH = w3.shape
-    out = _cached(("convw", w3.data_ptr(), w3.device, Co, Ci, KH, Cop, Cip), lambda: w3.new_zeros(Cop, KH, Cip))
+    out = _cached(w3, ("convw", Co, Ci, KH, Cop, Cip), lambda: w3.new_zeros(Cop, KH, Cip))
     out[:Co, :, :Ci].copy_(w3.permute(0, 2, 1))
     return out.view(Cop, KH * Cip)
 

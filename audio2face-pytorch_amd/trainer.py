@@ -73,6 +73,12 @@ class FlatAdam:
             p.grad = v
         if src:
             torch._foreach_copy_(dst, src)
+            if src[0].is_cuda:
+                # a stolen gradient may have been allocated and accumulated on the pipelined step's side streams; the copy above reads it on the
+                # current stream and the tensor dies right here - tell the allocator, so the block is not handed out on its home stream while the copy runs
+                cur = torch.cuda.current_stream(src[0].device)
+                for g in src:
+                    g.record_stream(cur)
         if missing:
             torch._foreach_zero_(missing)
 
@@ -172,7 +178,13 @@ class BucketedAllReduce:
 
     def _hook(self, p):
         if self.active:
-            self._launch_down_to(self.bucket_of[id(p)])
+            b = self.bucket_of[id(p)]
+            if b > self.next:
+                # the order assumption above does not hold for this model (a parameter registered early but used late, e.g. a final norm filed
+                # under the front bucket): bucket b went out before this gradient existed.  Nothing can repair a sum that is already on the wire.
+                raise RuntimeError(f"BucketedAllReduce: a gradient of bucket {b} arrived after that bucket's all-reduce was started (buckets are "
+                                   f"launched in reverse parameter order); this model needs A2F_DP_BUCKETS=0 (one all-reduce after the backward)")
+            self._launch_down_to(b)
 
     def finish(self) -> bool:
         """Launch the remaining buckets, wait for every all-reduce.  Returns True when the gradients are reduced (begin() was called)."""

@@ -322,3 +322,41 @@ def test_flat_adam_release_and_collect_grads(emu):
     for p in ps[:2]:
         o, n = opt._offsets[id(p)][0], p.numel()
         assert torch.equal(opt.flat_g[o:o + n], want[o:o + n])
+
+
+def test_bucketed_allreduce_refuses_a_model_that_breaks_its_order_assumption():
+    """trainer.BucketedAllReduce launches buckets in reverse parameter order as the backward passes them.  A parameter that is registered early but used late
+    (filed under the first bucket, its gradient arrives first) would send every later bucket out before its gradients exist: the hook must fail loudly."""
+    import torch.nn as nn
+    from a2f_amd.trainer import BucketedAllReduce, FlatAdam
+
+    class Net(nn.Module):
+        def __init__(self, late_front):
+            super().__init__()
+            self.front = nn.Linear(4, 4)
+            self.layers = nn.ModuleList(nn.Linear(4, 4) for _ in range(3))
+            self.late_front = late_front
+
+        def forward(self, x):
+            if not self.late_front:
+                x = self.front(x)
+            for l in self.layers:
+                x = torch.tanh(l(x))
+            return self.front(x) if self.late_front else x
+
+    key = lambda name: int(name.split(".")[1]) + 1 if name.startswith("layers.") else 0
+    for late in (False, True):
+        torch.manual_seed(0)
+        m = Net(late)
+        opt = FlatAdam(m.parameters(), lr=1e-3)
+        br = BucketedAllReduce(opt, list(m.named_parameters()), key)
+        opt.zero_grad()
+        loss = m(torch.randn(5, 4)).square().sum()
+        br.begin()
+        if late:
+            with pytest.raises(RuntimeError, match="arrived after that bucket's all-reduce was started"):
+                loss.backward()
+        else:
+            loss.backward()
+            assert br.finish() and br.launch_log == [3, 2, 1, 0]
+        br.close()

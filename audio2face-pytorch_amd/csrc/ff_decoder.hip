@@ -41,7 +41,7 @@ constexpr int FB2_U = 4;               // key slots per trip and wave in that fo
 constexpr int GR_QKV = 0, GR_SA = 192, GR_HP = 256, GR_F = 384, GR_EMB = 448, GR_Y2 = 512, GR_Y = 576, GR_DC = 640, GR_RS = 704, FF_GREC = 720;
 // blocked form of the backward (sequences of FF_BLK_MIN frames and more): the recurrence runs in blocks of FF_BLK steps, attention terms that cross a block
 // boundary are batched over the whole chip (ff_bwd_prep_kernel / ff_bwd_rect_kernel below).  FF_NREC floats per frame: Nt[h][a'][b], then n[h][b]
-constexpr int FF_BLK = 128, FF_BLK_MIN = 256, FF_NREC = 4 * 272, NR_N = 1024;
+constexpr int FF_BLK = 128, FF_BLK_MIN = FF_BLK + 1, FF_NREC = 4 * 272, NR_N = 1024;
 #ifndef FA_U_SET
 #define FA_U_SET 1
 #endif
@@ -657,9 +657,11 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
           const float ds = a * (da - rowsum);
           dqa.x += ds * kk[u].x; dqa.y += ds * kk[u].y; dqa.z += ds * kk[u].z; dqa.w += ds * kk[u].w;
           if (valid) {
+            const float4 ndk = make_float4(dk[u].x + ds * qv.x, dk[u].y + ds * qv.y, dk[u].z + ds * qv.z, dk[u].w + ds * qv.w);
+            const float4 ndv = make_float4(dv[u].x + ad * dcv.x, dv[u].y + ad * dcv.y, dv[u].z + ad * dcv.z, dv[u].w + ad * dcv.w);
             const int64_t off = (int64_t)j * SV_STRIDE;
-            *reinterpret_cast<float4*>(dkbase + off) = make_float4(dk[u].x + ds * qv.x, dk[u].y + ds * qv.y, dk[u].z + ds * qv.z, dk[u].w + ds * qv.w);
-            *reinterpret_cast<float4*>(dvbase + off) = make_float4(dv[u].x + ad * dcv.x, dv[u].y + ad * dcv.y, dv[u].z + ad * dcv.z, dv[u].w + ad * dcv.w);
+            *reinterpret_cast<float4*>(dkbase + off) = ndk;
+            *reinterpret_cast<float4*>(dvbase + off) = ndv;
           }
         }
       }
@@ -745,7 +747,12 @@ __global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const flo
   }
 }
 
-template <bool DROP>
+// LACC (launches that cover at most FF_BLK steps: every launch of the blocked form): the dK / dV accumulators of the launch's own keys live in LDS
+// ([key - i_lo][64] floats each, the 16-byte chunk index XORed with 4 (key & 3) so that the four key slots a 16-lane group touches hit four bank
+// quarters) instead of being read, added to and written back in global memory by every step - that round trip through L2 was 5.3 k of the 13.9 k clocks
+// of a step (round-3 stamps).  What earlier-launched (later-time) blocks left in the global rows through ff_bwd_rect_kernel is complete before this
+// launch; the helper wave parks it beside the step's saved rows and it is added when row i is finished.
+template <bool DROP, bool LACC>
 __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(const float* __restrict__ P, const float* __restrict__ dy, int T,
                                                                               int period, float* __restrict__ save, float* __restrict__ grec,
                                                                               float* __restrict__ dcross, float* __restrict__ dstyle, const FFDrop dm,
@@ -774,8 +781,9 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
   float* mrg = qs + FD;                     // [64] dq partial of the heads' second waves
   // Saved rows of a step (the first 576 floats of its record: x, q, ctx, xh1, xh2, h, xh3, stats), its dy row and its keep words, parked here one
   // step ahead by the helper wave (see the loop top): [2][FB_STG]
-  constexpr int FB_STG = 576 + FD + 16;
+  constexpr int FB_STG = 576 + FD + 16 + (LACC ? 2 * FD : 0);
   float* stg = mrg + FD;
+  float* dkv = stg + 2 * FB_STG;            // LACC: [FF_BLK][64] dK, then [FF_BLK][64] dV
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int head = wave & 3, apart = wave >> 2;     // attention sweep: head and which half of the key trips
@@ -785,6 +793,8 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
   for (int e = t; e < 192 * FD; e += FF_BWD2_THREADS) Wqkv[e] = P[A2F_FF_WQKV + e];
   for (int e = t; e < FD * FD; e += FF_BWD2_THREADS) { Wo[e] = P[A2F_FF_WO + e]; Am[e] = P[A2F_FF_A + e]; }
   if (t < FD) dembs[t] = 0.f;
+  if constexpr (LACC)
+    for (int e = t; e < 2 * FF_BLK * FD; e += FF_BWD2_THREADS) dkv[e] = 0.f;
   // zero this sequence's dK / dV accumulators (first launch of the sequence)
   if (i_hi == T)
     for (int64_t e = t; e < (int64_t)T * 128; e += FF_BWD2_THREADS) svbase[(e >> 7) * SV_STRIDE + SV_DK + (e & 127)] = 0.f;
@@ -827,12 +837,13 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
   // around the loop (cf. the forward).  Read where they are used they cost an L2 round trip at the head of S1, S5 and S7 each (s_memtime stamps:
   // S1 2 444 clk of a 13.9 k step).
   constexpr int HELPER = FF_BWD2_THREADS / 64 - 1;
-  float pf[9], pf_dy = 0.f;
+  float pf[9], pf_dy = 0.f, pf_dk = 0.f, pf_dv = 0.f;
   unsigned pf_kw = 0;
   auto request_rows = [&](int step) {
     const float* r = svbase + (int64_t)step * SV_STRIDE;
 #pragma unroll
     for (int q = 0; q < 9; ++q) pf[q] = r[q * 64 + lane];
+    if constexpr (LACC) { pf_dk = r[SV_DK + lane]; pf_dv = r[SV_DV + lane]; }
     pf_dy = dy[(s * T + step) * FD + lane];
     if constexpr (DROP) pf_kw = dm.row[(s * T + step) * FF_ROW_WORDS + min(lane, FF_ROW_WORDS - 1)];
   };
@@ -842,6 +853,7 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
     for (int q = 0; q < 9; ++q) d[q * 64 + lane] = pf[q];
     d[576 + lane] = pf_dy;
     if constexpr (DROP) { if (lane < FF_ROW_WORDS) reinterpret_cast<unsigned*>(d)[576 + FD + lane] = pf_kw; }
+    if constexpr (LACC) { d[576 + FD + 16 + lane] = pf_dk; d[576 + FD + 16 + FD + lane] = pf_dv; }
   };
   if (wave == HELPER) {
     request_rows(i_hi - 1);
@@ -995,8 +1007,15 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
           const int64_t off = (int64_t)jj * SV_STRIDE;
           kk[u] = *reinterpret_cast<const float4*>(kbase + off);
           vv[u] = *reinterpret_cast<const float4*>(vbase + off);
-          dk[u] = *reinterpret_cast<const float4*>(dkbase + off);
-          dv[u] = *reinterpret_cast<const float4*>(dvbase + off);
+          if constexpr (LACC) {
+            const int lk = jj - i_lo;
+            const int a = lk * FD + (((head * 4 + dq) ^ ((lk & 3) << 2)) << 2);
+            dk[u] = *reinterpret_cast<const float4*>(dkv + a);
+            dv[u] = *reinterpret_cast<const float4*>(dkv + FF_BLK * FD + a);
+          } else {
+            dk[u] = *reinterpret_cast<const float4*>(dkbase + off);
+            dv[u] = *reinterpret_cast<const float4*>(dvbase + off);
+          }
           if constexpr (DROP) kw[u] = abits[jj >> 5];
         }
 #pragma unroll
@@ -1019,9 +1038,18 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
           const float ds = a * (da - rowsum);
           dqa.x += ds * kk[u].x; dqa.y += ds * kk[u].y; dqa.z += ds * kk[u].z; dqa.w += ds * kk[u].w;
           if (valid) {
-            const int64_t off = (int64_t)j * SV_STRIDE;
-            *reinterpret_cast<float4*>(dkbase + off) = make_float4(dk[u].x + ds * qv.x, dk[u].y + ds * qv.y, dk[u].z + ds * qv.z, dk[u].w + ds * qv.w);
-            *reinterpret_cast<float4*>(dvbase + off) = make_float4(dv[u].x + ad * dcv.x, dv[u].y + ad * dcv.y, dv[u].z + ad * dcv.z, dv[u].w + ad * dcv.w);
+            const float4 ndk = make_float4(dk[u].x + ds * qv.x, dk[u].y + ds * qv.y, dk[u].z + ds * qv.z, dk[u].w + ds * qv.w);
+            const float4 ndv = make_float4(dv[u].x + ad * dcv.x, dv[u].y + ad * dcv.y, dv[u].z + ad * dcv.z, dv[u].w + ad * dcv.w);
+            if constexpr (LACC) {
+              const int lk = j - i_lo;
+              const int a = lk * FD + (((head * 4 + dq) ^ ((lk & 3) << 2)) << 2);
+              *reinterpret_cast<float4*>(dkv + a) = ndk;
+              *reinterpret_cast<float4*>(dkv + FF_BLK * FD + a) = ndv;
+            } else {
+              const int64_t off = (int64_t)j * SV_STRIDE;
+              *reinterpret_cast<float4*>(dkbase + off) = ndk;
+              *reinterpret_cast<float4*>(dvbase + off) = ndv;
+            }
           }
         }
       }
@@ -1044,7 +1072,17 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
         *reinterpret_cast<float4*>(gr + GR_QKV + head * FHD + dq * 4) = r;
       }
     }
-    if (t >= 64 && t < 192) { const float g = sv[SV_DK + (t - 64)]; dqkvs[t] = g; gr[GR_QKV + t] = g; }     // SV_DV follows SV_DK: columns 64..127 are dV
+    if (t >= 64 && t < 192) {                                                                               // SV_DV follows SV_DK: columns 64..127 are dV
+      float g;
+      if constexpr (LACC) {
+        const int e = t - 64, lk = i - i_lo, col = e & 63;
+        g = dkv[(e >> 6) * FF_BLK * FD + lk * FD + ((((col >> 2) ^ ((lk & 3) << 2)) << 2) | (col & 3))] + sr[576 + FD + 16 + e];
+      } else {
+        g = sv[SV_DK + (t - 64)];
+      }
+      dqkvs[t] = g;
+      gr[GR_QKV + t] = g;
+    }
     __syncthreads();
     FFB_STAMP(9);
     // ---- S9: dWqkv += dqkv (x) x ; dx += Wqkv^T dqkv (4 partial sums per output) ----
@@ -1291,24 +1329,33 @@ static int ff_bwd2_run(const float* params, const float* dy, int64_t S, int64_t 
                        float* dstyle, const a2f::FFDrop& dm, bool drop, bool blocked, hipStream_t st) {
   using namespace a2f;
   constexpr size_t LDS = FF_BWD_LDS + (64 + 2 * (576 + FD + 16)) * sizeof(float);
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[drop]) {
-    const void* k = drop ? reinterpret_cast<const void*>(&ff_decoder_bwd2_kernel<true>) : reinterpret_cast<const void*>(&ff_decoder_bwd2_kernel<false>);
-    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-    if (e != hipSuccess) return set_err(A2F_ELAUNCH, "ff_decoder_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set[drop] = true;
-  }
+  constexpr size_t LDS_LACC = FF_BWD_LDS + (64 + 2 * (576 + FD + 16 + 2 * FD) + 2 * FF_BLK * FD) * sizeof(float);      // + parked dK / dV rows + the block's accumulators
+  static_assert(LDS_LACC <= 160 * 1024, "the LDS-accumulator form of the backward recurrence must fit one CU");
+  static bool attr_set[2][2] = {{false, false}, {false, false}};
+  auto kernel_of = [](bool dr, bool lacc) -> const void* {
+    return dr ? (lacc ? reinterpret_cast<const void*>(&ff_decoder_bwd2_kernel<true, true>) : reinterpret_cast<const void*>(&ff_decoder_bwd2_kernel<true, false>))
+              : (lacc ? reinterpret_cast<const void*>(&ff_decoder_bwd2_kernel<false, true>) : reinterpret_cast<const void*>(&ff_decoder_bwd2_kernel<false, false>));
+  };
+  static const bool lacc_on = [] { const char* e = getenv("A2F_FF_BWD_LACC"); return !(e && e[0] == '0'); }();      // A-B hook: 0 = global read-add-write accumulators
   float* slabs = save + (size_t)S * T * SV_STRIDE;
   float* grec = slabs + (size_t)S * A2F_FF_PARAM_FLOATS;
   float* ws = grec + (size_t)S * T * FF_GREC;
   float* nrec = ws + FF_GEMM_WS_FLOATS;
+  int launch_rc = A2F_OK;
   auto recurrence = [&](int lo, int hi) {
-    if (drop)
-      hipLaunchKernelGGL(ff_decoder_bwd2_kernel<true>, dim3((unsigned)S), dim3(FF_BWD2_THREADS), LDS, st, params, dy, (int)T, (int)period, save, grec, dcross, dstyle, dm,
-                         (const float*)nrec, lo, hi);
-    else
-      hipLaunchKernelGGL(ff_decoder_bwd2_kernel<false>, dim3((unsigned)S), dim3(FF_BWD2_THREADS), LDS, st, params, dy, (int)T, (int)period, save, grec, dcross, dstyle, dm,
-                         (const float*)nrec, lo, hi);
+    const bool lacc = lacc_on && hi - lo <= FF_BLK;
+    const size_t lds = lacc ? LDS_LACC : LDS;
+    if (!attr_set[drop][lacc]) {
+      hipError_t e = hipFuncSetAttribute(kernel_of(drop, lacc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { launch_rc = set_err(A2F_ELAUNCH, "ff_decoder_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return; }
+      attr_set[drop][lacc] = true;
+    }
+#define FF_BWD2_LAUNCH(DR, LA)                                                                                                                         \
+    hipLaunchKernelGGL((ff_decoder_bwd2_kernel<DR, LA>), dim3((unsigned)S), dim3(FF_BWD2_THREADS), lds, st, params, dy, (int)T, (int)period, save, grec, \
+                       dcross, dstyle, dm, (const float*)nrec, lo, hi)
+    if (drop) { if (lacc) FF_BWD2_LAUNCH(true, true); else FF_BWD2_LAUNCH(true, false); }
+    else      { if (lacc) FF_BWD2_LAUNCH(false, true); else FF_BWD2_LAUNCH(false, false); }
+#undef FF_BWD2_LAUNCH
   };
   if (!blocked || T < FF_BLK_MIN) {
     recurrence(0, (int)T);
@@ -1328,6 +1375,7 @@ static int ff_bwd2_run(const float* params, const float* dy, int64_t S, int64_t 
       hi = lo;
     }
   }
+  if (launch_rc != A2F_OK) return launch_rc;
   A2F_CHECK_LAUNCH("ff_decoder_bwd (recurrence)");
   hipLaunchKernelGGL(ff_decoder_fold_range_kernel, dim3(2), dim3(256), 0, st, (const float*)slabs, (int)S, dparams, (int)A2F_FF_LN, 6 * FD);
   A2F_CHECK_LAUNCH("ff_decoder_bwd (LayerNorm fold)");

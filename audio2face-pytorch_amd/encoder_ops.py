@@ -33,10 +33,12 @@ def bump_weights_epoch():
 
 
 IMG_MIN_ROWS = int(_os.environ.get("A2F_MM_IMG_MIN_ROWS", "2048"))   # below this many rows the 256 x 256 image tiles leave the chip empty: fp32-operand kernels
-# Weight gradients on a second stream beside the data-gradient chain: paid 1 ms of 157 in round 2 (tile tails of the 128 x 128 kernels filled each other);
-# with the 256 x 256 image-operand kernels it measures 131.0 (on) vs 129.9 ms (off), and every extra stream of the process can alias a hardware queue another
-# stream uses - so OFF by default since round 4 (A2F_WGRAD_STREAM=1 brings it back)
-WGRAD_STREAM = _os.environ.get("A2F_WGRAD_STREAM", "0") != "0"
+# Weight gradients on a second stream beside the data-gradient chain.  History: paid 1 ms of 157 in round 2 (tile tails of the 128 x 128 kernels filled each
+# other); with the 256 x 256 image kernels on the unsplit batch it measured 131.0 (on) vs 129.9 ms (off) and, while every TrainStep of a process still made its
+# own capture stream, aliased a hardware queue inside the full bench run (+25 ms): off.  Since the step runs as two half-batches (19 200 rows: the N = 768
+# launches have 225 tiles for 256 CUs) the lane fills those idle CUs: 122.6 -> 119.8 ms standalone, 119.2 -> 117.4 ms inside the full bench run, 12 x 3000
+# 206.8 -> 204.9 ms, batch 1 17.0 -> 16.6 ms (same box each, one capture stream per device): ON again (A2F_WGRAD_STREAM=0 switches it off).
+WGRAD_STREAM = _os.environ.get("A2F_WGRAD_STREAM", "1") != "0"
 _wgrad_streams = {}
 
 

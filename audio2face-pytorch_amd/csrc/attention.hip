@@ -110,6 +110,11 @@ __device__ __forceinline__ f32x16 mac(const u32x4_t (&a)[2], const u32x4_t (&b)[
   }
   return mfma(a[0], b[0], c);
 }
+// x if bit BP of `word` is set, else +0 (a bit-field-extract + AND form in pinned inline asm measured the same as this select: the kernels are not bound by
+// their vector instructions, profiles/r04_t_attention_ab.txt)
+template <int BP>
+__device__ __forceinline__ float keep_if(float x, unsigned word) { return ((word >> BP) & 1u) ? x : 0.f; }
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 __device__ __forceinline__ const float* uniform_ptr(const float* p) {
   const unsigned long long v = (unsigned long long)p;
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -293,36 +298,38 @@ __global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
         for (int r = 0; r < 16; ++r)
           if (it * TILE + 32 * kb + rho(r, h) >= T) st[kb][r] = -INFINITY;
     }
-    // ---- online softmax (per lane = per query; the two lane halves hold disjoint keys of the same query)
+    // ---- online softmax (per lane = per query; the two lane halves hold disjoint keys of the same query).  The running maximum is kept in
+    // units of log2: p = exp2(s log2e - m2) is one fused multiply-add and one v_exp_f32 per score (exp(s - m) is a subtract, a multiply and the v_exp_f32)
     float mx = st[0][0];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx);
-    const float alpha = __expf(m - mn);
+    const float mn = fmaxf(m, mx * LOG2E);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
     m = mn;
     float ps = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        st[kb][r] = __expf(st[kb][r] - mn);
+        st[kb][r] = __builtin_amdgcn_exp2f(fmaf(st[kb][r], LOG2E, -mn));
         ps += st[kb][r];
       }
     l = l * alpha + ps;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 16; ++r) {                              // (skipping this while the maximum stands still - a wave-uniform branch - measured no gain)
       o[0][r] *= alpha;
       o[1][r] *= alpha;
     }
     if constexpr (DROP) {                                       // the normaliser l keeps every key; only the value sum is thinned
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        st[0][r] = ((keep.x >> ((r & 3) + 8 * (r >> 2))) & 1u) ? st[0][r] : 0.f;
-        st[1][r] = ((keep.y >> ((r & 3) + 8 * (r >> 2))) & 1u) ? st[1][r] : 0.f;
-      }
+#define A2F_KEEP_FWD(R)                                                  \
+      st[0][R] = keep_if<((R) & 3) + 8 * ((R) >> 2)>(st[0][R], keep.x); \
+      st[1][R] = keep_if<((R) & 3) + 8 * ((R) >> 2)>(st[1][R], keep.y);
+      A2F_KEEP_FWD(0) A2F_KEEP_FWD(1) A2F_KEEP_FWD(2) A2F_KEEP_FWD(3) A2F_KEEP_FWD(4) A2F_KEEP_FWD(5) A2F_KEEP_FWD(6) A2F_KEEP_FWD(7)
+      A2F_KEEP_FWD(8) A2F_KEEP_FWD(9) A2F_KEEP_FWD(10) A2F_KEEP_FWD(11) A2F_KEEP_FWD(12) A2F_KEEP_FWD(13) A2F_KEEP_FWD(14) A2F_KEEP_FWD(15)
+#undef A2F_KEEP_FWD
     }
     // ---- O^T += V^T P: P straight from the accumulator registers
 #pragma unroll
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
         *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * gq + 4 * h) = v;
         if (a.out_ctx_img) img::store4(a.out_ctx_img + ((long long)seq * T + q) * a.ldo * 4, hc + 32 * dt + 8 * gq + 4 * h, v);
       }
-    if (h == 0) a.out_lse[((long long)seq * a.H + head) * T + q] = m + __logf(lt);
+    if (h == 0) a.out_lse[((long long)seq * a.H + head) * T + q] = m * LN2 + __logf(lt);
   }
 }
 
@@ -403,8 +410,15 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) 
   const int hc = head * D;
   const float* lse = a.lse + ((long long)seq * a.H + head) * T;
   const float* dlt = a.delta + ((long long)seq * a.H + head) * T;
-  const unsigned* keepk = nullptr;                             // this lane's key: word (qw) at + qw * 32 TW, bit = query 32 qw + b
-  if constexpr (DROP) keepk = a.keep_k + ((long long)seq * a.H + head) * a.TW * (32ll * a.TW) + min(key, 32 * a.TW - 1);
+  // this lane's key: word (qw) at + qw * 32 TW, bit = query 32 qw + b.  Through a buffer resource of the (sequence, head) block: a 32-bit lane offset
+  // instead of a 64-bit pointer per lane (the kernel sits at its 256 registers)
+  rsrc_t rkeep = rs;
+  unsigned keep_lane = 0u;
+  if constexpr (DROP) {
+    rkeep = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(reinterpret_cast<const unsigned*>(uniform_ptr(reinterpret_cast<const float*>(
+                a.keep_k + ((long long)seq * a.H + head) * a.TW * (32ll * a.TW))))), 0, a.TW * 32 * a.TW * 4, 0x00020000);
+    keep_lane = (unsigned)min(key, 32 * a.TW - 1) * 4u;
+  }
 
   u32x4_t kf[4][2], vf[4][2];
   reg_operand<PREC>(rs, key, a.ld, a.koff + hc, lane, 1.f, kf);
@@ -416,22 +430,36 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) 
 
   const int nt = (T + TILE - 1) / TILE;
   Tile<PREC> qt_, dt_;
+  // lse (in units of log2: times log2e) and delta of a tile's 64 queries travel with the tile through LDS ([stage][lse2 64 | delta 64]): read back as four
+  // float4 per 32-query sub-tile instead of 64 scalar global loads per tile and wave.  A query beyond T gets lse2 = +inf: its probability is exp2(-inf) = 0.
+  float* lsd = reinterpret_cast<float*>(smem + 2 * STAGE);
+  float aux_r = 0.f;
+  auto aux_load = [&](int tile) {
+    if (t < 128) {
+      const int qq = tile * TILE + (t & 63);
+      aux_r = t < 64 ? (qq < T ? lse[qq] * LOG2E : INFINITY) : (qq < T ? dlt[qq] : 0.f);
+    }
+  };
+  auto aux_commit = [&](int stage) { if (t < 128) lsd[stage * 128 + t] = aux_r; };
   qt_.load(rs, 0, a.ld, hc, t);
   dt_.load(rd, 0, a.ldo, hc, t);
+  aux_load(0);
   qt_.commit(smem, t, a.scale);
   dt_.commit(smem + NIMG * IMG, t);
+  aux_commit(0);
   __syncthreads();
 
   for (int it = 0; it < nt; ++it) {
     const char* qimg = smem + (it & 1) * STAGE;
     const char* dimg = qimg + NIMG * IMG;
+    const float* lq = lsd + (it & 1) * 128;
     if (it + 1 < nt) {
       qt_.load(rs, (it + 1) * TILE, a.ld, hc, t);
       dt_.load(rd, (it + 1) * TILE, a.ldo, hc, t);
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {                          // two 32-query sub-tiles
+#pragma unroll 1
+    for (int qb = 0; qb < 2; ++qb) {                          // two 32-query sub-tiles (not unrolled: interleaved, the two sub-tiles' values do not fit the register file)
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
@@ -443,23 +471,23 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) 
         s = mac<PREC>(qa, kf[ks], s);
         dp = mac<PREC>(da, vf[ks], dp);
       }
-      // rows = queries it*64 + 32 qb + rho(r, h); P = exp(S - lse), dS = P (dP - delta); queries beyond T contribute nothing
+      // rows = queries it*64 + 32 qb + rho(r, h); P = exp(S - lse), dS = P (dP - delta)
       unsigned keep = 0u;
-      if constexpr (DROP) keep = keepk[(long long)(2 * it + qb) * (32ll * a.TW)] >> (unsigned)(4 * h);
+      if constexpr (DROP) keep = __builtin_amdgcn_raw_buffer_load_b32(rkeep, keep_lane, (unsigned)((2 * it + qb) * 32 * a.TW * 4), 0) >> (unsigned)(4 * h);
+      if constexpr (DROP) {          // dP = (dO V^T) o D first, as a pass of its own (one live mask word; fused into the exponential pass below the kernel spilled 98 registers)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = ((keep >> ((r & 3) + 8 * (r >> 2))) & 1u) ? dp[r] * a.keep_scale : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int qq = it * TILE + 32 * qb + rho(r, h);
-        const bool ok = qq < T;
-        const float ls = ok ? lse[qq] : 0.f, de = ok ? dlt[qq] : 0.f;
-        const float p = ok ? __expf(s[r] - ls) : 0.f;
-        if constexpr (DROP) {                                  // ctx = (P o D) V: dV sees the thinned P (its 1/(1-p) at the end), dP = (dO V^T) o D
-          const bool kp = ((keep >> ((r & 3) + 8 * (r >> 2))) & 1u) != 0u;
-          s[r] = kp ? p : 0.f;
-          dp[r] = p * ((kp ? dp[r] * a.keep_scale : 0.f) - de);
-        } else {
-          s[r] = p;
-          dp[r] = p * (dp[r] - de);
-        }
+        const int ql = 32 * qb + rho(r, h);
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -lq[ql]));
+        dp[r] = p * (dp[r] - lq[64 + ql]);
+        s[r] = p;
+      }
+      if constexpr (DROP) {          // ctx = (P o D) V: dV sees the thinned P (its 1 / (1 - p) at the end)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = ((keep >> ((r & 3) + 8 * (r >> 2))) & 1u) ? s[r] : 0.f;
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
@@ -481,6 +509,8 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) 
       char* nq = smem + ((it + 1) & 1) * STAGE;
       qt_.commit(nq, t, a.scale);
       dt_.commit(nq + NIMG * IMG, t);
+      aux_load(it + 1);                                      // 128 L2-resident floats, requested here so that they hold no register across the products above
+      aux_commit((it + 1) & 1);
     }
     __syncthreads();
   }
@@ -523,7 +553,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dq_kernel(const Args a) {
   const rsrc_t rd = seq_rsrc(a.dctx + (long long)seq * T * a.ldo, (long long)T * a.ldo * 4);
   const int hc = head * D;
   const bool qok = q < T;
-  const float ls = qok ? a.lse[((long long)seq * a.H + head) * T + q] : 0.f;
+  const float ls2 = qok ? a.lse[((long long)seq * a.H + head) * T + q] * LOG2E : 0.f;       // a query beyond T has zero q and dO rows: its dS is zero whatever ls2 is
   const float de = qok ? a.delta[((long long)seq * a.H + head) * T + q] : 0.f;
   const unsigned* keepq = nullptr;
   if constexpr (DROP) keepq = a.keep_q + (((long long)seq * a.H + head) * T + min(q, T - 1)) * a.TW;
@@ -567,17 +597,20 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dq_kernel(const Args a) {
         s = mac<PREC>(ka, qf[ks], s);
         dp = mac<PREC>(va, of[ks], dp);
       }
+      const unsigned kw = kb == 0 ? keep2.x : keep2.y;
+#define A2F_DQ_ELEM(R)                                                                                              \
+      {                                                                                                           \
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[R], LOG2E, -ls2));                                          \
+        if constexpr (DROP) dp[R] = p * (keep_if<((R) & 3) + 8 * ((R) >> 2)>(dp[R] * a.keep_scale, kw) - de);     \
+        else dp[R] = p * (dp[R] - de);                                                                            \
+      }
+      A2F_DQ_ELEM(0) A2F_DQ_ELEM(1) A2F_DQ_ELEM(2) A2F_DQ_ELEM(3) A2F_DQ_ELEM(4) A2F_DQ_ELEM(5) A2F_DQ_ELEM(6) A2F_DQ_ELEM(7)
+      A2F_DQ_ELEM(8) A2F_DQ_ELEM(9) A2F_DQ_ELEM(10) A2F_DQ_ELEM(11) A2F_DQ_ELEM(12) A2F_DQ_ELEM(13) A2F_DQ_ELEM(14) A2F_DQ_ELEM(15)
+#undef A2F_DQ_ELEM
+      if ((it + 1) * TILE > T) {                               // ragged last tile (wave-uniform): keys beyond T do not exist
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool ok = qok && (it * TILE + 32 * kb + rho(r, h) < T);
-        const float p = ok ? __expf(s[r] - ls) : 0.f;
-        if constexpr (DROP) {
-          const unsigned kw = kb == 0 ? keep2.x : keep2.y;
-          const bool kp = ((kw >> ((r & 3) + 8 * (r >> 2))) & 1u) != 0u;
-          dp[r] = p * ((kp ? dp[r] * a.keep_scale : 0.f) - de);
-        } else {
-          dp[r] = p * (dp[r] - de);
-        }
+        for (int r = 0; r < 16; ++r)
+          if (it * TILE + 32 * kb + rho(r, h) >= T) dp[r] = 0.f;
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
@@ -692,9 +725,9 @@ static int attn_bwd_impl(const float* qkv, const float* ctx, const float* dctx, 
   const int lds = precision == 1 ? 2 * 4 * IMG : 2 * 2 * IMG;
 #define A2F_ATTN_BWD(P, D)                                                            \
   do {                                                                                \
-    if ((rc = set_lds(attn_bwd_dkv_kernel<P, D>, lds, dk[2 * P + D]))) return rc;     \
+    if ((rc = set_lds(attn_bwd_dkv_kernel<P, D>, lds + 1024, dk[2 * P + D]))) return rc;     \
     if ((rc = set_lds(attn_bwd_dq_kernel<P, D>, lds, dq[2 * P + D]))) return rc;      \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, D>), grid, dim3(THREADS), lds, st, a); \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, D>), grid, dim3(THREADS), lds + 1024, st, a); \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<P, D>), grid, dim3(THREADS), lds, st, a);  \
   } while (0)
   if (precision == 1) { if (keep_q) A2F_ATTN_BWD(1, true); else A2F_ATTN_BWD(1, false); }

@@ -42,6 +42,7 @@ constexpr int GR_QKV = 0, GR_SA = 192, GR_HP = 256, GR_F = 384, GR_EMB = 448, GR
 // blocked form of the backward (sequences of FF_BLK_MIN frames and more): the recurrence runs in blocks of FF_BLK steps, attention terms that cross a block
 // boundary are batched over the whole chip (ff_bwd_prep_kernel / ff_bwd_rect_kernel below).  FF_NREC floats per frame: Nt[h][a'][b], then n[h][b]
 constexpr int FF_BLK = 128, FF_BLK_MIN = FF_BLK + 1, FF_NREC = 4 * 272, NR_N = 1024;
+static_assert(FF_BLK == 2 * 16 * FB2_U, "a block of the backward is one sweep trip of a head's two waves (ff_decoder_bwd2_kernel, LACC)");
 #ifndef FA_U_SET
 #define FA_U_SET 1
 #endif
@@ -998,7 +999,8 @@ __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(con
       }
       const unsigned* abits = DROP ? dm.attn + ((s * FH + head) * T + i) * dm.TW : nullptr;
       constexpr int FB_U = FB2_U;                          // two waves per head: half the slots per trip, alternate trips
-      for (int j0 = i_lo + js + apart * 16 * FB_U; j0 <= i; j0 += 2 * 16 * FB_U) {
+      // LACC: a launch covers at most FF_BLK = 2 x 16 x FB_U keys, so the sweep is ONE trip (no loop-carried state for the compiler to keep)
+      for (int j0 = i_lo + js + apart * 16 * FB_U; j0 <= i; j0 += LACC ? (1 << 30) : 2 * 16 * FB_U) {
         float4 kk[FB_U], vv[FB_U], dk[FB_U], dv[FB_U];
         unsigned kw[FB_U];
 #pragma unroll

@@ -279,16 +279,23 @@ __global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
     if constexpr (DROP) keep = *reinterpret_cast<const u32x2_t*>(keepq + 2 * it) >> (unsigned)(4 * h);     // bit (r & 3) + 8 (r >> 2) <-> register r
     __builtin_amdgcn_sched_barrier(0);
     // ---- S^T = K Q^T: keys on the registers, this lane's query on the lane
+    // the K fragment of step n + 1 is requested before the three MFMAs of step n (left alone, the compiler waited for every ds_read_b128 right where it
+    // issued it: sixteen exposed LDS round trips per tile)
     f32x16 st[2];
+    {
+      u32x4_t kfr[2][2];
+      frag_rows<PREC>(kimg, 0, 0, lane, kfr[0]);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+      for (int n = 0; n < 8; ++n) {
+        const int kb = n >> 2, ks = n & 3;
+        if (n + 1 < 8) frag_rows<PREC>(kimg, 32 * ((n + 1) >> 2), (n + 1) & 3, lane, kfr[(n + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);                      // the reads above stay above the products below
+        if (ks == 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        u32x4_t kf[2];
-        frag_rows<PREC>(kimg, 32 * kb, ks, lane, kf);
-        st[kb] = mac<PREC>(kf, qf[ks], st[kb]);
+          for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+        }
+        st[kb] = mac<PREC>(kfr[n & 1], qf[ks], st[kb]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if ((it + 1) * TILE > T) {                                  // ragged last tile: keys beyond T do not exist
@@ -463,13 +470,21 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) 
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+      {                                                        // fragments of k-step ks + 1 requested before the six MFMAs of step ks (cf. the forward)
+        u32x4_t qa[2][2], da[2][2];
+        frag_rows<PREC>(qimg, 32 * qb, 0, lane, qa[0]);
+        frag_rows<PREC>(dimg, 32 * qb, 0, lane, da[0]);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        u32x4_t qa[2], da[2];
-        frag_rows<PREC>(qimg, 32 * qb, ks, lane, qa);
-        frag_rows<PREC>(dimg, 32 * qb, ks, lane, da);
-        s = mac<PREC>(qa, kf[ks], s);
-        dp = mac<PREC>(da, vf[ks], dp);
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks + 1 < 4) {
+            frag_rows<PREC>(qimg, 32 * qb, ks + 1, lane, qa[(ks + 1) & 1]);
+            frag_rows<PREC>(dimg, 32 * qb, ks + 1, lane, da[(ks + 1) & 1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          s = mac<PREC>(qa[ks & 1], kf[ks], s);
+          dp = mac<PREC>(da[ks & 1], vf[ks], dp);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       // rows = queries it*64 + 32 qb + rho(r, h); P = exp(S - lse), dS = P (dP - delta)
       unsigned keep = 0u;
@@ -589,13 +604,21 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dq_kernel(const Args a) {
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+      {
+        u32x4_t ka[2][2], va[2][2];
+        frag_rows<PREC>(kimg, 32 * kb, 0, lane, ka[0]);
+        frag_rows<PREC>(vimg, 32 * kb, 0, lane, va[0]);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        u32x4_t ka[2], va[2];
-        frag_rows<PREC>(kimg, 32 * kb, ks, lane, ka);
-        frag_rows<PREC>(vimg, 32 * kb, ks, lane, va);
-        s = mac<PREC>(ka, qf[ks], s);
-        dp = mac<PREC>(va, of[ks], dp);
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks + 1 < 4) {
+            frag_rows<PREC>(kimg, 32 * kb, ks + 1, lane, ka[(ks + 1) & 1]);
+            frag_rows<PREC>(vimg, 32 * kb, ks + 1, lane, va[(ks + 1) & 1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          s = mac<PREC>(ka[ks & 1], qf[ks], s);
+          dp = mac<PREC>(va[ks & 1], of[ks], dp);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       const unsigned kw = kb == 0 ? keep2.x : keep2.y;
 #define A2F_DQ_ELEM(R)                                                                                              \

@@ -111,8 +111,8 @@ SIGNATURES = {
     "a2f_layernorm_bwd_img": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, f32, c_f32p,
                                         C.c_void_p, sz, C.c_void_p]),
     "a2f_colsum_img": (C.c_int, [c_f32p, i64, i64, i64, c_f32p, C.c_void_p, sz, C.c_void_p]),
-    "a2f_attn_fwd_img": (C.c_int, [c_f32p, i64, i64, i64, i64, f32, i32, c_f32p, i64, c_f32p, c_f32p, f32, c_f32p, C.c_void_p]),
-    "a2f_attn_bwd_img": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, i64, i64, i64, f32, i32, c_f32p, c_f32p, c_f32p, c_f32p, f32, i32,
+    "a2f_attn_fwd_img": (C.c_int, [c_f32p, i32, i64, i64, i64, i64, f32, i32, c_f32p, i64, c_f32p, c_f32p, f32, c_f32p, C.c_void_p]),
+    "a2f_attn_bwd_img": (C.c_int, [c_f32p, c_f32p, c_f32p, i32, c_f32p, i64, i64, i64, i64, i64, f32, i32, c_f32p, c_f32p, c_f32p, c_f32p, f32, i32,
                                    C.c_void_p]),
     "a2f_layernorm_bwd_ws_bytes": (sz, [i64, i64]),
     "a2f_layernorm_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),

@@ -19,6 +19,7 @@
 // No atomics anywhere: every output element has exactly one owner (deterministic).
 #include "a2f_common.h"
 #include "img.h"
+#include <type_traits>
 
 namespace a2f {
 namespace attn {
@@ -48,6 +49,9 @@ struct Args {
   float* dqkv;           // (S*T, ld)
   char* out_ctx_img;     // optional: the context also as a split-32 image (S*T, ldo) - the operand format of the out-projection GEMM and of its weight gradient
   int dqkv_img;          // 1: dqkv is written as a split-32 image (its only readers are the q|k|v weight-gradient / data-gradient GEMMs)
+  int qkv_img;           // 1: qkv ARRIVES as a split-32 image (written by the q|k|v projection's GEMM epilogue): tiles and fragments are copied, nothing is converted,
+                         //    and q is not pre-scaled - the scale rides in the exponent's fused multiply-add (scale is a power of two for head_dim 64: exact)
+  int dctx_img;          // 1: dctx arrives as a split-32 image (written by the out-projection's data-gradient GEMM)
   int ld, ldo, koff, voff;
   int S, T, H;
   float scale;
@@ -162,6 +166,32 @@ struct Tile {
   }
 };
 
+// The same tile from a split-32 IMAGE (img.h: per 32 elements 32 bf16 hi then 32 bf16 lo): a head's 64 columns of a row are 256 bytes = 16 chunks of
+// 16 bytes = 8 bf16 each, chunk c: block c >> 3, lo part if (c >> 2) & 1, elements 32 (c >> 3) + 8 (c & 3) .. + 7.  A chunk IS a 16-byte piece of the
+// LDS image row (hi or lo image): thread t copies chunk t & 15 of rows (t >> 4) + 16 i - no conversion, no multiply.
+template <int PREC>
+struct TileImg {
+  u32x4_t reg[4];
+  __device__ __forceinline__ void load(rsrc_t rs, int row0, int ld, int col0, int t) {
+    const int c = t & 15;
+    if (PREC != 1 && ((c >> 2) & 1)) return;                   // single-term products never read the lo parts
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = row0 + (t >> 4) + 16 * i;
+      reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(row * ld + col0) * 4u + (unsigned)((c >> 3) * 128 + ((c >> 2) & 1) * 64 + (c & 3) * 16), 0, 0);
+    }
+  }
+  __device__ __forceinline__ void commit(char* img, int t) const {
+    const int c = t & 15;
+    if (PREC != 1 && ((c >> 2) & 1)) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (t >> 4) + 16 * i;
+      *reinterpret_cast<u32x4_t*>(img + img_off(row, 4 * (c >> 3) + (c & 3)) + (((c >> 2) & 1) ? IMG : 0)) = reg[i];
+    }
+  }
+};
+
 // MFMA operand along d (k = d): lane (r, h) <- row (rb + r), d = 16 ks + 8 h .. + 7
 template <int PREC>
 __device__ __forceinline__ void frag_rows(const char* img, int rb, int ks, int lane, u32x4_t (&f)[2]) {
@@ -235,10 +265,25 @@ __device__ __forceinline__ void reg_operand(rsrc_t rs, int row, int ld, int col0
   }
 }
 
+// the same from a split-32 image: d = 16 ks + 8 h .. + 7 is one 16-byte chunk of the hi part and one of the lo part
+template <int PREC>
+__device__ __forceinline__ void reg_operand_img(rsrc_t rs, int row, int ld, int col0, int lane, u32x4_t (&f)[4][2]) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int d0 = 16 * ks + 8 * h;
+    const unsigned off = (unsigned)(row * ld + col0) * 4u + (unsigned)((d0 >> 5) * 128 + ((d0 & 31) >> 3) * 16);
+    f[ks][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    if constexpr (PREC == 1) f[ks][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 64u, 0, 0);
+    if constexpr (PREC == 2) f[ks][0] = bf16x8_to_fp8(f[ks][0]);
+  }
+}
+
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
-template <int PREC, bool DROP>
+// QIMG: qkv arrives as a split-32 image (Args.qkv_img)
+template <int PREC, bool DROP, bool QIMG>
 __global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
   constexpr int NIMG = PREC == 1 ? 2 : 1;
   constexpr int STAGE = 2 * NIMG * IMG;                       // K images, V images
@@ -251,7 +296,9 @@ __global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
   const int hc = head * D;
 
   u32x4_t qf[4][2];
-  reg_operand<PREC>(rs, q, a.ld, hc, lane, a.scale, qf);
+  if constexpr (QIMG) reg_operand_img<PREC>(rs, q, a.ld, hc, lane, qf);
+  else reg_operand<PREC>(rs, q, a.ld, hc, lane, a.scale, qf);
+  const float sl2 = (QIMG ? a.scale : 1.f) * LOG2E;             // scores -> units of log2 (image operands are not pre-scaled)
 
   f32x16 o[2];
 #pragma unroll
@@ -261,22 +308,26 @@ __global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
   if constexpr (DROP) keepq = a.keep_q + (((long long)seq * a.H + head) * T + min(q, T - 1)) * a.TW;
 
   const int nt = (T + TILE - 1) / TILE;
-  Tile<PREC> kt_, vt_;
+  std::conditional_t<QIMG, TileImg<PREC>, Tile<PREC>> kt_, vt_;
   kt_.load(rs, 0, a.ld, a.koff + hc, t);
   vt_.load(rs, 0, a.ld, a.voff + hc, t);
   kt_.commit(smem, t);
   vt_.commit(smem + NIMG * IMG, t);
+  // the keep words of tile it + 1 are requested with that tile's rows, one iteration ahead: read where they are used they put an s_waitcnt vmcnt(0) in front
+  // of the softmax, which also waits for the K / V rows just requested - an exposed global round trip per tile in train mode
+  u32x2_t keep_nx = {0u, 0u};
+  if constexpr (DROP) keep_nx = *reinterpret_cast<const u32x2_t*>(keepq);
   __syncthreads();
 
   for (int it = 0; it < nt; ++it) {
     const char* kimg = smem + (it & 1) * STAGE;
     const char* vimg = kimg + NIMG * IMG;
+    const u32x2_t keep = keep_nx >> (unsigned)(4 * h);          // bit (r & 3) + 8 (r >> 2) <-> register r
     if (it + 1 < nt) {
       kt_.load(rs, (it + 1) * TILE, a.ld, a.koff + hc, t);
       vt_.load(rs, (it + 1) * TILE, a.ld, a.voff + hc, t);
+      if constexpr (DROP) keep_nx = *reinterpret_cast<const u32x2_t*>(keepq + 2 * (it + 1));
     }
-    u32x2_t keep = {0u, 0u};
-    if constexpr (DROP) keep = *reinterpret_cast<const u32x2_t*>(keepq + 2 * it) >> (unsigned)(4 * h);     // bit (r & 3) + 8 (r >> 2) <-> register r
     __builtin_amdgcn_sched_barrier(0);
     // ---- S^T = K Q^T: keys on the registers, this lane's query on the lane
     // the K fragment of step n + 1 is requested before the three MFMAs of step n (left alone, the compiler waited for every ds_read_b128 right where it
@@ -313,7 +364,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx * LOG2E);
+    const float mn = fmaxf(m, mx * sl2);
     const float alpha = __builtin_amdgcn_exp2f(m - mn);
     m = mn;
     float ps = 0.f;
@@ -321,7 +372,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_fwd_kernel(const Args a) {
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        st[kb][r] = __builtin_amdgcn_exp2f(fmaf(st[kb][r], LOG2E, -mn));
+        st[kb][r] = __builtin_amdgcn_exp2f(fmaf(st[kb][r], sl2, -mn));
         ps += st[kb][r];
       }
     l = l * alpha + ps;
@@ -387,7 +438,7 @@ __global__ __launch_bounds__(THREADS) void attn_delta_kernel(const Args a) {
   const int ncol = a.H * D;
   for (int c = 4 * lane; c < ncol; c += 256) {
     const f32x4 x = *reinterpret_cast<const f32x4*>(a.ctx + row * a.ldo + c);
-    const f32x4 y = *reinterpret_cast<const f32x4*>(a.dctx + row * a.ldo + c);
+    const f32x4 y = a.dctx_img ? img::load4(reinterpret_cast<const char*>(a.dctx) + row * a.ldo * 4, c) : *reinterpret_cast<const f32x4*>(a.dctx + row * a.ldo + c);
     float s = (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
     // 16 lanes share a head (64 columns = 16 float4)
     s += __shfl_xor(s, 1, 64);
@@ -403,7 +454,8 @@ __global__ __launch_bounds__(THREADS) void attn_delta_kernel(const Args a) {
 //   S[q][key] = Qs K^T (query on the registers, key on the lane);  P = exp(S - lse[q]);  dP = dO V^T;  dS = P (dP - delta[q])
 //   dV^T[d][key] += dO^T P;   dK^T[d][key] += Qs^T dS           (Qs = scale * Q, so dK needs no further factor)
 // =====================================================================================================================
-template <int PREC, bool DROP>
+// INIMG: qkv AND dctx arrive as split-32 images (Args.qkv_img, Args.dctx_img)
+template <int PREC, bool DROP, bool INIMG>
 __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) {
   constexpr int NIMG = PREC == 1 ? 2 : 1;
   constexpr int STAGE = 2 * NIMG * IMG;                       // Q images, dO images
@@ -420,38 +472,50 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) 
   // this lane's key: word (qw) at + qw * 32 TW, bit = query 32 qw + b.  Through a buffer resource of the (sequence, head) block: a 32-bit lane offset
   // instead of a 64-bit pointer per lane (the kernel sits at its 256 registers)
   rsrc_t rkeep = rs;
-  unsigned keep_lane = 0u;
+  unsigned keep_wg = 0u;
   if constexpr (DROP) {
     rkeep = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(reinterpret_cast<const unsigned*>(uniform_ptr(reinterpret_cast<const float*>(
                 a.keep_k + ((long long)seq * a.H + head) * a.TW * (32ll * a.TW))))), 0, a.TW * 32 * a.TW * 4, 0x00020000);
-    keep_lane = (unsigned)min(key, 32 * a.TW - 1) * 4u;
+    keep_wg = (unsigned)(blockIdx.x * 128) * 4u;                 // word (qw, key) at qw * 32 TW + key; keys beyond 32 TW are out of range of the resource: 0
   }
 
   u32x4_t kf[4][2], vf[4][2];
-  reg_operand<PREC>(rs, key, a.ld, a.koff + hc, lane, 1.f, kf);
-  reg_operand<PREC>(rs, key, a.ld, a.voff + hc, lane, 1.f, vf);
+  if constexpr (INIMG) {
+    reg_operand_img<PREC>(rs, key, a.ld, a.koff + hc, lane, kf);
+    reg_operand_img<PREC>(rs, key, a.ld, a.voff + hc, lane, vf);
+  } else {
+    reg_operand<PREC>(rs, key, a.ld, a.koff + hc, lane, 1.f, kf);
+    reg_operand<PREC>(rs, key, a.ld, a.voff + hc, lane, 1.f, vf);
+  }
+  const float sl2 = (INIMG ? a.scale : 1.f) * LOG2E;              // image Q tiles are not pre-scaled: the scale rides in the exponent, and on dK at the end
 
   f32x16 dk[2], dv[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) dk[0][r] = dk[1][r] = dv[0][r] = dv[1][r] = 0.f;
 
   const int nt = (T + TILE - 1) / TILE;
-  Tile<PREC> qt_, dt_;
+  std::conditional_t<INIMG, TileImg<PREC>, Tile<PREC>> qt_, dt_;
   // lse (in units of log2: times log2e) and delta of a tile's 64 queries travel with the tile through LDS ([stage][lse2 64 | delta 64]): read back as four
   // float4 per 32-query sub-tile instead of 64 scalar global loads per tile and wave.  A query beyond T gets lse2 = +inf: its probability is exp2(-inf) = 0.
   float* lsd = reinterpret_cast<float*>(smem + 2 * STAGE);
+  unsigned* kws = reinterpret_cast<unsigned*>(lsd + 256);       // train mode: [stage][sub-tile][key of the workgroup] keep words, the same way (one word per thread)
   float aux_r = 0.f;
+  unsigned aux_k = 0u;
   auto aux_load = [&](int tile) {
     if (t < 128) {
       const int qq = tile * TILE + (t & 63);
       aux_r = t < 64 ? (qq < T ? lse[qq] * LOG2E : INFINITY) : (qq < T ? dlt[qq] : 0.f);
     }
+    if constexpr (DROP) aux_k = __builtin_amdgcn_raw_buffer_load_b32(rkeep, keep_wg + (unsigned)(t & 127) * 4u, (unsigned)((2 * tile + (t >> 7)) * 32 * a.TW * 4), 0);
   };
-  auto aux_commit = [&](int stage) { if (t < 128) lsd[stage * 128 + t] = aux_r; };
+  auto aux_commit = [&](int stage) {
+    if (t < 128) lsd[stage * 128 + t] = aux_r;
+    if constexpr (DROP) kws[stage * 256 + t] = aux_k;
+  };
   qt_.load(rs, 0, a.ld, hc, t);
   dt_.load(rd, 0, a.ldo, hc, t);
   aux_load(0);
-  qt_.commit(smem, t, a.scale);
+  if constexpr (INIMG) qt_.commit(smem, t); else qt_.commit(smem, t, a.scale);
   dt_.commit(smem + NIMG * IMG, t);
   aux_commit(0);
   __syncthreads();
@@ -488,7 +552,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) 
       }
       // rows = queries it*64 + 32 qb + rho(r, h); P = exp(S - lse), dS = P (dP - delta)
       unsigned keep = 0u;
-      if constexpr (DROP) keep = __builtin_amdgcn_raw_buffer_load_b32(rkeep, keep_lane, (unsigned)((2 * it + qb) * 32 * a.TW * 4), 0) >> (unsigned)(4 * h);
+      if constexpr (DROP) keep = kws[(it & 1) * 256 + qb * 128 + wave * 32 + (lane & 31)] >> (unsigned)(4 * h);
       if constexpr (DROP) {          // dP = (dO V^T) o D first, as a pass of its own (one live mask word; fused into the exponential pass below the kernel spilled 98 registers)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dp[r] = ((keep >> ((r & 3) + 8 * (r >> 2))) & 1u) ? dp[r] * a.keep_scale : 0.f;
@@ -496,7 +560,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ql = 32 * qb + rho(r, h);
-        const float p = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -lq[ql]));
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lq[ql]));
         dp[r] = p * (dp[r] - lq[64 + ql]);
         s[r] = p;
       }
@@ -522,7 +586,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) 
     __builtin_amdgcn_sched_barrier(0);
     if (it + 1 < nt) {
       char* nq = smem + ((it + 1) & 1) * STAGE;
-      qt_.commit(nq, t, a.scale);
+      if constexpr (INIMG) qt_.commit(nq, t); else qt_.commit(nq, t, a.scale);
       dt_.commit(nq + NIMG * IMG, t);
       aux_load(it + 1);                                      // 128 L2-resident floats, requested here so that they hold no register across the products above
       aux_commit((it + 1) & 1);
@@ -535,7 +599,8 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) 
     for (int dd = 0; dd < 2; ++dd)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const f32x4 x = {dk[dd][4 * gq], dk[dd][4 * gq + 1], dk[dd][4 * gq + 2], dk[dd][4 * gq + 3]};
+        const float kscl = INIMG ? a.scale : 1.f;
+        const f32x4 x = {dk[dd][4 * gq] * kscl, dk[dd][4 * gq + 1] * kscl, dk[dd][4 * gq + 2] * kscl, dk[dd][4 * gq + 3] * kscl};
         const float vs = DROP ? a.keep_scale : 1.f;
         const f32x4 y = {dv[dd][4 * gq] * vs, dv[dd][4 * gq + 1] * vs, dv[dd][4 * gq + 2] * vs, dv[dd][4 * gq + 3] * vs};
         if (a.dqkv_img) {
@@ -555,7 +620,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dkv_kernel(const Args a) 
 //   S^T[key][q] = K Qs^T;  P^T = exp(S^T - lse[q]);  dP^T = V dO^T;  dS^T = P^T (dP^T - delta[q]);  dQ^T[d][q] += K^T dS^T
 //   dQ = scale * dQ^T^T
 // =====================================================================================================================
-template <int PREC, bool DROP>
+template <int PREC, bool DROP, bool INIMG>
 __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dq_kernel(const Args a) {
   constexpr int NIMG = PREC == 1 ? 2 : 1;
   constexpr int STAGE = 2 * NIMG * IMG;                       // K images, V images
@@ -574,30 +639,38 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dq_kernel(const Args a) {
   if constexpr (DROP) keepq = a.keep_q + (((long long)seq * a.H + head) * T + min(q, T - 1)) * a.TW;
 
   u32x4_t qf[4][2], of[4][2];
-  reg_operand<PREC>(rs, q, a.ld, hc, lane, a.scale, qf);
-  reg_operand<PREC>(rd, q, a.ldo, hc, lane, 1.f, of);
+  if constexpr (INIMG) {
+    reg_operand_img<PREC>(rs, q, a.ld, hc, lane, qf);
+    reg_operand_img<PREC>(rd, q, a.ldo, hc, lane, of);
+  } else {
+    reg_operand<PREC>(rs, q, a.ld, hc, lane, a.scale, qf);
+    reg_operand<PREC>(rd, q, a.ldo, hc, lane, 1.f, of);
+  }
+  const float sl2 = (INIMG ? a.scale : 1.f) * LOG2E;
 
   f32x16 dq[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) dq[0][r] = dq[1][r] = 0.f;
 
   const int nt = (T + TILE - 1) / TILE;
-  Tile<PREC> kt_, vt_;
+  std::conditional_t<INIMG, TileImg<PREC>, Tile<PREC>> kt_, vt_;
   kt_.load(rs, 0, a.ld, a.koff + hc, t);
   vt_.load(rs, 0, a.ld, a.voff + hc, t);
   kt_.commit(smem, t);
   vt_.commit(smem + NIMG * IMG, t);
+  u32x2_t keep_nx = {0u, 0u};                                   // keep words one tile ahead (cf. the forward)
+  if constexpr (DROP) keep_nx = *reinterpret_cast<const u32x2_t*>(keepq);
   __syncthreads();
 
   for (int it = 0; it < nt; ++it) {
     const char* kimg = smem + (it & 1) * STAGE;
     const char* vimg = kimg + NIMG * IMG;
+    const u32x2_t keep2 = keep_nx >> (unsigned)(4 * h);
     if (it + 1 < nt) {
       kt_.load(rs, (it + 1) * TILE, a.ld, a.koff + hc, t);
       vt_.load(rs, (it + 1) * TILE, a.ld, a.voff + hc, t);
+      if constexpr (DROP) keep_nx = *reinterpret_cast<const u32x2_t*>(keepq + 2 * (it + 1));
     }
-    u32x2_t keep2 = {0u, 0u};
-    if constexpr (DROP) keep2 = *reinterpret_cast<const u32x2_t*>(keepq + 2 * it) >> (unsigned)(4 * h);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -623,7 +696,7 @@ __global__ __launch_bounds__(THREADS, 2) void attn_bwd_dq_kernel(const Args a) {
       const unsigned kw = kb == 0 ? keep2.x : keep2.y;
 #define A2F_DQ_ELEM(R)                                                                                              \
       {                                                                                                           \
-        const float p = __builtin_amdgcn_exp2f(fmaf(s[R], LOG2E, -ls2));                                          \
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[R], sl2, -ls2));                                            \
         if constexpr (DROP) dp[R] = p * (keep_if<((R) & 3) + 8 * ((R) >> 2)>(dp[R] * a.keep_scale, kw) - de);     \
         else dp[R] = p * (dp[R] - de);                                                                            \
       }
@@ -692,7 +765,7 @@ static int check_common(const float* qkv, int64_t S, int64_t T, int64_t H, int64
 }  // namespace a2f
 
 static int attn_fwd_impl(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx, int64_t ldo,
-                         float* lse, const uint32_t* keep_q, float keep_scale, a2f_stream_t stream, void* ctx_img = nullptr) {
+                         float* lse, const uint32_t* keep_q, float keep_scale, a2f_stream_t stream, void* ctx_img = nullptr, int32_t qkv_format = 0) {
   using namespace a2f;
   using namespace a2f::attn;
   int rc = check_common(qkv, S, T, H, ld, ldo, precision);
@@ -702,17 +775,24 @@ static int attn_fwd_impl(const float* qkv, int64_t S, int64_t T, int64_t H, int6
   a.qkv = qkv; a.out_ctx = ctx; a.out_lse = lse;
   A2F_CHECK_ARG(ctx_img == nullptr || (ldo % 32 == 0 && ((uintptr_t)ctx_img & 127) == 0), "attn_fwd: an image output needs ldo %% 32 == 0 and a 128-byte aligned buffer");
   a.out_ctx_img = (char*)ctx_img;
+  A2F_CHECK_ARG(qkv_format == 0 || (qkv_format == 1 && ld % 32 == 0 && ((uintptr_t)qkv & 127) == 0), "attn_fwd: qkv_format %d (1 = image: ld %% 32 == 0, 128-byte aligned)", qkv_format);
+  a.qkv_img = qkv_format;
   a.ld = (int)ld; a.ldo = (int)ldo; a.koff = (int)(H * 64); a.voff = (int)(2 * H * 64);
   a.S = (int)S; a.T = (int)T; a.H = (int)H; a.scale = scale;
   a.keep_q = keep_q; a.TW = (int)a2f_attn_keep_words(T); a.keep_scale = keep_scale;
   const dim3 grid((unsigned)cdiv(T, 128), (unsigned)H, (unsigned)S);
   hipStream_t st = (hipStream_t)stream;
-  static bool done[6] = {false, false, false, false, false, false};
+  static bool done[2][6] = {{false, false, false, false, false, false}, {false, false, false, false, false, false}};
   const int lds = precision == 1 ? 2 * 4 * IMG : 2 * 2 * IMG;
-#define A2F_ATTN_FWD(P, D)                                                        \
-  do {                                                                            \
-    if ((rc = set_lds(attn_fwd_kernel<P, D>, lds, done[2 * P + D]))) return rc;   \
-    hipLaunchKernelGGL((attn_fwd_kernel<P, D>), grid, dim3(THREADS), lds, st, a); \
+#define A2F_ATTN_FWD(P, D)                                                                  \
+  do {                                                                                      \
+    if (a.qkv_img) {                                                                        \
+      if ((rc = set_lds(attn_fwd_kernel<P, D, true>, lds, done[1][2 * P + D]))) return rc;  \
+      hipLaunchKernelGGL((attn_fwd_kernel<P, D, true>), grid, dim3(THREADS), lds, st, a);   \
+    } else {                                                                                \
+      if ((rc = set_lds(attn_fwd_kernel<P, D, false>, lds, done[0][2 * P + D]))) return rc; \
+      hipLaunchKernelGGL((attn_fwd_kernel<P, D, false>), grid, dim3(THREADS), lds, st, a);  \
+    }                                                                                       \
   } while (0)
   if (precision == 1) { if (keep_q) A2F_ATTN_FWD(1, true); else A2F_ATTN_FWD(1, false); }
   else if (precision == 2) { if (keep_q) A2F_ATTN_FWD(2, true); else A2F_ATTN_FWD(2, false); }
@@ -724,7 +804,7 @@ static int attn_fwd_impl(const float* qkv, int64_t S, int64_t T, int64_t H, int6
 
 static int attn_bwd_impl(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
                          int64_t ldo, float scale, int32_t precision, float* dqkv, float* delta_ws, const uint32_t* keep_q, const uint32_t* keep_k,
-                         float keep_scale, a2f_stream_t stream, int32_t dqkv_format = 0) {
+                         float keep_scale, a2f_stream_t stream, int32_t dqkv_format = 0, int32_t in_format = 0) {
   using namespace a2f;
   using namespace a2f::attn;
   int rc = check_common(qkv, S, T, H, ld, ldo, precision);
@@ -739,22 +819,27 @@ static int attn_bwd_impl(const float* qkv, const float* ctx, const float* dctx, 
   a.S = (int)S; a.T = (int)T; a.H = (int)H; a.scale = scale;
   a.keep_q = keep_q; a.keep_k = keep_k; a.TW = (int)a2f_attn_keep_words(T); a.keep_scale = keep_scale;
   a.dqkv_img = dqkv_format;
+  A2F_CHECK_ARG(in_format == 0 || (in_format == 1 && ld % 32 == 0 && ldo % 32 == 0 && (((uintptr_t)qkv | (uintptr_t)dctx) & 127) == 0),
+                "attn_bwd: in_format %d (1 = qkv and dctx are images: ld, ldo %% 32 == 0, 128-byte aligned)", in_format);
+  a.qkv_img = a.dctx_img = in_format;
   if (precision == 2) precision = 0;          // fp8 is a forward mode: gradients would need dynamic scaling; the backward runs its bf16 kernels
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv(S * T, THREADS / 64)), dim3(THREADS), 0, st, a);
   A2F_CHECK_LAUNCH("attn_bwd delta");
   const dim3 grid((unsigned)cdiv(T, 128), (unsigned)H, (unsigned)S);
-  static bool dk[4] = {false, false, false, false}, dq[4] = {false, false, false, false};
+  static bool dk[2][4] = {{false, false, false, false}, {false, false, false, false}}, dq[2][4] = {{false, false, false, false}, {false, false, false, false}};
   const int lds = precision == 1 ? 2 * 4 * IMG : 2 * 2 * IMG;
-#define A2F_ATTN_BWD(P, D)                                                            \
-  do {                                                                                \
-    if ((rc = set_lds(attn_bwd_dkv_kernel<P, D>, lds + 1024, dk[2 * P + D]))) return rc;     \
-    if ((rc = set_lds(attn_bwd_dq_kernel<P, D>, lds, dq[2 * P + D]))) return rc;      \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, D>), grid, dim3(THREADS), lds + 1024, st, a); \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<P, D>), grid, dim3(THREADS), lds, st, a);  \
+#define A2F_ATTN_BWD_I(P, D, I)                                                                     \
+  do {                                                                                              \
+    if ((rc = set_lds(attn_bwd_dkv_kernel<P, D, I>, lds + 3072, dk[I][2 * P + D]))) return rc;      \
+    if ((rc = set_lds(attn_bwd_dq_kernel<P, D, I>, lds, dq[I][2 * P + D]))) return rc;              \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<P, D, I>), grid, dim3(THREADS), lds + 3072, st, a);     \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<P, D, I>), grid, dim3(THREADS), lds, st, a);             \
   } while (0)
+#define A2F_ATTN_BWD(P, D) do { if (a.qkv_img) A2F_ATTN_BWD_I(P, D, true); else A2F_ATTN_BWD_I(P, D, false); } while (0)
   if (precision == 1) { if (keep_q) A2F_ATTN_BWD(1, true); else A2F_ATTN_BWD(1, false); }
   else { if (keep_q) A2F_ATTN_BWD(0, true); else A2F_ATTN_BWD(0, false); }
+#undef A2F_ATTN_BWD_I
 #undef A2F_ATTN_BWD
   A2F_CHECK_LAUNCH("attn_bwd");
   return A2F_OK;
@@ -783,13 +868,14 @@ extern "C" int a2f_attn_bwd_drop(const float* qkv, const float* ctx, const float
   return attn_bwd_impl(qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, precision, dqkv, delta_ws, keep_qmajor, keep_kmajor, keep_scale, stream);
 }
 
-extern "C" int a2f_attn_fwd_img(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx, int64_t ldo,
-                                float* lse, const uint32_t* keep_qmajor, float keep_scale, void* ctx_img, a2f_stream_t stream) {
-  return attn_fwd_impl(qkv, S, T, H, ld, scale, precision, ctx, ldo, lse, keep_qmajor, keep_scale, stream, ctx_img);
+extern "C" int a2f_attn_fwd_img(const void* qkv, int32_t qkv_format, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx,
+                                int64_t ldo, float* lse, const uint32_t* keep_qmajor, float keep_scale, void* ctx_img, a2f_stream_t stream) {
+  return attn_fwd_impl((const float*)qkv, S, T, H, ld, scale, precision, ctx, ldo, lse, keep_qmajor, keep_scale, stream, ctx_img, qkv_format);
 }
 
-extern "C" int a2f_attn_bwd_img(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
-                                int64_t ldo, float scale, int32_t precision, void* dqkv, float* delta_ws, const uint32_t* keep_qmajor,
+extern "C" int a2f_attn_bwd_img(const void* qkv, const float* ctx, const void* dctx, int32_t in_format, const float* lse, int64_t S, int64_t T, int64_t H,
+                                int64_t ld, int64_t ldo, float scale, int32_t precision, void* dqkv, float* delta_ws, const uint32_t* keep_qmajor,
                                 const uint32_t* keep_kmajor, float keep_scale, int32_t dqkv_format, a2f_stream_t stream) {
-  return attn_bwd_impl(qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, precision, (float*)dqkv, delta_ws, keep_qmajor, keep_kmajor, keep_scale, stream, dqkv_format);
+  return attn_bwd_impl((const float*)qkv, ctx, (const float*)dctx, lse, S, T, H, ld, ldo, scale, precision, (float*)dqkv, delta_ws, keep_qmajor, keep_kmajor, keep_scale,
+                       stream, dqkv_format, in_format);
 }

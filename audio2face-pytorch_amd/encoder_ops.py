@@ -22,6 +22,7 @@ POSCONV_WGRAD_T = _os.environ.get("A2F_POSCONV_WGRAD_T", "1") != "0"   # A-B hoo
 
 
 MM_IMG = _os.environ.get("A2F_MM_IMG", "1") != "0"               # A-B hook: 0 = the Transformer layers' products on the fp32-operand kernels
+ATTN_IMG = _os.environ.get("A2F_ATTN_IMG", "1") != "0"            # A-B hook: 0 = the attention kernels read fp32 q|k|v / dctx and convert them tile by tile
 WIMG_CACHE = _os.environ.get("A2F_WIMG_CACHE", "1") != "0"        # A-B hook: 0 = every layer call re-splits its weights
 _WIMG_CACHE = {}
 WEIGHTS_EPOCH = 0            # bumped by whoever rewrites parameters behind torch's back (trainer.FlatAdam.step)
@@ -280,11 +281,14 @@ class EncoderLayerFn(torch.autograd.Function):
             x_img = _new(xc, M, d)
             be.split_img(xc, M, d, d, x_img, d)
         Wqkv, bqkv, Wqkv_i, Wqkv_t, Wo_i, Wo_t, W1_i, W1_t, W2_i, W2_t = EncoderLayerFn._layer_weight_images(be, Wq, Wk, Wv, bq, bk, bv, Wo, W1, W2)
+        # q|k|v exists only as the image the attention kernels copy their tiles and fragments from (their inner loops are bound by vector instructions: converting
+        # every K / V tile once per 128-query block was a fifth of them)
+        ctx.attn_img = ATTN_IMG
         qkv = _new(xc, M, 3 * d)
-        be.mm(I(x_img, d), I(Wqkv_i, d), qkv, M, 3 * d, d, 3 * d, bias=bqkv)
+        be.mm(I(x_img, d), I(Wqkv_i, d), qkv, M, 3 * d, d, 3 * d, bias=bqkv, c_img=ctx.attn_img)
         att, att_img, lse = _new(xc, M, d), _new(xc, M, d), _new(xc, S, heads, T)
         scale = float((d // heads) ** -0.5)
-        be.attn_fwd_img(qkv, S, T, heads, 3 * d, scale, att, d, lse, att_img, keep=(mk["attn"][0], mk["attn"][2]) if "attn" in mk else None)
+        be.attn_fwd_img(qkv, S, T, heads, 3 * d, scale, att, d, lse, att_img, keep=(mk["attn"][0], mk["attn"][2]) if "attn" in mk else None, qkv_img=ctx.attn_img)
         a1 = _new(xc, M, d)
         be.mm(I(att_img, d), I(Wo_i, d), a1, M, d, d, d, bias=bo, aux=xc, ldaux=d, aux_mode=MM_AUX_ADD, keep=mk.get("hid1"))
         h1, h1_img, m1, r1 = _new(xc, M, d), _new(xc, M, d), _new(xc, M), _new(xc, M)
@@ -332,10 +336,10 @@ class EncoderLayerFn(torch.autograd.Function):
         dWo = new(d, d)
         lane.run(lambda: be.mm(I(dy1_img, d, trans=True), I(att_img, d, trans=True), dWo, d, d, M, d, split_k=0))
         datt = new(M, d)
-        be.mm(I(dy1_img, d), I(Wo_t, d), datt, M, d, d, d)
+        be.mm(I(dy1_img, d), I(Wo_t, d), datt, M, d, d, d, c_img=ctx.attn_img)
         dqkv_img = new(M, 3 * d)
         be.attn_bwd_img(qkv, att, datt, lse, S, T, heads, 3 * d, d, scale, dqkv_img,
-                        keep=(mk["attn"][0], mk["attn"][1], mk["attn"][2]) if "attn" in mk else None)
+                        keep=(mk["attn"][0], mk["attn"][1], mk["attn"][2]) if "attn" in mk else None, inputs_img=ctx.attn_img)
         dbqkv, dWqkv = new(3 * d), new(3 * d, d)
         lane.run(lambda: (be.mm(I(dqkv_img, 3 * d, trans=True), I(x_img, d, trans=True), dWqkv, 3 * d, d, M, d, split_k=0),
                           be.colsum_img(dqkv_img, M, 3 * d, 3 * d, dbqkv)))

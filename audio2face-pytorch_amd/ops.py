@@ -311,20 +311,22 @@ class HipBackend:
                                               keep_k.data_ptr(), float(keep_scale), self._stream(qkv)), "a2f_attn_bwd_drop")
         self._prof_end("attn", ev)
 
-    def attn_fwd_img(self, qkv, S, T, H, ld, scale, ctx, ldo, lse, ctx_img, keep=None, precision=None):
-        """attention forward that also writes the context as a split-32 image; keep = (query-major bits, scale) or None."""
+    def attn_fwd_img(self, qkv, S, T, H, ld, scale, ctx, ldo, lse, ctx_img, keep=None, precision=None, qkv_img=False):
+        """attention forward that also writes the context as a split-32 image; keep = (query-major bits, scale) or None.
+        qkv_img: `qkv` holds the split-32 image the q|k|v projection wrote (nothing is converted in the kernel)."""
         _chk(qkv, ctx, lse, ctx_img)
         kq, ks = (None, 1.0)
         if keep is not None:
             _chk_bits(keep[0])
             kq, ks = keep[0].data_ptr(), float(keep[1])
         ev = self._prof_begin("attn")
-        _lib.check(self.lib.a2f_attn_fwd_img(_ptr(qkv), S, T, H, ld, scale, self._attn_prec(precision), _ptr(ctx), ldo, _ptr(lse), kq, ks,
+        _lib.check(self.lib.a2f_attn_fwd_img(_ptr(qkv), int(bool(qkv_img)), S, T, H, ld, scale, self._attn_prec(precision), _ptr(ctx), ldo, _ptr(lse), kq, ks,
                                              _ptr(ctx_img), self._stream(qkv)), "a2f_attn_fwd_img")
         self._prof_end("attn", ev)
 
-    def attn_bwd_img(self, qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, dqkv_img, keep=None, precision=None):
-        """attention backward whose dqkv is written as a split-32 image; keep = (query-major bits, key-major bits, scale) or None."""
+    def attn_bwd_img(self, qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, dqkv_img, keep=None, precision=None, inputs_img=False):
+        """attention backward whose dqkv is written as a split-32 image; keep = (query-major bits, key-major bits, scale) or None.
+        inputs_img: `qkv` and `dctx` hold split-32 images (ctx stays fp32)."""
         _chk(qkv, ctx, dctx, lse, dqkv_img)
         ws = torch.empty(S * H * T, dtype=torch.float32, device=qkv.device)
         kq, kk, ks = (None, None, 1.0)
@@ -332,7 +334,7 @@ class HipBackend:
             _chk_bits(keep[0], keep[1])
             kq, kk, ks = keep[0].data_ptr(), keep[1].data_ptr(), float(keep[2])
         ev = self._prof_begin("attn")
-        _lib.check(self.lib.a2f_attn_bwd_img(_ptr(qkv), _ptr(ctx), _ptr(dctx), _ptr(lse), S, T, H, ld, ldo, scale, self._attn_prec(precision),
+        _lib.check(self.lib.a2f_attn_bwd_img(_ptr(qkv), _ptr(ctx), _ptr(dctx), int(bool(inputs_img)), _ptr(lse), S, T, H, ld, ldo, scale, self._attn_prec(precision),
                                              _ptr(dqkv_img), _ptr(ws), kq, kk, ks, 1, self._stream(qkv)), "a2f_attn_bwd_img")
         self._prof_end("attn", ev)
 

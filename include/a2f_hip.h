@@ -458,11 +458,14 @@ int a2f_attn_fwd(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, 
 int a2f_attn_bwd(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
                  int64_t ldo, float scale, int32_t precision, float* dqkv, float* delta_ws, a2f_stream_t stream);
 /* Image forms (keep bits optional: NULL = no dropout): a2f_attn_fwd_img also writes the context as a split-32 image (ctx_img, (S*T, ldo), may be NULL);
- * a2f_attn_bwd_img with dqkv_format 1 writes dqkv as a split-32 image INSTEAD of fp32 (its readers are the image-operand GEMMs of the q|k|v projection). */
-int a2f_attn_fwd_img(const float* qkv, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx, int64_t ldo,
-                     float* lse, const uint32_t* keep_qmajor, float keep_scale, void* ctx_img, a2f_stream_t stream);
-int a2f_attn_bwd_img(const float* qkv, const float* ctx, const float* dctx, const float* lse, int64_t S, int64_t T, int64_t H, int64_t ld,
-                     int64_t ldo, float scale, int32_t precision, void* dqkv, float* delta_ws, const uint32_t* keep_qmajor,
+ * a2f_attn_bwd_img with dqkv_format 1 writes dqkv as a split-32 image INSTEAD of fp32 (its readers are the image-operand GEMMs of the q|k|v projection).
+ * qkv_format / in_format 1: the INPUTS arrive as split-32 images - qkv as the q|k|v projection's GEMM writes it (c_format 1), and (backward) dctx as the
+ * out-projection's data-gradient GEMM writes it; ctx stays fp32.  Tiles and MFMA fragments are then copied, not converted, and q is not pre-scaled
+ * (the scale multiplies the scores inside the exponent's fused multiply-add; exact for the power-of-two scale of head_dim 64). */
+int a2f_attn_fwd_img(const void* qkv, int32_t qkv_format, int64_t S, int64_t T, int64_t H, int64_t ld, float scale, int32_t precision, float* ctx,
+                     int64_t ldo, float* lse, const uint32_t* keep_qmajor, float keep_scale, void* ctx_img, a2f_stream_t stream);
+int a2f_attn_bwd_img(const void* qkv, const float* ctx, const void* dctx, int32_t in_format, const float* lse, int64_t S, int64_t T, int64_t H,
+                     int64_t ld, int64_t ldo, float scale, int32_t precision, void* dqkv, float* delta_ws, const uint32_t* keep_qmajor,
                      const uint32_t* keep_kmajor, float keep_scale, int32_t dqkv_format, a2f_stream_t stream);
 /* The same with dropout on the probabilities (HF eager attention: softmax -> nn.functional.dropout(p = attention_dropout) -> @ v):
  * ctx = (P o D) v with D = keep ? keep_scale : 0; lse is that of the un-thinned scores.  keep bits as a2f_keep_bits_attn lays them out. */

@@ -392,7 +392,9 @@ class EmuBackend:
             out[:, :, off:off + 64 * H] = t.grad.permute(0, 2, 1, 3).reshape(S, T, 64 * H).float()
 
     # ------------------------------------------------------------------ dropout keep masks (contract of csrc/dropout.hip)
-    def attn_fwd_img(self, qkv, S, T, H, ld, scale, ctx, ldo, lse, ctx_img, keep=None, precision=None):
+    def attn_fwd_img(self, qkv, S, T, H, ld, scale, ctx, ldo, lse, ctx_img, keep=None, precision=None, qkv_img=False):
+        if qkv_img:
+            qkv = img_decode(qkv.reshape(S * T, ld))
         if keep is None:
             self.attn_fwd(qkv, S, T, H, ld, scale, ctx, ldo, lse, precision)
         else:
@@ -400,7 +402,9 @@ class EmuBackend:
         if ctx_img is not None:
             ctx_img.reshape(S * T, ldo).copy_(img_encode(ctx.reshape(S * T, ldo)))
 
-    def attn_bwd_img(self, qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, dqkv_img, keep=None, precision=None):
+    def attn_bwd_img(self, qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, dqkv_img, keep=None, precision=None, inputs_img=False):
+        if inputs_img:
+            qkv, dctx = img_decode(qkv.reshape(S * T, ld)), img_decode(dctx.reshape(S * T, ldo))
         tmp = torch.zeros(S * T, ld)
         if keep is None:
             self.attn_bwd(qkv, ctx, dctx, lse, S, T, H, ld, ldo, scale, tmp, precision)

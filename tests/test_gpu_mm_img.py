@@ -269,3 +269,33 @@ def test_featenc0_image_output_is_the_split_of_the_fp32_output():
     be.featenc0_fwd(wave.to(DEV), S, N, w.to(DEV), g.to(DEV), b.to(DEV), C, 1e-5, oi, st, out_img=True)
     d = (img_decode(oi.cpu()) - o32.cpu().double()).abs()
     assert bool((d <= o32.cpu().double().abs() * 2.0 ** -16 + 1e-30).all())
+
+
+@pytest.mark.parametrize("T,drop", [(150, False), (150, True), (600, True), (70, True)])
+def test_attention_image_inputs_equal_fp32_inputs(T, drop):
+    """a2f_attn_fwd_img / a2f_attn_bwd_img with qkv_format / in_format 1 (q|k|v and dctx arrive as the split-32 images the projection GEMMs wrote: tiles and MFMA
+    fragments are copied, q is not pre-scaled) against the same kernels fed the fp32 tensors those images stand for: context, log-sum-exp and dqkv agree to the
+    rounding of the bf16x3 products (the operands are bit-identical hi / lo pairs; only where the scale 1/8 is applied differs, and it is a power of two)."""
+    from emu_backend import img_encode
+    S, H = 2, 12
+    ld, ldo = 3 * 64 * H, 64 * H
+    qkv, dctx = rnd(S * T, ld, seed=11, scale=0.5), rnd(S * T, ldo, seed=12)
+    qkv_i, dctx_i = img_encode(qkv), img_encode(dctx)
+    qkv_v, dctx_v = img_decode(qkv_i).float(), img_decode(dctx_i).float()          # what the images stand for (differs from qkv below 2^-16 relative)
+    be = ops.HipBackend()
+    keep_f = keep_b = None
+    if drop:
+        TW = be.attn_keep_words(T)
+        kq = torch.empty(S * H * T, TW, dtype=torch.int32, device=DEV)
+        kk = torch.empty(S * H, TW, 32 * TW, dtype=torch.int32, device=DEV)
+        be.keep_bits_attn(99, 3, S * H, T, 0.1, kq, kk)
+        keep_f, keep_b = (kq, 1.0 / 0.9), (kq, kk, 1.0 / 0.9)
+    out = {}
+    for tag, q_in, d_in, flag in (("fp32", qkv_v, dctx_v, False), ("img", qkv_i, dctx_i, True)):
+        ctx, ctx_i, lse = (torch.zeros(S * T, ldo, device=DEV), torch.zeros(S * T, ldo, device=DEV), torch.zeros(S, H, T, device=DEV))
+        be.attn_fwd_img(q_in.to(DEV), S, T, H, ld, 0.125, ctx, ldo, lse, ctx_i, keep=keep_f, qkv_img=flag)
+        dq_i = torch.zeros(S * T, ld, device=DEV)
+        be.attn_bwd_img(q_in.to(DEV), ctx, d_in.to(DEV), lse, S, T, H, ld, ldo, 0.125, dq_i, keep=keep_b, inputs_img=flag)
+        out[tag] = (ctx.cpu(), lse.cpu(), img_decode(dq_i.cpu()))
+    for a, b, name in zip(out["img"], out["fp32"], ("ctx", "lse", "dqkv")):
+        assert bool(torch.isfinite(a).all()) and rel_l2(a, b) < 2e-5, (name, rel_l2(a, b))

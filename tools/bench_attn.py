@@ -41,10 +41,15 @@ for S, T in ((32, 600), (6, 3000)):
     kk = torch.empty(S * H, TW, 32 * TW, dtype=torch.int32, device=dev)
     be.keep_bits_attn(1234, 7, S * H, T, 0.1, kq, kk)
     scale = 0.125
+    qkv_i, datt_i = torch.empty_like(qkv), torch.empty_like(datt)
+    be.split_img(qkv, M, 3 * d, 3 * d, qkv_i, 3 * d)
+    be.split_img(datt, M, d, d, datt_i, d)
     res = {"S": S, "T": T}
     for name, keep_f, keep_b in (("eval", None, None), ("train", (kq, 1.0 / 0.9), (kq, kk, 1.0 / 0.9))):
-        fwd = timeit(lambda: be.attn_fwd_img(qkv, S, T, H, 3 * d, scale, att, d, lse, att_img, keep=keep_f))
-        bwd = timeit(lambda: be.attn_bwd_img(qkv, att, datt, lse, S, T, H, 3 * d, d, scale, dqkv, keep=keep_b))
-        fl = 4.0 * T * T * 64 * S * H
-        res[name] = {"fwd_ms": round(fwd, 4), "bwd_ms": round(bwd, 4), "fwd_PF_executed": round(3 * fl / fwd / 1e12, 3), "bwd_PF_executed": round(3 * 2.5 * fl / bwd / 1e12, 3)}
+        for mode, q_in, d_in, flag in (("fp32 in", qkv, datt, False), ("img in", qkv_i, datt_i, True)):
+            fwd = timeit(lambda: be.attn_fwd_img(q_in, S, T, H, 3 * d, scale, att, d, lse, att_img, keep=keep_f, qkv_img=flag))
+            bwd = timeit(lambda: be.attn_bwd_img(q_in, att, d_in, lse, S, T, H, 3 * d, d, scale, dqkv, keep=keep_b, inputs_img=flag))
+            fl = 4.0 * T * T * 64 * S * H
+            res[f"{name}, {mode}"] = {"fwd_ms": round(fwd, 4), "bwd_ms": round(bwd, 4), "fwd_PF_executed": round(3 * fl / fwd / 1e12, 3),
+                                      "bwd_PF_executed": round(3 * 2.5 * fl / bwd / 1e12, 3)}
     print(json.dumps(res))

@@ -52,7 +52,8 @@ class _WeightGradLane:
     hygiene).  Inputs of fn must stay alive and unmodified until join()."""
 
     def __init__(self, ref: torch.Tensor):
-        self.on = WGRAD_STREAM and ref.is_cuda
+        # not under stream capture: a captured batch-1 step with the fork / join events of the lane in its graph replayed in 29.5 ms against 15.9 ms eager
+        self.on = WGRAD_STREAM and ref.is_cuda and not torch.cuda.is_current_stream_capturing()
         if self.on:
             self.cur = torch.cuda.current_stream(ref.device)
             key = (ref.device, self.cur.cuda_stream)

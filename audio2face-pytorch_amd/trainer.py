@@ -253,6 +253,7 @@ class TrainStep:
         # models that expose `grad_bucket_key(name)` (FaceFormer: 386 MB of gradients) exchange them bucket by bucket under the backward
         # (A2F_DP_BUCKETS=0: one blocking all-reduce after the backward, as round 2 did)
         self.buckets = None
+        self._mid_collect = False
         if (hasattr(model, "grad_bucket_key") and (self.opt.world() > 1 or self.opt.force_collectives)
                 and os.environ.get("A2F_DP_BUCKETS", "1") != "0"):
             self.buckets = BucketedAllReduce(self.opt, list(model.named_parameters()), model.grad_bucket_key)
@@ -392,8 +393,12 @@ class TrainStep:
         if self.fused and hasattr(self.model, "train_step_direct"):
             # autograd-free launch sequence that overwrites the flat gradient views (no zero fill, no accumulation kernels)
             return self._direct((x, one_hot, gt, template), 0)
-        # bucketed exchange: its hooks all-reduce ranges of the flat buffer while the backward runs, so the gradients must land there directly
-        stolen = self.buckets is None and os.environ.get("A2F_GRAD_STEAL", "1") != "0"       # A-B hook: 0 = zero-fill + accumulate
+        # bucketed exchange: its hooks all-reduce ranges of the flat buffer while the LAST backward pass runs, so that pass must accumulate there
+        # directly.  A pipelined step has an earlier pass: its gradients are still taken as autograd hands them out and moved into the flat buffer
+        # right before the last pass (_begin_exchange) - no zero fill and no accumulation kernel per parameter for the first half (215 launches)
+        self._mid_collect = self.buckets is not None and self._pipelined(x)
+        stolen = (self.buckets is None or self._mid_collect) and os.environ.get("A2F_GRAD_STEAL", "1") != "0"       # A-B hook: 0 = zero-fill + accumulate
+        self._mid_collect = self._mid_collect and stolen
         if stolen:
             self.opt.release_grads()
         else:
@@ -404,17 +409,30 @@ class TrainStep:
             if stolen:
                 self.opt.collect_grads()
 
+    def _pipelined(self, x) -> bool:
+        """FaceFormer with several sequences per step on a GPU: the step runs as two half-batches on two streams (Faceformer.train_step_pipelined)."""
+        if not (self.fused and hasattr(self.model, "forward_with_loss_batch") and hasattr(self.model, "train_step_pipelined")):
+            return False
+        if not (self.pipeline and x.is_cuda and x.dim() == 2 and x.shape[0] >= 2):
+            return False
+        frames = x.shape[1] * 60 // 16000
+        return frames >= self.pipeline_min_frames and x.shape[0] * frames >= self.pipeline_min_seqs * 600
+
+    def _begin_exchange(self):
+        """Right before the last backward pass of a pipelined step under the bucketed exchange."""
+        if self._mid_collect:
+            self.opt.collect_grads()           # the first half's gradients -> flat buffer; p.grad = the flat views the hooks reduce
+        self.buckets.begin()
+
     def _fwd_bwd_autograd(self, x, one_hot, gt, template) -> Dict[str, torch.Tensor]:
         if self.fused:
             lf = getattr(self.loss_fn, "loss", self.loss_fn)          # FaceFormerLoss wraps a VocaLoss
             if hasattr(self.model, "forward_with_loss_batch") and x.dim() == 2 and x.shape[0] > 1:
                 # S independent batch-1 FaceFormer problems per step (train.py:33 fixes batch = 1; SURVEY §8(d) C3)
-                frames = x.shape[1] * 60 // 16000
-                if (self.pipeline and x.is_cuda and x.shape[0] >= 2 and frames >= self.pipeline_min_frames
-                        and x.shape[0] * frames >= self.pipeline_min_seqs * 600 and hasattr(self.model, "train_step_pipelined")):
+                if self._pipelined(x):
                     # two half-batches on two streams: each half's decoder recurrence runs under the other half's encoder work
                     loss = self.model.train_step_pipelined(x, one_hot, template, gt, lf.k_rec, lf.k_vel,
-                                                           before_last_backward=self.buckets.begin if self.buckets is not None else None)
+                                                           before_last_backward=self._begin_exchange if self.buckets is not None else None)
                     loss["err"] = loss["rec_loss"] / 3.0
                     return loss
                 _pred, loss = self.model.forward_with_loss_batch(x, one_hot, template, gt, lf.k_rec, lf.k_vel)

@@ -1202,6 +1202,44 @@ def test_faceformer_full_size_pipelined_step_is_bitwise_reproducible(S, T):
     assert torch.equal(finals[0][0], finals[1][0])
 
 
+def test_faceformer_pipelined_step_under_the_bucketed_exchange_equals_the_plain_step(monkeypatch):
+    """The data-parallel form of the pipelined step on the one GPU of the box: the bucketed exchange forced on (A2F_DP_FORCE_COLLECTIVES: hooks, launch
+    order and the flat-buffer flow run; without a process group the all-reduce itself is skipped).  The first half's gradients are taken as autograd
+    hands them out and moved into the flat buffer right before the last backward pass, which accumulates in place where the hooks reduce
+    (trainer.TrainStep._begin_exchange).  Train mode with LayerDrop: parameters after two steps BITWISE equal to the step without the exchange, every
+    bucket launched once in descending order."""
+    import bench
+    from a2f_amd.trainer import TrainStep
+    S, T = 6, 90
+    audio, one_hot, gt, templ = bench.make_ff_batch(S, T, 0, torch.device(DEV))
+    finals = []
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("A2F_DP_FORCE_COLLECTIVES", "1")
+        torch.manual_seed(1234)
+        m = a2f_amd.Faceformer(n_verts=NV, n_onehot=12).to(DEV)
+        with torch.no_grad():
+            m.vertice_map_r.weight.normal_(0, 0.1); m.vertice_map.weight.normal_(0, 0.001)
+        m.train()
+        m.audio_encoder.config.layerdrop = 0.3                          # some layers receive no gradient in one half or in both
+        step = TrainStep(m, a2f_amd.FaceFormerLoss(), lr=1e-4)
+        assert (step.buckets is not None) == forced
+        step.pipeline_min_seqs, step.pipeline_min_frames = 0, 1         # the two-stream form at this small size
+        assert step._pipelined(audio)
+        torch.manual_seed(99)
+        for _ in range(2):
+            out = step(audio, one_hot, gt, templ)
+            if forced:
+                assert step._mid_collect
+                assert step.buckets.launch_log == list(range(len(step.buckets.bounds) - 1, -1, -1))
+        torch.cuda.synchronize()
+        finals.append((step.opt.flat_p.clone(), float(out["loss"].detach())))
+        step.close()
+        del step, m
+    assert finals[0][1] == finals[1][1]
+    assert torch.equal(finals[0][0], finals[1][0])
+
+
 def test_keep_bits_with_a_device_resident_seed_is_the_same_mask():
     """a2f_keep_bits_dev / a2f_keep_bits_attn_dev (seed read from device memory at run time: hipGraph-captured steps) against the by-value entry points."""
     be = ops.backend()

@@ -736,11 +736,12 @@ def test_faceformer_config5_T3000_encoder_vs_oracle():
     assert errs["bf16x3_gemms_fp8_attention"] > 1e-3
 
 
-@pytest.mark.parametrize("force_pipeline", [False, True])
+@pytest.mark.parametrize("force_pipeline", [True])
 def test_bench_self_launches_two_ranks(force_pipeline):
     """`python bench.py --gpus 2` with no torchrun environment (as the driver starts it): the script must launch the two
     ranks itself as a child torchrun before touching the GPU, relay ONE JSON line and exit 0.  Rehearsal mode on the one-GPU
-    box: both ranks share cuda:0, collectives over gloo."""
+    box: both ranks share cuda:0, collectives over gloo.  (Only the pipelined FaceFormer form runs here - 70 s per case; the single-pass
+    bucketed exchange is what tests/test_distributed_cpu.py runs at world 2 / 4 / 8.)"""
     import json
     import subprocess
     import sys

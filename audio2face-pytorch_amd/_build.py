@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "liba2f_hip.so")
 OBJ_DIR = os.path.join(PKG_DIR, "..", "build", "obj")
 SOURCES = ["capi.hip", "gemm.hip", "wgrad.hip", "voca_trunk.hip", "loss.hip", "pack.hip", "adam.hip", "bn.hip", "head_fused.hip",
-           "ff_decoder.hip", "interp.hip", "util.hip", "gemm_mfma.hip", "gemm_img.hip", "rowops.hip", "attention.hip", "featenc.hip", "dropout.hip"]
+           "ff_decoder.hip", "interp.hip", "util.hip", "gemm_mfma.hip", "gemm_img.hip", "rowops.hip", "attention.hip", "featenc.hip", "dropout.hip", "posconv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

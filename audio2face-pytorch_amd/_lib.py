@@ -106,6 +106,8 @@ SIGNATURES = {
     "a2f_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, f32, f32, f32, f32, f32, f32, i32, C.c_void_p]),
     "a2f_mm": (C.c_int, [C.POINTER(MMDesc), C.c_void_p]),
     "a2f_split_img": (C.c_int, [c_f32p, i64, i64, i64, i32, C.c_void_p, i64, C.c_void_p]),
+    "a2f_posconv_nt": (C.c_int, [c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, i64, i64, i64, i64, i32, C.c_void_p]),
+    "a2f_posconv_wgrad": (C.c_int, [c_f32p, c_f32p, c_f32p, i64, i64, i64, i64, i64, i64, C.c_void_p]),
     "a2f_layernorm_fwd": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, f32, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "a2f_layernorm_fwd_img": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, f32, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "a2f_layernorm_bwd_img": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, f32, c_f32p,

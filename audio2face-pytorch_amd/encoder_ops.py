@@ -19,6 +19,7 @@ import os as _os
 GELU_SAVED = _os.environ.get("A2F_GELU_SAVED", "1") != "0"       # A-B hook: 0 = pre-activation saved + streaming GELU' pass in the backward
 FUSED_QKV = _os.environ.get("A2F_FUSED_QKV", "1") != "0"         # A-B hook: 0 = three launches per projection group instead of one
 POSCONV_WGRAD_T = _os.environ.get("A2F_POSCONV_WGRAD_T", "1") != "0"   # A-B hook: 0 = positional-conv weight gradient with the 48 channels on the m axis
+POSCONV_KERNEL = _os.environ.get("A2F_POSCONV_KERNEL", "1") != "0"     # A-B hook: 0 = the positional convolution as batched windowed a2f_mm launches (rounds 2-4)
 
 
 MM_IMG = _os.environ.get("A2F_MM_IMG", "1") != "0"               # A-B hook: 0 = the Transformer layers' products on the fp32-operand kernels
@@ -737,6 +738,20 @@ class PosConvFn(torch.autograd.Function):
         Cg, K = wc.shape[1], wc.shape[2]
         G = groups
         pad = K // 2
+        if POSCONV_KERNEL and (G, Cg, K) == (16, 48, 128):
+            # the kernels of csrc/posconv.hip: the frame block of a group sits in LDS once for all 128 taps; no group-major copies
+            keep = any(ctx.needs_input_grad)
+            wimg = _new(hc, C, K * Cg)
+            be.split_img(wc.view(G, Cg, Cg, K).permute(0, 1, 3, 2).contiguous().view(C, K * Cg), C, K * Cg, K * Cg, wimg, K * Cg)     # [g*Cg+co][kk*Cg+ci]
+            z = _new(hc, S * T, C) if keep else None
+            y = _new(hc, S * T, C)
+            be.posconv_nt(hc, wimg, y, S, T, C, G, K, -pad, bias=bc, aux=hc, z=z, act=1)
+            if keep:
+                ctx.save_for_backward(hc, wc, z)
+                ctx.dims = (S, T, C, Cg, K, G)
+                ctx.own_kernel = True
+            return y.view(S, T, C)
+        ctx.own_kernel = False
         hg = hc.view(S, T, G, Cg).permute(2, 0, 1, 3).contiguous()                       # (G,S,T,Cg)
         wg = wc.view(G, Cg, Cg, K).permute(0, 1, 3, 2).contiguous().view(G, Cg, K * Cg)   # [g][co][kk*Cg+ci]
         keep = any(ctx.needs_input_grad)
@@ -762,6 +777,21 @@ class PosConvFn(torch.autograd.Function):
         be.gelu_bwd(dy, z, dz)
         db = _new(dy, C)
         be.colsum(dz, S * T, C, C, db)
+        if ctx.own_kernel:
+            hc = hg                                                               # saved as (S, T, C)
+            dwg = _new(dy, G, K, Cg, Cg)                                          # [g][kk][ci][co]
+            be.posconv_wgrad(hc, dz, dwg, S, T, C, G, K, pad)
+            dw = dwg.permute(0, 3, 2, 1).reshape(C, Cg, K)                        # -> (g*Cg + co, ci, kk)
+            dh = None
+            if ctx.needs_input_grad[0]:
+                # dh[s,t',g,ci] = sum_{kk',co} dz[s, t'-(K/2-1)+kk', g, co] * w[g*Cg+co, ci, K-1-kk']  (+ the residual branch)
+                wd = wc.view(G, Cg, Cg, K).flip(-1).permute(0, 2, 3, 1).contiguous().view(C, K * Cg)       # [g*Cg+ci][kk'*Cg+co]
+                wdimg = _new(dy, C, K * Cg)
+                be.split_img(wd, C, K * Cg, K * Cg, wdimg, K * Cg)
+                dh = _new(dy, S * T, C)
+                be.posconv_nt(dz, wdimg, dh, S, T, C, G, K, -(pad - 1), aux=dy)
+                dh = dh.view(S, T, C)
+            return dh, dw, db, None
         # weight gradient: dwg[g][co][kk*Cg+ci] = sum_rows dz[row, g*Cg+co] * window(hg[g])[row, kk*Cg+ci]
         # computed TRANSPOSED, (K*Cg) x Cg per group: with the 48 output channels on the n axis the 128 x 64 tile wastes a quarter of its
         # MFMAs; with them on the m axis (48 of a 128- or 256-row tile) 60-80 % were wasted (this product was 6.5 ms of the 64 x 600 step)

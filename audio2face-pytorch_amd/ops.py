@@ -97,6 +97,17 @@ class HipBackend:
             ev[1].record()
             self.prof.setdefault(tag, []).append(ev)
 
+    def _prof_flops(self, tag, ev, flops, key):
+        """End a profiled launch (see _prof_begin) and book its flops under `tag` / its shape key (bench.py's gemm_family and per-shape tables)."""
+        self._prof_end(tag, ev)
+        if self.prof is not None and tag is not None:
+            pf = getattr(self, "prof_flops", None)
+            if pf is not None:
+                pf[tag] = pf.get(tag, 0.0) + flops
+            ps = getattr(self, "prof_shapes", None)
+            if ps is not None and ev is not None:
+                ps.setdefault(key, {"events": [], "flops": flops})["events"].append(ev)
+
     # ---- a2f_gemm_f32 -------------------------------------------------------------------------
     def gemm(self, A, B, Cout, M, N, K, a: Tuple[int, int, int], b: Tuple[int, int, int], ldc, *, c_off=0, bias=None,
              act=ACT_NONE, aux=None, aux_off=0, ldaux=0, aux_mode=AUX_NONE, accumulate=False, split_k=1, ones_out=None,
@@ -208,6 +219,22 @@ class HipBackend:
         """fp32 rows -> split-32 image (a2f_split_img); transpose: the image of x^T."""
         _chk(x, out)
         _lib.check(self.lib.a2f_split_img(_ptr(x), R, Cc, ld, int(transpose), _ptr(out), ldo, self._stream(x)), "a2f_split_img")
+
+    # ---- grouped positional convolution (csrc/posconv.hip) ----------------------------------------
+    def posconv_nt(self, x, w_img, y, S, T, Cc, groups, taps, off, *, bias=None, aux=None, z=None, act=0, tag="gemm_mfma"):
+        """y = [aux +] act(bias + grouped window product of x (S,T,C) with the weight image w_img (C, taps*C/groups)) (a2f_posconv_nt)."""
+        _chk(x, w_img, y, bias, aux, z)
+        ev = self._prof_begin(tag)
+        _lib.check(self.lib.a2f_posconv_nt(_ptr(x), _ptr(w_img), _ptr(bias) if bias is not None else None, _ptr(aux) if aux is not None else None, _ptr(y),
+                                           _ptr(z) if z is not None else None, S, T, Cc, groups, taps, off, int(act), self._stream(x)), "a2f_posconv_nt")
+        self._prof_flops(tag, ev, 2.0 * S * T * Cc * taps * (Cc // groups), ("NT", S * T, Cc // groups, taps * (Cc // groups), groups, True, 1, False))
+
+    def posconv_wgrad(self, x, dz, dw, S, T, Cc, groups, taps, pad, tag="gemm_mfma"):
+        """dw (G, taps, C/G, C/G) [g][tap][ci][co] = sum over frames of x windows x dz (a2f_posconv_wgrad)."""
+        _chk(x, dz, dw)
+        ev = self._prof_begin(tag)
+        _lib.check(self.lib.a2f_posconv_wgrad(_ptr(x), _ptr(dz), _ptr(dw), S, T, Cc, groups, taps, pad, self._stream(x)), "a2f_posconv_wgrad")
+        self._prof_flops(tag, ev, 2.0 * S * T * Cc * taps * (Cc // groups), ("TN", taps * (Cc // groups), Cc // groups, S * T, groups, True, 1, False))
 
     # ---- row-wise encoder kernels (csrc/rowops.hip) ----------------------------------------------
     def layernorm_fwd(self, x, R, Cc, gamma, beta, eps, y, mean, rstd):

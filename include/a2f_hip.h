@@ -384,6 +384,19 @@ int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream);
  * A streaming pass for operands no producer emits as images (weights once per step; activations in tests).  C % 4 == 0, ld % 4 == 0. */
 int a2f_split_img(const float* x, int64_t R, int64_t C, int64_t ld, int32_t transpose, void* out, int64_t ldo, a2f_stream_t stream);
 
+/* The grouped positional convolution of the wav2vec2 encoder as kernels of its own (csrc/posconv.hip; replaces what HF's
+ * Wav2Vec2PositionalConvEmbedding - nn.Conv1d(768, 768, kernel_size 128, padding 64, groups 16) behind /root/reference/src/model/wav2vec.py:91-189 -
+ * hands to MIOpen).  Activations are channels-last fp32 (S, T, C), C = groups * 48, groups = 16, taps = 128 (anything else: A2F_EINVAL); bf16x3 products.
+ *   a2f_posconv_nt:    y[s,t,g*48+co] = [aux +] act(bias + sum_{kk<taps, ci<48} x[s, t+off+kk, g*48+ci] * W[g*48+co][kk*48+ci]), frames outside [0, T) read as zero.
+ *                      w_img = the split-32 image (a2f_split_img) of W as a (C, taps*48) matrix.  act: 0 none, 1 exact GELU; z (optional) receives the
+ *                      pre-activation (bias added).  Forward: off = -taps/2, bias, act 1, aux = x.  Data gradient: x = dz, W = flipped / transposed weights
+ *                      [g*48+ci][kk'*48+co] = w[g*48+co][ci][taps-1-kk'], off = -(taps/2 - 1), aux = dy.
+ *   a2f_posconv_wgrad: dw[g][kk][ci][co] = sum_{s,t} x[s, t-pad+kk, g*48+ci] * dz[s, t, g*48+co]   (G, taps, 48, 48), one pass, fixed summation order. */
+int a2f_posconv_nt(const float* x, const void* w_img, const float* bias, const float* aux, float* y, float* z, int64_t S, int64_t T, int64_t C,
+                   int64_t groups, int64_t taps, int64_t off, int32_t act, a2f_stream_t stream);
+int a2f_posconv_wgrad(const float* x, const float* dz, float* dw, int64_t S, int64_t T, int64_t C, int64_t groups, int64_t taps, int64_t pad,
+                      a2f_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Row-wise kernels of the wav2vec2 encoder path (csrc/rowops.hip; HF Wav2Vec2Model as wrapped by
  * /root/reference/src/model/wav2vec.py:91-189: nn.LayerNorm of feature projection / encoder / the 12 post-norm layers,

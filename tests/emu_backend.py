@@ -315,6 +315,39 @@ class EmuBackend:
             F.interpolate(z.transpose(1, 2), size=L_out, align_corners=True, mode="linear").transpose(1, 2).backward(x.reshape(N, L_out, C_).double())
         y.copy_(z.grad.float())
 
+    def posconv_nt(self, x, w_img, y, S, T, Cc, groups, taps, off, *, bias=None, aux=None, z=None, act=0, tag=None):
+        """a2f_posconv_nt in float64: grouped window product with the decoded weight image (C, taps * C/groups), [g*Cg+co][kk*Cg+ci]."""
+        self.calls.append(("posconv_nt", S, T, off))
+        Cg = Cc // groups
+        W = img_decode(w_img.reshape(Cc, taps * Cg)).double().view(groups, Cg, taps, Cg)                  # [g][co][kk][ci]
+        xd = x.reshape(S, T, groups, Cg).double()
+        xp = torch.zeros(S, T + 2 * taps, groups, Cg, dtype=torch.float64)
+        xp[:, taps:taps + T] = xd
+        v = torch.zeros(S, T, groups, Cg, dtype=torch.float64)
+        for kk in range(taps):
+            v += torch.einsum("stgi,goi->stgo", xp[:, taps + off + kk: taps + off + kk + T], W[:, :, kk, :])
+        v = v.reshape(S, T, Cc)
+        if bias is not None:
+            v = v + bias.double().view(1, 1, Cc)
+        if z is not None:
+            z.copy_(v.float().view_as(z))
+        if act:
+            v = 0.5 * v * (1 + torch.erf(v / math.sqrt(2.0)))
+        if aux is not None:
+            v = v + aux.reshape(S, T, Cc).double()
+        y.copy_(v.float().view_as(y))
+
+    def posconv_wgrad(self, x, dz, dw, S, T, Cc, groups, taps, pad, tag=None):
+        self.calls.append(("posconv_wgrad", S, T, pad))
+        Cg = Cc // groups
+        xp = torch.zeros(S, T + 2 * taps, groups, Cg, dtype=torch.float64)
+        xp[:, taps:taps + T] = x.reshape(S, T, groups, Cg).double()
+        dzd = dz.reshape(S, T, groups, Cg).double()
+        out = torch.zeros(groups, taps, Cg, Cg, dtype=torch.float64)
+        for kk in range(taps):
+            out[:, kk] = torch.einsum("stgi,stgo->gio", xp[:, taps - pad + kk: taps - pad + kk + T], dzd)
+        dw.copy_(out.float().view_as(dw))
+
     def gelu_bwd(self, dy, z, out):
         zd = z.double()
         g = 0.5 * (1 + torch.erf(zd / math.sqrt(2.0))) + zd * torch.exp(-0.5 * zd * zd) / math.sqrt(2 * math.pi)

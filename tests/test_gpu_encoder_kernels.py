@@ -205,3 +205,40 @@ def test_attention_fp8_forward_mode(S, T, H):
     assert torch.equal(dq2, dq0)
 
 
+
+
+@pytest.mark.parametrize("S,T", [(2, 17), (3, 50), (1, 600), (2, 700), (1, 385)])
+def test_positional_convolution_kernels_against_torch_conv1d_float64(S, T):
+    """csrc/posconv.hip through encoder_ops.PosConvFn (forward, data gradient, weight gradient, bias gradient) against torch's own grouped conv1d in float64
+    (HF Wav2Vec2PositionalConvEmbedding: Conv1d(768, 768, 128, padding 64, groups 16), last frame dropped, GELU, + input): one block per sequence, two blocks
+    (T = 700, 385: the block edge inside a sequence), sequences shorter than the kernel; and the kernels alone against the float64 emulator of their contract."""
+    import torch.nn.functional as F
+    from a2f_amd import encoder_ops
+    assert encoder_ops.POSCONV_KERNEL
+    C, G, K = 768, 16, 128
+    h = rnd(S, T, C, seed=1)
+    w = rnd(C, C // G, K, seed=2, scale=0.02)
+    b = rnd(C, seed=3, scale=0.1)
+    dy = rnd(S, T, C, seed=4)
+    hd, wd, bd = (t.double().requires_grad_(True) for t in (h, w, b))
+    ref = hd + F.gelu(F.conv1d(hd.transpose(1, 2), wd, bd, padding=K // 2, groups=G)[:, :, :-1].transpose(1, 2))
+    ref.backward(dy.double())
+    hg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (h, w, b))
+    out = encoder_ops.PosConvFn.apply(hg, wg, bg, G)
+    out.backward(dy.to(DEV))
+    assert rel_l2(out.detach().cpu(), ref.detach()) < 2e-5
+    for name, got, want in (("dh", hg.grad, hd.grad), ("dw", wg.grad, wd.grad), ("db", bg.grad, bd.grad)):
+        assert rel_l2(got.cpu(), want) < 3e-5, name
+    # the two entry points against the emulator (other offsets / epilogues than PosConvFn uses)
+    hip, emu = ops.HipBackend(), EmuBackend()
+    w2 = w.view(G, C // G, C // G, K).permute(0, 1, 3, 2).contiguous().view(C, K * (C // G))
+    res = []
+    for be, dev in ((hip, DEV), (emu, "cpu")):
+        wi = torch.empty(C, K * (C // G), device=dev)
+        be.split_img(w2.to(dev), C, K * (C // G), K * (C // G), wi, K * (C // G))
+        y, z, dw = torch.zeros(S, T, C, device=dev), torch.zeros(S, T, C, device=dev), torch.zeros(G, K, C // G, C // G, device=dev)
+        be.posconv_nt(h.to(dev), wi, y, S, T, C, G, K, -5, z=z, act=0)
+        be.posconv_wgrad(h.to(dev), dy.to(dev), dw, S, T, C, G, K, 3)
+        res.append((y.cpu(), z.cpu(), dw.cpu()))
+    for g_, r_, name in zip(res[0], res[1], ("y", "z", "dw")):
+        assert rel_l2(g_, r_) < 2e-5, name

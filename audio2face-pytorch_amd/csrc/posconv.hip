@@ -372,15 +372,21 @@ extern "C" int a2f_posconv_nt(const float* x, const void* w_img, const float* bi
                 (long long)C, (long long)groups, (long long)taps);
   A2F_CHECK_ARG((((uintptr_t)x | (uintptr_t)w_img | (uintptr_t)y | (uintptr_t)z | (uintptr_t)bias | (uintptr_t)aux) & 15) == 0, "a2f_posconv_nt: 16-byte aligned buffers");
   A2F_CHECK_ARG(off <= 0 && off > -TAPS && S * T * C < (1ll << 40), "a2f_posconv_nt: window offset in (-128, 0]");
-  const int nblk = (int)cdiv(T, MAXBT);
+  // blocks per sequence: as few as fit the LDS (the 127-frame halo is re-staged per block), but at least enough workgroups for the chip when there are few
+  // sequences (the reference's batch-1 step: 16 workgroups per block), down to 64-frame blocks
+  int64_t nblk = cdiv(T, MAXBT);
+  const int64_t want = cdiv(256, S * groups);
+  if (want > nblk) nblk = want < cdiv(T, 64) ? want : cdiv(T, 64);
+  if (nblk < cdiv(T, MAXBT)) nblk = cdiv(T, MAXBT);
   const int BT = (int)cdiv(cdiv(T, nblk), 16) * 16;
+  nblk = cdiv(T, BT);                                         // rounding the block up to whole 16-frame tiles may have made the last block empty
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(posconv_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS) != hipSuccess)
       return set_err(A2F_ELAUNCH, "a2f_posconv_nt: cannot reserve %d bytes of LDS", NT_LDS);
     attr_done = true;
   }
-  NtArgs a{x, (const char*)w_img, bias, aux, y, z, (int)S, (int)T, (int)C, (int)groups, (int)off, BT, nblk, act};
+  NtArgs a{x, (const char*)w_img, bias, aux, y, z, (int)S, (int)T, (int)C, (int)groups, (int)off, BT, (int)nblk, act};
   hipLaunchKernelGGL(posconv_nt_kernel, dim3((unsigned)(S * nblk * groups)), dim3(TH), NT_LDS, (hipStream_t)stream, a);
   A2F_CHECK_LAUNCH("a2f_posconv_nt");
   return A2F_OK;

@@ -11,9 +11,10 @@
 //                        image ([g][48 rows][6144]), 32-deep k-tiles of 6 KB by LDS-DMA; a k-tile is 32 consecutive k of a row = channels of one tap or the tails
 //                        of two (8 consecutive k never straddle a tap: every lane group addresses its own frame).  8 waves = 4 (frame tiles) x 2 (even / odd
 //                        k-tiles, ping-pong one barrier apart: one group's fragment reads under the other's MFMAs), summed through LDS at the end.
-//   posconv_wgrad_kernel dW[g][kk][ci][co] = sum_{s, t} x[s, t - 64 + kk, g, ci] * dz[s, t, g, co].  Workgroup = (group, 8 taps), wave = one tap: a 48 x 48
-//                        accumulator (9 tiles) over ALL frames - no split-K slabs, fixed order; per 160-frame block the dz rows and the x rows the eight taps
-//                        need sit in LDS (double-buffered), both operands by transposing reads (ds_read_b64_tr_b16).
+//   posconv_wgrad_kernel dW[g][kk][ci][co] = sum_{s, t} x[s, t - 64 + kk, g, ci] * dz[s, t, g, co].  Workgroup = (group, 8 taps) over ALL frames - no split-K slabs,
+//                        fixed order.  8 waves = 4 (tap pairs: the dz fragments of a k-tile serve both taps) x 2 (even / odd k-tiles of a block), two 48 x 48
+//                        accumulators (18 tiles) per wave, the k-parity halves summed through LDS at the end; per 128-frame block the dz rows and the x rows
+//                        the eight taps need sit in LDS (double-buffered), both operands by transposing reads (ds_read_b64_tr_b16).
 #include "a2f_common.h"
 #include "gemm_mfma.h"
 #include "img.h"
@@ -235,15 +236,16 @@ __global__ __launch_bounds__(TH, 2) void posconv_nt_kernel(const NtArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int WG_BK = 160;                                    // frames per staged block: 5 k-tiles
-constexpr int WG_TAPS = 8;                                    // taps per workgroup = waves
-constexpr int WG_DZ = WG_BK * PITCH;                          // 33 280 B
-constexpr int WG_X = (WG_BK + WG_TAPS - 1 + 1) * PITCH;       // 168 rows (one spare): 34 944 B
+constexpr int WG_BK = 128;                                    // frames per staged block: 4 k-tiles, two per k-parity wave group
+constexpr int WG_TAPS = 8;                                    // taps per workgroup: four wave columns x two taps
+constexpr int WG_DZ = WG_BK * PITCH;                          // 26 624 B
+constexpr int WG_X = (WG_BK + WG_TAPS) * PITCH;               // 136 rows (135 used): 28 288 B
 constexpr int WG_STAGE = WG_DZ + WG_X;
 constexpr int WG_LDS = 2 * WG_STAGE;
-static_assert(WG_LDS <= 160 * 1024 && WG_BK % 32 == 0, "LDS / k-tiles");
+static_assert(WG_LDS <= 160 * 1024 && WG_BK % 64 == 0, "LDS / k-tiles");
 constexpr int WG_NDZ = WG_BK * 12, WG_NX = (WG_BK + WG_TAPS - 1) * 12;          // float4s per block
-constexpr int WG_PER = (WG_NDZ + WG_NX + TH - 1) / TH;                           // 8 per thread
+constexpr int WG_PER = (WG_NDZ + WG_NX + TH - 1) / TH;                           // 7 per thread
+static_assert(4 * 72 * 64 * 4 <= WG_LDS, "the k-parity reduction reuses the stages");
 
 struct WgArgs {
   const float* x;        // (S, T, C)
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(TH, 2) void posconv_wgrad_kernel(const WgArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wp = wave & 3, wk = wave >> 2;                     // tap pair of the slice; k-tile parity inside a block
   const int bid = blockIdx.x;                                  // 16 groups x 16 tap slices; a group's slices on one XCD pair share its x / dz rows in L2
   const int g = (bid & 7) * 2 + ((bid >> 3) & 1);
   const int slice = bid >> 4;
@@ -303,11 +306,13 @@ __global__ __launch_bounds__(TH, 2) void posconv_wgrad_kernel(const WgArgs a) {
   // transposing fragment: lane (q = lane >> 4, i = lane & 15) -> k-rows 8 q + (i >> 2) and + 4, columns 4 (i & 3) .. + 3 of a 16-column tile
   const int q = lane >> 4, li = lane & 15;
   const int frag0 = (8 * q + (li >> 2)) * PITCH + 8 * (li & 3);
-  f32x4v acc[3][3];
+  f32x4v acc[2][3][3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[tp][i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
   auto frag = [](const char* p) {
     const u32x2_t r0 = tr_read(p), r1 = tr_read(p + 4 * PITCH);
     return u32x4_t{r0.x, r0.y, r1.x, r1.y};
@@ -321,42 +326,65 @@ __global__ __launch_bounds__(TH, 2) void posconv_wgrad_kernel(const WgArgs a) {
     const int st = it & 1;
     if (it + 1 < nit) fetch(it + 1);                          // the next block's rows are on their way while this one is multiplied
     const char* dzb = smem + st * WG_STAGE + frag0;
-    const char* xbk = smem + st * WG_STAGE + WG_DZ + wave * PITCH + frag0;        // this wave's tap: x row of frame r is row r + wave
+    const char* xbk = smem + st * WG_STAGE + WG_DZ + 2 * wp * PITCH + frag0;      // tap 2 wp (+ 1): x row of frame r is row r + tap
 #pragma unroll
-    for (int kt = 0; kt < WG_BK / 32; ++kt) {
-      u32x4_t fz[2][3], fx[2][3];
+    for (int kk = 0; kk < WG_BK / 64; ++kk) {
+      const int kt = 2 * kk + wk;
+      u32x4_t fz[2][3];                                       // the dz fragments serve both taps of this wave
 #pragma unroll
       for (int lo = 0; lo < 2; ++lo)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          fz[lo][j] = frag(dzb + kt * 32 * PITCH + lo * 96 + j * 32);
-          fx[lo][j] = frag(xbk + kt * 32 * PITCH + lo * 96 + j * 32);
+        for (int j = 0; j < 3; ++j) fz[lo][j] = frag(dzb + kt * 32 * PITCH + lo * 96 + j * 32);
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) {
+        u32x4_t fx[2][3];
+#pragma unroll
+        for (int lo = 0; lo < 2; ++lo)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) fx[lo][i] = frag(xbk + (kt * 32 + tp) * PITCH + lo * 96 + i * 32);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[tp][i][j] = mfma16(fz[1][j], fx[0][i], acc[tp][i][j]);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[tp][i][j] = mfma16(fz[0][j], fx[1][i], acc[tp][i][j]);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[tp][i][j] = mfma16(fz[0][j], fx[0][i], acc[tp][i][j]);
         }
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(fz[1][j], fx[0][i], acc[i][j]);
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(fz[0][j], fx[1][i], acc[i][j]);
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(fz[0][j], fx[0][i], acc[i][j]);
+      }
     }
     if (it + 1 < nit) park(st ^ 1);                           // stage st ^ 1 was last read in iteration it - 1: the barrier below that iteration
     __syncthreads();
   }
-  // D = (tile of dz)^T-fragment x (tile of x)^T-fragment: lane = ci (li of tile i), registers = co 4 q .. + 3 of tile j
-  float* out = a.dw + ((size_t)g * TAPS + tap0 + wave) * (CG * CG);
+  // the odd k-tiles' sums join the even ones through LDS ([wave column][register][lane]), then D = lane ci (li of tile i), registers co 4 q .. + 3 of tile j
+  float* red = reinterpret_cast<float*>(smem) + wp * (72 * 64);
+  if (wk == 1) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+    for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      *reinterpret_cast<f32x4*>(out + (i * 16 + li) * CG + j * 16 + q * 4) = v;
-    }
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(((tp * 3 + i) * 3 + j) * 4 + r) * 64 + lane] = acc[tp][i][j][r];
+  }
+  __syncthreads();
+  if (wk == 1) return;
+#pragma unroll
+  for (int tp = 0; tp < 2; ++tp) {
+    float* out = a.dw + ((size_t)g * TAPS + tap0 + 2 * wp + tp) * (CG * CG);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        f32x4 v;
+        v.x = acc[tp][i][j][0] + red[(((tp * 3 + i) * 3 + j) * 4 + 0) * 64 + lane];
+        v.y = acc[tp][i][j][1] + red[(((tp * 3 + i) * 3 + j) * 4 + 1) * 64 + lane];
+        v.z = acc[tp][i][j][2] + red[(((tp * 3 + i) * 3 + j) * 4 + 2) * 64 + lane];
+        v.w = acc[tp][i][j][3] + red[(((tp * 3 + i) * 3 + j) * 4 + 3) * 64 + lane];
+        *reinterpret_cast<f32x4*>(out + (i * 16 + li) * CG + j * 16 + q * 4) = v;
+      }
+  }
 }
 
 }  // namespace pc

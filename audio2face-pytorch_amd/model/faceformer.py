@@ -241,7 +241,7 @@ class Faceformer(nn.Module):
             # second half's recurrence has to start while the first half's is still running, not queue behind it
             Faceformer._pipe_stream = [torch.cuda.Stream(device=audio.device, priority=-1) for _ in range(2)]     # short dependent chains go first in dispatch
         sides = Faceformer._pipe_stream
-        if frame_num < 1200:
+        if frame_num < 1200 or os.environ.get("A2F_FF_PIPELINE_SIDES") == "1":     # (A-B / diagnostic hook: one side stream at any length)
             # at 600 frames a half's recurrence (11 ms) is over long before the other half's starts: one side stream does - and a further stream
             # can land on a hardware queue another stream of the process already uses (measured inside the full bench run: 182 vs 157 ms)
             sides = [sides[0], sides[0]]

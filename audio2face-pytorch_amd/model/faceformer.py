@@ -274,8 +274,9 @@ class Faceformer(nn.Module):
                 outs.append(out3.detach() * w)
                 halves.append((enc, enc_d.grad, side.record_event()))
                 del y, _pred, out3, enc_d
-            if os.environ.get("A2F_FF_PIPELINE_DIAG_SYNC") == "2":       # diagnostic hook: the main stream waits for the side stream (no GPU overlap; the host still runs ahead)
-                cur.wait_stream(side)
+            _diag = os.environ.get("A2F_FF_PIPELINE_DIAG_SYNC")
+            if _diag == "2" or (_diag == "2a" and g == 0) or (_diag == "2b" and g == parts - 1):
+                cur.wait_stream(side)      # diagnostic hook: the main stream waits for the side stream (no GPU overlap; the host still runs ahead); 2a / 2b: after the first / last part only
             if os.environ.get("A2F_FF_PIPELINE_DIAG_SYNC") == "1":       # diagnostic hook: no overlap of a half's decoder side with the encoder work that follows
                 torch.cuda.synchronize()                                 # (tools/repro_loop.py: with it 0 of 200 repetitions differ)
         for i, (enc, d_enc, done) in enumerate(halves):

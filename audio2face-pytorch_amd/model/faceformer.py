@@ -50,6 +50,9 @@ class PeriodicPositionalEncoding(nn.Module):
         return self.pe[0, : self.period]          # one period; the kernel indexes it with i mod period
 
 
+OVERLAP_HEAD = os.environ.get("A2F_FF_PIPELINE_OVERLAP_HEAD") == "1"      # 1: the last part's decoder forward + head may overlap the encoder backward (not bitwise reproducible)
+
+
 class Faceformer(nn.Module):
     def __init__(self, n_verts: int, n_onehot: int, audio_encoder: nn.Module | None = None):
         super().__init__()
@@ -266,7 +269,9 @@ class Faceformer(nn.Module):
                 enc.record_stream(side)
                 enc_d = enc.detach().requires_grad_(True)
                 y = self.decode_hidden(enc_d, one_hot[lo:hi])
+                _e1 = side.record_event()
                 _pred, out3 = self._head_loss_batch(y, template[lo:hi], gt[lo:hi], k_rec, k_vel)
+                _e2 = side.record_event()
                 w = (hi - lo) / S
                 if halves:
                     side.wait_event(halves[-1][2])                              # the halves add into the same decoder-side .grad tensors: in half order
@@ -275,6 +280,15 @@ class Faceformer(nn.Module):
                 halves.append((enc, enc_d.grad, side.record_event()))
                 del y, _pred, out3, enc_d
             _diag = os.environ.get("A2F_FF_PIPELINE_DIAG_SYNC")
+            if g == parts - 1 and _diag == "2c":
+                cur.wait_event(_e1)                               # diagnostic: the main stream waits until the last part's decoder forward is over
+            if g == parts - 1 and (_diag == "2d" or (_diag is None and not OVERLAP_HEAD)):
+                # The encoder backward does not start before the LAST part's decoder forward and head are over (its decoder backward still runs beside it).
+                # With those two kernels - 146 / 150 KB of LDS per workgroup, the recurrence for ~3 ms on one CU per sequence - overlapping encoder-backward
+                # kernels, two runs of the step from the same state differed in the last bits of their updates: 1 step pair in ~30 in train mode, 1 in 3 with the
+                # regularisers off (tools/repro_loop.py: 12 / 40; this wait 0 / 160 and 0 / 100; the wait after the decoder forward only 2 / 40).
+                # Costs 3.4 % at 64 x 600 (112.0 -> 115.8 ms), 0.5 % at 12 x 3000.  A2F_FF_PIPELINE_OVERLAP_HEAD=1 restores the full overlap.
+                cur.wait_event(_e2)
             if _diag == "2" or (_diag == "2a" and g == 0) or (_diag == "2b" and g == parts - 1):
                 cur.wait_stream(side)      # diagnostic hook: the main stream waits for the side stream (no GPU overlap; the host still runs ahead); 2a / 2b: after the first / last part only
             if os.environ.get("A2F_FF_PIPELINE_DIAG_SYNC") == "1":       # diagnostic hook: no overlap of a half's decoder side with the encoder work that follows

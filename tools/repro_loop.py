@@ -27,6 +27,8 @@ for rep in range(N):
         with torch.no_grad():
             m.vertice_map_r.weight.normal_(0, 0.1); m.vertice_map.weight.normal_(0, 0.001)
         m.train()
+        if os.environ.get("REPRO_NO_REGULARISERS") == "1":          # the deterministic function in train mode: no dropout-variant kernels (the only scratch users of the step)
+            m.audio_encoder.train_regularisers = m.decoder_regularisers = False
         step = TrainStep(m, a2f_amd.FaceFormerLoss(), lr=1e-4)
         step.pipeline = pipeline
         step.pipeline_min_seqs, step.pipeline_min_frames = 1, 1

@@ -18,8 +18,16 @@ LIB_PATH = os.path.join(PKG_DIR, "liba2f_hip.so")
 OBJ_DIR = os.path.join(PKG_DIR, "..", "build", "obj")
 SOURCES = ["capi.hip", "gemm.hip", "wgrad.hip", "voca_trunk.hip", "loss.hip", "pack.hip", "adam.hip", "bn.hip", "head_fused.hip",
            "ff_decoder.hip", "interp.hip", "util.hip", "gemm_mfma.hip", "gemm_img.hip", "rowops.hip", "attention.hip", "featenc.hip", "dropout.hip", "posconv.hip"]
+# -fno-slp-vectorize: hipcc's SLP vectoriser packs neighbouring fp32 subtractions / multiplications into v_pk_*_f32.  When the common operand sits in the HIGH register
+# of a pair, the LOW result selects it with op_sel[1] = 1 (`v_pk_add_f32 vD, vX, v[M0:M1] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]`).  On MI355X that form was caught
+# reading 0 instead of the register in lanes 48..63 of one wave - only while kernels of other queues overlapped the launch, about once per 10 pipelined FaceFormer
+# steps, always in layernorm_bwd_kernel (per-lane register dumps; 9 / 60 step pairs differ with the form, 0 / 70 with those four subtractions as scalar
+# v_sub_f32 in an otherwise identical library, 0 / 200 + 0 / 100 with this flag).  Without the vectoriser the library holds no such instruction (86 before:
+# tools/scan_packed_opsel.py, tests/test_build_cpu.py) and no workload is slower (VOCA 0.97 -> 0.95 ms, FaceFormer 12 x 3000 196 -> 192 ms, the rest equal).
+# A2F_BUILD_SLP=1 builds the vulnerable form again (the reproducer of DESIGN 2.4 needs it; never for a product build).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-
+if os.environ.get("A2F_BUILD_SLP") != "1":
+    FLAGS.append("-fno-slp-vectorize")
 
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):

@@ -24,8 +24,6 @@ from __future__ import annotations
 
 import math
 
-import os
-
 import torch
 import torch.nn as nn
 
@@ -49,8 +47,6 @@ class PeriodicPositionalEncoding(nn.Module):
     def table(self):
         return self.pe[0, : self.period]          # one period; the kernel indexes it with i mod period
 
-
-OVERLAP_HEAD = os.environ.get("A2F_FF_PIPELINE_OVERLAP_HEAD") == "1"      # 1: the last part's decoder forward + head may overlap the encoder backward (not bitwise reproducible)
 
 
 class Faceformer(nn.Module):
@@ -209,6 +205,7 @@ class Faceformer(nn.Module):
         return pred, {"loss": tot[0], "rec_loss": tot[1].detach(), "vel_loss": tot[2].detach()}
 
     _pipe_stream = None
+    pipeline_parts = 2            # parts of the pipelined step (the measurements in train_step_pipelined; tests exercise 4)
 
     @staticmethod
     def grad_bucket_key(name: str):
@@ -244,17 +241,14 @@ class Faceformer(nn.Module):
             # second half's recurrence has to start while the first half's is still running, not queue behind it
             Faceformer._pipe_stream = [torch.cuda.Stream(device=audio.device, priority=-1) for _ in range(2)]     # short dependent chains go first in dispatch
         sides = Faceformer._pipe_stream
-        if frame_num < 1200 or os.environ.get("A2F_FF_PIPELINE_SIDES") == "1":     # (A-B / diagnostic hook: one side stream at any length)
+        if frame_num < 1200:
             # at 600 frames a half's recurrence (11 ms) is over long before the other half's starts: one side stream does - and a further stream
             # can land on a hardware queue another stream of the process already uses (measured inside the full bench run: 182 vs 157 ms)
             sides = [sides[0], sides[0]]
         # Parts: two equal halves (measured best at 600 frames: 7/16 .. 5/16 for the first half +0.4 .. +1.4 %).  More parts would start the first
         # recurrence earlier (at long T a part's recurrence outlasts a half's encoder forward), but measured at 12 x 3000 they lose more in the
         # products than they win: 2 parts 239.1 ms, 3 parts 248.4, 4 parts 250.5, 6 parts 299.0 (same box) - A2F_FF_PIPELINE_PARTS keeps the hook.
-        parts = 2
-        env_parts = os.environ.get("A2F_FF_PIPELINE_PARTS")                    # A-B hook
-        if env_parts:
-            parts = max(2, min(int(env_parts), S))
+        parts = max(2, min(int(self.pipeline_parts), S))
         cuts = [(S * g + parts - 1) // parts for g in range(parts)] + [S]
         enc_params = {id(p) for p in self.audio_encoder.parameters()}
         dec_params = [p for p in self.parameters() if p.requires_grad and id(p) not in enc_params]
@@ -269,9 +263,7 @@ class Faceformer(nn.Module):
                 enc.record_stream(side)
                 enc_d = enc.detach().requires_grad_(True)
                 y = self.decode_hidden(enc_d, one_hot[lo:hi])
-                _e1 = side.record_event()
                 _pred, out3 = self._head_loss_batch(y, template[lo:hi], gt[lo:hi], k_rec, k_vel)
-                _e2 = side.record_event()
                 w = (hi - lo) / S
                 if halves:
                     side.wait_event(halves[-1][2])                              # the halves add into the same decoder-side .grad tensors: in half order
@@ -279,20 +271,9 @@ class Faceformer(nn.Module):
                 outs.append(out3.detach() * w)
                 halves.append((enc, enc_d.grad, side.record_event()))
                 del y, _pred, out3, enc_d
-            _diag = os.environ.get("A2F_FF_PIPELINE_DIAG_SYNC")
-            if g == parts - 1 and _diag == "2c":
-                cur.wait_event(_e1)                               # diagnostic: the main stream waits until the last part's decoder forward is over
-            if g == parts - 1 and (_diag == "2d" or (_diag is None and not OVERLAP_HEAD)):
-                # The encoder backward does not start before the LAST part's decoder forward and head are over (its decoder backward still runs beside it).
-                # With those two kernels - 146 / 150 KB of LDS per workgroup, the recurrence for ~3 ms on one CU per sequence - overlapping encoder-backward
-                # kernels, two runs of the step from the same state differed in the last bits of their updates: 1 step pair in ~30 in train mode, 1 in 3 with the
-                # regularisers off (tools/repro_loop.py: 12 / 40; this wait 0 / 160 and 0 / 100; the wait after the decoder forward only 2 / 40).
-                # Costs 3.4 % at 64 x 600 (112.0 -> 115.8 ms), 0.5 % at 12 x 3000.  A2F_FF_PIPELINE_OVERLAP_HEAD=1 restores the full overlap.
-                cur.wait_event(_e2)
-            if _diag == "2" or (_diag == "2a" and g == 0) or (_diag == "2b" and g == parts - 1):
-                cur.wait_stream(side)      # diagnostic hook: the main stream waits for the side stream (no GPU overlap; the host still runs ahead); 2a / 2b: after the first / last part only
-            if os.environ.get("A2F_FF_PIPELINE_DIAG_SYNC") == "1":       # diagnostic hook: no overlap of a half's decoder side with the encoder work that follows
-                torch.cuda.synchronize()                                 # (tools/repro_loop.py: with it 0 of 200 repetitions differ)
+        # (Rounds 4-5: with the last part's decoder forward + head beside the encoder backward, two runs of the step differed in their last bits once in ~10.  It
+        # was no missing dependency: one packed-fp32 instruction form in layernorm_bwd_kernel misread a register while other queues' kernels overlapped it -
+        # DESIGN 2.4; the library is built without that form (_build.FLAGS), the full overlap is the only order again.)
         for i, (enc, d_enc, done) in enumerate(halves):
             cur.wait_event(done)
             d_enc.record_stream(cur)

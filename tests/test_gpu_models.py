@@ -990,8 +990,8 @@ def test_faceformer_pipelined_step_equals_single_stream_step(S, T, parts, monkey
     BITWISE equal to the same parts run one after the other on one stream (same kernels, same accumulation order - any
     missing stream dependency or allocator reuse hazard shows as a difference), twice in a row (the second step reuses freed
     blocks); and equal within the summation-order noise of the weight-gradient GEMMs to the unsplit batch step."""
-    monkeypatch.setenv("A2F_FF_PIPELINE_PARTS", str(parts))                     # two parts is the shipped setting; more parts stay selectable (A-B hook)
     m, _, _ = _faceformer_full()
+    m.pipeline_parts = parts                                                    # two parts is the shipped setting; the step is written for any number
     m.train()
     m.audio_encoder.train_regularisers = m.decoder_regularisers = False          # every call of this comparison must compute the same function
     gen = torch.Generator().manual_seed(77)
@@ -1180,9 +1180,11 @@ def test_faceformer_full_size_pipelined_step_is_bitwise_reproducible(S, T):
     is deterministic, so any difference is a missing stream dependency or an allocator reuse hazard - which only long-running kernels at this size would
     expose.  8 x 3000 frames (configs[4]'s length): there the second half's recurrence runs WHILE the first half's is still going (89 ms each).
 
-    Round 4: with the last half's decoder forward and head overlapping encoder-backward kernels this test failed in about 1 run of 30 (last-bit
-    differences of 17-221 parameters; tools/repro_loop.py); the step now starts the encoder backward after those two kernels (0 of 260 pairs differ).  On a
-    failure the message names the parameters that differ."""
+    Rounds 4-5: with the last half's decoder forward and head overlapping encoder-backward kernels this test failed in 1 run of 10-30 (last-bit
+    differences of 17-221 parameters).  No dependency was missing: layernorm_bwd_kernel held `v_pk_add_f32 ... op_sel:[0,1]` (made by the compiler's SLP
+    vectoriser), which misread its broadcast operand in lanes 48..63 of one wave while other queues' kernels overlapped the launch; the library is built without
+    that instruction form (tests/test_build_cpu.py guards it) and the full overlap is back: 0 of 200 + 0 of 100 pairs (tools/repro_loop.py, hash_bisect.py).
+    On a failure the message names the parameters that differ."""
     import bench
     from a2f_amd.trainer import TrainStep
     audio, one_hot, gt, templ = bench.make_ff_batch(S, T, 0, torch.device(DEV))

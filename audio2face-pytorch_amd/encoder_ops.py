@@ -25,7 +25,7 @@ POSCONV_KERNEL = _os.environ.get("A2F_POSCONV_KERNEL", "1") != "0"     # A-B hoo
 MM_IMG = _os.environ.get("A2F_MM_IMG", "1") != "0"               # A-B hook: 0 = the Transformer layers' products on the fp32-operand kernels
 ATTN_IMG = _os.environ.get("A2F_ATTN_IMG", "1") != "0"            # A-B hook: 0 = the attention kernels read fp32 q|k|v / dctx and convert them tile by tile
 WIMG_CACHE = _os.environ.get("A2F_WIMG_CACHE", "1") != "0"        # A-B hook: 0 = every layer call re-splits its weights
-_WIMG_CACHE = {}
+WIMG_VERIFY = _os.environ.get("A2F_WIMG_VERIFY") == "1"           # debug guard: every cache hit re-splits the weights and compares (raises on stale images)
 WEIGHTS_EPOCH = 0            # bumped by whoever rewrites parameters behind torch's back (trainer.FlatAdam.step)
 
 
@@ -198,6 +198,7 @@ class EncoderLayerFn(torch.autograd.Function):
         be = ops.backend()
         _save_prec(ctx)
         xc = _f32c(x)
+        ctx.wimg_owner = Wq                       # the module's parameter object: the weight-image cache entry lives on it (_layer_weight_images)
         P = [_f32c(p) for p in (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2)]
         Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, b1, W1, c1, W2, c2, g2, b2 = P
         mk = masks or {}
@@ -250,28 +251,33 @@ class EncoderLayerFn(torch.autograd.Function):
         return wi, wt
 
     @staticmethod
-    def _layer_weight_images(be, Wq, Wk, Wv, bq, bk, bv, Wo, W1, W2):
+    def _layer_weight_images(be, owner, Wq, Wk, Wv, bq, bk, bv, Wo, W1, W2):
         """The fused q|k|v weight / bias and the (image, transposed image) pairs of a layer's four weights.  They depend on the weights alone, and a step
         runs every layer several times on unchanged weights (the parts of the pipelined step): built once per (weights state, stream), 16 small launches per
-        layer and part otherwise (1.35 ms of the 64 x 600 step).  A cache entry holds its source tensors, so their addresses cannot be handed to other tensors
-        while it exists; a change of the weights shows as a tensor version (in-place torch ops) or as a new `WEIGHTS_EPOCH` (trainer.FlatAdam: its Adam
-        kernel writes the parameters through raw pointers).  Never used under stream capture (a replay must run the splitting passes)."""
+        layer and part otherwise (1.35 ms of the 64 x 600 step).  The entry lives ON the layer's q_proj.weight parameter (`owner`: the tensor the caller's
+        module holds), so it dies with the model and no process-wide table pins flat buffers of deleted models.  It is valid for one state of the weights: the
+        addresses and tensor versions of all nine sources (in-place torch ops, load_state_dict) and `WEIGHTS_EPOCH`, which trainer.FlatAdam bumps (its Adam
+        kernel writes the parameters through raw pointers).  A write through `p.data` or by a foreign kernel moves none of these - INTEGRATION.md 4; the debug
+        guard `A2F_WIMG_VERIFY=1` re-splits on every hit and raises when the cached images are not what the weights give.  Never used under stream capture
+        (a replay must run the splitting passes)."""
         def build():
             Wqkv, bqkv = torch.cat((Wq, Wk, Wv), 0), torch.cat((bq, bk, bv), 0)
             return (Wqkv, bqkv) + EncoderLayerFn._wimg(be, Wqkv) + EncoderLayerFn._wimg(be, Wo) + EncoderLayerFn._wimg(be, W1) + EncoderLayerFn._wimg(be, W2)
         if not WIMG_CACHE or not Wq.is_cuda or torch.cuda.is_current_stream_capturing():
             return build()
         src = (Wq, Wk, Wv, bq, bk, bv, Wo, W1, W2)
-        key = tuple(t.data_ptr() for t in src)
-        tag = (WEIGHTS_EPOCH, torch.cuda.current_stream(Wq.device).cuda_stream) + tuple(t._version for t in src)
-        ent = _WIMG_CACHE.get(key)
+        tag = (WEIGHTS_EPOCH, torch.cuda.current_stream(Wq.device).cuda_stream) + tuple(t.data_ptr() for t in src) + tuple(t._version for t in src)
+        ent = owner.__dict__.get("_a2f_wimg")
         if ent is not None and ent[0] == tag:
-            return ent[2]
+            if WIMG_VERIFY:
+                fresh = build()
+                for name, a, b in zip(("Wqkv", "bqkv", "Wqkv_i", "Wqkv_t", "Wo_i", "Wo_t", "W1_i", "W1_t", "W2_i", "W2_t"), ent[1], fresh):
+                    if not torch.equal(a, b):
+                        raise ops.A2FError(f"stale weight images ({name}): the layer's weights were rewritten behind torch's version counters (a write through "
+                                           "`.data` or a foreign kernel) - call encoder_ops.bump_weights_epoch() after such a write")
+            return ent[1]
         out = build()
-        _WIMG_CACHE.pop(key, None)
-        while len(_WIMG_CACHE) >= 64:                              # a handful of models at most (12 layers each); oldest first
-            _WIMG_CACHE.pop(next(iter(_WIMG_CACHE)))
-        _WIMG_CACHE[key] = (tag, src, out)
+        owner.__dict__["_a2f_wimg"] = (tag, out)
         return out
 
     @staticmethod
@@ -282,7 +288,7 @@ class EncoderLayerFn(torch.autograd.Function):
         if x_img is None:
             x_img = _new(xc, M, d)
             be.split_img(xc, M, d, d, x_img, d)
-        Wqkv, bqkv, Wqkv_i, Wqkv_t, Wo_i, Wo_t, W1_i, W1_t, W2_i, W2_t = EncoderLayerFn._layer_weight_images(be, Wq, Wk, Wv, bq, bk, bv, Wo, W1, W2)
+        Wqkv, bqkv, Wqkv_i, Wqkv_t, Wo_i, Wo_t, W1_i, W1_t, W2_i, W2_t = EncoderLayerFn._layer_weight_images(be, ctx.wimg_owner, Wq, Wk, Wv, bq, bk, bv, Wo, W1, W2)
         # q|k|v exists only as the image the attention kernels copy their tiles and fragments from (their inner loops are bound by vector instructions: converting
         # every K / V tile once per 128-query block was a fifth of them)
         ctx.attn_img = ATTN_IMG

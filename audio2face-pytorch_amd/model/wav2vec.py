@@ -83,7 +83,16 @@ class _PosConv(nn.Module):
         super().__init__()
         self.conv = nn.Conv1d(hidden, hidden, k, padding=k // 2, groups=groups)
         nn.utils.parametrize.register_parametrization(self.conv, "weight", _WeightNormDim2())
+        self.conv._register_load_state_dict_pre_hook(_PosConv._legacy_weight_norm_keys)
         self.k = k
+
+    @staticmethod
+    def _legacy_weight_norm_keys(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """What torch.nn.utils.parametrizations.weight_norm registers (_weight_norm_compat_hook): checkpoints written through the old nn.utils.weight_norm - the
+        published facebook/wav2vec2-base-960h weights and Lightning checkpoints of older torch / transformers - hold `conv.weight_g` / `conv.weight_v`."""
+        for old, new in (("weight_g", "parametrizations.weight.original0"), ("weight_v", "parametrizations.weight.original1")):
+            if prefix + old in state_dict and prefix + new not in state_dict:
+                state_dict[prefix + new] = state_dict.pop(prefix + old)
 
 
 class _Attention(nn.Module):

@@ -31,6 +31,9 @@ class FlatAdam:
         self.pg = process_group
         # rehearsal hook: run the collectives even in a one-rank group (exercises RCCL + hipGraph interplay on one GPU)
         self.force_collectives = os.environ.get("A2F_DP_FORCE_COLLECTIVES") == "1"
+        # TEST HOOK (tests/test_gpu_models.py): `collective(tensor, async_op) -> work | None` in place of dist.all_reduce - a one-GPU box cannot hold two RCCL
+        # ranks and a one-rank RCCL all-reduce launches no kernel, so the rehearsal of "a collective's kernels beside the backward" injects its own stream + kernel
+        self.collective = None
         self.step_count = 0
         offs, total = [], 0
         for p in self.params:
@@ -87,6 +90,8 @@ class FlatAdam:
 
     def allreduce_grads(self, lo: int = 0, hi: Optional[int] = None, async_op: bool = False):
         """Sum the flat gradient range [lo, hi) over the ranks (the 1/world factor lives in the Adam kernel)."""
+        if self.collective is not None:
+            return self.collective(self.flat_g[lo:self.numel if hi is None else hi], async_op)
         if self.world() > 1 or (self.force_collectives and dist.is_available() and dist.is_initialized()):
             return dist.all_reduce(self.flat_g[lo:self.numel if hi is None else hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
         return None
@@ -250,6 +255,7 @@ class TrainStep:
         self.pipeline_min_seqs = int(os.environ.get("A2F_FF_PIPELINE_MIN_SEQS", "48"))    # in sequences of 600 frames: the test is on frames per step
         self.pipeline_min_frames = int(os.environ.get("A2F_FF_PIPELINE_MIN_FRAMES", "600"))
         self._graph2 = None
+        self._rand = None             # dropout.StepRandomness of a captured FaceFormer step (_static_randomness)
         # models that expose `grad_bucket_key(name)` (FaceFormer: 386 MB of gradients) exchange them bucket by bucket under the backward
         # (A2F_DP_BUCKETS=0: one blocking all-reduce after the backward, as round 2 did)
         self.buckets = None
@@ -268,6 +274,8 @@ class TrainStep:
         if getattr(self, "buckets", None) is not None:
             self.buckets.close()
             self.buckets = None
+        self._graph = self._graph2 = None     # a captured graph reads the device buffers of self._rand: they go together
+        self._rand = None
 
     def __del__(self):
         try:
@@ -311,22 +319,41 @@ class TrainStep:
 
     def _static_randomness(self, x):
         """Captured FaceFormer step: the step's random state (mask seeds, LayerDrop decisions, SpecAugment rows) must live on the device - a value drawn on
-        the host inside the captured region would be frozen into the graph.  Creates the model's dropout.StepRandomness once and refreshes it (host draws +
-        non-blocking copies, OUTSIDE the graph) before every warm-up / capture / replay."""
+        the host inside the captured region would be frozen into the graph.  The dropout.StepRandomness belongs to THIS step object (`self._rand`): created once,
+        refreshed (host draws + non-blocking copies on the current stream, OUTSIDE the graph) before every warm-up / capture / replay, and visible to the model
+        only while this step runs its Python forward (`_installed_randomness`): a later eager forward of the same model draws on the host as ever."""
         enc = getattr(self.model, "audio_encoder", None)
         if enc is None or not hasattr(enc, "static_rand") or not x.is_cuda or x.dim() != 2:
-            return
+            return None
         from .dropout import StepRandomness
         S, T = x.shape[0], x.shape[1] * 60 // 16000
-        sr = enc.static_rand
+        sr = self._rand
         if sr is None or (sr.S, sr.T) != (S, T):
-            sr = enc.static_rand = StepRandomness(x.device, len(enc.encoder.layers), S, T)
+            sr = self._rand = StepRandomness(x.device, len(enc.encoder.layers), S, T)
         sr.refresh(enc.config, train_encoder=bool(enc.training and enc.train_regularisers and enc.injected_masks is None),
                    train_decoder=bool(self.model.training and getattr(self.model, "decoder_regularisers", False)))
+        return sr
+
+    def _installed_randomness(self, sr):
+        """Context: the model's encoder sees `sr` as its device-resident random state for the duration of a warm-up step or a capture, and what it had before
+        (normally None) afterwards - also when the body raises."""
+        import contextlib
+        enc = getattr(self.model, "audio_encoder", None)
+        if sr is None or enc is None:
+            return contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def scope():
+            old, enc.static_rand = enc.static_rand, sr
+            try:
+                yield
+            finally:
+                enc.static_rand = old
+        return scope()
 
     def _graph_step(self, x, one_hot, gt, template):
         ins = (x, one_hot, gt, template)
-        self._static_randomness(x)
+        sr = self._static_randomness(x)
         if self._graph is None:
             # Warm-up and capture run on ONE side stream: autograd's AccumulateGrad nodes remember the stream their
             # gradient buffers were last used on, and a capture that has to synchronise with another stream is illegal.
@@ -341,7 +368,8 @@ class TrainStep:
                 self._side.wait_stream(torch.cuda.current_stream())
             if self._warm < 2:                                  # eager warm-up: allocator pools, LDS attributes, autotune-free
                 self._warm += 1
-                with torch.cuda.stream(self._side):
+                self._side.wait_stream(torch.cuda.current_stream())     # the refresh above copied this step's random state on the current stream
+                with torch.cuda.stream(self._side), self._installed_randomness(sr):
                     loss = self._direct(ins, 1) if self.overlap else self._fwd_bwd(*ins)
                 torch.cuda.current_stream().wait_stream(self._side)
                 if self.overlap:
@@ -360,7 +388,7 @@ class TrainStep:
             # watchdog polls events while the ranks are between collectives)
             try:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self._side, capture_error_mode="thread_local"):
+                with self._installed_randomness(sr), torch.cuda.graph(g, stream=self._side, capture_error_mode="thread_local"):
                     out = self._direct(ins, 1) if self.overlap else self._fwd_bwd(*ins)
                 if self.overlap:                                # second graph: trunk backward, same memory pool
                     g2 = torch.cuda.CUDAGraph()
@@ -375,8 +403,7 @@ class TrainStep:
                 torch.cuda.synchronize()
                 self.use_graph = False
                 self._graph = self._graph2 = None
-                if getattr(getattr(self.model, "audio_encoder", None), "static_rand", None) is not None:
-                    self.model.audio_encoder.static_rand = None       # the eager step draws on the host again
+                self._rand = None                                     # the eager step draws on the host again
                 return self.__call__(*ins)
             self._graph, self._graph_inputs, self._graph_out = g, ins, out
         else:
@@ -414,6 +441,8 @@ class TrainStep:
         if not (self.fused and hasattr(self.model, "forward_with_loss_batch") and hasattr(self.model, "train_step_pipelined")):
             return False
         if not (self.pipeline and x.is_cuda and x.dim() == 2 and x.shape[0] >= 2):
+            return False
+        if self.use_graph:                     # a captured step is one stream and one StepRandomness for the whole batch: the single-stream order
             return False
         frames = x.shape[1] * 60 // 16000
         return frames >= self.pipeline_min_frames and x.shape[0] * frames >= self.pipeline_min_seqs * 600

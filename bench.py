@@ -50,7 +50,7 @@ MFMA_BF16_PEAK_TF = 2500.0        # dense bf16 matrix peak
 FF_MFLOP_PER_FRAME = 857.0        # 3 x 2 x (141.9 M encoder + 1.0 M decoder/head) MAC at T = 600
 A2M_MFLOP_PER_FRAME = 393.0       # 3 x 2 x 65 509 514 MAC
 FF_LAYER_MFLOP_PER_FRAME = 6.0 * (7.078 + 0.92) # one of the 12 Transformer layers: 3 x 2 x (7.08 M MAC of projections / FFN + 0.92 M MAC of attention at T = 600)
-PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"   # this round's PMC measurement of the dominant kernels (tools/pmc_head.sh, tools/pmc_gemm.sh)
+PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"   # this round's PMC measurement of the dominant kernels (tools/pmc_traffic.sh)
 
 
 # ------------------------------------------------------------------------------------------------ self launch (N > 1)
@@ -708,7 +708,13 @@ def main():
     for r in [dict(result, model=args.workload)] + list(result.get("secondary") or []):
         roof = r.get("roofline") or {}
         e = {"ms_per_step": r.get("ms_per_step"), "frames_per_s": r.get("value"), "frames_per_gpu_step": (r.get("config") or {}).get("frames_per_gpu_step"),
-             "whole_step_frac": roof.get("frac"), "bound": roof.get("bound")}
+             # VOCA's roofline.frac is its dominant KERNEL's fraction; the whole step's is roofline.whole_step_frac.  The MFMA-bound entries' roofline.frac
+             # already is the whole step (executed flops); their algorithmic fraction rides along.
+             "whole_step_frac": roof.get("whole_step_frac", roof.get("frac")), "bound": roof.get("bound")}
+        if "whole_step_frac" in roof:
+            e["dominant_kernel_frac"] = roof.get("frac")
+        if "algorithmic_frac" in roof:
+            e["algorithmic_frac"] = roof["algorithmic_frac"]
         if "gemm_family" in roof:
             e["gemm_family_frac"] = roof["gemm_family"].get("frac")
         pts = {p["seqs_per_step"]: p["ms_per_step"] for p in r.get("sequences_per_step_points") or []}

@@ -1056,13 +1056,14 @@ def test_weight_image_cache_follows_the_weights(monkeypatch):
     runs = []
     for cache in (True, False):
         monkeypatch.setattr(encoder_ops, "WIMG_CACHE", cache)
-        encoder_ops._WIMG_CACHE.clear()
+        monkeypatch.setattr(encoder_ops, "WIMG_VERIFY", cache)               # the debug guard on: every hit re-splits and compares (must stay silent here)
         m, _, _ = _faceformer_full()
         m.train()
         m.audio_encoder.train_regularisers = m.decoder_regularisers = False
         step = TrainStep(m, a2f_amd.FaceFormerLoss(), lr=1e-3)
         losses = [float(step(audio, oh, gt, template)["loss"]) for _ in range(3)]
-        assert (len(encoder_ops._WIMG_CACHE) > 0) == cache
+        # the entry lives on the layer's q_proj.weight parameter (it dies with the model; no process-wide table)
+        assert all(("_a2f_wimg" in lay.attention.q_proj.weight.__dict__) == cache for lay in m.audio_encoder.encoder.layers)
         params = [p.detach().clone() for p in m.parameters()]
         with torch.no_grad():
             m.audio_encoder.encoder.layers[3].feed_forward.intermediate_dense.weight.mul_(1.25)          # a torch in-place edit: version counter
@@ -1072,6 +1073,19 @@ def test_weight_image_cache_follows_the_weights(monkeypatch):
     assert l1 == l0 and l1[0] != l1[1] != l1[2]
     assert all(torch.equal(a, b) for a, b in zip(p1, p0))
     assert torch.equal(y1, y0)
+    # what the version counters cannot see - a write through `.data` - is what A2F_WIMG_VERIFY exists for: it raises instead of training on stale images
+    monkeypatch.setattr(encoder_ops, "WIMG_CACHE", True)
+    monkeypatch.setattr(encoder_ops, "WIMG_VERIFY", False)
+    m, _, _ = _faceformer_full()
+    m.eval()
+    with torch.no_grad():
+        m(audio[:1], oh[:1], template[:1])                                    # fills the entries
+        m.audio_encoder.encoder.layers[0].attention.out_proj.weight.data.mul_(1.5)
+        monkeypatch.setattr(encoder_ops, "WIMG_VERIFY", True)
+        with pytest.raises(a2f_amd.A2FError, match="stale weight images"):
+            m(audio[:1], oh[:1], template[:1])
+        encoder_ops.bump_weights_epoch()                                      # what a caller does after such a write
+        m(audio[:1], oh[:1], template[:1])
 
 
 @pytest.mark.parametrize("images", [False, True])
@@ -1251,6 +1265,68 @@ def test_faceformer_pipelined_step_under_the_bucketed_exchange_equals_the_plain_
     assert torch.equal(finals[0][0], finals[1][0])
 
 
+@pytest.mark.parametrize("S,T,steps", [(6, 90, 200), (48, 600, 4)])
+def test_faceformer_step_beside_collective_kernels_is_bitwise_the_plain_step(S, T, steps, monkeypatch):
+    """The data-parallel step with KERNELS of a communication stream in flight beside the backward (what RCCL's all-reduce kernels are on a multi-GPU node; a
+    one-GPU box cannot hold two RCCL ranks and a one-rank all-reduce launches nothing, so FlatAdam.collective injects the stand-in): every bucket's exchange is a
+    copy of the gradient range out and back on its own stream, ordered like a collective library orders it (the communication stream waits for the launching
+    stream; `wait()` makes the launching stream wait for it).  Summing over one rank is the identity, so the parameters after `steps` train-mode steps (LayerDrop:
+    some buckets carry no gradient) must be BITWISE those of the plain step - at the small size for 200 steps, at bench size (two half-batches on two streams + the
+    weight-gradient lane + the communication stream: four queues) for 4."""
+    import bench
+    from a2f_amd.trainer import TrainStep
+    audio, one_hot, gt, templ = bench.make_ff_batch(S, T, 0, torch.device(DEV))
+    comm = torch.cuda.Stream()
+    launched = []
+
+    class Work:
+        def wait(self):
+            torch.cuda.current_stream().wait_stream(comm)
+
+    def collective(t, async_op):
+        cur = torch.cuda.current_stream()
+        comm.wait_stream(cur)
+        with torch.cuda.stream(comm):
+            tmp = torch.empty_like(t)
+            for _ in range(2):                                          # the bytes a ring all-reduce moves, twice over: kernels that stay in flight for a while
+                tmp.copy_(t)
+                t.copy_(tmp)
+        launched.append(t.numel())
+        w = Work()
+        if not async_op:
+            w.wait()
+            return None
+        return w
+
+    finals = []
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("A2F_DP_FORCE_COLLECTIVES", "1")
+        torch.manual_seed(1234)
+        m = a2f_amd.Faceformer(n_verts=NV, n_onehot=12).to(DEV)
+        with torch.no_grad():
+            m.vertice_map_r.weight.normal_(0, 0.1); m.vertice_map.weight.normal_(0, 0.001)
+        m.train()
+        m.audio_encoder.config.layerdrop = 0.3
+        step = TrainStep(m, a2f_amd.FaceFormerLoss(), lr=1e-4)
+        assert (step.buckets is not None) == forced
+        if forced:
+            step.opt.collective = collective
+        step.pipeline_min_seqs, step.pipeline_min_frames = 0, 1
+        assert step._pipelined(audio)
+        torch.manual_seed(99)
+        for _ in range(steps):
+            out = step(audio, one_hot, gt, templ)
+        torch.cuda.synchronize()
+        finals.append((step.opt.flat_p.clone(), float(out["loss"].detach())))
+        if forced:
+            assert len(launched) == steps * len(step.buckets.bounds) and sum(launched) == steps * step.opt.numel     # every bucket, every step, the whole buffer
+        step.close()
+        del step, m
+    assert finals[0][1] == finals[1][1]
+    assert torch.equal(finals[0][0], finals[1][0])
+
+
 def test_keep_bits_with_a_device_resident_seed_is_the_same_mask():
     """a2f_keep_bits_dev / a2f_keep_bits_attn_dev (seed read from device memory at run time: hipGraph-captured steps) against the by-value entry points."""
     be = ops.backend()
@@ -1295,9 +1371,14 @@ def test_faceformer_batch1_step_as_one_hipgraph_equals_the_eager_step():
         for _ in range(5):                                           # graph mode: two eager warm-ups, the capture step, two replays
             out = step(audio, oh, gt, template)
             ls.append(float(out["loss"].detach()))
+            # the device-resident random state belongs to the step object and is visible to the model only inside its warm-up / capture: an eager forward
+            # of the same model between (or after) graph steps draws on the host as ever
+            assert m.audio_encoder.static_rand is None
         torch.cuda.synchronize()
         if mode == "graph":
             assert step.use_graph and step._graph is not None, "the capture failed"
+            step.pipeline_min_seqs, step.pipeline_min_frames = 1, 1
+            assert not step._pipelined(torch.zeros(2, audio.shape[1], device=DEV))      # a captured step never takes the two-stream form
         finals[mode], losses[mode] = step.opt.flat_p.clone(), ls
         step.close()
         del step, m

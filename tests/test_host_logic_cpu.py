@@ -205,6 +205,35 @@ def test_wav2vec2_module_matches_hf_golden():
     assert packed_error(g, f"T{T}::last_hidden_state", out) < 2e-5
 
 
+def test_wav2vec2_module_loads_both_weight_norm_key_styles():
+    """The positional convolution's weight norm: checkpoints written through the old nn.utils.weight_norm (the published facebook/wav2vec2-base-960h weights,
+    Lightning checkpoints of older torch / transformers) hold `conv.weight_g` / `conv.weight_v`, new ones `conv.parametrizations.weight.original0 / 1`.  Both load
+    (torch's own weight_norm parametrization accepts both through the same kind of pre-hook) and give the same effective weight as torch's."""
+    from a2f_amd.model.wav2vec import Wav2Vec2Model
+    m = Wav2Vec2Model(layers=1).eval()
+    new = {k: torch.randn_like(v) for k, v in m.state_dict().items()}
+    pre = "encoder.pos_conv_embed.conv."
+    assert pre + "parametrizations.weight.original0" in new and pre + "parametrizations.weight.original1" in new
+    m.load_state_dict(new)
+    w_new = m.encoder.pos_conv_embed.conv.weight.detach().clone()
+    legacy = dict(new)
+    legacy[pre + "weight_g"] = legacy.pop(pre + "parametrizations.weight.original0")
+    legacy[pre + "weight_v"] = legacy.pop(pre + "parametrizations.weight.original1")
+    m2 = Wav2Vec2Model(layers=1).eval()
+    m2.load_state_dict(legacy)                                      # strict: no missing / unexpected keys
+    assert torch.equal(m2.encoder.pos_conv_embed.conv.weight, w_new)
+    ref = torch.nn.utils.parametrizations.weight_norm(torch.nn.Conv1d(768, 768, 128, padding=64, groups=16), name="weight", dim=2)
+    ref.load_state_dict({k[len(pre):]: v for k, v in legacy.items() if k.startswith(pre)})
+    assert torch.allclose(ref.weight, w_new, rtol=1e-6, atol=1e-7)
+    # a Faceformer-level dict (keys under audio_encoder.) goes through the same hook
+    import a2f_amd
+    ff = a2f_amd.Faceformer(n_verts=15, n_onehot=12, audio_encoder=Wav2Vec2Model(layers=1))
+    sd = ff.state_dict()
+    p2 = "audio_encoder." + pre
+    sd[p2 + "weight_g"], sd[p2 + "weight_v"] = sd.pop(p2 + "parametrizations.weight.original0"), sd.pop(p2 + "parametrizations.weight.original1")
+    ff.load_state_dict(sd)
+
+
 def test_wav2vec2_module_has_no_cpu_path():
     """The product module has one forward - the HIP path: with the real backend, off-device tensors fail loudly."""
     from a2f_amd.model.wav2vec import Wav2Vec2Model

@@ -445,319 +445,17 @@ __global__ __launch_bounds__(FF_FWD_THREADS, 1) __attribute__((amdgpu_waves_per_
 // =====================================================================================================================
 // backward (reverse time)
 // =====================================================================================================================
-template <bool DROP>
-__global__ __launch_bounds__(FF_THREADS, 1) void ff_decoder_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dy, int T,
-                                                                        int period, float* __restrict__ save,
-                                                                        float* __restrict__ dcross, float* __restrict__ dstyle, const FFDrop dm) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  __builtin_amdgcn_s_setprio(3);          // a latency-bound chain: when it shares a CU with GEMM waves of another stream (the pipelined step), its waves issue first
-  float* Wqkv = lds;                        // [192][64] row-major: lane = input index for the transposed products
-  float* Wo = Wqkv + 192 * FD;              // [64][64]
-  float* Am = Wo + FD * FD;                 // [64][64]
-  float* xs = Am + FD * FD;                 // [64]  x_i
-  float* cs = xs + FD;                      // [64]  ctx_i
-  float* hs = cs + FD;                      // [128] h_i (post-ReLU)
-  float* y2s = hs + FFF;                    // [64]
-  float* ys = y2s + FD;                     // [64]  y_i (decoder output row)
-  float* dfs = ys + FD;                     // [64]
-  float* dhps = dfs + FD;                   // [128]
-  float* pbuf = dhps + FFF;                 // [4][64] / [2][128] partial sums
-  float* dsas = pbuf + 4 * FD;              // [64]
-  float* dcs = dsas + FD;                   // [64]
-  float* dqkvs = dcs + FD;                  // [192]
-  float* dembs = dqkvs + 192;               // [64] gradient w.r.t. emb_{i+1} from the previous (later-time) iteration
-  float* qs = dembs + FD;                   // [64]
-
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int64_t s = blockIdx.x;
-  float* svbase = save + s * (int64_t)T * SV_STRIDE;
-
-  for (int e = t; e < 192 * FD; e += FF_THREADS) Wqkv[e] = P[A2F_FF_WQKV + e];
-  for (int e = t; e < FD * FD; e += FF_THREADS) { Wo[e] = P[A2F_FF_WO + e]; Am[e] = P[A2F_FF_A + e]; }
-  if (t < FD) dembs[t] = 0.f;
-  // zero this sequence's dK / dV accumulators
-  for (int64_t e = t; e < (int64_t)T * 128; e += FF_THREADS) svbase[(e >> 7) * SV_STRIDE + SV_DK + (e & 127)] = 0.f;
-
-  // weight columns for the transposed FFN products, in registers
-  //   W1^T dhp : output k = t & 63, rows [32*(t>>6), +32)          -> w1c[r] = W1[32*(t>>6)+r][k]
-  //   W2^T df  : output u = t & 127, rows [32*(t>>7), +32)         -> w2c[r] = W2[32*(t>>7)+r][u]
-  float w1c[32], w2c[32];
-#pragma unroll
-  for (int r = 0; r < 32; ++r) {
-    w1c[r] = P[A2F_FF_W1 + ((t >> 6) * 32 + r) * FD + (t & 63)];
-    w2c[r] = P[A2F_FF_W2 + ((t >> 7) * 32 + r) * FFF + (t & 127)];
-  }
-  // gradient accumulators (registers, whole sequence)
-  float gA[FD];        // t < 192: dWqkv row t ; t >= 192: dWo row (t - 192)
-  float gB[FD];        // t < 128: dW1 row t  ; 128 <= t < 192: dA row (t - 128)
-  float gC[32];        // dW2[o = t & 63][32*(t>>6) + k]
-#pragma unroll
-  for (int k = 0; k < FD; ++k) { gA[k] = 0.f; gB[k] = 0.f; }
-#pragma unroll
-  for (int k = 0; k < 32; ++k) gC[k] = 0.f;
-  float gbA = 0.f;     // dbqkv[t] (t<192) / dbo[t-192]
-  float gbB = 0.f;     // db1[t] (t<128) / dc[t-128] (128<=t<192)
-  float gb2 = 0.f, gg1 = 0.f, gb1n = 0.f, gg2 = 0.f, gb2n = 0.f, gg3 = 0.f, gb3n = 0.f, gsty = 0.f;   // wave 0 lanes
-
-  const float ln_g1 = P[A2F_FF_LN + 0 * FD + lane], ln_b1 = P[A2F_FF_LN + 1 * FD + lane];
-  const float ln_g2 = P[A2F_FF_LN + 2 * FD + lane], ln_b2 = P[A2F_FF_LN + 3 * FD + lane];
-  const float ln_g3 = P[A2F_FF_LN + 4 * FD + lane], ln_b3 = P[A2F_FF_LN + 5 * FD + lane];
-  const float slope = exp2f(-2.f * (float)(wave + 1));
-  const int js = lane >> 2, dq = lane & 3;
-  float carry = 0.f;                                   // wave 0: (A^T demb_{i+1})[lane]
-  __syncthreads();
-
-  for (int i = T - 1; i >= 0; --i) {
-    float* sv = svbase + (int64_t)i * SV_STRIDE;
-    float dy2 = 0.f, xh2 = 0.f, xh1 = 0.f;
-    const unsigned* rowbits = DROP ? dm.row + (s * T + i) * FF_ROW_WORDS : nullptr;
-    // ---- S1: stage saved vectors; wave 0: LayerNorm-3 backward ----
-    if (wave == 0) {
-      const float xh3 = sv[SV_XH3 + lane];
-      const float rstd3 = sv[SV_ST + 2];
-      const float dy3 = dy[(s * T + i) * FD + lane] + carry;
-      gg3 += dy3 * xh3;
-      gb3n += dy3;
-      const float du3 = wave_layernorm_bwd(dy3 * ln_g3, xh3, rstd3);
-      dy2 = du3;                                       // residual branch of norm3(y2 + ffn)
-      float df = du3;                                  // the feed-forward branch sees it through dropout3
-      if constexpr (DROP) df = ((rowbits[8 + (lane >> 5)] >> (lane & 31)) & 1u) ? du3 * dm.scale : 0.f;
-      dfs[lane] = df;
-      gb2 += df;
-      ys[lane] = xh3 * ln_g3 + ln_b3;
-      xh2 = sv[SV_XH2 + lane];
-      y2s[lane] = xh2 * ln_g2 + ln_b2;
-    } else if (wave == 1) {
-      hs[lane] = sv[SV_H + lane];
-      hs[64 + lane] = sv[SV_H + 64 + lane];
-    } else if (wave == 2) {
-      xs[lane] = sv[SV_X + lane];
-      cs[lane] = sv[SV_CTX + lane];
-    } else {
-      qs[lane] = sv[SV_Q + lane];
-    }
-    __syncthreads();
-    // ---- S2: dW2 += df (x) h ; dh = W2^T df (partials) ; dA += demb_{i+1} (x) y_i ; dc += demb_{i+1} ----
-    {
-      const float dfo = dfs[lane];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) gC[k] += dfo * hs[wave * 32 + k];
-      float acc = 0.f;
-      const int half = t >> 7;
-#pragma unroll
-      for (int r = 0; r < 32; ++r) acc += w2c[r] * dfs[half * 32 + r];
-      pbuf[half * FFF + (t & 127)] = acc;
-      if (t >= 128 && t < 192) {
-        const float de = dembs[t - 128];
-        gbB += de;
-#pragma unroll
-        for (int k = 0; k < FD; ++k) gB[k] += de * ys[k];
-      }
-    }
-    __syncthreads();
-    // ---- S3: ReLU backward ; dW1 += dhp (x) y2 ----
-    if (t < FFF) {
-      const float dh = pbuf[t] + pbuf[FFF + t];
-      // hs is the activation AFTER its dropout: a dropped unit is 0 there, a kept one relu * scale - so (hs > 0) is both masks at once
-      const float dhp = hs[t] > 0.f ? (DROP ? dh * dm.scale : dh) : 0.f;
-      dhps[t] = dhp;
-      gbB += dhp;
-#pragma unroll
-      for (int k = 0; k < FD; ++k) gB[k] += dhp * y2s[k];
-    }
-    __syncthreads();
-    // ---- S4: W1^T dhp (4 partial sums per output) ----
-    {
-      float acc = 0.f;
-#pragma unroll
-      for (int r = 0; r < 32; ++r) acc += w1c[r] * dhps[wave * 32 + r];
-      __syncthreads();                                 // pbuf readers of S3 are done
-      pbuf[wave * FD + lane] = acc;
-    }
-    __syncthreads();
-    // ---- S5: wave 0: LayerNorm-2 and LayerNorm-1 backward ----
-    float dx = 0.f;
-    if (wave == 0) {
-      dy2 += pbuf[lane] + pbuf[FD + lane] + pbuf[2 * FD + lane] + pbuf[3 * FD + lane];
-      const float rstd2 = sv[SV_ST + 1], rstd1 = sv[SV_ST + 0];
-      gg2 += dy2 * xh2;
-      gb2n += dy2;
-      const float du2 = wave_layernorm_bwd(dy2 * ln_g2, xh2, rstd2);
-      dcross[(s * T + i) * FD + lane] = du2;           // u2 = y1 + cross_i
-      xh1 = sv[SV_XH1 + lane];
-      gg1 += du2 * xh1;
-      gb1n += du2;
-      const float du1 = wave_layernorm_bwd(du2 * ln_g1, xh1, rstd1);
-      dx = du1;                                        // u1 = x + dropout1(self_attn(x))
-      float dsa = du1;
-      if constexpr (DROP) dsa = ((rowbits[2 + (lane >> 5)] >> (lane & 31)) & 1u) ? du1 * dm.scale : 0.f;
-      dsas[lane] = dsa;
-    }
-    __syncthreads();
-    // ---- S6: out-projection: dWo += dsa (x) ctx (wave 3) ; dctx = Wo^T dsa (wave 0) ----
-    if (wave == 3) {
-      const float dsa = dsas[lane];
-      gbA += dsa;
-#pragma unroll
-      for (int k = 0; k < FD; ++k) gA[k] += dsa * cs[k];
-    } else if (wave == 0) {
-      float acc = 0.f;
-#pragma unroll 16
-      for (int r = 0; r < FD; ++r) acc += Wo[r * FD + lane] * dsas[r];
-      dcs[lane] = acc;
-    }
-    __syncthreads();
-    // ---- S7: attention backward for head = wave ----
-    {
-      const float4 qv = *reinterpret_cast<const float4*>(qs + wave * FHD + dq * 4);
-      const float4 dcv = *reinterpret_cast<const float4*>(dcs + wave * FHD + dq * 4);
-      const float m = sv[SV_ST + 4 + wave];
-      const float invl = 1.f / sv[SV_ST + 8 + wave];
-      float* kbase = svbase + SV_K + wave * FHD + dq * 4;
-      float* vbase = svbase + SV_V + wave * FHD + dq * 4;
-      float* dkbase = svbase + SV_DK + wave * FHD + dq * 4;
-      float* dvbase = svbase + SV_DV + wave * FHD + dq * 4;
-      // sum_j a_j da_j = dctx . ctx (ctx = sum_j a_j v_j is saved), so ONE pass over the keys does everything: a, da, ds,
-      // dq, dK += ds q, dV += a dctx.  FB_U key slots per trip, all loads issued before use (L2 latency bound);
-      // a slot past i re-reads row i and neither accumulates nor stores.
-      float rowsum = dot4(dcv, *reinterpret_cast<const float4*>(cs + wave * FHD + dq * 4));
-      rowsum += ff_dpp<0xB1>(rowsum);
-      rowsum += ff_dpp<0x4E>(rowsum);
-      float4 dqa = make_float4(0.f, 0.f, 0.f, 0.f);
-      const unsigned* abits = DROP ? dm.attn + ((s * FH + wave) * T + i) * dm.TW : nullptr;
-      for (int j0 = js; j0 <= i; j0 += 16 * FB_U) {
-        float4 kk[FB_U], vv[FB_U], dk[FB_U], dv[FB_U];
-        unsigned kw[FB_U];
-#pragma unroll
-        for (int u = 0; u < FB_U; ++u) {
-          const int jj = min(j0 + 16 * u, i);
-          const int64_t off = (int64_t)jj * SV_STRIDE;
-          kk[u] = *reinterpret_cast<const float4*>(kbase + off);
-          vv[u] = *reinterpret_cast<const float4*>(vbase + off);
-          dk[u] = *reinterpret_cast<const float4*>(dkbase + off);
-          dv[u] = *reinterpret_cast<const float4*>(dvbase + off);
-          if constexpr (DROP) kw[u] = abits[jj >> 5];
-        }
-#pragma unroll
-        for (int u = 0; u < FB_U; ++u) {
-          const int j = j0 + 16 * u;
-          const bool valid = j <= i;
-          float p = dot4(qv, kk[u]);
-          p += ff_dpp<0xB1>(p);
-          p += ff_dpp<0x4E>(p);
-          float da = dot4(dcv, vv[u]);
-          da += ff_dpp<0xB1>(da);
-          da += ff_dpp<0x4E>(da);
-          const float a = valid ? expf(p - slope * (float)((i - min(j, i)) / period) - m) * invl : 0.f;
-          float ad = a;                                // ctx = sum_j a_j D_j v_j: dV sees a D, da_j = D_j (dctx . v_j); sum_j a_j da_j = dctx . ctx still
-          if constexpr (DROP) {
-            const float dj = ((kw[u] >> (min(j, i) & 31)) & 1u) ? dm.scale : 0.f;
-            ad = a * dj;
-            da *= dj;
-          }
-          const float ds = a * (da - rowsum);
-          dqa.x += ds * kk[u].x; dqa.y += ds * kk[u].y; dqa.z += ds * kk[u].z; dqa.w += ds * kk[u].w;
-          if (valid) {
-            const float4 ndk = make_float4(dk[u].x + ds * qv.x, dk[u].y + ds * qv.y, dk[u].z + ds * qv.z, dk[u].w + ds * qv.w);
-            const float4 ndv = make_float4(dv[u].x + ad * dcv.x, dv[u].y + ad * dcv.y, dv[u].z + ad * dcv.z, dv[u].w + ad * dcv.w);
-            const int64_t off = (int64_t)j * SV_STRIDE;
-            *reinterpret_cast<float4*>(dkbase + off) = ndk;
-            *reinterpret_cast<float4*>(dvbase + off) = ndv;
-          }
-        }
-      }
-      // fold the 16 key slots into lanes 0..3 (js == 0: the only readers): row rotations by 4 and 8 pair those lanes exactly like the xor butterfly
-      // did ((v[l] + v[l+4]) + (v[l+8] + v[l+12])), the rows are joined by two shuffles
-      dqa.x += ff_dpp<0x124>(dqa.x); dqa.y += ff_dpp<0x124>(dqa.y); dqa.z += ff_dpp<0x124>(dqa.z); dqa.w += ff_dpp<0x124>(dqa.w);
-      dqa.x += ff_dpp<0x128>(dqa.x); dqa.y += ff_dpp<0x128>(dqa.y); dqa.z += ff_dpp<0x128>(dqa.z); dqa.w += ff_dpp<0x128>(dqa.w);
-#pragma unroll
-      for (int off = 16; off < 64; off <<= 1) {
-        dqa.x += __shfl_xor(dqa.x, off, 64); dqa.y += __shfl_xor(dqa.y, off, 64);
-        dqa.z += __shfl_xor(dqa.z, off, 64); dqa.w += __shfl_xor(dqa.w, off, 64);
-      }
-      if (js == 0)                                     // q was stored pre-scaled: d(q_raw) = 0.25 d(q_scaled)
-        *reinterpret_cast<float4*>(dqkvs + wave * FHD + dq * 4) = make_float4(0.25f * dqa.x, 0.25f * dqa.y, 0.25f * dqa.z, 0.25f * dqa.w);
-    }
-    __syncthreads();                                   // dK / dV row i complete (includes this step's j = i term)
-    if (t >= 64 && t < 192) dqkvs[t] = sv[SV_DK + (t - 64)];     // SV_DV follows SV_DK: columns 64..127 are dV
-    __syncthreads();
-    // ---- S9: dWqkv += dqkv (x) x ; dx += Wqkv^T dqkv (4 partial sums per output) ----
-    {
-      if (t < 192) {
-        const float g = dqkvs[t];
-        gbA += g;
-#pragma unroll
-        for (int k = 0; k < FD; ++k) gA[k] += g * xs[k];
-      }
-      float acc = 0.f;
-#pragma unroll 16
-      for (int r = 0; r < 48; ++r) acc += Wqkv[(wave * 48 + r) * FD + lane] * dqkvs[wave * 48 + r];
-      pbuf[wave * FD + lane] = acc;
-    }
-    __syncthreads();
-    // ---- S10: wave 0: gradient w.r.t. emb_i; carry A^T demb to step i-1 ----
-    if (wave == 0) {
-      float demb = dx + pbuf[lane] + pbuf[FD + lane] + pbuf[2 * FD + lane] + pbuf[3 * FD + lane];
-      if constexpr (DROP) demb = ((rowbits[lane >> 5] >> (lane & 31)) & 1u) ? demb * dm.scale : 0.f;      // through the PPE dropout
-      gsty += demb;                                    // style enters every emb (emb_0 = style, emb_i = A y + c + style)
-      dembs[lane] = demb;
-    }
-    __syncthreads();
-    if (wave == 0) {
-      float acc = 0.f;
-#pragma unroll 16
-      for (int r = 0; r < FD; ++r) acc += Am[r * FD + lane] * dembs[r];
-      carry = acc;
-    }
-    // dembs stays valid for the dA / dc accumulation of the next (earlier-time) iteration
-  }
-  // demb_0 belongs to emb_0 = style only: it must not reach dA / dc (no feedback produced emb_0) - nothing to do.
-
-  // ---- flush accumulators: this sequence's gradient block goes to its own slab (plain stores, every entry written exactly
-  // once); ff_decoder_fold_kernel sums the slabs in sequence order - deterministic, no atomics
-  float* dP = save + (int64_t)gridDim.x * T * SV_STRIDE + s * (int64_t)A2F_FF_PARAM_FLOATS;
-  if (t < 192) {
-    dP[A2F_FF_BQKV + t] = gbA;
-#pragma unroll
-    for (int k = 0; k < FD; ++k) dP[A2F_FF_WQKV + t * FD + k] = gA[k];
-  } else {
-    dP[A2F_FF_BO + (t - 192)] = gbA;
-#pragma unroll
-    for (int k = 0; k < FD; ++k) dP[A2F_FF_WO + (t - 192) * FD + k] = gA[k];
-  }
-  if (t < FFF) {
-    dP[A2F_FF_B1 + t] = gbB;
-#pragma unroll
-    for (int k = 0; k < FD; ++k) dP[A2F_FF_W1 + t * FD + k] = gB[k];
-  } else if (t < 192) {
-    dP[A2F_FF_C + (t - 128)] = gbB;
-#pragma unroll
-    for (int k = 0; k < FD; ++k) dP[A2F_FF_A + (t - 128) * FD + k] = gB[k];
-  }
-#pragma unroll
-  for (int k = 0; k < 32; ++k) dP[A2F_FF_W2 + (t & 63) * FFF + (t >> 6) * 32 + k] = gC[k];
-  if (wave == 0) {
-    dP[A2F_FF_B2 + lane] = gb2;
-    dP[A2F_FF_LN + 0 * FD + lane] = gg1;
-    dP[A2F_FF_LN + 1 * FD + lane] = gb1n;
-    dP[A2F_FF_LN + 2 * FD + lane] = gg2;
-    dP[A2F_FF_LN + 3 * FD + lane] = gb2n;
-    dP[A2F_FF_LN + 4 * FD + lane] = gg3;
-    dP[A2F_FF_LN + 5 * FD + lane] = gb3n;
-    dstyle[s * FD + lane] = gsty;
-  }
-}
-
 // LACC (launches that cover at most FF_BLK steps: every launch of the blocked form): the dK / dV accumulators of the launch's own keys live in LDS
 // ([key - i_lo][64] floats each, the 16-byte chunk index XORed with 4 (key & 3) so that the four key slots a 16-lane group touches hit four bank
 // quarters) instead of being read, added to and written back in global memory by every step - that round trip through L2 was 5.3 k of the 13.9 k clocks
 // of a step (round-3 stamps).  What earlier-launched (later-time) blocks left in the global rows through ff_bwd_rect_kernel is complete before this
 // launch; the helper wave parks it beside the step's saved rows and it is added when row i is finished.
-template <bool DROP, bool LACC>
+template <bool DROP>
 __global__ __launch_bounds__(FF_BWD2_THREADS, 1) void ff_decoder_bwd2_kernel(const float* __restrict__ P, const float* __restrict__ dy, int T,
                                                                               int period, float* __restrict__ save, float* __restrict__ grec,
                                                                               float* __restrict__ dcross, float* __restrict__ dstyle, const FFDrop dm,
                                                                               const float* __restrict__ nrec, int i_lo, int i_hi) {
+  constexpr bool LACC = true;      // every launch covers at most FF_BLK steps (the global read-add-write form of rounds 2-3 was deleted in round 5)
   // steps i_hi-1 .. i_lo of the reverse-time recurrence (the whole sequence: i_lo = 0, i_hi = T).  Blocked form: the attention sweep covers the keys
   // j >= i_lo only; the keys of earlier blocks enter dq through the precomputed Nt / n (nrec) and receive their dK / dV from ff_bwd_rect_kernel; the
   // state carried from launch to launch (feedback carry, LayerNorm / style sums) lives in this sequence's slab.
@@ -1256,15 +954,8 @@ __global__ __launch_bounds__(256) void ff_bwd_rect_kernel(float* __restrict__ sa
 }
 
 // dparams[i] = sum over sequences (fixed order) of the per-sequence slabs the backward kernel left behind `save`
-__global__ __launch_bounds__(256) void ff_decoder_fold_kernel(const float* __restrict__ slabs, int S, float* __restrict__ dP) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= A2F_FF_PARAM_FLOATS) return;
-  float acc = 0.f;
-  for (int s = 0; s < S; ++s) acc += slabs[(int64_t)s * A2F_FF_PARAM_FLOATS + i];
-  dP[i] = acc;
-}
-
 constexpr size_t FF_FWD_LDS = (size_t)(FD * 192 + 2 * FD * FD + 4 * FD + FFF + 4 * FD + FD + 2 * FD + 2 * FH * 2 + 8 * FHD * 64 + FD * FFF + 4 * FD + 32) * sizeof(float);
+// dparams[off + i] = sum over sequences (fixed order) of the per-sequence slabs the backward kernel left behind `save`
 __global__ __launch_bounds__(256) void ff_decoder_fold_range_kernel(const float* __restrict__ slabs, int S, float* __restrict__ dP, int off, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -1328,38 +1019,31 @@ static int ff_fwd_impl(const float* params, const float* pe, const float* cross,
 // Record form of the backward: the recurrence kernel (8 waves) leaves per-frame gradient factors in `grec`; the weight gradients are five
 // a2f_mm products over all S*T frames (bias gradients ride along as row sums), LayerNorm gradients are folded from the per-sequence slabs.
 static int ff_bwd2_run(const float* params, const float* dy, int64_t S, int64_t T, int32_t period, float* save, float* dparams, float* dcross,
-                       float* dstyle, const a2f::FFDrop& dm, bool drop, bool blocked, hipStream_t st) {
+                       float* dstyle, const a2f::FFDrop& dm, bool drop, hipStream_t st) {
   using namespace a2f;
-  constexpr size_t LDS = FF_BWD_LDS + (64 + 2 * (576 + FD + 16)) * sizeof(float);
   constexpr size_t LDS_LACC = FF_BWD_LDS + (64 + 2 * (576 + FD + 16 + 2 * FD) + 2 * FF_BLK * FD) * sizeof(float);      // + parked dK / dV rows + the block's accumulators
   static_assert(LDS_LACC <= 160 * 1024, "the LDS-accumulator form of the backward recurrence must fit one CU");
-  static bool attr_set[2][2] = {{false, false}, {false, false}};
-  auto kernel_of = [](bool dr, bool lacc) -> const void* {
-    return dr ? (lacc ? reinterpret_cast<const void*>(&ff_decoder_bwd2_kernel<true, true>) : reinterpret_cast<const void*>(&ff_decoder_bwd2_kernel<true, false>))
-              : (lacc ? reinterpret_cast<const void*>(&ff_decoder_bwd2_kernel<false, true>) : reinterpret_cast<const void*>(&ff_decoder_bwd2_kernel<false, false>));
-  };
-  static const bool lacc_on = [] { const char* e = getenv("A2F_FF_BWD_LACC"); return !(e && e[0] == '0'); }();      // A-B hook: 0 = global read-add-write accumulators
+  static bool attr_set[2] = {false, false};
   float* slabs = save + (size_t)S * T * SV_STRIDE;
   float* grec = slabs + (size_t)S * A2F_FF_PARAM_FLOATS;
   float* ws = grec + (size_t)S * T * FF_GREC;
   float* nrec = ws + FF_GEMM_WS_FLOATS;
   int launch_rc = A2F_OK;
   auto recurrence = [&](int lo, int hi) {
-    const bool lacc = lacc_on && hi - lo <= FF_BLK;
-    const size_t lds = lacc ? LDS_LACC : LDS;
-    if (!attr_set[drop][lacc]) {
-      hipError_t e = hipFuncSetAttribute(kernel_of(drop, lacc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!attr_set[drop]) {
+      const void* k = drop ? reinterpret_cast<const void*>(&ff_decoder_bwd2_kernel<true>) : reinterpret_cast<const void*>(&ff_decoder_bwd2_kernel<false>);
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LACC);
       if (e != hipSuccess) { launch_rc = set_err(A2F_ELAUNCH, "ff_decoder_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return; }
-      attr_set[drop][lacc] = true;
+      attr_set[drop] = true;
     }
-#define FF_BWD2_LAUNCH(DR, LA)                                                                                                                         \
-    hipLaunchKernelGGL((ff_decoder_bwd2_kernel<DR, LA>), dim3((unsigned)S), dim3(FF_BWD2_THREADS), lds, st, params, dy, (int)T, (int)period, save, grec, \
-                       dcross, dstyle, dm, (const float*)nrec, lo, hi)
-    if (drop) { if (lacc) FF_BWD2_LAUNCH(true, true); else FF_BWD2_LAUNCH(true, false); }
-    else      { if (lacc) FF_BWD2_LAUNCH(false, true); else FF_BWD2_LAUNCH(false, false); }
-#undef FF_BWD2_LAUNCH
+    if (drop)
+      hipLaunchKernelGGL((ff_decoder_bwd2_kernel<true>), dim3((unsigned)S), dim3(FF_BWD2_THREADS), LDS_LACC, st, params, dy, (int)T, (int)period, save, grec, dcross, dstyle, dm,
+                         (const float*)nrec, lo, hi);
+    else
+      hipLaunchKernelGGL((ff_decoder_bwd2_kernel<false>), dim3((unsigned)S), dim3(FF_BWD2_THREADS), LDS_LACC, st, params, dy, (int)T, (int)period, save, grec, dcross, dstyle, dm,
+                         (const float*)nrec, lo, hi);
   };
-  if (!blocked || T < FF_BLK_MIN) {
+  if (T < FF_BLK_MIN) {
     recurrence(0, (int)T);
   } else {
     const dim3 pg((unsigned)((T - FF_BLK + 63) / 64), FH, (unsigned)S);
@@ -1417,30 +1101,12 @@ static int ff_bwd_impl(const float* params, const float* dy, int64_t S, int64_t 
   A2F_CHECK_ARG(S > 0 && S < (1 << 20) && T > 0 && T < (1 << 20) && period > 0, "ff_decoder_bwd: S=%lld T=%lld period=%d", (long long)S, (long long)T, period);
   A2F_CHECK_ARG((((uintptr_t)save) & 255) == 0, "ff_decoder_bwd: save buffer must be 256-byte aligned");
   if (save_bytes < a2f_ff_save_bytes(S, T)) return set_err(A2F_EWORKSPACE, "ff_decoder_bwd: save buffer %zu < %zu", save_bytes, a2f_ff_save_bytes(S, T));
-  static bool attr_set[2] = {false, false};
   const bool drop = row_bits != nullptr;
-  if (!attr_set[drop]) {
-    const void* k = drop ? reinterpret_cast<const void*>(&ff_decoder_bwd_kernel<true>) : reinterpret_cast<const void*>(&ff_decoder_bwd_kernel<false>);
-    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FF_BWD_LDS);
-    if (e != hipSuccess) return set_err(A2F_ELAUNCH, "ff_decoder_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set[drop] = true;
-  }
   const FFDrop dm{row_bits, attn_bits, (int)a2f_attn_keep_words(T), keep_scale};
-  const char* form = getenv("A2F_FF_BWD");                                   // A-B hook, read per call: 1 = register-accumulator form
-  const bool legacy = form && form[0] == '1';
-  if (!legacy && (uint64_t)S * T * SV_STRIDE * 4ull < 0xFFFFFFF0ull)            // 2 = record form in one launch (no blocks)
-    return ff_bwd2_run(params, dy, S, T, period, (float*)save, dparams, dcross, dstyle, dm, drop, !(form && form[0] == '2'), (hipStream_t)stream);
-  if (drop)
-    hipLaunchKernelGGL(ff_decoder_bwd_kernel<true>, dim3((unsigned)S), dim3(FF_THREADS), FF_BWD_LDS, (hipStream_t)stream, params, dy, (int)T, (int)period,
-                       (float*)save, dcross, dstyle, dm);
-  else
-    hipLaunchKernelGGL(ff_decoder_bwd_kernel<false>, dim3((unsigned)S), dim3(FF_THREADS), FF_BWD_LDS, (hipStream_t)stream, params, dy, (int)T, (int)period,
-                       (float*)save, dcross, dstyle, dm);
-  A2F_CHECK_LAUNCH("ff_decoder_bwd");
-  hipLaunchKernelGGL(ff_decoder_fold_kernel, dim3((unsigned)cdiv(A2F_FF_PARAM_FLOATS, 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)save + (size_t)S * T * SV_STRIDE, (int)S, dparams);
-  A2F_CHECK_LAUNCH("ff_decoder_bwd fold");
-  return A2F_OK;
+  // record form: the recurrence leaves per-frame gradient factors, the weight gradients are products over all frames; blocks of FF_BLK steps from FF_BLK_MIN frames on
+  A2F_CHECK_ARG((uint64_t)S * T * SV_STRIDE * 4ull < 0xFFFFFFF0ull, "ff_decoder_bwd: S * T = %lld frames exceed the 4-GiB span of the saved rows (split the batch)",
+                (long long)(S * T));
+  return ff_bwd2_run(params, dy, S, T, period, (float*)save, dparams, dcross, dstyle, dm, drop, (hipStream_t)stream);
 }
 
 extern "C" int a2f_ff_decoder_fwd(const float* params, const float* pe, const float* cross, const float* style, int64_t S, int64_t T,

@@ -764,9 +764,8 @@ static int launch_img_t(const Args& a, hipStream_t st) {
 
 // both operands format 1; trans flags equal (NT: both k-contiguous, TN: both line-contiguous); checked by the caller (a2f_mm)
 int launch_img(const Args& a, bool tn, hipStream_t st) {
-  static const int shape16 = [] { const char* e = getenv("A2F_MM_IMG_MFMA"); return !(e && e[0] == '3'); }();       // A-B hook: 32 = the 32 x 32 x 16 form
   const bool chk = !tn && a.A.lps > 0 && (a.A.off < 0 || (long long)(a.A.lps - 1) * a.A.ld + a.A.off + a.K > a.A.seq_elems);      // padded windows of A
-  const int rc = tn ? launch_img_t<true>(a, st) : (chk ? launch_img16<true>(a, st) : shape16 ? launch_img16<false>(a, st) : launch_img_t<false>(a, st));
+  const int rc = tn ? launch_img_t<true>(a, st) : (chk ? launch_img16<true>(a, st) : launch_img16<false>(a, st));
   if (rc) return rc;
   if (!tn && a.c_colsum) {
     const int P = 2 * (int)cdiv(a.M, img::TB);

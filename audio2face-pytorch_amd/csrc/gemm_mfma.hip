@@ -678,7 +678,7 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   // 32-bit epilogue offsets (gemm_mfma.h tile_epilogue_band): every element offset of C / C2 / like-C aux, of the (m, ldaux) aux, of the keep words and
   // of one split-K slab, in bytes from its (per-batch) base, below 2^31
   {
-    static const bool off32 = [] { const char* e = getenv("A2F_MM_EPI32"); return !(e && e[0] == '0'); }();       // A-B hook
+    static const bool off32 = [] { const char* e = getenv("A2F_MM_EPI32"); return !(e && e[0] == '0'); }();       // TEST HOOK: 0 forces the 64-bit pointer form (the >= 2 GiB fallback) on small operands
     const long long lim = 0x80000000ll / 4;
     const long long M1 = d->M - 1;
     const long long c_max = (d->c_rows_per_seq > 0 ? (M1 / d->c_rows_per_seq) * d->c_seq_stride + (M1 % d->c_rows_per_seq) * d->ldc : M1 * d->ldc) + d->N;
@@ -690,7 +690,7 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   // tile order (tile_origin): panel-major when the B operand does not fit an XCD's L2 and panels re-read A less than row-major re-reads B
   a.group_n = 0;
   {
-    static const int forced = [] { const char* e = getenv("A2F_MM_GROUP_N"); return e ? atoi(e) : -1; }();      // A-B hook: 0 = always row-major
+    static const int forced = [] { const char* e = getenv("A2F_MM_GROUP_N"); return e ? atoi(e) : -1; }();      // TEST HOOK: 0 = always row-major (the two orders must give the same bits)
     const long long bn = d->N <= 64 ? 64 : 128;
     const long long b_bytes = (long long)d->N * d->K * 4, a_bytes = (long long)d->M * d->K * 4;
     const long long tiles_n = cdiv(d->N, bn), tiles_m = cdiv(d->M, 128);
@@ -712,13 +712,8 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   // (bf16x6: three images per operand = one workgroup per CU whatever the tile, so the 8-wave 128 x 128 form wins there too: 8.4 vs 10.6 ms
   // for the Audio2Mesh step)
   if (cfg == 3 && at && bt && d->precision != 2) cfg = (cdiv(d->M, 256) * cdiv(d->N, 128) * batch * split >= 200) ? 2 : 0;
-  {
-    const char* force = getenv("A2F_MM_CFG");                 // tuning / A-B hook: 0 | 1 | 2
-    if (force && force[0] >= '0' && force[0] <= '3') cfg = force[0] - '0';
-  }
   hipStream_t st = (hipStream_t)stream;
-  static const bool no_plain = [] { const char* e = getenv("A2F_MM_PLAIN"); return e && e[0] == '0'; }();     // A-B hook
-  const bool plain = !no_plain && a.A.lps == 0 && a.B.lps == 0 && (d->K % BK) == 0;
+  const bool plain = a.A.lps == 0 && a.B.lps == 0 && (d->K % BK) == 0;
   if (d->precision == 2) {                 // three images per operand: the 256 x 128 tile does not fit
     if (cfg == 2) cfg = 3;
     rc = cfg == 0 ? dispatch_layout<2, 0>(a, at, bt, plain, st) : cfg == 1 ? dispatch_layout<2, 1>(a, at, bt, plain, st) : dispatch_layout<2, 3>(a, at, bt, plain, st);

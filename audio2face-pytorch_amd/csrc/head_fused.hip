@@ -4,32 +4,19 @@
 //   rec, vel partial sums               (loss.py:29-40)
 //   G = dloss/dpred (registers only) -> dH = G W, dW = G^T H, dbias = colsum G
 //
-// HBM traffic is the algorithmic minimum: template and gt are read once, pred is written once
-// (3 x 60 276 B per frame); G is never materialised.  Everything else lives on chip:
+// HBM traffic is the algorithmic minimum: template and gt are read once, pred is written once (3 x 60 276 B per frame); G is never materialised.
+// One kernel, `head_x3_kernel` (section below): every product on the bf16 matrix pipe as a bf16x3 split product, fp32 everywhere else.  The exact-fp32 MFMA kernels of
+// rounds 1-2 (five tile shapes behind A2F_HEAD_CFG: 1.55-2.4 ms against 0.70 at B = 19 200) were deleted in round 5; the kernel contracts are pinned against the float64
+// emulator (tests/test_gpu_kernels.py), not against another kernel.
 //
-//  * grid = CG column groups x RG row groups (<= one workgroup per CU); a workgroup = 4 waves owns 512 columns
-//    (128 per wave, four 32-column MFMA chunks) and walks its row range in blocks of 32 frames;
-//  * LDS: W slice [512][K|1] (both the forward B-operand and the dH B-operand, odd pitch = conflict-free),
-//    H^T tile [64][33], per-wave G^T staging [32][33] (also the cross-wave dH reduction buffer);
-//  * f32-input MFMA 32x32x2 (exact fp32 fma chains).  The forward accumulator tile (column on the lane, rows in
-//    the 16 registers) IS the A-operand of dW += G^T H with no data movement (k-step q takes register q; the
-//    B-operand supplies the matching frame rows); dH = G W needs G with the row on the lane: one LDS transpose
-//    per chunk inside the wave (no barrier);
-//  * dW (128 VGPR/lane) and dbias stay in registers for the whole row range; dH is reduced across the 4 waves in
-//    LDS and leaves as one partial slab per column group; slabs are folded by small reduce kernels;
-//  * template/gt for chunk i+1 are requested before the MFMAs of chunk i (one wave per SIMD: ILP hides HBM).
-//
-// n = 15069 is odd, so rows are 4-byte aligned only: global accesses are dword per lane, two 128-byte row
-// segments per wave-instruction.
+// n = 15069 is odd, so rows are 4-byte aligned only: a tile row is fetched as ONE 1-KB run with a dword-multiple buffer load per lane.
 #include "a2f_common.h"
 #include <stdlib.h>
 
 namespace a2f {
 
-constexpr int HF_MAXCOLS = 512;       // widest column group (workspace sizing)
 constexpr int HF_ROWS = 32;           // frames per row block
 constexpr int HF_KP = 64;             // K padded (two 32-wide MFMA tiles)
-constexpr int HF_HP = 33;             // pitch of the [k][row] and [col][row] LDS tiles
 
 struct HeadArgs {
   const float* H; const float* W; const float* bias; const float* templ; const float* gt;
@@ -73,14 +60,6 @@ __device__ __forceinline__ void buf_store(rsrc_t r, int byte_off, float v, int s
 #ifndef X3_ISSUE_AT
 #define X3_ISSUE_AT 0
 #endif
-// dH = G W: 0 (default) = every wave contracts its own 32 columns for the whole 32 x 64 tile and the eight partial tiles are
-// folded through LDS; 1 = every wave contracts over ALL 256 columns of the workgroup for its own 16-row x 16-k output tile
-// (16x16x32 MFMAs fed from the eight per-wave G images after one barrier; no fp32 partials, no LDS fold) - parity-green
-// but measured SLOWER (0.787 vs 0.755 ms): the 24 MFMAs + 48 LDS reads + 64-byte slab pieces sit behind the barrier on the
-// block's critical path, where the fold has 8 reads and one 16-byte store
-#ifndef X3_DH_FULL
-#define X3_DH_FULL 0
-#endif
 __device__ __forceinline__ float buf_load_stream(rsrc_t r, int byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, X3_STREAM_LD));
 }
@@ -88,11 +67,6 @@ __device__ __forceinline__ void buf_store_stream(rsrc_t r, int byte_off, float v
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, X3_STREAM_ST);
 }
 
-// NW waves per workgroup, each owning CPW = 16/NW chunks of 32 columns.  NW = 8 (two waves per SIMD, <= 256 registers
-// each: 64 dW accumulators) hides LDS / HBM latency behind the partner wave's MFMAs and is used when the LDS budget
-// allows (K = 50); NW = 4 (one wave per SIMD, 128 dW accumulators) is the K = 64 configuration.
-// COLS columns per workgroup (512: one workgroup per CU; 256: half the LDS, two independent workgroups per CU whose
-// memory stalls and MFMA phases overlap each other), WPS = resident waves per SIMD the register budget is sized for.
 #ifdef HF_STAMPS
 #define HF_STAMP(var)                                                            \
   do {                                                                           \
@@ -104,371 +78,10 @@ __device__ __forceinline__ void buf_store_stream(rsrc_t r, int byte_off, float v
 #define HF_STAMP(var) do { } while (0)
 #endif
 
-template <int K, int NW, int COLS, int WPS>
-__global__ __launch_bounds__(64 * NW, WPS) void head_fused_kernel(const HeadArgs a) {
-  constexpr int HF_COLS = COLS;
-  constexpr int HF_THREADS = 64 * NW;
-  constexpr int CPW = COLS / (32 * NW);
-  constexpr int HF_WCOLS = 32 * CPW;
-  constexpr int PITCH = K | 1;
-  constexpr int WS_FLOATS = HF_COLS * PITCH + 64;
-  constexpr int HS_FLOATS = HF_KP * HF_HP;
-  constexpr int GS_FLOATS = HF_ROWS * HF_HP;          // per wave
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Ws = lds;
-  float* Hs = lds + WS_FLOATS;
-  float* Gs_all = Hs + HS_FLOATS;
-  // dedicated [NW][32][64] dH fold buffer when LDS allows: the fold then needs one barrier per row block instead of four
-  constexpr bool BIGRED = (WS_FLOATS + HS_FLOATS + NW * GS_FLOATS + NW * 2048) * 4 <= 160 * 1024;
-  float* redbig = Gs_all + NW * GS_FLOATS;
-
-  const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);          // scalar: keeps tile base addresses in SGPRs
-  const int cg = blockIdx.x % a.CG, rg = blockIdx.x / a.CG;
-  const int c0 = cg * HF_COLS;
-  const int n = a.n, B = a.B;
-  float* Gs = Gs_all + wave * GS_FLOATS;
-
-  // ---- stage the W slice (rows = columns of pred) and clear the padding ----
-  for (int e = t; e < HF_COLS * K; e += HF_THREADS) {
-    const int col = e / K, k = e - col * K;
-    const int gc = c0 + col;
-    Ws[col * PITCH + k] = gc < n ? a.W[(int64_t)gc * K + k] : 0.f;
-  }
-  if (PITCH != K)
-    for (int col = t; col < HF_COLS; col += HF_THREADS) Ws[col * PITCH + K] = 0.f;
-  if (t < 64) Ws[HF_COLS * PITCH + t] = 0.f;
-  for (int e = t; e < HS_FLOATS; e += HF_THREADS) Hs[e] = 0.f;        // rows K..63 of H^T stay zero for ever
-
-  float bias_r[CPW];
-  int colg[CPW];
-#pragma unroll
-  for (int ct = 0; ct < CPW; ++ct) {
-    colg[ct] = c0 + wave * HF_WCOLS + ct * 32 + l31;
-    bias_r[ct] = colg[ct] < n ? a.bias[colg[ct]] : 0.f;
-  }
-
-  f32x16 dW[CPW][2];
-  float db_acc[CPW];
-#pragma unroll
-  for (int ct = 0; ct < CPW; ++ct) {
-    db_acc[ct] = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dW[ct][kt][r] = 0.f;
-  }
-  double rec_d = 0.0, vel_d = 0.0;
-  unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, acc_t[6] = {0, 0, 0, 0, 0, 0};
-  (void)st0; (void)st1; (void)st2; (void)st3; (void)st4; (void)st5; (void)acc_t;                    // per-lane totals; fp32 partials are folded in once per row block
-
-  const int rb0 = (int)(((int64_t)rg * a.NRB) / a.RG);
-  const int rb1 = (int)(((int64_t)(rg + 1) * a.NRB) / a.RG);
-
-  // Tile addressing: wave-uniform tile base (SGPR pair) + 32-bit lane offset (4h*n + lane column) + r-dependent
-  // scalar row offset.  Out-of-range elements of boundary tiles read the tile's first element instead (always
-  // valid), so loads never branch; such elements are neutralised in the epilogue.
-  // LDS lane bases: every tile index below is (lane base) + (compile-time constant), so the constant lands in the
-  // ds_read/ds_write immediate-offset field instead of a per-row address register
-  const int lb_rowmajor = h * HF_HP + l31;             // [k or col][row]-tiles read along rows:   + 2*s*HF_HP
-  const int lb_colmajor = l31 * HF_HP + 4 * h;         // same tiles addressed by (lane column, row 4h + rr)
-  const int lb_wfwd = l31 * PITCH + h;                 // W slice as forward B operand:           + cl*PITCH + 2*s
-  const int lb_wbwd = h * PITCH + l31;                 // W slice as dH B operand:                + (cl + 2*s)*PITCH + 32*kt
-  const int lane_off = 4 * h * n + l31;
-  const int lane_off_t = 4 * h * (int)a.ldt + l31;
-  // (tc, gcur): template / gt tile of the chunk whose epilogue runs next.  They are refilled row-register by
-  // row-register during the backward MFMAs of the current chunk (their previous contents died in its epilogue).
-  float tc[16], gcur[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { tc[r] = 0.f; gcur[r] = 0.f; }
-  // one row-register (r) of a tile: the forms below interleave these with the MFMA stream so the vector-memory queue
-  // never backs up (32 back-to-back tile loads stall the issuing wave until the queue drains: measured, the memory time
-  // then ADDS to the matrix time instead of hiding under it)
-  auto issue_row = [&](int rb, int ct, int r, float* tt, float* gg) {
-    const int cl = wave * HF_WCOLS + ct * 32;
-    const rsrc_t gb = tile_rsrc(a.gt + ((int64_t)rb * HF_ROWS * n + (c0 + cl)));
-    const rsrc_t tb = tile_rsrc(a.templ + ((int64_t)rb * HF_ROWS * a.ldt + (c0 + cl)));
-    const int rlim = B - rb * HF_ROWS;
-    const int mcol = ((colg[ct] - n) >> 31) & ((rb - rb1) >> 31);
-    int lo = lane_off, lot = lane_off_t, h4 = 4 * h;
-    asm volatile("" : "+v"(lo), "+v"(lot), "+v"(h4));
-    const int rr = (r & 3) + 8 * (r >> 2);
-    const int inval = ~(mcol & ((rr + h4 - rlim) >> 31));
-    // (a scalar-soffset form - zero VALU per access on interior tiles - was measured 30 % SLOWER end to end: the uniform
-    //  interior/boundary branch per row splits the scheduling region; keep the branch-free per-lane offsets)
-#ifdef HF_ABL_NOLOAD
-    tt[r] = __int_as_float(inval & 0x3f800000); gg[r] = __int_as_float(lo & 0x3f000000);
-#else
-    tt[r] = buf_load(tb, (4 * (rr * (int)a.ldt + lot)) | inval);
-    gg[r] = buf_load(gb, (4 * (rr * n + lo)) | inval);
-#endif
-  };
-  auto issue_loads = [&](int rb, int ct, float* tc, float* gcur) {
-    const int cl = wave * HF_WCOLS + ct * 32;
-    {
-      const rsrc_t gb = tile_rsrc(a.gt + ((int64_t)rb * HF_ROWS * n + (c0 + cl)));
-      const rsrc_t tb = tile_rsrc(a.templ + ((int64_t)rb * HF_ROWS * a.ldt + (c0 + cl)));
-      const int rlim = B - rb * HF_ROWS;
-      // validity as integer masks (-1 valid / 0 invalid): pure ALU, so hipcc cannot turn the predication into branches
-      const int mcol = ((colg[ct] - n) >> 31) & ((rb - rb1) >> 31);
-      // opaque copies: stop LICM from hoisting 4 chunks x 16 rows x 3 arrays of per-lane offsets out of the row loop
-      // (that costs >200 VGPRs and spills); recomputing them is 2 VALU ops per element, hidden under the MFMAs
-      int lo = lane_off, lot = lane_off_t, h4 = 4 * h;
-      asm volatile("" : "+v"(lo), "+v"(lot), "+v"(h4));
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = (r & 3) + 8 * (r >> 2);         // compile-time part of the tile row; + 4h on the lane
-        const int inval = ~(mcol & ((rr + h4 - rlim) >> 31));             // -1 -> offset 0xFFFFFFFF -> load returns 0
-#ifdef HF_ABL_NOLOAD      // timing ablation only (wrong results): no template / gt traffic
-        tc[r] = __int_as_float(inval & 0x3f800000); gcur[r] = __int_as_float(lo & 0x3f000000);
-#else
-        tc[r] = buf_load(tb, (4 * (rr * (int)a.ldt + lot)) | inval);
-        gcur[r] = buf_load(gb, (4 * (rr * n + lo)) | inval);
-#endif
-      }
-    }
-  };
-  issue_loads(rb0, 0, tc, gcur);
-
-  // H tile of the NEXT row block travels in registers: requested at the top of a row block (older than every tile
-  // prefetch, so consuming it never drains the in-order vmcnt queue behind younger tile loads), written to LDS at the
-  // bottom.  A synchronous stage here cost a full HBM round trip per row block behind the tile prefetches.
-  constexpr bool LEAN = (WPS >= 2);                    // two waves per SIMD: 256 registers each -> no deferred stores, no H registers
-  constexpr int HPT = (HF_ROWS * K + HF_THREADS - 1) / HF_THREADS;
-  float hreg[HPT];
-  auto h_request = [&](int rb) {
-#pragma unroll
-    for (int i = 0; i < HPT; ++i) {
-      const int e = t + i * HF_THREADS;
-      const int row = e / K, k = e - row * K;
-      const int grow = rb * HF_ROWS + row;
-      hreg[i] = (e < HF_ROWS * K && grow < B && rb < rb1) ? a.H[(int64_t)grow * K + k] : 0.f;
-    }
-  };
-  auto h_commit = [&](int rb) {
-    (void)rb;
-#pragma unroll
-    for (int i = 0; i < HPT; ++i) {
-      const int e = t + i * HF_THREADS;
-      const int row = e / K, k = e - row * K;
-      if (e < HF_ROWS * K) Hs[k * HF_HP + row] = hreg[i];
-    }
-  };
-  h_request(rb0);
-  __syncthreads();                                     // W slice staged, Hs zeroed
-  h_commit(rb0);
-
-  for (int rb = rb0; rb < rb1; ++rb) {
-    HF_STAMP(st5);
-    __syncthreads();                                   // Hs of this row block is complete; reduction buffer is free
-    h_request(rb + 1);
-    HF_STAMP(st0);
-#ifdef HF_STAMPS
-    acc_t[4] += st0 - st5;
-#endif
-
-    f32x16 dH[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dH[kt][r] = 0.f;
-    float rec = 0.f, vel = 0.f;
-
-#pragma unroll
-    for (int ct = 0; ct < CPW; ++ct) {
-      const int cl = wave * HF_WCOLS + ct * 32;        // first column of the chunk inside the slice
-      // (chunks that lie wholly beyond column n run on zeros: straight-line code keeps the 160 accumulator
-      //  registers free of control-flow copies; only the last column group has such chunks)
-      f32x16 acc;
-      float pv[16];                                     // pred values / store offsets of this chunk, stored during the dH MFMAs
-      int so[16];
-      rsrc_t pbuf;
-      // opaque zero: keeps hipcc from caching this row block's H fragments (57 VGPRs) across the chunks of the wave;
-      // re-reading them from LDS per chunk is free (the LDS pipe is far from saturated)
-      int hz = 0;
-      asm volatile("" : "+v"(hz));
-      const float* Hq = Hs + hz;
-      const float* Wc = Ws + cl * PITCH + hz;           // this chunk's rows of the W slice
-      HF_STAMP(st0);
-      {
-        // ---- forward tile: acc[row][col] = sum_k H[row][k] W[col][k] ----
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < K / 2; ++s) {
-          const float av = Hq[lb_rowmajor + 2 * s * HF_HP];
-          const float bv = Wc[lb_wfwd + 2 * s];
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-        }
-        HF_STAMP(st1);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- epilogue: pred, loss partials, G (in place of acc) ----
-        const bool colok = colg[ct] < n;
-        const bool interior = ((rb + 1) * HF_ROWS <= B) && (c0 + cl + 32 <= n);     // wave-uniform
-        const int rlim = B - rb * HF_ROWS;
-        const int mint = interior ? -1 : 0;            // whole tile inside the matrix (wave-uniform)
-        const int mcolv = (colg[ct] - n) >> 31;        // -1 where this lane's column exists
-        pbuf = tile_rsrc(a.pred + ((int64_t)rb * HF_ROWS * n + (c0 + cl)));
-        int lo = lane_off, h4 = 4 * h;
-        asm volatile("" : "+v"(lo), "+v"(h4));         // see issue_loads: keep store offsets local to the chunk
-        float gsum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const int rr = (r & 3) + 8 * (r >> 2);
-          const float p0 = acc[r] + bias_r[ct] + tc[r];
-          const float p1 = acc[r + 1] + bias_r[ct] + tc[r + 1];
-          const int so0 = (4 * (rr * n + lo)) | ~(mint | (mcolv & ((rr + h4 - rlim) >> 31)));
-          const int so1 = (4 * ((rr + 1) * n + lo)) | ~(mint | (mcolv & ((rr + 1 + h4 - rlim) >> 31)));
-          if (!LEAN) { pv[r] = p0; pv[r + 1] = p1; so[r] = so0; so[r + 1] = so1; }
-#ifdef HF_ABL_NOSTORE
-          else { asm volatile("" :: "v"(p0), "v"(p1), "v"(so0), "v"(so1)); }
-#else
-          else { buf_store(pbuf, so0, p0); buf_store(pbuf, so1, p1); }
-#endif
-
-          const bool in_loss = colok && (rb * HF_ROWS + rr + h4 + 1 < a.Bloss);
-          const float d0 = in_loss ? p0 - gcur[r] : 0.f;
-          const float d1 = in_loss ? p1 - gcur[r + 1] : 0.f;
-          const float dv = d1 - d0;
-          rec += d0 * d0 + d1 * d1;
-          vel += dv * dv;
-          const float g0 = a.cr * d0 - a.cv * dv;
-          const float g1 = a.cr * d1 + a.cv * dv;
-          acc[r] = g0;
-          acc[r + 1] = g1;
-          gsum += g0 + g1;
-        }
-        db_acc[ct] += gsum;
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // template / gt registers are free again: request the next chunk's tile now, so the loads fly under the
-      // 64 backward MFMAs of this chunk (one wave per SIMD: ILP, not occupancy, hides HBM latency)
-      HF_STAMP(st2);
-      const int lin1 = ct + 1;                          // next chunk in linear order
-      const int rbn = rb + lin1 / CPW, ctn = lin1 % CPW;
-      {
-        // ---- dW[col][k] += sum_row G[row][col] H[row][k]: accumulator register q is the A operand of k-step q ----
-#ifdef HF_ABL_NODW        // timing ablation only: no dW product
-        asm volatile("" :: "v"(acc[0]), "v"(acc[5]), "v"(acc[10]), "v"(acc[15]));
-#else
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int rrc = (q & 3) + 8 * (q >> 2);
-#pragma unroll
-          for (int kt = 0; kt < 2; ++kt) {
-            const float bv = Hq[lb_colmajor + kt * 32 * HF_HP + rrc];
-            dW[ct][kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[q], bv, dW[ct][kt], 0, 0, 0);
-          }
-          issue_row(rbn, ctn, q, tc, gcur);             // two tile loads ride behind each pair of MFMAs
-        }
-#endif
-        HF_STAMP(st3);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- dH[row][k] += sum_col G[row][col] W[col][k]: transpose G through the wave's LDS tile ----
-#ifndef HF_ABL_NODH       // timing ablation only: no dH product
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Gs[lb_colmajor + (r & 3) + 8 * (r >> 2)] = acc[r];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          const float av = Gs[lb_rowmajor + 2 * s * HF_HP];
-#pragma unroll
-          for (int kt = 0; kt < 2; ++kt) {
-            const float bv = Wc[lb_wbwd + 2 * s * PITCH + kt * 32];
-            dH[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, dH[kt], 0, 0, 0);
-          }
-#ifdef HF_ABL_NOSTORE
-          if (!LEAN) asm volatile("" :: "v"(pv[s]), "v"(so[s]));
-#else
-          if (!LEAN) buf_store(pbuf, so[s], pv[s]);     // one pred row-register per k-step
-#endif
-        }
-#endif
-      }
-      HF_STAMP(st4);
-#ifdef HF_STAMPS
-      acc_t[0] += st1 - st0; acc_t[1] += st2 - st1; acc_t[2] += st3 - st2; acc_t[3] += st4 - st3;
-#endif
-    }
-
-    HF_STAMP(st5);
-    rec_d += (double)rec;
-    vel_d += (double)vel;
-    // ---- fold the four waves' dH partials (two 32-wide halves) and emit this column group's slab rows ----
-    if (BIGRED) {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) redbig[(wave * 2048 + 4 * h * 64 + kt * 32 + l31) + ((r & 3) + 8 * (r >> 2)) * 64] = dH[kt][r];
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 2048 / HF_THREADS; ++i) {
-        const int e = t + i * HF_THREADS;               // 0..2047: row = e/64, k = e%64
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) v += redbig[w * 2048 + e];
-        const int row = rb * HF_ROWS + (e >> 6);
-        if (row < B && (e & 63) < ((K + 3) & ~3)) a.dH_slab[((int64_t)cg * B + row) * HF_KP + (e & 63)] = v;   // quads the fold reads
-      }
-    } else {
-      float* red = Gs_all;                              // [NW][32][32] floats, reuses the staging tiles
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[(wave * 1024 + 4 * h * 32 + l31) + ((r & 3) + 8 * (r >> 2)) * 32] = dH[kt][r];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 1024 / HF_THREADS; ++i) {
-          const int e = t + i * HF_THREADS;             // 0..1023: row = e/32, k = e%32
-          float v = 0.f;
-#pragma unroll
-          for (int w = 0; w < NW; ++w) v += red[w * 1024 + e];
-          const int row = rb * HF_ROWS + (e >> 5);
-          if (row < B && kt * 32 + (e & 31) < ((K + 3) & ~3)) a.dH_slab[((int64_t)cg * B + row) * HF_KP + kt * 32 + (e & 31)] = v;
-        }
-      }
-    }
-    h_commit(rb + 1);                                  // every wave passed a barrier after its last Hs read of this block
-    HF_STAMP(st0);
-#ifdef HF_STAMPS
-    acc_t[5] += st0 - st5;
-#endif
-  }
-
-#ifdef HF_STAMPS
-  if (lane == 0 && a.dbg)
-    for (int i = 0; i < 6; ++i) a.dbg[((int64_t)blockIdx.x * NW + wave) * 8 + i] = acc_t[i];
-#endif
-  // ---- workgroup epilogue: dW / dbias slabs of this row group, loss partials ----
-  const int64_t ncols_pad = (int64_t)a.CG * HF_COLS;
-#pragma unroll
-  for (int ct = 0; ct < CPW; ++ct) {
-    const int cl = wave * HF_WCOLS + ct * 32;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        a.dW_slab[((int64_t)rg * ncols_pad + c0 + cl + rho(r, h)) * HF_KP + kt * 32 + l31] = dW[ct][kt][r];
-    const float s = db_acc[ct] + __shfl_xor(db_acc[ct], 32, 64);
-    if (h == 0) a.db_slab[(int64_t)rg * ncols_pad + c0 + cl + l31] = s;
-  }
-  __syncthreads();                                      // staging tiles are free: reuse them for the loss fold
-  double* lsum = reinterpret_cast<double*>(Gs_all);     // [2][4]; byte offset of Gs_all is a multiple of 8
-  const double rs = wave_sum_d(rec_d), vs = wave_sum_d(vel_d);
-  if (lane == 0) { lsum[wave] = rs; lsum[NW + wave] = vs; }
-  __syncthreads();
-  if (t == 0) {
-    double r = 0.0, v = 0.0;
-    for (int w = 0; w < NW; ++w) { r += lsum[w]; v += lsum[NW + w]; }
-    a.loss_part[2 * blockIdx.x] = r;
-    a.loss_part[2 * blockIdx.x + 1] = v;
-  }
-}
-
 // =====================================================================================================================
-// Split-precision variant (configuration 5): the same pass with every product on the bf16 matrix pipe.
+// The kernel: the whole pass with every product on the bf16 matrix pipe.
 //
-// The ablation builds show the fp32-MFMA kernel is bound by the matrix pipe (compute-only 1.10 ms of 1.31 ms at
+// The ablation builds showed the (deleted) fp32-MFMA kernel bound by the matrix pipe (compute-only 1.10 ms of 1.31 ms at
 // B = 19 200): v_mfma_f32_32x32x2_f32 retires 2 k per 64 cycles, v_mfma_f32_32x32x16_bf16 16 k per 32 cycles.  Every fp32
 // operand x is split as x = hi + lo with hi = bf16(x) (round to nearest even) and lo = bf16(x - hi), and a product is
 // evaluated as lo*hi' + hi*lo' + hi*hi' with fp32 accumulation: three MFMAs, 5.3x less matrix time than the fp32 form,
@@ -513,7 +126,7 @@ __device__ __forceinline__ f32x16 x3_mac(u32x4_t ah, u32x4_t al, u32x4_t bh, u32
   return x3_mfma(ah, bh, c);
 }
 
-constexpr int X3_NW = 8, X3_COLS = 256, X3_THREADS = 64 * X3_NW;
+constexpr int X3_NW = 8, X3_THREADS = 64 * X3_NW;
 constexpr int X3_HROW_PITCH = 72 * 2;                 // bytes per row of the row-major H image   [split][row][k]   (k padded to 72)
 constexpr int X3_HCOL_PITCH = 40 * 2;                 // bytes per k of the k-major H image        [split][k][p(row)] (rows padded to 40)
 constexpr int X3_HROW_BYTES = 2 * HF_ROWS * X3_HROW_PITCH;      // 9216
@@ -551,23 +164,9 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
   // G as bf16 hi / lo images [32 cols][32 rows] (72-byte pitch) inside this wave's fold slice: written from the
   // accumulator layout (column on the lane), read back with the row on the lane by transposing LDS reads
   char* gimg_w = reinterpret_cast<char*>(red + wave * (HF_ROWS * HF_KP)) + l31 * X3_GIMG_PITCH + 8 * h;             // + 16 g  (+ X3_GIMG_BYTES: lo)
-#if X3_DH_FULL
-  // full-contraction dH: wave w owns the output tile rows 16 (w & 1) .. + 15, k = 16 (w >> 1) .. + 15 and reads EVERY wave's G
-  // image: A fragment of column chunk c (16x16x32: lane l holds row l & 15, columns 8 (l >> 4) .. + 7 of the chunk) = two
-  // transposing reads, lane 4q + p of a 16-lane group supplying column 8 (l >> 4) + 4u + q, rows 16 (w & 1) + 4p .. + 3
-  const char* gimg_r = reinterpret_cast<const char*>(red) + (8 * (lane >> 4) + ((lane & 15) >> 2)) * X3_GIMG_PITCH
-                       + (16 * (wave & 1) + 4 * (lane & 3)) * 2;                           // + c * 8192 + 4 u * pitch (+ X3_GIMG_BYTES: lo)
-#else
   const char* gimg_r = reinterpret_cast<const char*>(red + wave * (HF_ROWS * HF_KP)) + (8 * h + ((lane & 15) >> 2)) * X3_GIMG_PITCH
                        + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;                                             // + (16 s + 4 u) * pitch
-#endif
-#if X3_DH_FULL
-  // dH B fragments [k quarter][column chunk][split][lane] x 16 B: W[c0 + 32 c + 8 (l >> 4) + j][16 kq + (l & 15)]
-  u32x4_t* wb_all = reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(red + X3_RED_FLOATS)) + lane;       // + 64 * ((kq * 8 + c) * 2 + split)
-  const u32x4_t* wbq = wb_all + 64 * ((wave >> 1) * 16);                                                   // this wave's k quarter: + 64 * (2 c + split)
-#else
   u32x4_t* wbl = reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(red + X3_RED_FLOATS) + wave * (8 * 64 * 16)) + lane;   // + 64 * ((kt*2 + s)*2 + split)
-#endif
 
   // both H images start as zeros: k >= K and rows >= B never get written
   for (int e = t; e < (X3_HROW_BYTES + X3_HCOL_BYTES) / 4; e += X3_THREADS) reinterpret_cast<unsigned*>(Hrow)[e] = 0u;
@@ -588,24 +187,6 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
     }
   // dH B operand [kt][s]: W[c0 + cl + 16s + 8h + j][32kt + l31]; parked in this wave's private LDS region (lane-linear
   // 16-byte fragments: one conflict-free ds_read_b128 each) - 32 fewer live registers than keeping them next to wf
-#if X3_DH_FULL
-  // wave w fills k quarter w >> 1, column chunks 4 (w & 1) .. + 3 (the two waves of a quarter share what they read later)
-#pragma unroll
-  for (int cc = 0; cc < 4; ++cc) {
-    const int c = 4 * (wave & 1) + cc, kq = wave >> 1;
-    u32x4_t fh, fl;
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-      const int k = 16 * kq + (lane & 15), col = c0 + 32 * c + 8 * (lane >> 4) + j;
-      const float v0 = buf_load(wres, k < K ? (col * K + k) * 4 : -1), v1 = buf_load(wres, k < K ? ((col + 1) * K + k) * 4 : -1);
-      unsigned hi, lo;
-      x3_split2(v0, v1, hi, lo);
-      fh[j >> 1] = hi; fl[j >> 1] = lo;
-    }
-    wb_all[64 * ((kq * 8 + c) * 2 + 0)] = fh;
-    wb_all[64 * ((kq * 8 + c) * 2 + 1)] = fl;
-  }
-#else
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -622,7 +203,6 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
       wbl[64 * ((kt * 2 + s) * 2 + 0)] = fh;
       wbl[64 * ((kt * 2 + s) * 2 + 1)] = fl;
     }
-#endif
   const int cend = (c0 + a.CW < n) ? c0 + a.CW : n;      // first column this group does not own
   const float bias_r = colg < cend ? a.bias[colg] : 0.f;
 
@@ -853,44 +433,6 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
 #endif
 
     X3_PHASE(5);                                        // 5: G split / transpose store + dW products (+ next tile requests)
-#if X3_DH_FULL
-    // ---- dH[row][k] = sum over the workgroup's 256 columns of G[row][col] W[col][k]: this wave's 16 x 16 output tile ----
-    X3_PHASE(6);
-    __syncthreads();                                    // every wave's G images are complete
-    {
-      f32x4 dh = {0.f, 0.f, 0.f, 0.f};
-#ifndef X3_ABL_NODH
-#pragma unroll
-      for (int c = 0; c < X3_NW; ++c) {
-        u32x4_t gh, gl;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const u32x2_t xh = x3_tr_read(gimg_r + c * 8192 + 4 * u * X3_GIMG_PITCH);
-          const u32x2_t xl = x3_tr_read(gimg_r + c * 8192 + X3_GIMG_BYTES + 4 * u * X3_GIMG_PITCH);
-          gh[2 * u] = xh[0]; gh[2 * u + 1] = xh[1];
-          gl[2 * u] = xl[0]; gl[2 * u + 1] = xl[1];
-        }
-        const u32x4_t bh = wbq[64 * (2 * c)], bl = wbq[64 * (2 * c + 1)];
-        dh = x3_mfma16(gl, bh, dh);
-        dh = x3_mfma16(gh, bl, dh);
-        dh = x3_mfma16(gh, bh, dh);
-      }
-#endif
-      // C layout of the 16x16 tile: lane l holds k = 16 kq + (l & 15), rows 16 (w & 1) + 4 (l >> 4) + r; slab rows are K4 * 4
-      // floats back to back (every line of the slab is written whole by the eight waves of the block)
-      constexpr int KS = (K + 3) & ~3;
-      const int kk = 16 * (wave >> 1) + (lane & 15);
-#ifndef X3_ABL_NOSLAB
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rb * HF_ROWS + 16 * (wave & 1) + 4 * (lane >> 4) + r;
-        if (kk < KS && row < B) a.dH_slab[((int64_t)cg * B + row) * KS + kk] = dh[r];
-      }
-#else
-      asm volatile("" :: "v"(dh));
-#endif
-    }
-#else
     // ---- dH[row][k] += sum_col G[row][col] W[col][k]: G with the row on the lane, through the wave's LDS tile ----
     f32x16 dH[2];
 #pragma unroll
@@ -946,7 +488,6 @@ __global__ __launch_bounds__(X3_THREADS, 2) void head_x3_kernel(const HeadArgs a
 #else
     asm volatile("" :: "v"(dH[0][0]), "v"(dH[1][7]));
     __syncthreads();
-#endif
 #endif
     X3_PHASE(7);                                        // 7: fold barrier + fold
 #ifndef X3_ABL_NOHC
@@ -1107,26 +648,6 @@ static int g_prof_n = 0;
 static hipEvent_t g_prof_ev[64][2];
 static bool g_prof_init = false;
 
-template <int K, int NW, int COLS, int WPS>
-static int head_launch(const HeadArgs& a, const HeadPlan& p, hipStream_t s) {
-  constexpr int PITCH = K | 1;
-  size_t lds_floats = (size_t)(COLS * PITCH + 64 + HF_KP * HF_HP + NW * HF_ROWS * HF_HP);
-  if ((lds_floats + NW * 2048) * 4 <= 160 * 1024) lds_floats += NW * 2048;          // BIGRED (see kernel)
-  const size_t lds_bytes = lds_floats * sizeof(float);
-  static bool attr_set = false;       // idempotent; a benign race sets the same value
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fused_kernel<K, NW, COLS, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds_bytes);
-    if (e != hipSuccess) return set_err(A2F_ELAUNCH, "head_fused: hipFuncSetAttribute(%zu B LDS): %s", lds_bytes, hipGetErrorString(e));
-    attr_set = true;
-  }
-  const bool prof = g_prof_on && g_prof_n < 64;
-  if (prof) hipEventRecord(g_prof_ev[g_prof_n][0], s);
-  hipLaunchKernelGGL((head_fused_kernel<K, NW, COLS, WPS>), dim3((unsigned)(p.CG * p.RG)), dim3(64 * NW), lds_bytes, s, a);
-  if (prof) { hipEventRecord(g_prof_ev[g_prof_n][1], s); ++g_prof_n; }
-  return A2F_OK;
-}
-
 template <int K, bool PRED>
 static int head_x3_launch(const HeadArgs& a, const HeadPlan& p, hipStream_t s) {
   static bool attr_set = false;
@@ -1145,17 +666,6 @@ static int head_x3_launch(const HeadArgs& a, const HeadPlan& p, hipStream_t s) {
 }  // namespace a2f
 
 namespace a2f {
-// kernel configuration: 0 = 512 columns x 8 waves, 1 = 512 x 4 waves, 2 = 256 x 4 (two workgroups per CU),
-// 3 = 384 x 4 (no spills at one wave per SIMD), 4 = 256 x 8 (two waves per SIMD, 183 VGPRs, no spills; K = 50 only):
-// all exact-fp32 MFMA; 5 = 256 x 8 with bf16x3 split-precision products (default).  A2F_HEAD_CFG overrides.
-static int head_cfg(int64_t K) {
-  static const int env = [] { const char* e = getenv("A2F_HEAD_CFG"); return e ? atoi(e) : -1; }();
-  if (env == 5 || env < 0 || env > 5) return 5;
-  if (K == 64) return (env >= 1 && env <= 3) ? env : 3;
-  // fp32 variants measured on MI355X (B = 19200, K = 50, kernel + slab folds): cfg4 1.55 ms, cfg3 1.61, cfg1 1.71-1.79, cfg0 2.0+, cfg2 2.4
-  return env;
-}
-static bool cfg_is_x3(int64_t K) { return head_cfg(K) == 5; }
 // head_x3: narrow the column groups so that CG x RG workgroups fill all 256 CUs (n = 15069: 59 x 4 = 236 -> 64 x 4 = 256
 // with 236-column groups: +5.6 % streaming rate measured)
 static void head_plan_balance(HeadPlan& p, int64_t n) {
@@ -1169,15 +679,11 @@ static void head_plan_balance(HeadPlan& p, int64_t n) {
   p.CG = cg; p.CW = cw;
 }
 static HeadPlan head_plan_for(int64_t B, int64_t n, int64_t K) {
-  const int cfg = head_cfg(K);
-  if (cfg == 5) {
-    HeadPlan q = head_plan(B, n, 256, 256);
-    head_plan_balance(q, n);
-    head_layout(q, B);
-    return q;
-  }
-  return cfg == 2 ? head_plan(B, n, 256, (K == 64) ? 256 : 512) : cfg == 3 ? head_plan(B, n, 384, 256)
-       : (cfg == 4 || cfg == 5) ? head_plan(B, n, 256, 256) : head_plan(B, n, 512, 256);
+  (void)K;
+  HeadPlan q = head_plan(B, n, 256, 256);
+  head_plan_balance(q, n);
+  head_layout(q, B);
+  return q;
 }
 }  // namespace a2f
 
@@ -1221,7 +727,6 @@ extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias,
                               a2f_stream_t stream) {
   using namespace a2f;
   A2F_CHECK_ARG(H && W && bias && templ && gt && out3 && dH && dW && dbias && ws, "head_fused: null pointer");
-  A2F_CHECK_ARG(pred != nullptr || head_cfg(K) == 5, "head_fused: pred may only be NULL (no prediction written: a training step that reads the loss alone) on the x3 kernel");
   A2F_CHECK_ARG(K == 50 || K == 64, "head_fused: K=%lld unsupported (50: VOCA/Audio2Mesh bottleneck, 64: FaceFormer)", (long long)K);
   A2F_CHECK_ARG(B >= 2 && B < (1 << 30), "head_fused: B=%lld", (long long)B);
   A2F_CHECK_ARG(Bloss >= 2 && (Bloss % 2) == 0 && Bloss <= B, "head_fused: Bloss=%lld must be even, >= 2 and <= B (loss.py:13-15,33-35)", (long long)Bloss);
@@ -1229,8 +734,7 @@ extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias,
   A2F_CHECK_ARG(template_rows >= 1 && template_rows <= B && B % template_rows == 0, "head_fused: template_rows=%lld must divide B=%lld",
                 (long long)template_rows, (long long)B);
   const bool per_seq = template_rows != 1 && template_rows != B;          // one template row per run of B / template_rows frames
-  A2F_CHECK_ARG(!per_seq || (cfg_is_x3(K) && B < (1 << 22) && template_rows * n < (1 << 28)),
-                "head_fused: per-sequence template rows need the bf16x3 kernel (A2F_HEAD_CFG unset or 5), B < 2^22");
+  A2F_CHECK_ARG(!per_seq || (B < (1 << 22) && template_rows * n < (1 << 28)), "head_fused: per-sequence template rows need B < 2^22");
   const HeadPlan p = head_plan_for(B, n, K);
   if (ws_bytes < p.total) return set_err(A2F_EWORKSPACE, "head_fused: workspace %zu < %zu", ws_bytes, p.total);
   hipStream_t s = (hipStream_t)stream;
@@ -1243,19 +747,13 @@ extern "C" int a2f_head_fused(const float* H, const float* W, const float* bias,
   a.ldt = template_rows == B ? n : 0;
   a.rpt = per_seq ? (int)(B / template_rows) : 0; a.ntempl = (int)template_rows;
   a.inv_rpt = per_seq ? 1.0f / (float)a.rpt : 0.f;
-  a.ldh = cfg_is_x3(K) ? (int)((K + 3) & ~(int64_t)3) : HF_KP;
+  a.ldh = (int)((K + 3) & ~(int64_t)3);
   a.B = (int)B; a.Bloss = (int)Bloss; a.n = (int)n; a.CG = p.CG; a.RG = p.RG; a.NRB = p.NRB; a.CW = p.CW;
   const double V = (double)(n / 3);
   a.cr = (float)(2.0 * k_rec / ((double)Bloss * V));
   a.cv = (float)(2.0 * k_vel / ((double)(Bloss / 2) * V));
-  const int cfg = head_cfg(K);
-  int rc;
-  if (cfg == 5) rc = K == 50 ? (pred ? head_x3_launch<50, true>(a, p, s) : head_x3_launch<50, false>(a, p, s))
-                             : (pred ? head_x3_launch<64, true>(a, p, s) : head_x3_launch<64, false>(a, p, s));
-  else if (K == 50) rc = cfg == 0 ? head_launch<50, 8, 512, 2>(a, p, s) : cfg == 1 ? head_launch<50, 4, 512, 1>(a, p, s)
-                  : cfg == 2 ? head_launch<50, 4, 256, 2>(a, p, s) : cfg == 4 ? head_launch<50, 8, 256, 2>(a, p, s)
-                  : head_launch<50, 4, 384, 1>(a, p, s);
-  else rc = cfg == 2 ? head_launch<64, 4, 256, 1>(a, p, s) : cfg == 3 ? head_launch<64, 4, 384, 1>(a, p, s) : head_launch<64, 4, 512, 1>(a, p, s);
+  const int rc = K == 50 ? (pred ? head_x3_launch<50, true>(a, p, s) : head_x3_launch<50, false>(a, p, s))
+                         : (pred ? head_x3_launch<64, true>(a, p, s) : head_x3_launch<64, false>(a, p, s));
   if (rc != A2F_OK) return rc;
   const int64_t ncols_pad = (int64_t)p.CG * p.CW;
   {

@@ -16,17 +16,14 @@ from .ops import MM_ACT_GELU, MM_ACT_GELU_SAVE_GRAD, MM_ACT_NONE, MM_AUX_ADD, MM
 
 LN_EPS = 1e-5
 import os as _os
-GELU_SAVED = _os.environ.get("A2F_GELU_SAVED", "1") != "0"       # A-B hook: 0 = pre-activation saved + streaming GELU' pass in the backward
-FUSED_QKV = _os.environ.get("A2F_FUSED_QKV", "1") != "0"         # A-B hook: 0 = three launches per projection group instead of one
-POSCONV_WGRAD_T = _os.environ.get("A2F_POSCONV_WGRAD_T", "1") != "0"   # A-B hook: 0 = positional-conv weight gradient with the 48 channels on the m axis
-POSCONV_KERNEL = _os.environ.get("A2F_POSCONV_KERNEL", "1") != "0"     # A-B hook: 0 = the positional convolution as batched windowed a2f_mm launches (rounds 2-4)
 
-
-MM_IMG = _os.environ.get("A2F_MM_IMG", "1") != "0"               # A-B hook: 0 = the Transformer layers' products on the fp32-operand kernels
-ATTN_IMG = _os.environ.get("A2F_ATTN_IMG", "1") != "0"            # A-B hook: 0 = the attention kernels read fp32 q|k|v / dctx and convert them tile by tile
-WIMG_CACHE = _os.environ.get("A2F_WIMG_CACHE", "1") != "0"        # A-B hook: 0 = every layer call re-splits its weights
+# Module switches (plain attributes: the tests set them; none is an environment knob).  Rounds 2-4 carried an A-B variant behind most forms below (pre-activation
+# saved + streaming GELU' pass, three q / k / v launches, the positional convolution as batched a2f_mm launches, attention on fp32 q|k|v beside image GEMMs ...):
+# measured slower every time they were compared (docs/DESIGN_rounds_1-3.md) and deleted in round 5.
+MM_IMG = True                    # the Transformer layers' and the feature-encoder stack's products on split-32 image operands (from IMG_MIN_ROWS rows)
+WIMG_CACHE = True                # a layer's weight images are built once per state of the weights
 WIMG_VERIFY = _os.environ.get("A2F_WIMG_VERIFY") == "1"           # debug guard: every cache hit re-splits the weights and compares (raises on stale images)
-WEIGHTS_EPOCH = 0            # bumped by whoever rewrites parameters behind torch's back (trainer.FlatAdam.step)
+WEIGHTS_EPOCH = 0                # bumped by whoever rewrites parameters behind torch's back (trainer.FlatAdam.step)
 
 
 def bump_weights_epoch():
@@ -34,13 +31,13 @@ def bump_weights_epoch():
     WEIGHTS_EPOCH += 1
 
 
-IMG_MIN_ROWS = int(_os.environ.get("A2F_MM_IMG_MIN_ROWS", "2048"))   # below this many rows the 256 x 256 image tiles leave the chip empty: fp32-operand kernels
+IMG_MIN_ROWS = 2048            # below this many rows the 256 x 256 image tiles leave the chip empty: fp32-operand kernels
 # Weight gradients on a second stream beside the data-gradient chain.  History: paid 1 ms of 157 in round 2 (tile tails of the 128 x 128 kernels filled each
 # other); with the 256 x 256 image kernels on the unsplit batch it measured 131.0 (on) vs 129.9 ms (off) and, while every TrainStep of a process still made its
 # own capture stream, aliased a hardware queue inside the full bench run (+25 ms): off.  Since the step runs as two half-batches (19 200 rows: the N = 768
 # launches have 225 tiles for 256 CUs) the lane fills those idle CUs: 122.6 -> 119.8 ms standalone, 119.2 -> 117.4 ms inside the full bench run, 12 x 3000
-# 206.8 -> 204.9 ms, batch 1 17.0 -> 16.6 ms (same box each, one capture stream per device): ON again (A2F_WGRAD_STREAM=0 switches it off).
-WGRAD_STREAM = _os.environ.get("A2F_WGRAD_STREAM", "1") != "0"
+# 206.8 -> 204.9 ms, batch 1 17.0 -> 16.6 ms (same box each, one capture stream per device): ON again.
+WGRAD_STREAM = True
 _wgrad_streams = {}
 
 
@@ -211,11 +208,7 @@ class EncoderLayerFn(torch.autograd.Function):
         # q | k | v as ONE product against the stacked (3d, d) weight (a 7 MB copy per call): one launch and one tile tail instead of three
         Wqkv, bqkv = torch.cat((Wq, Wk, Wv), 0), torch.cat((bq, bk, bv), 0)
         qkv = _new(xc, M, 3 * d)
-        if FUSED_QKV:
-            be.mm(MMOp(xc, d), MMOp(Wqkv, d), qkv, M, 3 * d, d, 3 * d, bias=bqkv)
-        else:
-            for i in range(3):
-                be.mm(MMOp(xc, d), MMOp(Wqkv, d, ptr_off=i * d * d), qkv, M, d, d, 3 * d, c_off=i * d, bias=bqkv[i * d:(i + 1) * d])
+        be.mm(MMOp(xc, d), MMOp(Wqkv, d), qkv, M, 3 * d, d, 3 * d, bias=bqkv)
         att, lse = _new(xc, M, d), _new(xc, S, heads, T)
         scale = float((d // heads) ** -0.5)
         if "attn" in mk:
@@ -228,7 +221,7 @@ class EncoderLayerFn(torch.autograd.Function):
         be.layernorm_fwd(a1, M, d, g1, b1, LN_EPS, h1, m1, r1)
         z = _new(xc, M, F) if keep else None                     # gelu'(pre-activation): what the backward multiplies by
         g = _new(xc, M, F)
-        be.mm(MMOp(h1, d), MMOp(W1, d), g, M, F, d, F, bias=c1, act=MM_ACT_GELU_SAVE_GRAD if (keep and GELU_SAVED) else MM_ACT_GELU, C2=z,
+        be.mm(MMOp(h1, d), MMOp(W1, d), g, M, F, d, F, bias=c1, act=MM_ACT_GELU_SAVE_GRAD if keep else MM_ACT_GELU, C2=z,
               keep=mk.get("act"))
         a2 = _new(xc, M, d)
         be.mm(MMOp(g, F), MMOp(W2, F), a2, M, d, F, d, bias=c2, aux=h1, ldaux=d, aux_mode=MM_AUX_ADD, keep=mk.get("hid2"))
@@ -291,7 +284,7 @@ class EncoderLayerFn(torch.autograd.Function):
         Wqkv, bqkv, Wqkv_i, Wqkv_t, Wo_i, Wo_t, W1_i, W1_t, W2_i, W2_t = EncoderLayerFn._layer_weight_images(be, ctx.wimg_owner, Wq, Wk, Wv, bq, bk, bv, Wo, W1, W2)
         # q|k|v exists only as the image the attention kernels copy their tiles and fragments from (their inner loops are bound by vector instructions: converting
         # every K / V tile once per 128-query block was a fifth of them)
-        ctx.attn_img = ATTN_IMG
+        ctx.attn_img = True                      # q|k|v and dctx travel as the images the projection GEMMs write
         qkv = _new(xc, M, 3 * d)
         be.mm(I(x_img, d), I(Wqkv_i, d), qkv, M, 3 * d, d, 3 * d, bias=bqkv, c_img=ctx.attn_img)
         att, att_img, lse = _new(xc, M, d), _new(xc, M, d), _new(xc, S, heads, T)
@@ -387,11 +380,7 @@ class EncoderLayerFn(torch.autograd.Function):
         dz = new(M, F)
         # through GELU: the forward epilogue saved gelu'(pre-activation), so this epilogue only multiplies (evaluating erf / exp here
         # per element dropped the K = 768 product from 245 to 122 TFLOP/s; a separate streaming GELU' pass cost 3 % of the step)
-        if GELU_SAVED:
-            ops.mm_linear_dgrad(be, dy2, W2, dz, M, d, F, keep=mk.get("act"), aux=z, aux_mode=MM_AUX_MUL_LIKE_C)
-        else:
-            ops.mm_linear_dgrad(be, dy2, W2, dz, M, d, F, keep=mk.get("act"))
-            be.gelu_bwd(dz, z, dz)
+        ops.mm_linear_dgrad(be, dy2, W2, dz, M, d, F, keep=mk.get("act"), aux=z, aux_mode=MM_AUX_MUL_LIKE_C)
         dc1 = new(F)
         dW1 = new(F, d)
         lane.run(lambda: ops.mm_linear_wgrad(be, dz, h1, dW1, M, F, d, db=dc1))      # bias gradients ride along in the weight-gradient kernels
@@ -417,21 +406,11 @@ class EncoderLayerFn(torch.autograd.Function):
         else:
             be.attn_bwd(qkv, att, datt, lse, S, T, heads, 3 * d, d, scale, dqkv)
         dbqkv, dWqkv = new(3 * d), new(3 * d, d)
-        if FUSED_QKV:
-            lane.run(lambda: ops.mm_linear_wgrad(be, dqkv, xc, dWqkv, M, 3 * d, d, db=dbqkv))     # the three projections' gradients in one product
-        else:
-            for i in range(3):
-                be.mm(MMOp(dqkv, 3 * d, trans=True, ptr_off=i * d), MMOp(xc, d, trans=True), dWqkv[i * d:(i + 1) * d], d, d, M, d, split_k=0,
-                      a_rowsum=dbqkv[i * d:(i + 1) * d])
+        lane.run(lambda: ops.mm_linear_wgrad(be, dqkv, xc, dWqkv, M, 3 * d, d, db=dbqkv))     # the three projections' gradients in one product
         dx = None
         if ctx.needs_input_grad[0]:
             dx = new(M, d)
-            if FUSED_QKV:
-                ops.mm_linear_dgrad(be, dqkv, Wqkv, dx, M, 3 * d, d, aux=da1, aux_mode=MM_AUX_ADD)   # K = 3d in one pass, + residual branch
-            else:
-                for i in range(3):
-                    be.mm(MMOp(dqkv, 3 * d, ptr_off=i * d), MMOp(Wqkv, d, trans=True, ptr_off=i * d * d), dx, M, d, d, d, accumulate=i > 0,
-                          **(dict(aux=da1, ldaux=d, aux_mode=MM_AUX_ADD) if i == 0 else {}))
+            ops.mm_linear_dgrad(be, dqkv, Wqkv, dx, M, 3 * d, d, aux=da1, aux_mode=MM_AUX_ADD)   # K = 3d in one pass, + residual branch
         lane.join()                                  # outputs were allocated on the launch stream; the lane only wrote them
         return (dx, None, None, None, None, None, dWqkv[0:d], dbqkv[0:d], dWqkv[d:2 * d], dbqkv[d:2 * d], dWqkv[2 * d:], dbqkv[2 * d:], dWo, dbo, dg1, db1,
                 dW1, dc1, dW2, dc2, dg2, db2)
@@ -513,47 +492,6 @@ class FeatEnc0Fn(torch.autograd.Function):
 # =================================================================================================
 # channels-last Conv1d + GELU (feature-encoder layers 1..6: bias-free, k = 3 or 2, stride 2)
 # =================================================================================================
-class ConvGeluFn(torch.autograd.Function):
-    """x (S, Lin, Ci) -> gelu(conv1d(x)) (S, Lout, Co); w is the nn.Conv1d weight (Co, Ci, KH), no bias, no padding."""
-
-    @staticmethod
-    def forward(ctx, x, w, stride):
-        be = ops.backend()
-        _save_prec(ctx)
-        xc, wc = _f32c(x), _f32c(w)
-        S, Lin, Ci = xc.shape
-        Co, _, KH = wc.shape
-        Lout = (Lin - KH) // stride + 1
-        wg = _new(xc, Co, KH * Ci)
-        be.conv_weight_pack(wc, wg, Co, Ci, KH, 0)
-        keep = any(ctx.needs_input_grad)
-        z = _new(xc, S, Lout, Co) if keep else None
-        y = _new(xc, S, Lout, Co)
-        ops.mm_conv_fwd(be, xc, wg, y, S, Lin, Lout, Ci, Co, KH, stride, act=MM_ACT_GELU, pre=z)
-        if keep:
-            ctx.save_for_backward(xc, wg, z)
-            ctx.dims = (S, Lin, Lout, Ci, Co, KH, stride)
-        return y
-
-    @staticmethod
-    @_restores_precision
-    def backward(ctx, dy):
-        be = ops.backend()
-        xc, wg, z = ctx.saved_tensors
-        S, Lin, Lout, Ci, Co, KH, stride = ctx.dims
-        dz = _new(xc, S, Lout, Co)
-        be.gelu_bwd(_f32c(dy), z, dz)
-        dwg = _new(xc, Co, KH * Ci)
-        ops.mm_conv_wgrad(be, xc, dz, dwg, S, Lin, Lout, Ci, Co, KH, stride)
-        dw = _new(xc, Co, Ci, KH)
-        be.conv_weight_pack(dwg, dw, Co, Ci, KH, 1)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.zeros(S, Lin, Ci, device=xc.device, dtype=torch.float32)
-            ops.mm_conv_dgrad(be, dz, wg, dx, S, Lin, Lout, Ci, Co, KH, stride)
-        return dx, dw, None
-
-
 class ConvStackFn(torch.autograd.Function):
     """Feature-encoder layers 1..n in one autograd node: x (S, L0, C0) -> gelu(conv_n(... gelu(conv_1(x)))) channels-last; weights are
     the nn.Conv1d weights (Co, Ci, KH), no bias, no padding; ``strides`` a tuple.  Forward epilogues save gelu'(pre-activation) of every
@@ -730,10 +668,9 @@ class ConvStackFn(torch.autograd.Function):
 # grouped positional convolution (HF Wav2Vec2PositionalConvEmbedding): h + gelu(conv1d(h, k=128, pad=64, groups=16)[:-1])
 # =================================================================================================
 class PosConvFn(torch.autograd.Function):
-    """h (S, T, C) , w (C, C/groups, K) (weight-norm already applied), bias (C) -> h + gelu(grouped conv)  (S, T, C).
-
-    One batched a2f_mm per direction: the 16 groups are 16 independent GEMMs over group-major copies of the activations
-    (G, S, T, C/G), whose rows are contiguous K x C/G windows (left pad K/2, even kernel: the last output frame is dropped)."""
+    """h (S, T, C) , w (C, C/groups, K) (weight-norm already applied), bias (C) -> h + gelu(grouped conv)  (S, T, C) on the kernels of csrc/posconv.hip: the frame
+    block of a group sits in LDS once for all 128 taps, the activation is read in place (left pad K/2, even kernel: the last output frame is dropped).  wav2vec2-base's
+    shape only (16 groups x 48 channels x 128 taps) - the shape the reference's encoder has (wav2vec.py:87-109)."""
 
     @staticmethod
     def forward(ctx, h, w, bias, groups):
@@ -744,30 +681,16 @@ class PosConvFn(torch.autograd.Function):
         Cg, K = wc.shape[1], wc.shape[2]
         G = groups
         pad = K // 2
-        if POSCONV_KERNEL and (G, Cg, K) == (16, 48, 128):
-            # the kernels of csrc/posconv.hip: the frame block of a group sits in LDS once for all 128 taps; no group-major copies
-            keep = any(ctx.needs_input_grad)
-            wimg = _new(hc, C, K * Cg)
-            be.split_img(wc.view(G, Cg, Cg, K).permute(0, 1, 3, 2).contiguous().view(C, K * Cg), C, K * Cg, K * Cg, wimg, K * Cg)     # [g*Cg+co][kk*Cg+ci]
-            z = _new(hc, S * T, C) if keep else None
-            y = _new(hc, S * T, C)
-            be.posconv_nt(hc, wimg, y, S, T, C, G, K, -pad, bias=bc, aux=hc, z=z, act=1)
-            if keep:
-                ctx.save_for_backward(hc, wc, z)
-                ctx.dims = (S, T, C, Cg, K, G)
-                ctx.own_kernel = True
-            return y.view(S, T, C)
-        ctx.own_kernel = False
-        hg = hc.view(S, T, G, Cg).permute(2, 0, 1, 3).contiguous()                       # (G,S,T,Cg)
-        wg = wc.view(G, Cg, Cg, K).permute(0, 1, 3, 2).contiguous().view(G, Cg, K * Cg)   # [g][co][kk*Cg+ci]
+        if (G, Cg, K) != (16, 48, 128):
+            raise ops.A2FError(f"positional convolution: the HIP kernels are built for 16 groups x 48 channels x 128 taps (wav2vec2-base); got {G} x {Cg} x {K}")
         keep = any(ctx.needs_input_grad)
+        wimg = _new(hc, C, K * Cg)
+        be.split_img(wc.view(G, Cg, Cg, K).permute(0, 1, 3, 2).contiguous().view(C, K * Cg), C, K * Cg, K * Cg, wimg, K * Cg)     # [g*Cg+co][kk*Cg+ci]
         z = _new(hc, S * T, C) if keep else None
         y = _new(hc, S * T, C)
-        A = MMOp(hg, Cg, lines_per_seq=T, seq_stride=T * Cg, off=-pad * Cg, seq_elems=T * Cg)
-        be.mm(A, MMOp(wg, K * Cg), y, S * T, Cg, K * Cg, C, bias=bc, act=MM_ACT_GELU, C2=z, aux=hc, ldaux=C, aux_mode=MM_AUX_ADD,
-              batch=G, a_bstride=S * T * Cg, b_bstride=Cg * K * Cg, c_bstride=Cg, bias_bstride=Cg, aux_bstride=Cg)
+        be.posconv_nt(hc, wimg, y, S, T, C, G, K, -pad, bias=bc, aux=hc, z=z, act=1)
         if keep:
-            ctx.save_for_backward(hg, wc, z)
+            ctx.save_for_backward(hc, wc, z)
             ctx.dims = (S, T, C, Cg, K, G)
         return y.view(S, T, C)
 
@@ -775,7 +698,7 @@ class PosConvFn(torch.autograd.Function):
     @_restores_precision
     def backward(ctx, dy):
         be = ops.backend()
-        hg, wc, z = ctx.saved_tensors
+        hc, wc, z = ctx.saved_tensors
         S, T, C, Cg, K, G = ctx.dims
         pad = K // 2
         dy = _f32c(dy).view(S * T, C)
@@ -783,41 +706,16 @@ class PosConvFn(torch.autograd.Function):
         be.gelu_bwd(dy, z, dz)
         db = _new(dy, C)
         be.colsum(dz, S * T, C, C, db)
-        if ctx.own_kernel:
-            hc = hg                                                               # saved as (S, T, C)
-            dwg = _new(dy, G, K, Cg, Cg)                                          # [g][kk][ci][co]
-            be.posconv_wgrad(hc, dz, dwg, S, T, C, G, K, pad)
-            dw = dwg.permute(0, 3, 2, 1).reshape(C, Cg, K)                        # -> (g*Cg + co, ci, kk)
-            dh = None
-            if ctx.needs_input_grad[0]:
-                # dh[s,t',g,ci] = sum_{kk',co} dz[s, t'-(K/2-1)+kk', g, co] * w[g*Cg+co, ci, K-1-kk']  (+ the residual branch)
-                wd = wc.view(G, Cg, Cg, K).flip(-1).permute(0, 2, 3, 1).contiguous().view(C, K * Cg)       # [g*Cg+ci][kk'*Cg+co]
-                wdimg = _new(dy, C, K * Cg)
-                be.split_img(wd, C, K * Cg, K * Cg, wdimg, K * Cg)
-                dh = _new(dy, S * T, C)
-                be.posconv_nt(dz, wdimg, dh, S, T, C, G, K, -(pad - 1), aux=dy)
-                dh = dh.view(S, T, C)
-            return dh, dw, db, None
-        # weight gradient: dwg[g][co][kk*Cg+ci] = sum_rows dz[row, g*Cg+co] * window(hg[g])[row, kk*Cg+ci]
-        # computed TRANSPOSED, (K*Cg) x Cg per group: with the 48 output channels on the n axis the 128 x 64 tile wastes a quarter of its
-        # MFMAs; with them on the m axis (48 of a 128- or 256-row tile) 60-80 % were wasted (this product was 6.5 ms of the 64 x 600 step)
-        A = MMOp(hg, Cg, trans=True, lines_per_seq=T, seq_stride=T * Cg, off=-pad * Cg, seq_elems=T * Cg)
-        if POSCONV_WGRAD_T:
-            dwgT = _new(dy, G, K * Cg, Cg)
-            be.mm(A, MMOp(dz, C, trans=True), dwgT, K * Cg, Cg, S * T, Cg, batch=G, a_bstride=S * T * Cg, b_bstride=Cg, c_bstride=K * Cg * Cg, split_k=0)
-            dw = dwgT.view(G, K, Cg, Cg).permute(0, 3, 2, 1).reshape(C, Cg, K)          # [g][kk][ci][co] -> (g*Cg + co, ci, kk)
-        else:
-            dwg = _new(dy, G, Cg, K * Cg)
-            be.mm(MMOp(dz, C, trans=True), A, dwg, Cg, K * Cg, S * T, K * Cg, batch=G, a_bstride=Cg, b_bstride=S * T * Cg, c_bstride=Cg * K * Cg, split_k=0)
-            dw = dwg.view(G, Cg, K, Cg).permute(0, 1, 3, 2).reshape(C, Cg, K)
+        dwg = _new(dy, G, K, Cg, Cg)                                          # [g][kk][ci][co]
+        be.posconv_wgrad(hc, dz, dwg, S, T, C, G, K, pad)
+        dw = dwg.permute(0, 3, 2, 1).reshape(C, Cg, K)                        # -> (g*Cg + co, ci, kk)
         dh = None
         if ctx.needs_input_grad[0]:
-            # data gradient: dh[s,t',g,ci] = sum_{kk',co} dz[s, t'-(K/2-1)+kk', g, co] * w[g*Cg+co, ci, K-1-kk']  (+ the residual branch)
-            dzg = dz.view(S, T, G, Cg).permute(2, 0, 1, 3).contiguous()
-            wd = wc.view(G, Cg, Cg, K).flip(-1).permute(0, 2, 3, 1).contiguous().view(G, Cg, K * Cg)   # [g][ci][kk'*Cg+co]
+            # dh[s,t',g,ci] = sum_{kk',co} dz[s, t'-(K/2-1)+kk', g, co] * w[g*Cg+co, ci, K-1-kk']  (+ the residual branch)
+            wd = wc.view(G, Cg, Cg, K).flip(-1).permute(0, 2, 3, 1).contiguous().view(C, K * Cg)       # [g*Cg+ci][kk'*Cg+co]
+            wdimg = _new(dy, C, K * Cg)
+            be.split_img(wd, C, K * Cg, K * Cg, wdimg, K * Cg)
             dh = _new(dy, S * T, C)
-            A = MMOp(dzg, Cg, lines_per_seq=T, seq_stride=T * Cg, off=-(pad - 1) * Cg, seq_elems=T * Cg)
-            be.mm(A, MMOp(wd, K * Cg), dh, S * T, Cg, K * Cg, C, aux=dy, ldaux=C, aux_mode=MM_AUX_ADD, batch=G, a_bstride=S * T * Cg,
-                  b_bstride=Cg * K * Cg, c_bstride=Cg, aux_bstride=Cg)
+            be.posconv_nt(dz, wdimg, dh, S, T, C, G, K, -(pad - 1), aux=dy)
             dh = dh.view(S, T, C)
         return dh, dw, db, None

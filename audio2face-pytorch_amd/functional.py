@@ -157,7 +157,7 @@ def voca_trunk_fwd_layerwise(be, x, one_hot, params):
 
 # a2f_gemm_desc.precision of the VOCA trunk's batched weight gradients: 1 (default) = bf16x3 split products (the contraction
 # runs over 1e4 .. 1e5 rows of smooth products: 1e-5-class error, 5.3x less matrix time), 0 = exact fp32 MFMA
-VOCA_WGRAD_PRECISION = int(os.environ.get("A2F_VOCA_WGRAD_PRECISION", "1"))
+VOCA_WGRAD_PRECISION = 1      # a2f_gemm_desc.precision of the trunk weight gradients: bf16x3 (0 = exact fp32 MFMA, 5.3x the matrix time)
 
 
 def voca_trunk_bwd(be, saved, dh3, out=None):

@@ -195,7 +195,7 @@ class Wav2Vec2Model(nn.Module):
 
     def _forward_hip(self, wave, frame_num):
         """The encoder on the HIP path; wave (S, N) normalised -> (S, frame_num, hidden)."""
-        from ..encoder_ops import GELU_SAVED, ConvGeluFn, ConvStackFn, DropoutFn, EncoderLayerFn, FeatEnc0Fn, LayerNormFn, LinearMMFn, PosConvFn
+        from ..encoder_ops import ConvStackFn, DropoutFn, EncoderLayerFn, FeatEnc0Fn, LayerNormFn, LinearMMFn, PosConvFn
         S = wave.shape[0]
         fe = self.feature_extractor.conv_layers
         # feature encoder, in chunks of sequences: the sequences are independent there and an a2f_mm operand spans < 4 GiB (the layer-0
@@ -210,14 +210,10 @@ class Wav2Vec2Model(nn.Module):
         for s0 in range(0, S, per):
             ns = min(per, S - s0)
             # the stack on split-32 image operands (encoder_ops.ConvStackFn): layer 0 then writes its output as the image layer 1 reads
-            imgs = GELU_SAVED and len(fe) > 1 and ConvStackFn.use_images(_ops.backend(), torch.empty(ns, L0, C0, device="meta"), stack_w)
+            imgs = len(fe) > 1 and ConvStackFn.use_images(_ops.backend(), torch.empty(ns, L0, C0, device="meta"), stack_w)
             # layer 0 (1 -> 512 channels, k = 10, stride 5) + GroupNorm(512 groups) + GELU: 10 MACs per output, memory-bound
             z = FeatEnc0Fn.apply(wave[s0:s0 + per], fe[0].conv.weight, fe[0].layer_norm.weight, fe[0].layer_norm.bias, imgs)      # channels-last (s, L, 512)
-            if GELU_SAVED:
-                z = ConvStackFn.apply(z, tuple(CONV_STRIDE[1:len(fe)]), imgs, *stack_w)
-            else:
-                for i in range(1, len(fe)):
-                    z = ConvGeluFn.apply(z, fe[i].conv.weight, CONV_STRIDE[i])
+            z = ConvStackFn.apply(z, tuple(CONV_STRIDE[1:len(fe)]), imgs, *stack_w)
             outs.append(z)
         z = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
         if frame_num is not None:

@@ -60,8 +60,7 @@ def _chk(*ts):
             raise A2FError("a2f ops need contiguous tensors")
 
 
-_NO_FUSED_ROWSUM = os.environ.get("A2F_MM_ROWSUM", "1") == "0"
-SMALL_M_SPLIT = int(os.environ.get("A2F_MM_SMALL_M", "1024"))     # products of at most this many rows are cut along K automatically (0: never; A-B hook)
+SMALL_M_SPLIT = 1024      # products of at most this many rows are cut along K automatically (module attribute; 0: never)
 
 
 def _chk_bits(*ts):
@@ -190,10 +189,7 @@ class HipBackend:
             d.ws, d.c_colsum = _ptr(ws), _ptr(c_colsum)
         if a_rowsum is not None:
             _chk(a_rowsum)
-            if _NO_FUSED_ROWSUM:                                # A-B hook: the bias gradient as its own pass over dY
-                self.colsum(A.t, K, M, A.ld, a_rowsum, x_off=A.ptr_off)
-            else:
-                d.a_rowsum = _ptr(a_rowsum)
+            d.a_rowsum = _ptr(a_rowsum)
         d.batch, d.accumulate = batch, int(accumulate)
         d.a_bstride, d.b_bstride, d.c_bstride, d.bias_bstride, d.aux_bstride = a_bstride, b_bstride, c_bstride, bias_bstride, aux_bstride
         d.alpha = alpha
@@ -722,14 +718,11 @@ def mm_linear_fwd(be, x, W, bias, out, M, N, K, *, act=MM_ACT_NONE, pre=None, au
     be.mm(MMOp(x, K), MMOp(W, K), out, M, N, K, N, bias=bias, act=act, C2=pre, aux=aux, ldaux=N, aux_mode=aux_mode, tag=tag)
 
 
-DGRAD_TRANSPOSED_W = os.environ.get("A2F_DGRAD_WT", "1") != "0"     # A-B hook
-
-
 def mm_linear_dgrad(be, dy, W, dx, M, N, K, *, aux=None, aux_mode=MM_AUX_NONE, tag="gemm_mfma", keep=None):
     """dx[M,K] = dy[M,N] W[N,K], optionally times an activation derivative evaluated on aux[M,K].  The weight is read through a
     transposed copy (K, N) so that BOTH operands are k-contiguous: the row-image staging path (one ds_read_b128 per fragment) is
     12-15 % faster than the transposing one, and the copy is 1/M of the product's traffic."""
-    if DGRAD_TRANSPOSED_W and W.is_cuda and M >= 1024:
+    if W.is_cuda and M >= 1024:
         be.mm(MMOp(dy, N), MMOp(W.t().contiguous(), N), dx, M, K, N, K, aux=aux, ldaux=K, aux_mode=aux_mode, tag=tag, keep=keep)
         return
     be.mm(MMOp(dy, N), MMOp(W, K, trans=True), dx, M, K, N, K, aux=aux, ldaux=K, aux_mode=aux_mode, tag=tag, keep=keep)
@@ -763,7 +756,7 @@ def mm_conv_dgrad(be, dy, Wg, dx, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, ta
     epilogue (the saved activation derivative of the layer below: dx then IS that layer's pre-activation gradient)."""
     ex = dict(aux=mul, aux_mode=MM_AUX_MUL_LIKE_C) if mul is not None else {}
     # plain products read the packed weight through a transposed copy (KH*Ci, Co): both operands k-contiguous (see mm_linear_dgrad)
-    WgT = Wg.t().contiguous() if (DGRAD_TRANSPOSED_W and Wg.is_cuda and S * Lout >= 1024) else None
+    WgT = Wg.t().contiguous() if (Wg.is_cuda and S * Lout >= 1024) else None
     if KH == stride and pad == 0:
         Bop = MMOp(WgT, Co) if WgT is not None else MMOp(Wg, KH * Ci, trans=True)
         be.mm(MMOp(dy, Co), Bop, dx, S * Lout, KH * Ci, Co, KH * Ci, c_rows_per_seq=Lout, c_seq_stride=Lin * Ci, tag=tag, **ex)

@@ -424,7 +424,7 @@ class TrainStep:
         # directly.  A pipelined step has an earlier pass: its gradients are still taken as autograd hands them out and moved into the flat buffer
         # right before the last pass (_begin_exchange) - no zero fill and no accumulation kernel per parameter for the first half (215 launches)
         self._mid_collect = self.buckets is not None and self._pipelined(x)
-        stolen = (self.buckets is None or self._mid_collect) and os.environ.get("A2F_GRAD_STEAL", "1") != "0"       # A-B hook: 0 = zero-fill + accumulate
+        stolen = self.buckets is None or self._mid_collect
         self._mid_collect = self._mid_collect and stolen
         if stolen:
             self.opt.release_grads()

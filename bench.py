@@ -418,7 +418,7 @@ def main():
             torch.cuda.synchronize()
             head_ms, nl = be.profile_head_ms()
             be.profile_head(False)
-            dom = "head_x3_kernel" if os.environ.get("A2F_HEAD_CFG", "5") == "5" else "head_fused_kernel"   # library default: cfg 5
+            dom = "head_x3_kernel"
             bytes_per_launch = ALGO_BYTES_PER_FRAME["head_fused"] * B
             achieved = bytes_per_launch / (head_ms * 1e-3) / 1e9
             # HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes: tools/pmc_head.sh writes the

@@ -435,11 +435,6 @@ __device__ __forceinline__ f32x4v mfma16(u32x4_t a, u32x4_t b, f32x4v c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
-#ifdef A2F_EPI_NT
-#define EPI_ST_AUX 2          // nt: streaming stores of the outputs (ablation)
-#else
-#define EPI_ST_AUX 0
-#endif
 __device__ __forceinline__ void epilogue_wave16(const Args& a, const f32x4v (&acc)[8][4], int m0, int n0, int wm, int wn, int lane) {
   constexpr unsigned NOWHERE = 0x80000000u;
   constexpr int AHEAD = 4;                                            // row blocks whose aux loads are in flight ahead of the one being finished
@@ -519,10 +514,10 @@ __device__ __forceinline__ void epilogue_wave16(const Args& a, const f32x4v (&ac
         if (a.act == 4) {
           f32x4 g, dg;
           gelu_pair(v, g, dg);
-          if (a.C2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, dg), rc2, off, 0, EPI_ST_AUX);
+          if (a.C2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, dg), rc2, off, 0, 0);
           v = g;
         } else {
-          if (a.C2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rc2, off, 0, EPI_ST_AUX);
+          if (a.C2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rc2, off, 0, 0);
           if (a.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
           else if (a.act == 3) {
             f32x4 g, dg;
@@ -547,7 +542,7 @@ __device__ __forceinline__ void epilogue_wave16(const Args& a, const f32x4v (&ac
           else if (ok) a2f::img::store8(reinterpret_cast<char*>(a.C) + (size_t)crow * 4u, n - 4, held, v);
         }
       } else {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rc, off, 0, EPI_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rc, off, 0, 0);
       }
     }
     if (a.aux_mode && i + AHEAD < 8) load_aux(i + AHEAD, ax[i % AHEAD]);

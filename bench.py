@@ -50,7 +50,7 @@ MFMA_BF16_PEAK_TF = 2500.0        # dense bf16 matrix peak
 FF_MFLOP_PER_FRAME = 857.0        # 3 x 2 x (141.9 M encoder + 1.0 M decoder/head) MAC at T = 600
 A2M_MFLOP_PER_FRAME = 393.0       # 3 x 2 x 65 509 514 MAC
 FF_LAYER_MFLOP_PER_FRAME = 6.0 * (7.078 + 0.92) # one of the 12 Transformer layers: 3 x 2 x (7.08 M MAC of projections / FFN + 0.92 M MAC of attention at T = 600)
-PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"   # this round's PMC measurement of the dominant kernels (tools/pmc_traffic.sh)
+PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"   # this round's PMC measurement of the dominant kernels (tools/pmc_traffic.sh)
 
 
 # ------------------------------------------------------------------------------------------------ self launch (N > 1)

@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Generator of the full-size oracle fixtures G15 (tests/golden/g15_*.npz): the CPU oracle's FaceFormer step at BASELINE configs[2] / configs[4] sizes, once in
+fp32 (the arithmetic the parity bar is defined on) and once in float64 (the truth ill-conditioned gradients are judged by), so that the GPU suite compares the HIP
+path with committed vectors instead of running minutes of CPU autograd per test.  Test infrastructure only (oracle/ + its formula weights; nothing of the
+reference is read).  Inputs are NOT stored: the tests regenerate them from the same seeds.
+
+Per case: `pred_off` (vertex offsets of the fp32 run, packed), `enc` (the encoder output of the fp32 run, packed), `loss32` / `loss64`, for every gradient key `g64::<key>` (the float64 gradient, packed as a strided
+sample + L2 norm), `eref::<key>` (relative L2 distance of the fp32 oracle's gradient from it), `g32::<key>` (the fp32 oracle's gradient, packed) wherever that distance
+exceeds 2e-5 - a draw on which the reference's own fp32 arithmetic and float64 take different sides of a ReLU kink shows as eref ~ 1e-3 on EVERY gradient (g15_c2_wellcond_s602_subj2) -
+and `relu_margin64`: the smallest |pre-activation| of the
+decoder's feed-forward ReLU over all frames and units in float64 (a draw whose margin is ~1e-7 has a unit on its kink: fp32-class arithmetic may land on the
+other side and move every gradient upstream by ~2e-4 - a property of the function, which the multi-draw test then reports instead of excusing silently).
+
+usage: python tests/golden/gen_golden_fullsize.py [case-name-substring ...]          (8 cores: ~25 min for all cases)"""
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import faceformer as o_ff, losses as o_loss, wav2vec2 as o_w2v, weights as W
+
+NV = 15069
+FF_GAINS = {"vertice_map_r.weight": 4.0, "vertice_map.weight": 0.05, "obj_vector": 2.0, "in_proj_weight": 1.5}                   # = tests/test_gpu_models.py
+WELL_CONDITIONED_GAINS = {"original0": 40.0, "attention.out_proj": 0.25, "feed_forward.output_dense": 0.25}
+SAMPLES = 1024
+G32_FROM = 2e-5
+
+
+def pack(prefix, t, out):
+    a = t.detach().to(torch.float32).contiguous().cpu().numpy().copy()
+    if a.size <= 2 * SAMPLES:
+        out[prefix] = a
+        return
+    stride = max(a.size // SAMPLES, 1) | 1
+    out[prefix + "::sample"] = a.reshape(-1)[::stride].copy()
+    out[prefix + "::stride"] = np.int64(stride)
+    out[prefix + "::l2"] = np.float64(np.sqrt((a.astype(np.float64) ** 2).sum()))
+    out[prefix + "::shape"] = np.asarray(a.shape, dtype=np.int64)
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().flatten(), b.detach().double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def inputs_T600(seed, subject):
+    """= test_faceformer_config2_full_size_* (seed 600, subject 5 there)."""
+    T = 600
+    gen = torch.Generator().manual_seed(seed)
+    audio = torch.randn(1, T * 16000 // 60 + 8, generator=gen) * 0.1
+    oh = torch.zeros(1, 12); oh[0, subject] = 1
+    template = torch.randn(1, 5023, 3, generator=gen) * 5
+    gt = template.view(1, 1, 5023, 3) + torch.randn(1, T, 5023, 3, generator=gen) * 0.5
+    return audio, oh, template, gt
+
+
+def inputs_long(T, seed):
+    """= tests/test_gpu_models.py::_ff_long_inputs."""
+    gen = torch.Generator().manual_seed(seed)
+    audio = torch.randn(1, T * 16000 // 60 + 8, generator=gen) * 0.1
+    oh = torch.zeros(1, 12); oh[0, 2] = 1
+    template = torch.randn(1, 5023, 3, generator=gen) * 5
+    gt = template.view(1, 1, 5023, 3) + torch.randn(1, T, 5023, 3, generator=gen) * 0.5
+    return audio, oh, template, gt
+
+
+def oracle_run(esd, dsd, audio, oh, template, gt, T, dtype, enc_states=None, checkpoint=False):
+    c = lambda t: t.clone().to(dtype)
+    P = {k: (c(v).requires_grad_(True) if v.is_floating_point() and not k.startswith("PPE") else v) for k, v in dsd.items()}
+    E, a, e = {}, None, None
+    margins = []
+    orig_relu = F.relu
+
+    def relu_rec(x, *args, **kw):
+        margins.append(float(x.detach().abs().min()))
+        return orig_relu(x, *args, **kw)
+
+    if enc_states is None:
+        E = {k: c(v).requires_grad_(True) for k, v in esd.items()}
+        a = c(audio).requires_grad_(True)
+        enc = o_w2v.wav2vec2_forward(E, o_w2v.normalize_waveform(a), T, checkpoint=checkpoint)
+    else:
+        enc = e = c(enc_states).requires_grad_(True)
+    F.relu = relu_rec                                    # the decoder's feed-forward is the only ReLU of the path (the encoder is GELU)
+    try:
+        ref = o_ff.decode_incremental(P, enc, c(oh), c(template))
+    finally:
+        F.relu = orig_relu
+    ol = o_loss.faceformer_loss(ref, c(gt))
+    ol["loss"].backward()
+    grads = {"audio_encoder." + k: v.grad.double() for k, v in E.items() if v.grad is not None}
+    grads.update({k: v.grad.double() for k, v in P.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None})
+    if a is not None:
+        grads["audio"] = a.grad.double()
+    if e is not None:
+        grads["enc"] = e.grad.double()
+    return {"pred": ref.detach().float(), "loss": float(ol["loss"].detach()), "grads": grads, "relu_margin": min(margins) if margins else float("nan"),
+            "enc": enc.detach().float() if enc_states is None else None}
+
+
+def case(name, esd, dsd, audio, oh, template, gt, T, enc_states=None, checkpoint=False):
+    t0 = time.time()
+    o32 = oracle_run(esd, dsd, audio, oh, template, gt, T, torch.float32, enc_states, checkpoint)
+    t1 = time.time()
+    o64 = oracle_run(esd, dsd, audio, oh, template, gt, T, torch.float64, enc_states, checkpoint)
+    out = {"loss32": np.float64(o32["loss"]), "loss64": np.float64(o64["loss"]), "relu_margin64": np.float64(o64["relu_margin"]),
+           "relu_margin32": np.float64(o32["relu_margin"]), "T": np.int64(T)}
+    pack("pred_off", o32["pred"] - template.view(1, 1, 5023, 3), out)
+    if o32["enc"] is not None:
+        pack("enc", o32["enc"], out)                      # the encoder's last_hidden_state (1, T, 768) of the fp32 run
+    worst = (0.0, "")
+    for k, g64 in o64["grads"].items():
+        pack("g64::" + k, g64, out)
+        er = rel_l2(o32["grads"][k], g64) if float(g64.abs().max()) > 0 else 0.0
+        out["eref::" + k] = np.float64(er)
+        if er > G32_FROM:                                  # the fp32 reference arithmetic itself resolves this gradient no better: keep ITS value too (the bar is defined on it)
+            pack("g32::" + k, o32["grads"][k], out)
+        worst = max(worst, (er, k))
+    path = os.path.join(HERE, "g15_" + name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: fp32 {t1 - t0:.0f} s, float64 {time.time() - t1:.0f} s; {len(o64['grads'])} gradients, fp32 oracle's worst distance from float64 {worst[0]:.2e} ({worst[1]}); "
+          f"ReLU margin {o64['relu_margin']:.3e}; {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+
+
+def main():
+    want = sys.argv[1:]
+    torch.set_num_threads(os.cpu_count() or 1)
+    dsd = W.formula_state_dict(W.faceformer_decoder_shapes(NV, 12, 64), gains=FF_GAINS)
+    jobs = []
+    esd_f = lambda: W.formula_state_dict(W.wav2vec2_shapes(), gains={"original0": 40.0})
+    esd_w = lambda: W.formula_state_dict(W.wav2vec2_shapes(), gains=WELL_CONDITIONED_GAINS)
+    jobs.append(("c2_formula_s600_subj5", lambda: case("c2_formula_s600_subj5", esd_f(), dsd, *inputs_T600(600, 5), 600)))
+    for seed in (600, 601, 602):
+        for subj in (2, 5):
+            nm = f"c2_wellcond_s{seed}_subj{subj}"
+            jobs.append((nm, lambda nm=nm, seed=seed, subj=subj: case(nm, esd_w(), dsd, *inputs_T600(seed, subj), 600)))
+    jobs.append(("c5_T3000_decoder_s3001", lambda: case("c5_T3000_decoder_s3001", None, dsd, *inputs_long(3000, 3001), 3000,
+                                                         enc_states=W.formula_input("t3000.enc", (1, 3000, 768)))))
+    jobs.append(("c5_T3000_full_s3002", lambda: case("c5_T3000_full_s3002", esd_f(), dsd, *inputs_long(3000, 3002), 3000, checkpoint=True)))
+    for nm, fn in jobs:
+        if want and not any(w in nm for w in want):
+            continue
+        fn()
+
+
+if __name__ == "__main__":
+    main()

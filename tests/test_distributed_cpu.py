@@ -143,8 +143,8 @@ def _run_ff(rank, world, port, out_path, layers=0, skip_by_rank=False, S=4):
             f = wave[:, : frame_num * 8].reshape(wave.shape[0], frame_num, 8)
             h = self.proj(f)
             for l, lin in enumerate(self.encoder.layers):
-                if skip_by_rank and l == rank:       # LayerDrop: every rank skips a different layer
-                    continue
+                if skip_by_rank and (l == rank or (skip_by_rank == "rank0_all" and rank == 0)):
+                    continue                         # LayerDrop: every rank skips a different layer; "rank0_all": rank 0 drops EVERY layer (none of its layer buckets' hooks fire)
                 h = h + torch.tanh(lin(h))
             return types.SimpleNamespace(last_hidden_state=h)
 
@@ -215,6 +215,13 @@ def test_faceformer_bucketed_allreduce_world_4_and_8(world, S):
         r0 = torch.load(p2)
         for r in range(1, world):
             assert torch.equal(r0["flat"], torch.load(p2 + f".rank{r}")["flat"]), r
+        if (world, S) == (8, 8):
+            # the extreme LayerDrop pattern: rank 0 drops EVERY Transformer layer (on that rank only the front-end and the decoder-side bucket ever see a gradient), the
+            # other ranks one each: rank 0 must still issue all ten collectives in the same descending order (asserted inside the ranks) or the job would hang / mis-sum
+            mp.spawn(_run_ff, args=(world, _free_port(), p2, layers, "rank0_all", S), nprocs=world, join=True)
+            r0 = torch.load(p2)
+            for r in range(1, world):
+                assert torch.equal(r0["flat"], torch.load(p2 + f".rank{r}")["flat"]), r
 
 
 def test_trainstep_with_use_graph_drops_the_bucket_hooks():

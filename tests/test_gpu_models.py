@@ -527,88 +527,57 @@ def _faceformer_full(gains=None):
 
 def test_faceformer_config2_full_size_vs_oracle(monkeypatch):
     """BASELINE configs[2] at full size: N = 160 008 samples -> T = 600 frames through the real wav2vec2-base encoder, the
-    incremental decoder, the 15069-wide head and FaceFormerLoss; forward <= 1e-4 on vertex offsets, and the gradients that
-    cross the whole encoder (d loss / d audio, first conv layer, feature projection, an attention projection of layer 0) against
-    the oracle's autograd (oracle/wav2vec2.py + decode_incremental; reference: faceformer.py:139-191, wav2vec.py:91-189).
+    incremental decoder, the 15069-wide head and FaceFormerLoss; forward <= 1e-4 on vertex offsets, the loss, d loss / d audio and EVERY parameter gradient
+    against the oracle's autograd (oracle/wav2vec2.py + decode_incremental; reference: faceformer.py:139-191, wav2vec.py:91-189) - the committed fixture
+    g15_c2_formula_s600_subj5 (fp32 oracle: forward, loss; float64 oracle: gradients + the fp32 oracle's own distance from them).
     Runs the path the 64-sequence bench step runs: Transformer products on split-32 image operands (forced: one sequence is 600 rows)."""
     from a2f_amd import encoder_ops
     monkeypatch.setattr(encoder_ops, "IMG_MIN_ROWS", 0)
-    from oracle import faceformer as o_ff, wav2vec2 as o_w2v
-    m, esd, dsd = _faceformer_full()
+    m, _esd, _dsd = _faceformer_full()
     T = 600
-    gen = torch.Generator().manual_seed(600)
-    audio = torch.randn(1, T * 16000 // 60 + 8, generator=gen) * 0.1
-    oh = torch.zeros(1, 12); oh[0, 5] = 1
-    template = torch.randn(1, 5023, 3, generator=gen) * 5
-    gt = template.view(1, 1, 5023, 3) + torch.randn(1, T, 5023, 3, generator=gen) * 0.5
-    # oracle: the reference's arithmetic in fp32 (what the parity bar is defined on) and in float64 (the truth the ill-conditioned gradients are judged by)
-    o32 = _oracle_ff_run(esd, dsd, audio, oh, template, gt, T, torch.float32)
-    o64 = _oracle_ff_run(esd, dsd, audio, oh, template, gt, T, torch.float64)
-    # HIP path
+    audio, oh, template, gt = _t600_inputs(600, 5)
+    fix = load("g15_c2_formula_s600_subj5")
     a_gpu = audio.to(DEV).requires_grad_(True)
     pred, loss = m.forward_with_loss(a_gpu, oh.to(DEV), template.to(DEV), gt.to(DEV))
     assert pred.shape == (1, T, 5023, 3)
-    assert rel_l2(pred.detach().cpu() - template.view(1, 1, 5023, 3), o32["pred"] - template.view(1, 1, 5023, 3)) < TOL
-    assert abs(float(loss["loss"].detach()) - o32["loss"]) <= 1e-4 * abs(o32["loss"])
+    assert packed_error(fix, "pred_off", pred.detach().cpu() - template.view(1, 1, 5023, 3)) < TOL
+    assert abs(float(loss["loss"].detach()) - float(fix["loss32"])) <= 1e-4 * abs(float(fix["loss32"]))
     loss["loss"].backward()
-    assert rel_l2(a_gpu.grad, o32["grads"]["audio"]) < TOL
-    floored = _assert_all_grads(m, o32["grads"], o64["grads"])
+    assert packed_error(fix, "g64::audio", a_gpu.grad) < TOL
+    floored = _assert_all_grads_g15(m, fix)
     # the ill-conditioned set is pinned: a gradient that needs the float64 floor and is not on the committed list fails (the list cannot silently grow)
     allowed = {l.strip() for l in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ill_conditioned_gradients_T600.txt")) if l.strip() and not l.startswith("#")}
     assert set(floored) <= allowed, sorted(set(floored) - allowed)
 
 
-def test_faceformer_config2_full_size_every_gradient_without_a_floor(monkeypatch):
-    """The same full-size step (N = 160 008 samples -> T = 600, real encoder, image-operand path forced) on the WELL-CONDITIONED weight set: all 223 parameter
-    gradients and d loss / d audio <= 1e-4 against the fp32 oracle, max_floor_share = 0 - no gradient is excused."""
+@pytest.mark.parametrize("seed,subject", [(600, 2), (600, 5), (601, 2), (601, 5), (602, 2), (602, 5)])
+def test_faceformer_config2_full_size_every_gradient_without_a_floor(seed, subject, monkeypatch):
+    """The same full-size step (N = 160 008 samples -> T = 600, real encoder, image-operand path forced) on the WELL-CONDITIONED weight set, SIX input draws
+    (fixtures g15_c2_wellcond_*): all 223 parameter gradients and d loss / d audio <= 1e-4, max_floor_share = 0 - no gradient is excused.
+    The only thing that can lift a draw over the bar without any arithmetic being wrong is a ReLU unit of the decoder's feed-forward sitting on its kink (its
+    pre-activation closer to zero than fp32 rounding: fp32 arithmetic - the reference's own included - then picks a side, and every gradient upstream of it
+    moves).  That is a checked fact here, not a comment: the fixtures hold the fp32 ORACLE's own distance from float64 per gradient - on draw (602, 2) it is 6.5e-4
+    in the median over all 223 gradients (2.2e-3 worst; float64 margin of the nearest unit 8e-6), on the other five 4e-6 - and, where that distance exceeds 2e-5, the fp32
+    oracle's gradient as well: every HIP gradient must be within 1e-4 of the float64 value or of the fp32 reference's, on every draw, no wider bar anywhere."""
     from a2f_amd import encoder_ops
     monkeypatch.setattr(encoder_ops, "IMG_MIN_ROWS", 0)
-    m, esd, dsd = _faceformer_full(WELL_CONDITIONED_GAINS)
-    T = 600
-    # the inputs of the formula-weight test above (tools/grad_parity_probe.py: worst gradient 3.8e-5, median 1.0e-5 on this set; another draw - seed 601,
-    # subject 2 - lands every gradient upstream of the decoder's feed-forward at 2e-4: one ReLU unit of the recurrence sits on its kink there, the same
-    # discontinuity the large-batch VOCA tests meet in the fp32 oracle itself)
-    gen = torch.Generator().manual_seed(600)
-    audio = torch.randn(1, T * 16000 // 60 + 8, generator=gen) * 0.1
-    oh = torch.zeros(1, 12); oh[0, 5] = 1
-    template = torch.randn(1, 5023, 3, generator=gen) * 5
-    gt = template.view(1, 1, 5023, 3) + torch.randn(1, T, 5023, 3, generator=gen) * 0.5
-    o32 = _oracle_ff_run(esd, dsd, audio, oh, template, gt, T, torch.float32)
-    o64 = _oracle_ff_run(esd, dsd, audio, oh, template, gt, T, torch.float64)
+    m, _esd, _dsd = _faceformer_full(WELL_CONDITIONED_GAINS)
+    audio, oh, template, gt = _t600_inputs(seed, subject)
+    fix = load(f"g15_c2_wellcond_s{seed}_subj{subject}")
+    import numpy as np
+    erefs = [float(fix[k]) for k in fix if k.startswith("eref::") and not k.endswith(_EXACT_ZERO_GRADS)]
+    margin, kink = float(fix["relu_margin64"]), float(np.median(erefs)) > TOL
+    print(f"draw (seed {seed}, subject {subject}): smallest decoder ReLU |pre-activation| in float64 {margin:.3e}; the fp32 ORACLE's own median distance from float64 over "
+          f"{len(erefs)} gradients {float(np.median(erefs)):.2e}" + ("  -> the reference's fp32 arithmetic and float64 sit on different sides of a ReLU kink on this draw" if kink else ""))
+    assert (seed, subject) == (602, 2) or not kink                  # one draw of the six has the kink (and shows it in the oracle itself): it stays in, judged by the nearer side
+    tol = TOL
     a_gpu = audio.to(DEV).requires_grad_(True)
     pred, loss = m.forward_with_loss(a_gpu, oh.to(DEV), template.to(DEV), gt.to(DEV))
-    assert rel_l2(pred.detach().cpu() - template.view(1, 1, 5023, 3), o32["pred"] - template.view(1, 1, 5023, 3)) < TOL
+    assert packed_error(fix, "pred_off", pred.detach().cpu() - template.view(1, 1, 5023, 3)) < TOL
     loss["loss"].backward()
-    print("d loss / d audio vs fp32 oracle:", rel_l2(a_gpu.grad, o32["grads"]["audio"]), "vs float64:", rel_l2(a_gpu.grad, o64["grads"]["audio"]),
-          "fp32 oracle vs float64:", rel_l2(o32["grads"]["audio"], o64["grads"]["audio"]))
-    assert _assert_all_grads(m, o32["grads"], o64["grads"], max_floor_share=0.0) == []
-    assert rel_l2(a_gpu.grad, o32["grads"]["audio"]) < TOL
-
-
-def _oracle_ff_run(esd, dsd, audio, oh, template, gt, T, dtype, enc_states=None, checkpoint=False):
-    """FaceFormer forward + FaceFormerLoss + backward through the CPU oracle in ``dtype``; returns pred (fp32), loss and every gradient
-    (float64 CPU tensors; encoder parameters under "audio_encoder.<HF name>", "audio" = d loss / d audio, "enc" = d loss / d encoder output
-    when ``enc_states`` pins the encoder output)."""
-    from oracle import faceformer as o_ff, wav2vec2 as o_w2v
-    c = lambda t: t.clone().to(dtype)
-    P = {k: (c(v).requires_grad_(True) if v.is_floating_point() and not k.startswith("PPE") else v) for k, v in dsd.items()}
-    E, a, e = {}, None, None
-    if enc_states is None:
-        E = {k: c(v).requires_grad_(True) for k, v in esd.items()}
-        a = c(audio).requires_grad_(True)
-        enc = o_w2v.wav2vec2_forward(E, o_w2v.normalize_waveform(a), T, checkpoint=checkpoint)
-    else:
-        enc = e = c(enc_states).requires_grad_(True)
-    ref = o_ff.decode_incremental(P, enc, c(oh), c(template))
-    ol = o_loss.faceformer_loss(ref, c(gt))
-    ol["loss"].backward()
-    grads = {"audio_encoder." + k: v.grad.double() for k, v in E.items() if v.grad is not None}
-    grads.update({k: v.grad.double() for k, v in P.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None})
-    if a is not None:
-        grads["audio"] = a.grad.double()
-    if e is not None:
-        grads["enc"] = e.grad.double()
-    return {"pred": ref.detach().float(), "loss": float(ol["loss"].detach()), "grads": grads}
+    print("d loss / d audio vs the oracle:", _g15_error(fix, "audio", a_gpu.grad), "fp32 oracle vs float64:", float(fix["eref::audio"]))
+    assert _assert_all_grads_g15(m, fix, tol=tol, max_floor_share=0.0) == []
+    assert _g15_error(fix, "audio", a_gpu.grad) < tol
 
 
 # gradients that are identically zero in exact arithmetic (only rounding noise on both sides): k_proj.bias shifts every score of a
@@ -622,26 +591,49 @@ _EXACT_ZERO_GRADS = ("attention.k_proj.bias",)
 _ILL_CONDITIONED_FLOOR = 256.0
 
 
-def _assert_all_grads(m, g32, g64, tol=TOL, max_floor_share=0.15):
-    """EVERY parameter gradient of the HIP path (encoder: HF names under audio_encoder., decoder side: the reference's names): <= tol
-    against the fp32 oracle, or - ill-conditioned gradients - against the float64 oracle with the floor above.  The share of parameters
-    that need the floor is bounded, and they are printed."""
+def _t600_inputs(seed, subject):
+    """= tests/golden/gen_golden_fullsize.py::inputs_T600 (the fixtures G15 store no inputs: both sides regenerate them from the seed)."""
+    T = 600
+    gen = torch.Generator().manual_seed(seed)
+    audio = torch.randn(1, T * 16000 // 60 + 8, generator=gen) * 0.1
+    oh = torch.zeros(1, 12); oh[0, subject] = 1
+    template = torch.randn(1, 5023, 3, generator=gen) * 5
+    gt = template.view(1, 1, 5023, 3) + torch.randn(1, T, 5023, 3, generator=gen) * 0.5
+    return audio, oh, template, gt
+
+
+def _g15_error(fix, key, t):
+    """Distance of a HIP gradient from the oracle: from the float64 value, or - where the fixture also holds the fp32 oracle's value (it does wherever the reference's
+    own fp32 arithmetic sits more than 2e-5 from float64) - from whichever of the two is nearer: the parity bar is defined on the fp32 reference, float64 is the truth
+    both are measured by."""
+    e = packed_error(fix, "g64::" + key, t)
+    if ("g32::" + key) in fix or ("g32::" + key + "::l2") in fix:
+        e = min(e, packed_error(fix, "g32::" + key, t))
+    return e
+
+
+def _assert_all_grads_g15(m, fix, tol=TOL, max_floor_share=0.15):
+    """EVERY parameter gradient of the HIP path against a full-size oracle fixture (G15, tests/golden/gen_golden_fullsize.py): <= tol from the oracle's gradient
+    (_g15_error), or - ill-conditioned gradients, where the fp32 ORACLE itself sits `eref` from float64 - <= 256 eref from float64 (_ILL_CONDITIONED_FLOOR above).
+    Wherever the fp32 oracle resolves a gradient (eref ~ 1e-6) the float64 value and the fp32 one are the same number at the bar's resolution."""
     params = dict(m.named_parameters())
     rows, floored = [], []
-    for k, ref64 in g64.items():
-        if k in ("audio", "enc") or k not in params or k.endswith(_EXACT_ZERO_GRADS) or float(ref64.abs().max()) == 0.0:
+    for key in sorted(k[len("eref::"):] for k in fix if k.startswith("eref::")):
+        if key in ("audio", "enc") or key not in params or key.endswith(_EXACT_ZERO_GRADS):
             continue
-        g = params[k].grad
-        e32 = rel_l2(g, g32[k])
-        if e32 < tol:
-            rows.append((e32, k))
+        l2 = float(fix["g64::" + key + "::l2"]) if ("g64::" + key + "::l2") in fix else float(abs(fix["g64::" + key]).max())
+        if l2 == 0.0:
             continue
-        e64, eref = rel_l2(g, ref64), rel_l2(g32[k], ref64)
-        floored.append((k, f"hip {e64:.2e}", f"fp32 oracle {eref:.2e}"))
-        assert e64 <= max(tol, _ILL_CONDITIONED_FLOOR * eref), (k, e64, eref)
+        e, eref = _g15_error(fix, key, params[key].grad), float(fix["eref::" + key])
+        if e < tol:
+            rows.append((e, key))
+            continue
+        e64 = packed_error(fix, "g64::" + key, params[key].grad)
+        floored.append((key, f"hip {e64:.2e}", f"fp32 oracle {eref:.2e}"))
+        assert e64 <= max(tol, _ILL_CONDITIONED_FLOOR * eref), (key, e64, eref)
     rows.sort(reverse=True)
     print("gradients compared:", len(rows) + len(floored), "worst well-conditioned:", [(f"{e:.2e}", k) for e, k in rows[:8]])
-    print("ill-conditioned (judged against float64):", floored)
+    print("ill-conditioned (judged with the float64 floor):", floored)
     assert len(rows) + len(floored) >= 10 and len(floored) <= max_floor_share * (len(rows) + len(floored))
     return [k for k, _h, _r in floored]
 
@@ -658,82 +650,72 @@ def _ff_long_inputs(T, seed):
 def test_faceformer_config5_T3000_decoder_gradients_vs_oracle():
     """BASELINE configs[4]'s length through the blocked backward: T = 3000 = 24 blocks of 128 steps (cross-block dK / dV kernels, prep
     pass, per-block recurrence launches) with a pinned encoder output - EVERY decoder-side gradient and d loss / d encoder-output
-    against the oracle's autograd through the whole 3000-step recurrence (faceformer.py:154-185)."""
+    against the oracle's autograd through the whole 3000-step recurrence (faceformer.py:154-185): fixture g15_c5_T3000_decoder_s3001."""
     T = 3000
     m = _faceformer()
-    dsd = W.formula_state_dict(W.faceformer_decoder_shapes(NV, 12, 64), gains=FF_GAINS)
     audio, oh, template, gt = _ff_long_inputs(T, 3001)
     enc = W.formula_input("t3000.enc", (1, T, 768))
-    o32 = _oracle_ff_run(None, dsd, audio, oh, template, gt, T, torch.float32, enc_states=enc)
-    o64 = _oracle_ff_run(None, dsd, audio, oh, template, gt, T, torch.float64, enc_states=enc)
+    fix = load("g15_c5_T3000_decoder_s3001")
     e_gpu = enc.to(DEV).requires_grad_(True)
     pred, loss = m.forward_with_loss(audio.to(DEV), oh.to(DEV), template.to(DEV), gt.to(DEV), encoder_states=e_gpu)
-    assert rel_l2(pred.detach().cpu() - template.view(1, 1, 5023, 3), o32["pred"] - template.view(1, 1, 5023, 3)) < TOL
-    assert abs(float(loss["loss"].detach()) - o32["loss"]) <= 1e-4 * abs(o32["loss"])
+    assert packed_error(fix, "pred_off", pred.detach().cpu() - template.view(1, 1, 5023, 3)) < TOL
+    assert abs(float(loss["loss"].detach()) - float(fix["loss32"])) <= 1e-4 * abs(float(fix["loss32"]))
     loss["loss"].backward()
-    assert rel_l2(e_gpu.grad, o32["grads"]["enc"]) < TOL
-    _assert_all_grads(m, o32["grads"], o64["grads"], max_floor_share=0.0)
+    assert packed_error(fix, "g64::enc", e_gpu.grad) < TOL
+    _assert_all_grads_g15(m, fix, max_floor_share=0.0)
 
 
 def test_faceformer_config5_T3000_full_gradients_vs_oracle():
-    """configs[4] end to end with the real encoder: N = 800 008 samples -> 3000 frames, forward + backward through the decoder's 24
-    blocks, the flash-attention backward over 3000 keys and the whole encoder, in the configuration's parity setting (bf16x3): d loss /
-    d audio and every parameter gradient against the oracle's autograd at the configuration's 1e-3 (the fp32-class path is held to the
-    usual 1e-4)."""
-    m, esd, dsd = _faceformer_full()
+    """configs[4] end to end with the real encoder: N = 800 008 samples -> 3000 frames (5x beyond the reference's 600-frame mask / PPE tables,
+    faceformer.py:118-120), forward + backward through the decoder's 24 blocks, the flash-attention backward over 3000 keys and the whole encoder, in the
+    configuration's parity setting (bf16x3): the encoder output, the vertex offsets, d loss / d audio and every parameter gradient against the oracle's autograd
+    (fixture g15_c5_T3000_full_s3002) at the fp32-class 1e-4 - ten times inside the configuration's stated 1e-3."""
+    m, _esd, _dsd = _faceformer_full()
     T = 3000
     audio, oh, template, gt = _ff_long_inputs(T, 3002)
-    o32 = _oracle_ff_run(esd, dsd, audio, oh, template, gt, T, torch.float32, checkpoint=True)
-    o64 = _oracle_ff_run(esd, dsd, audio, oh, template, gt, T, torch.float64, checkpoint=True)
+    fix = load("g15_c5_T3000_full_s3002")
+    with torch.no_grad():
+        assert packed_error(fix, "enc", m.encode(audio.to(DEV), T)) < TOL
     a_gpu = audio.to(DEV).requires_grad_(True)
     pred, loss = m.forward_with_loss(a_gpu, oh.to(DEV), template.to(DEV), gt.to(DEV))
-    err = rel_l2(pred.detach().cpu() - template.view(1, 1, 5023, 3), o32["pred"] - template.view(1, 1, 5023, 3))
+    assert pred.shape == (1, T, 5023, 3)
+    err = packed_error(fix, "pred_off", pred.detach().cpu() - template.view(1, 1, 5023, 3))
     print("T=3000 parity setting, vertex offsets vs oracle:", err)
     assert err < TOL
     loss["loss"].backward()
-    assert rel_l2(a_gpu.grad, o32["grads"]["audio"]) < TOL
-    _assert_all_grads(m, o32["grads"], o64["grads"])
+    assert packed_error(fix, "g64::audio", a_gpu.grad) < TOL
+    _assert_all_grads_g15(m, fix)
 
 
-def test_faceformer_config5_T3000_encoder_vs_oracle():
-    """BASELINE configs[4]'s sequence length: N = 800 008 samples -> T = 3000 frames (5x beyond the reference's 600-frame
-    mask / PPE tables, faceformer.py:118-120) through the real encoder and the decoder, forward against the oracle at the
-    configuration's stated tolerance of 1e-3 (the fp32 path is held to 1e-4 as everywhere else)."""
-    from oracle import faceformer as o_ff, wav2vec2 as o_w2v
-    m, esd, dsd = _faceformer_full()
-    T = 3000
-    gen = torch.Generator().manual_seed(3000)
-    audio = torch.randn(1, T * 16000 // 60 + 8, generator=gen) * 0.1
-    oh = torch.zeros(1, 12); oh[0, 2] = 1
-    template = torch.randn(1, 5023, 3, generator=gen) * 5
-    with torch.no_grad():
-        enc = o_w2v.wav2vec2_forward(esd, o_w2v.normalize_waveform(audio), T)
-        y_ref = o_ff.decode_incremental_hidden(dsd, enc, oh)                                    # (T,64)
-        enc_gpu = m.encode(audio.to(DEV), T)
-        assert rel_l2(enc_gpu, enc) < TOL
-        pred = m(audio.to(DEV), oh.to(DEV), template.to(DEV))
-    assert pred.shape == (1, T, 5023, 3)
-    ref_off = torch.nn.functional.linear(y_ref, dsd["vertice_map_r.weight"], dsd["vertice_map_r.bias"])
-    assert rel_l2(pred.cpu().view(T, -1) - template.view(1, -1), ref_off) < TOL
-    # bench.py's configs[4] entry is timed in the library's DEFAULT setting (bf16x3 GEMMs and attention) - the assert above, at 10x inside
-    # the configuration's 1e-3.  The other settings, measured the same way (bench.py carries the fp8 ones as labelled variants):
+def test_faceformer_config5_T3000_other_precision_settings_miss_the_tolerance():
+    """bench.py's configs[4] entry is timed in the library's DEFAULT setting (bf16x3 GEMMs and attention) - the test above, at 10x inside the configuration's
+    1e-3.  The cheaper settings, measured against the same fixture: single-term e4m3 attention misses the 1e-3 on the vertex offsets (bench.py carries it as a
+    labelled variant with its error); plain-bf16 attention under bf16x3 GEMMs meets it FORWARD (1-3e-4) but not on the gradients (d loss / d audio 2.5e-3, 49-156
+    of 235 parameter gradients above 1e-3: tools/attn_precision_probe.py) - so neither is a configs[4] setting, and if one ever were this test and bench.py's
+    labelling must change."""
     from a2f_amd import ops
+    m, _esd, _dsd = _faceformer_full()
+    T = 3000
+    audio, oh, template, gt = _ff_long_inputs(T, 3002)
+    fix = load("g15_c5_T3000_full_s3002")
     be = ops.backend()
     assert be.mm_precision == 1 and be.attn_precision is None          # what the timed bench entry runs
-    errs = {}
-    settings = {"bf16_everywhere": (0, None), "bf16x3_gemms_fp8_attention": (1, 2)}
-    for name, (mmp, ap) in settings.items():
+    errs, gerr = {}, {}
+    for name, (mmp, ap) in {"bf16_everywhere": (0, None), "bf16x3_gemms_fp8_attention": (1, 2), "bf16x3_gemms_bf16_attention": (1, 0)}.items():
         old = be.mm_precision, be.attn_precision
         be.mm_precision, be.attn_precision = mmp, ap
         try:
-            with torch.no_grad():
-                p2 = m(audio.to(DEV), oh.to(DEV), template.to(DEV))
+            m.zero_grad(set_to_none=True)
+            a_gpu = audio.to(DEV).requires_grad_(True)
+            p2, l2 = m.forward_with_loss(a_gpu, oh.to(DEV), template.to(DEV), gt.to(DEV))
+            l2["loss"].backward()
         finally:
             be.mm_precision, be.attn_precision = old
-        errs[name] = rel_l2(p2.cpu().view(T, -1) - template.view(1, -1), ref_off)
-    print("T=3000 vertex-offset error vs oracle:", errs)
-    # single-term e4m3 attention is NOT a configs[4] setting: if it ever met the tolerance this test (and bench.py's labelling) must change
+        errs[name] = packed_error(fix, "pred_off", p2.detach().cpu() - template.view(1, 1, 5023, 3))
+        gerr[name] = packed_error(fix, "g64::audio", a_gpu.grad)
+    print("T=3000 vertex-offset error vs oracle:", errs, "d loss / d audio:", gerr)
     assert errs["bf16x3_gemms_fp8_attention"] > 1e-3
+    assert errs["bf16x3_gemms_bf16_attention"] < 1e-3 < gerr["bf16x3_gemms_bf16_attention"]
 
 
 @pytest.mark.parametrize("force_pipeline", [True])

@@ -3,7 +3,7 @@
 #   head_x3_kernel<50> at B = 19200 (tools/bench_head.py) and gemm_mfma_kernel NT 38400 x 3072 x 768 bf16x3 (tools/bench_mm_one.py).
 # Separate rocprofv3 --pmc passes per counter (FETCH_SIZE, WRITE_SIZE), no trace domains; FETCH_SIZE is doubled (gfx950 tallies the 128-B
 # requests of 16-B/lane loads at 64 B: MI355X_MICROARCH.md, HBM section); counters are in KB (1024 B).
-# usage: tools/pmc_traffic.sh [outdir]  -> writes <outdir>/r04_pmc_traffic.json (copy it to profiles/)
+# usage: tools/pmc_traffic.sh [outdir]  -> writes <outdir>/r05_pmc_traffic.json (copy it to profiles/)
 cd "$(dirname "$0")/.."
 out=${1:-gpurun_out/pmc_traffic}
 mkdir -p $out
@@ -31,6 +31,6 @@ for key, tag, needle, extra in (("head_x3_kernel", "head", "head_x3_kernel", {"f
         continue
     res[key] = dict(extra, hbm_bytes_per_launch=int(2 * f * 1024 + w * 1024), fetch_size_kb_raw=round(f, 1), write_size_kb_raw=round(w, 1), launches=[nf, nw],
                     how="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_traffic.sh); 2 x FETCH_SIZE + WRITE_SIZE, KB = 1024 B")
-json.dump(res, open(f"{out}/r04_pmc_traffic.json", "w"), indent=1)
+json.dump(res, open(f"{out}/r05_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY

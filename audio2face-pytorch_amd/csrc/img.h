@@ -41,13 +41,8 @@ __device__ __forceinline__ void store8(char* row_base, int n, const f32x4 a, con
     lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
   }
   char* p = row_base + elem_byte(n);
-#ifdef A2F_EPI_NT
-  __builtin_nontemporal_store(u32x4_t{hi[0], hi[1], hi[2], hi[3]}, reinterpret_cast<u32x4_t*>(p));
-  __builtin_nontemporal_store(u32x4_t{lo[0], lo[1], lo[2], lo[3]}, reinterpret_cast<u32x4_t*>(p + 64));
-#else
   *reinterpret_cast<u32x4_t*>(p) = u32x4_t{hi[0], hi[1], hi[2], hi[3]};
   *reinterpret_cast<u32x4_t*>(p + 64) = u32x4_t{lo[0], lo[1], lo[2], lo[3]};
-#endif
 }
 
 // the values hi + lo of four consecutive elements

@@ -434,6 +434,7 @@ def main():
                                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(head_ms, 4), "launches_timed": nl,
                                "measured_stream_GBs": stream_rates,
                                "whole_step_frac": round(B * steps / elapsed * 182732 / 1e9 / HBM_PEAK_GBS, 4)}
+        stage("voca: timed blocks + head roofline done")
         if rank == 0 and world == 1 and not args.no_secondary:
             # LABELLED VARIANT, not the headline: the same step with no prediction written (Voca.store_pred = False).  The reference's training_step never
             # reads pred (mse_error = rec_loss / 3 comes from the loss sums), so a trainer may drop the store; the Module API (forward returns pred) is what
@@ -485,6 +486,7 @@ def main():
         enc.layers_run, enc.forwards_run = 0, 0
         elapsed, loss_val, tinfo = timed(lambda: step(audio, one_hot, gt, templ), steps, max(warmup, 2), barrier, world, device,
                                          budget_s=12.0 if not long else 4.0, max_blocks=5 if not long else 3)
+        stage(f"faceformer {S} x {T}: timed blocks done")
         layers_run = enc.layers_run / max(enc.forwards_run, 1) if getattr(enc, "forwards_run", 0) else 12.0
         fps = world * S * T * steps / elapsed
         enc_path = getattr(model.audio_encoder, "compute_path", "torch ops (rocBLAS / MIOpen / SDPA)")
@@ -563,6 +565,7 @@ def main():
                                     "frac": round(hb / (hms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(hms, 4), "launches_timed": len(hev)}
             be.prof = be.prof_shapes = None
             res["roofline"] = roof
+        stage(f"faceformer {S} x {T}: roofline pass done")
         # the reference trains ONE sequence per optimizer step (train.py:33): the same step at S = 1 and S = 16 beside the S-sequence figure
         pts = []
         if args.no_batch_points:
@@ -592,6 +595,7 @@ def main():
                 for p_ in pts:
                     if p_["seqs_per_step"] == 1:
                         p_["graph_error"] = repr(e)[:200]
+        stage(f"faceformer {S} x {T}: batch points done")
         if pts:
             res["sequences_per_step_points"] = pts
         if want_cpu and cpu:
@@ -681,8 +685,17 @@ def main():
         del model
         return res
 
+    t_start = time.perf_counter()
+
+    def stage(msg):
+        """Progress on stderr (rank 0): the driver's log shows where a long run is; stdout stays ONE JSON line."""
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:6.1f} s] {msg}", file=sys.stderr, flush=True)
+
     runners = {"voca": run_voca, "faceformer": run_faceformer_entry, "audio2mesh": run_audio2mesh, "faceformer_long": run_faceformer_long}
+    stage(f"{args.workload}: start (world {world})")
     main_res = runners[args.workload](args.steps, args.warmup)
+    stage(f"{args.workload}: done")
     result = {"metric": "mesh-frames/sec training (VOCASET 5023-vert)", "value": main_res.pop("value"), "unit": main_res.pop("unit"),
               "n_gpus": world, "steps": main_res.pop("steps"), "warmup": args.warmup, "ms_per_step": main_res.pop("ms_per_step"),
               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": main_res.pop("dtype"), "data": "synthetic"}
@@ -700,8 +713,10 @@ def main():
             if name == "voca":
                 continue                                           # VOCA is the default headline; as a secondary it adds nothing new
             torch.cuda.empty_cache()
-            r = runners[name](max(3, min(args.secondary_steps, args.steps)), 3)
+            # >= 3 timed steps per block unless the caller asks for fewer (the two-rank rehearsal test: over gloo a 385-MB gradient exchange takes seconds)
+            r = runners[name](max(3 if args.secondary_steps >= 3 else 1, min(args.secondary_steps, args.steps)), min(3, args.warmup))
             r["model"] = name
+            stage(f"secondary {name}: done")
             sec.append(r)
         result["secondary"] = sec
     ns = {}

@@ -7,6 +7,7 @@ reference is read).  Inputs are NOT stored: the tests regenerate them from the s
 Per case: `pred_off` (vertex offsets of the fp32 run, packed), `enc` (the encoder output of the fp32 run, packed), `loss32` / `loss64`, for every gradient key `g64::<key>` (the float64 gradient, packed as a strided
 sample + L2 norm), `eref::<key>` (relative L2 distance of the fp32 oracle's gradient from it), `g32::<key>` (the fp32 oracle's gradient, packed) wherever that distance
 exceeds 2e-5 - a draw on which the reference's own fp32 arithmetic and float64 take different sides of a ReLU kink shows as eref ~ 1e-3 on EVERY gradient (g15_c2_wellcond_s602_subj2) -
+`near_kink_{frame,unit,pre64}` (every feed-forward unit whose float64 pre-activation is within 1e-4 of zero),
 and `relu_margin64`: the smallest |pre-activation| of the
 decoder's feed-forward ReLU over all frames and units in float64 (a draw whose margin is ~1e-7 has a unit on its kink: fp32-class arithmetic may land on the
 other side and move every gradient upstream by ~2e-4 - a property of the function, which the multi-draw test then reports instead of excusing silently).
@@ -30,6 +31,7 @@ FF_GAINS = {"vertice_map_r.weight": 4.0, "vertice_map.weight": 0.05, "obj_vector
 WELL_CONDITIONED_GAINS = {"original0": 40.0, "attention.out_proj": 0.25, "feed_forward.output_dense": 0.25}
 SAMPLES = 1024
 G32_FROM = 2e-5
+NEAR_KINK = 1e-4      # decoder feed-forward pre-activations closer to zero than this (float64 run) are listed in the fixture: the forward bar itself
 
 
 def pack(prefix, t, out):
@@ -74,11 +76,14 @@ def oracle_run(esd, dsd, audio, oh, template, gt, T, dtype, enc_states=None, che
     c = lambda t: t.clone().to(dtype)
     P = {k: (c(v).requires_grad_(True) if v.is_floating_point() and not k.startswith("PPE") else v) for k, v in dsd.items()}
     E, a, e = {}, None, None
-    margins = []
+    margins, near = [], []
     orig_relu = F.relu
 
     def relu_rec(x, *args, **kw):
-        margins.append(float(x.detach().abs().min()))
+        xd = x.detach()
+        for u in (xd.abs() < NEAR_KINK).nonzero().flatten().tolist():      # (frame, unit, pre-activation): the units fp32-class arithmetic may put on either side
+            near.append((len(margins), u, float(xd[u])))
+        margins.append(float(xd.abs().min()))
         return orig_relu(x, *args, **kw)
 
     if enc_states is None:
@@ -101,7 +106,7 @@ def oracle_run(esd, dsd, audio, oh, template, gt, T, dtype, enc_states=None, che
     if e is not None:
         grads["enc"] = e.grad.double()
     return {"pred": ref.detach().float(), "loss": float(ol["loss"].detach()), "grads": grads, "relu_margin": min(margins) if margins else float("nan"),
-            "enc": enc.detach().float() if enc_states is None else None}
+            "enc": enc.detach().float() if enc_states is None else None, "near_kink": near}
 
 
 def case(name, esd, dsd, audio, oh, template, gt, T, enc_states=None, checkpoint=False):
@@ -111,6 +116,10 @@ def case(name, esd, dsd, audio, oh, template, gt, T, enc_states=None, checkpoint
     o64 = oracle_run(esd, dsd, audio, oh, template, gt, T, torch.float64, enc_states, checkpoint)
     out = {"loss32": np.float64(o32["loss"]), "loss64": np.float64(o64["loss"]), "relu_margin64": np.float64(o64["relu_margin"]),
            "relu_margin32": np.float64(o32["relu_margin"]), "T": np.int64(T)}
+    nk = o64["near_kink"]
+    out["near_kink_frame"] = np.asarray([f for f, _u, _v in nk], dtype=np.int64)
+    out["near_kink_unit"] = np.asarray([u for _f, u, _v in nk], dtype=np.int64)
+    out["near_kink_pre64"] = np.asarray([v for _f, _u, v in nk], dtype=np.float64)
     pack("pred_off", o32["pred"] - template.view(1, 1, 5023, 3), out)
     if o32["enc"] is not None:
         pack("enc", o32["enc"], out)                      # the encoder's last_hidden_state (1, T, 768) of the fp32 run

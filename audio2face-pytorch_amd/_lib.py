@@ -62,6 +62,12 @@ class MMDesc(C.Structure):
     ]
 
 
+class RelayoutItem(C.Structure):
+    """Mirror of ``a2f_relayout_item`` (include/a2f_hip.h)."""
+    _fields_ = [("src", c_f32p), ("dst", c_f32p), ("Co", i32), ("Ci", i32), ("KH", i32), ("Cop", i32), ("Cip", i32), ("mode", i32),
+                ("pad_value", f32), ("reserved", i32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/a2f_hip.h declares
 SIGNATURES = {
     "a2f_version": (C.c_int, []),
@@ -89,6 +95,7 @@ SIGNATURES = {
     "a2f_voca_trunk_bwd_data": (C.c_int, [c_f32p] * 12 + [i64] + [c_f32p] * 6 + [C.c_void_p]),
     "a2f_a2m_pack": (C.c_int, [c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, i64, i64, C.c_void_p]),
     "a2f_conv_weight_pack": (C.c_int, [c_f32p, c_f32p, i64, i64, i64, i32, C.c_void_p]),
+    "a2f_relayout_batch": (C.c_int, [C.POINTER(RelayoutItem), i32, C.c_void_p]),
     "a2f_bn_ws_bytes": (sz, [i64, i64]),
     "a2f_bn_fwd": (C.c_int, [c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, c_f32p, f32, f32, i32, i32,
                              c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
@@ -97,7 +104,7 @@ SIGNATURES = {
     "a2f_bn_fwd_conv0": (C.c_int, [c_f32p, c_f32p, c_f32p, i64, i64, i64, c_f32p, c_f32p, c_f32p, c_f32p, f32, f32, i32, i32,
                                    c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
     "a2f_bn_bwd_conv0": (C.c_int, [c_f32p, c_f32p, c_f32p, i64, c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, c_f32p, i32, i32,
-                                   c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
+                                   c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, sz, C.c_void_p]),
     "a2f_ff_save_bytes": (sz, [i64, i64]),
     "a2f_ff_decoder_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, i64, i64, i32, c_f32p, C.c_void_p, sz, C.c_void_p]),
     "a2f_ff_decoder_bwd": (C.c_int, [c_f32p, c_f32p, i64, i64, i32, C.c_void_p, sz, c_f32p, c_f32p, c_f32p, C.c_void_p]),

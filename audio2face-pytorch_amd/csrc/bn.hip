@@ -377,16 +377,27 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float* _
 // weights, bias and BatchNorm constants in registers and walks the rows of its workgroup's slab - no division, no LDS, no constant reloaded per element
 // (a one-float4-per-thread form with the constants in LDS spent ~80 instructions per 16 bytes and streamed at 3 TB/s: 5.71 -> 5.50 ms per step).  A workgroup writes one
 // contiguous slab of rows.  BWD = false: y = relu?(bn(x)); BWD = true: dx as in bn_bwd_apply_kernel.
-template <bool BWD>
+// WG (backward only): the convolution's OWN weight / bias gradient is collected in the same pass - dwg[c][kh] = sum_r dx(r, c) a0[2r - 1 + kh], dcbias[c] = sum_r dx(r, c)
+// (layer 0 has no data gradient, so dx has no other reader: with out == nullptr it is never written - 302 MB at B = 1024 - and the separate weight-gradient
+// kernel that read it back is gone).  Per thread 16 fp32 accumulators over its rows, the row-offset threads of a channel quad added in order through LDS, one
+// slab row [q][12 weights | 4 biases] per workgroup in wpart; bn_conv0_wgrad_fold_kernel adds the slab rows in double, fixed order.
+template <bool BWD, bool WG = false>
 __global__ __launch_bounds__(BN_THREADS) void bn_conv0_rows_kernel(const BnSrc src, const float* __restrict__ dy, int64_t R, int C, float invR,
                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                     const float* __restrict__ dgamma, const float* __restrict__ dbeta, int training, int relu,
-                                                                    float* __restrict__ out) {
+                                                                    float* __restrict__ out, float* __restrict__ wpart = nullptr) {
+  static_assert(BWD || !WG, "the weight gradient belongs to the backward pass");
+  __shared__ float s_wg[WG ? BN_THREADS * 16 : 1];
   const int t = threadIdx.x;
   const int Q = C >> 2, rpp = BN_THREADS / Q;
   const int q = t % Q, ro = t / Q;
-  if (ro >= rpp) return;
+  if (!WG && ro >= rpp) return;
+  float aw[12], ab[4];
+#pragma unroll
+  for (int e = 0; e < 12; ++e) aw[e] = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) ab[e] = 0.f;
   const int64_t rows_per_block = (R + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
@@ -405,7 +416,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_conv0_rows_kernel(const BnSrc s
     db[e] = (BWD && training) ? dbeta[c] * invR : 0.f;
     dg[e] = (BWD && training) ? dgamma[c] * invR : 0.f;
   }
-  for (int64_t r = r0 + ro; r < r1; r += rpp) {
+  for (int64_t r = r0 + ro; r < (ro < rpp ? r1 : r0); r += rpp) {
     const float4 xv = conv0_eval4(src.a0, r, src.P_out, w12, cb4);
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
     float o[4];
@@ -426,8 +437,56 @@ __global__ __launch_bounds__(BN_THREADS) void bn_conv0_rows_kernel(const BnSrc s
         o[e] = gi[e] * (g - db[e] - xhat * dg[e]);
       }
     }
-    *reinterpret_cast<float4*>(out + r * C + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+    if (!WG || out) *reinterpret_cast<float4*>(out + r * C + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+    if constexpr (WG) {
+      const float i1 = src.a0[2 * r], i2 = src.a0[2 * r + 1];
+      const float i0 = (r % src.P_out) ? src.a0[2 * r - 1] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        aw[3 * e] = fmaf(o[e], i0, aw[3 * e]);
+        aw[3 * e + 1] = fmaf(o[e], i1, aw[3 * e + 1]);
+        aw[3 * e + 2] = fmaf(o[e], i2, aw[3 * e + 2]);
+        ab[e] += o[e];
+      }
+    }
   }
+  if constexpr (WG) {
+#pragma unroll
+    for (int e = 0; e < 12; ++e) s_wg[t * 16 + e] = aw[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_wg[t * 16 + 12 + e] = ab[e];
+    __syncthreads();
+    for (int idx = t; idx < Q * 16; idx += BN_THREADS) {
+      const int qq = idx >> 4, e = idx & 15;
+      float v = 0.f;
+      for (int o2 = 0; o2 < rpp; ++o2) v += s_wg[(o2 * Q + qq) * 16 + e];
+      wpart[(int64_t)blockIdx.x * Q * 16 + idx] = v;
+    }
+  }
+}
+
+// dwg (C, 3), dcbias (C) from the slab rows of bn_conv0_rows_kernel<true, true>: one workgroup per 16 slab columns, thread (column t & 15, phase t >> 4) adds
+// its blocks in double, the sixteen phases are then added in order
+__global__ __launch_bounds__(256) void bn_conv0_wgrad_fold_kernel(const float* __restrict__ wpart, int nblk, int Q, float* __restrict__ dwg, float* __restrict__ dcbias) {
+  __shared__ double sh[16][17];
+  const int e = threadIdx.x & 15, ph = threadIdx.x >> 4;
+  const int qq = blockIdx.x;                                  // one channel quad per workgroup: 16 columns [12 weights | 4 biases]
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;            // four chains: the loads of a trip are in flight together
+  int b = ph;
+  for (; b + 48 < nblk; b += 64) {
+    const float x0 = wpart[((int64_t)b * Q + qq) * 16 + e], x1 = wpart[((int64_t)(b + 16) * Q + qq) * 16 + e];
+    const float x2 = wpart[((int64_t)(b + 32) * Q + qq) * 16 + e], x3 = wpart[((int64_t)(b + 48) * Q + qq) * 16 + e];
+    v0 += (double)x0; v1 += (double)x1; v2 += (double)x2; v3 += (double)x3;
+  }
+  for (; b < nblk; b += 16) v0 += (double)wpart[((int64_t)b * Q + qq) * 16 + e];
+  const double v = (v0 + v1) + (v2 + v3);
+  sh[ph][e] = v;
+  __syncthreads();
+  if (ph != 0) return;
+  double tot = 0.0;
+  for (int p2 = 0; p2 < 16; ++p2) tot += sh[p2][e];
+  if (e < 12) dwg[12 * qq + e] = (float)tot;                 // (c = 4 qq + e / 3, kh = e % 3): the (C, 3) layout itself
+  else dcbias[4 * qq + (e - 12)] = (float)tot;
 }
 
 }  // namespace a2f
@@ -484,10 +543,12 @@ static int bn_fwd_impl(const a2f::BnSrc src, bool conv0, int64_t R, int64_t C, c
 
 static int bn_bwd_impl(const a2f::BnSrc src, bool conv0, const float* beta, const float* dy, int64_t R, int64_t C, const float* gamma,
                        const float* save_mean, const float* save_invstd, int32_t training, int32_t relu, float* dx, float* dgamma, float* dbeta, void* ws,
-                       size_t ws_bytes, a2f_stream_t stream) {
+                       size_t ws_bytes, a2f_stream_t stream, float* dwg = nullptr, float* dcbias = nullptr) {
   using namespace a2f;
   const float* x = src.x;
-  A2F_CHECK_ARG((x || conv0) && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws && (beta || !relu), "bn_bwd: null pointer (beta is needed with relu)");
+  const bool wgrad = dwg != nullptr;
+  A2F_CHECK_ARG((x || conv0) && dy && gamma && save_mean && save_invstd && (dx || wgrad) && dgamma && dbeta && ws && (beta || !relu), "bn_bwd: null pointer (beta is needed with relu)");
+  A2F_CHECK_ARG(!wgrad || (conv0 && dcbias), "bn_bwd: the fused weight gradient exists for the conv0 form only and needs dcbias");
   A2F_CHECK_ARG(R > 0 && C > 0 && C <= BN_MAX_C, "bn_bwd: R=%lld C=%lld (C <= %d)", (long long)R, (long long)C, BN_MAX_C);
   if (ws_bytes < a2f_bn_ws_bytes(R, C)) return set_err(A2F_EWORKSPACE, "bn_bwd: workspace %zu < %zu", ws_bytes, a2f_bn_ws_bytes(R, C));
   hipStream_t s = (hipStream_t)stream;
@@ -508,9 +569,18 @@ static int bn_bwd_impl(const a2f::BnSrc src, bool conv0, const float* beta, cons
   A2F_CHECK_ARG(total / BN_THREADS < 0x7FFFFFFFll, "bn_bwd: R * C too large for one element per thread");
   if (conv0) {
     const int rpp = BN_THREADS / (int)(C / 4);
-    const int64_t blocks = std::min<int64_t>(cdiv(R, (int64_t)rpp * 32), 8192);
-    hipLaunchKernelGGL((bn_conv0_rows_kernel<true>), dim3((unsigned)blocks), dim3(BN_THREADS), 0, s, src, dy, R, (int)C, 1.0f / (float)R, gamma, beta, save_mean,
-                       save_invstd, (const float*)dgamma, (const float*)dbeta, (int)training, (int)relu, dx);
+    int64_t blocks = std::min<int64_t>(cdiv(R, (int64_t)rpp * 32), 8192);
+    if (!wgrad) {
+      hipLaunchKernelGGL((bn_conv0_rows_kernel<true>), dim3((unsigned)blocks), dim3(BN_THREADS), 0, s, src, dy, R, (int)C, 1.0f / (float)R, gamma, beta, save_mean,
+                         save_invstd, (const float*)dgamma, (const float*)dbeta, (int)training, (int)relu, dx, (float*)nullptr);
+    } else {
+      // the slab rows of the weight gradient take over the workspace (the statistics partials were consumed by bn_finish_bwd_kernel, earlier on this stream)
+      blocks = std::min<int64_t>(blocks, (int64_t)(ws_bytes / ((size_t)C * 4 * sizeof(float))));
+      A2F_CHECK_ARG(blocks >= 1, "bn_bwd_conv0: workspace too small for one weight-gradient slab row");
+      hipLaunchKernelGGL((bn_conv0_rows_kernel<true, true>), dim3((unsigned)blocks), dim3(BN_THREADS), 0, s, src, dy, R, (int)C, 1.0f / (float)R, gamma, beta,
+                         save_mean, save_invstd, (const float*)dgamma, (const float*)dbeta, (int)training, (int)relu, dx, (float*)ws);
+      hipLaunchKernelGGL(bn_conv0_wgrad_fold_kernel, dim3((unsigned)(C / 4)), dim3(256), 0, s, (const float*)ws, (int)blocks, (int)(C / 4), dwg, dcbias);
+    }
   } else if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)cdiv(total / 4, BN_THREADS)), dim3(BN_THREADS), 0, s, x, beta, dy, total, (int)C, 1.0f / (float)R,
                        gamma, save_mean, save_invstd, dgamma, dbeta, (int)training, (int)relu, dx);
@@ -554,8 +624,10 @@ extern "C" int a2f_bn_fwd_conv0(const float* a0, const float* wg, const float* c
 
 extern "C" int a2f_bn_bwd_conv0(const float* a0, const float* wg, const float* cbias, int64_t P_out, const float* beta, const float* dy, int64_t R, int64_t C,
                                 const float* gamma, const float* save_mean, const float* save_invstd, int32_t training, int32_t relu, float* dx,
-                                float* dgamma, float* dbeta, void* ws, size_t ws_bytes, a2f_stream_t stream) {
+                                float* dgamma, float* dbeta, float* dwg, float* dcbias, void* ws, size_t ws_bytes, a2f_stream_t stream) {
   if (int rc = bn_conv0_check(a0, wg, cbias, P_out, R, C, gamma, beta, dy, "bn_bwd_conv0")) return rc;
+  A2F_CHECK_ARG((dwg == nullptr) == (dcbias == nullptr), "bn_bwd_conv0: dwg and dcbias come together");
+  A2F_CHECK_ARG(dx == nullptr || (((uintptr_t)dx) & 15) == 0, "bn_bwd_conv0: dx must be 16-byte aligned");
   return bn_bwd_impl(a2f::BnSrc{nullptr, a0, wg, cbias, (int)P_out}, true, beta, dy, R, C, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta, ws, ws_bytes,
-                     stream);
+                     stream, dwg, dcbias);
 }

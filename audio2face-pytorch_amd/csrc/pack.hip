@@ -55,7 +55,49 @@ __global__ void conv_weight_pack_kernel(const float* __restrict__ src, float* __
   }
 }
 
+constexpr int RL_MAX = 32, RL_BLOCKS = 64;
+struct RelayoutBatch { a2f_relayout_item it[RL_MAX]; };
+
+// grid (RL_BLOCKS, n): the workgroups of column y walk item y's DESTINATION elements
+__global__ __launch_bounds__(256) void relayout_batch_kernel(const RelayoutBatch b) {
+  const a2f_relayout_item& it = b.it[blockIdx.y];
+  const int Co = it.Co, Ci = it.Ci, KH = it.KH, Cop = it.Cop, Cip = it.Cip;
+  const int kp = KH * Cip;
+  const int64_t total = it.mode == 2 ? (int64_t)Co * Ci * KH : (int64_t)Cop * kp;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)RL_BLOCKS * 256) {
+    if (it.mode == 2) {                                     // i = (co * Ci + ci) * KH + kh
+      const int kh = (int)(i % KH);
+      const int64_t r = i / KH;
+      const int ci = (int)(r % Ci), co = (int)(r / Ci);
+      it.dst[i] = it.src[(int64_t)co * kp + kh * Cip + ci];
+    } else {
+      int co, k;
+      if (it.mode == 0) { co = (int)(i / kp); k = (int)(i - (int64_t)co * kp); }
+      else { k = (int)(i / Cop); co = (int)(i - (int64_t)k * Cop); }
+      const int kh = k / Cip, ci = k - kh * Cip;
+      it.dst[i] = (co < Co && ci < Ci) ? it.src[((int64_t)co * Ci + ci) * KH + kh] : it.pad_value;
+    }
+  }
+}
+
 }  // namespace a2f
+
+extern "C" int a2f_relayout_batch(const a2f_relayout_item* items, int32_t n, a2f_stream_t stream) {
+  using namespace a2f;
+  A2F_CHECK_ARG(items && n >= 1 && n <= RL_MAX, "relayout_batch: n=%d (1 .. %d items)", (int)n, RL_MAX);
+  RelayoutBatch b;
+  for (int i = 0; i < n; ++i) {
+    const a2f_relayout_item& it = items[i];
+    A2F_CHECK_ARG(it.src && it.dst && it.src != it.dst, "relayout_batch: item %d: null or aliased pointers", i);
+    A2F_CHECK_ARG(it.Co >= 1 && it.Ci >= 1 && it.KH >= 1 && it.Cop >= it.Co && it.Cip >= it.Ci && it.mode >= 0 && it.mode <= 2 &&
+                  (int64_t)it.Cop * it.KH * it.Cip < (1ll << 31), "relayout_batch: item %d: Co=%d Ci=%d KH=%d Cop=%d Cip=%d mode=%d", i, it.Co, it.Ci, it.KH, it.Cop, it.Cip, it.mode);
+    b.it[i] = it;
+  }
+  for (int i = n; i < RL_MAX; ++i) b.it[i] = items[0];
+  hipLaunchKernelGGL(relayout_batch_kernel, dim3(RL_BLOCKS, (unsigned)n), dim3(256), 0, (hipStream_t)stream, b);
+  A2F_CHECK_LAUNCH("relayout_batch");
+  return A2F_OK;
+}
 
 extern "C" int a2f_voca_pack(const float* x, const float* one_hot, int64_t B, int64_t n_onehot, float* a0, float* cat72,
                              a2f_stream_t stream) {

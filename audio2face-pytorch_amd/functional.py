@@ -276,44 +276,41 @@ A2M_BN_MOMENTUM, A2M_BN_EPS = 0.1, 1e-5
 A2M_CHP = (1, 72, 108, 164, 244, 256)          # padded analysis channels
 
 
-# Padded / re-laid-out copies of parameters are refreshed every step (the parameters change); their BUFFERS are kept with the source tensor, so a
-# refresh is one copy into the valid region of a buffer whose padding was written once - not an allocation, a fill and a copy (the Audio2Mesh
-# step spent ~50 launches of ~5 us on exactly that).  A buffer lives in a dict ON its owner - the parameter / BatchNorm buffer itself, or the base
-# tensor of a view of one - so it exists exactly as long as the owner does: a captured hipGraph that has its address baked in and an autograd graph that
-# saved it both hold the model, hence the owner, hence the buffer (a process-global table keyed by address had to be emptied at some size, under
-# the feet of whoever still replayed a graph over those addresses).
-def _cached(src, key, make):
-    owner = src._base if src._base is not None else src
-    table = owner.__dict__.get("_a2f_padded")
-    if table is None:
-        table = owner.__dict__["_a2f_padded"] = {}
-    key = key + (src.data_ptr(), src.device)               # the owner may move (.to(), FlatAdam re-homing .data): stale entries simply stop matching
-    buf = table.get(key)
-    if buf is None:
-        for k in [k for k in table if k[:len(key) - 2] == key[:-2]]:
-            del table[k]                                   # the same view at an older address
-        buf = table[key] = make()
-    return buf
+# Padded / re-laid-out copies of parameters are refreshed every step (the parameters change).  Their BUFFERS belong to the model (`A2MPackBuffers`, kept by
+# Audio2Mesh in its __dict__ per device: they live exactly as long as the module, which is what a captured hipGraph with their addresses baked in and an
+# autograd graph that saved them both hold), and ONE a2f_relayout_batch launch fills all of them - nine packed convolution weights, their transposes for the
+# data-gradient products, two padded biases, eight padded BatchNorm vectors - where rounds 3-5 issued ~40 copies / fills of ~5 us each (a cache keyed on the
+# tensor objects never hit inside an autograd Function: its inputs are fresh aliases on every call).  The nine weight gradients take the way back in one launch too.
+A2M_PAD_LAYERS = (2, 3)                          # analysis blocks whose output channel count is padded (162 -> 164, 243 -> 244)
 
 
-def _padv(v, n, value=0.0):
-    if v.shape[0] == n:
-        return v
-    buf = _cached(v, ("padv", v.shape[0], n, float(value)), lambda: v.new_full((n,), value))
-    buf[: v.shape[0]].copy_(v)
-    return buf
+class A2MPackBuffers:
+    def __init__(self, device, KH9: int):
+        new = lambda *s: torch.empty(*s, device=device, dtype=torch.float32)
+        self.device, self.KH9 = device, KH9
+        self.dims = {}                                                         # layer -> (Co, Ci, KH, Cop, Cip)
+        for l in range(1, 5):
+            self.dims[l] = (A2M_CH[l + 1], A2M_CH[l], 3, A2M_CHP[l + 1], A2M_CHP[l])
+        for l in range(5, 9):
+            self.dims[l] = (256, 256, 3, 256, 256)
+        self.dims[9] = (256, 256, KH9, 256, 256)
+        self.wg = {l: new(d[3], d[2] * d[4]) for l, d in self.dims.items()}       # (Cop, KH * Cip), k = kh * Cip + ci
+        self.wgT = {l: new(d[2] * d[4], d[3]) for l, d in self.dims.items()}      # its transpose: both operands of a data-gradient product k-contiguous
+        self.bias = {l: new(A2M_CHP[l + 1]) for l in A2M_PAD_LAYERS}
+        self.bn = {l: tuple(new(A2M_CHP[l + 1]) for _ in range(4)) for l in A2M_PAD_LAYERS}     # gamma (pad 1), beta (0), running_mean (0), running_var (1)
 
-
-def _pack_conv_w(w3, Cop, Cip):
-    """w3 (Co, Ci, KH) -> (Cop, KH*Cip) with k = kh*Cip + ci, zero padded."""
-    Co, Ci, KH = w3.shape
-    out = _cached(w3, ("convw", Co, Ci, KH, Cop, Cip), lambda: w3.new_zeros(Cop, KH, Cip))
-    out[:Co, :, :Ci].copy_(w3.permute(0, 2, 1))
-    return out.view(Cop, KH * Cip)
-
-
-def _unpack_conv_w(dwg, Co, Ci, KH, Cip):
-    return dwg.view(-1, KH, Cip)[:Co, :, :Ci].permute(0, 2, 1).contiguous()
+    def refresh_items(self, convs, bns, bufs):
+        items = []
+        for l, (Co, Ci, KH, Cop, Cip) in self.dims.items():
+            w = convs[l][0]
+            items.append((w, self.wg[l], Co, Ci, KH, Cop, Cip, 0))
+            items.append((w, self.wgT[l], Co, Ci, KH, Cop, Cip, 1))
+        for l in A2M_PAD_LAYERS:
+            C, Cp = A2M_CH[l + 1], A2M_CHP[l + 1]
+            items.append((convs[l][1], self.bias[l], C, 1, 1, Cp, 1, 0))
+            for src, dst, pad in zip((bns[l][0], bns[l][1], bufs[2 * l], bufs[2 * l + 1]), self.bn[l], (1.0, 0.0, 0.0, 1.0)):
+                items.append((src, dst, C, 1, 1, Cp, 1, 0, pad))
+        return items
 
 
 # a2f_mm_desc.precision of the trunk's products on a2f_mm, per kind: "fwd,wgrad,dgrad" (or one number for all three); 2 = bf16x6
@@ -343,17 +340,18 @@ class A2MTrunkMMFn(torch.autograd.Function):
     analysis stage (B*64 rows-of-W, W, C), articulation stage (B, H, 256)."""
 
     @staticmethod
-    def forward(ctx, x, one_hot, training, *rest):
+    def forward(ctx, x, one_hot, training, pk, *rest):
         be = ops.backend()
         with _mm_precision(be, A2M_PREC_FWD):
-            return A2MTrunkMMFn._forward(ctx, be, x, one_hot, training, *rest)
+            return A2MTrunkMMFn._forward(ctx, be, x, one_hot, training, pk, *rest)
 
     @staticmethod
-    def _forward(ctx, be, x, one_hot, training, *rest):
+    def _forward(ctx, be, x, one_hot, training, pk, *rest):
         bufs, params = rest[:20], rest[20:]
         convs = [(_f32c(params[2 * i]), _f32c(params[2 * i + 1])) for i in range(10)]
         bns = [(_f32c(params[20 + 2 * i]), _f32c(params[21 + 2 * i])) for i in range(10)]
         fcs = [(_f32c(params[40 + 2 * i]), _f32c(params[41 + 2 * i])) for i in range(3)]
+        be.relayout_batch(pk.refresh_items(convs, bns, bufs))          # every packed / padded copy of this step's parameters: one launch
         B, no = x.shape[0], one_hot.shape[1]
         H0 = 52 + no
         dev = x.device
@@ -364,14 +362,9 @@ class A2MTrunkMMFn(torch.autograd.Function):
         sv = {"wg": [None] * 10, "conv_in": [None] * 10, "bn_x": [None] * 10, "bn_b": [None] * 10, "stats": [None] * 10, "bn_g": [None] * 10}
 
         def bn(i, xin, R, C, Cp, relu):
-            g, b = bns[i]
-            gp, bp = _padv(g, Cp, 1.0), _padv(b, Cp)
-            rm, rv = bufs[2 * i], bufs[2 * i + 1]
-            rmp, rvp = (rm, rv) if Cp == C else (_padv(rm, Cp), _padv(rv, Cp, 1.0))
+            gp, bp, rmp, rvp = pk.bn[i] if Cp != C else (bns[i][0], bns[i][1], bufs[2 * i], bufs[2 * i + 1])
             y, mu, istd = new(R, Cp), new(Cp), new(Cp)
             be.bn_fwd(xin, R, Cp, gp, bp, rmp, rvp, A2M_BN_MOMENTUM, A2M_BN_EPS, training, relu, y, mu, istd)
-            if Cp != C and training:
-                rm.copy_(rmp[:C]); rv.copy_(rvp[:C])
             sv["bn_x"][i], sv["bn_b"][i], sv["stats"][i], sv["bn_g"][i] = xin, bp, (mu, istd), gp
             return y
 
@@ -390,19 +383,17 @@ class A2MTrunkMMFn(torch.autograd.Function):
         Wd = 16
         for l in range(1, 5):                                  # analysis layers 1..4: windows over W, sequences = (frame, row)
             ci, co, cip, cop = A2M_CH[l], A2M_CH[l + 1], A2M_CHP[l], A2M_CHP[l + 1]
-            w, b = convs[l]
-            wg = _pack_conv_w(w.view(co, ci, 3), cop, cip)
+            wg = pk.wg[l]
             Wo = Wd // 2
             R = B * H0 * Wo
             z = new(R, cop)
-            ops.mm_conv_fwd(be, act, wg, z, B * H0, Wd, Wo, cip, cop, 3, 2, pad=1, bias=_padv(b, cop))
+            ops.mm_conv_fwd(be, act, wg, z, B * H0, Wd, Wo, cip, cop, 3, 2, pad=1, bias=pk.bias[l] if cop != co else convs[l][1])
             sv["wg"][l], sv["conv_in"][l] = wg, act
             act = bn(l, z, R, co, cop, True)
             Wd = Wo
         Hd = H0
         for l in range(5, 8):                                  # articulation: windows over H, sequences = frames
-            w, b = convs[l]
-            wg = _pack_conv_w(w.view(256, 256, 3), 256, 256)
+            wg, b = pk.wg[l], convs[l][1]
             Ho = Hd // 2
             z = new(B * Ho, 256)
             ops.mm_conv_fwd(be, act, wg, z, B, Hd, Ho, 256, 256, 3, 2, pad=1, bias=b)
@@ -410,17 +401,14 @@ class A2MTrunkMMFn(torch.autograd.Function):
             act = bn(l, z, B * Ho, 256, 256, True)
             Hd = Ho
         act = bn(8, act, B * Hd, 256, 256, False)              # BN -> conv -> ReLU   (order flip, audio2face.py:41-43)
-        w, b = convs[8]
-        wg = _pack_conv_w(w.view(256, 256, 3), 256, 256)
+        wg, b = pk.wg[8], convs[8][1]
         Ho = Hd // 2
         z8 = new(B * Ho, 256)
         ops.mm_conv_fwd(be, act, wg, z8, B, Hd, Ho, 256, 256, 3, 2, pad=1, bias=b, act=ops.MM_ACT_RELU)
         sv["wg"][8], sv["conv_in"][8] = wg, act
         Hd = Ho
         zb = bn(9, z8, B * Hd, 256, 256, False)                # BN -> conv(4,1)/s4 -> ReLU  (audio2face.py:44-46)
-        w, b = convs[9]
-        KH9 = w.shape[2]
-        wg = _pack_conv_w(w.view(256, 256, KH9), 256, 256)
+        wg, b, KH9 = pk.wg[9], convs[9][1], pk.KH9
         be.mm(ops.MMOp(zb, KH9 * 256), ops.MMOp(wg, KH9 * 256), cat, B, 256, KH9 * 256, ncat, bias=b, act=ops.MM_ACT_RELU)
         sv["wg"][9], sv["conv_in"][9] = wg, zb
         z1, z2, h3 = new(B, 72), new(B, 128), new(B, 50)
@@ -430,7 +418,9 @@ class A2MTrunkMMFn(torch.autograd.Function):
         ops.mm_linear_fwd(be, z1, fcs[1][0], fcs[1][1], z2, B, 128, 72)
         torch.tanh_(z2)
         ops.linear_fwd(be, z2, fcs[2][0], fcs[2][1], h3, B, 50, 128)
-        ctx.sv = sv
+        if training:                                         # the padded layers' running statistics go back into the module's buffers: one launch for the four
+            be.relayout_batch([(src, bufs[2 * l + j], A2M_CH[l + 1], 1, 1, A2M_CHP[l + 1], 1, 2) for l in A2M_PAD_LAYERS for j, src in enumerate(pk.bn[l][2:])])
+        ctx.sv, ctx.pk = sv, pk
         ctx.misc = (B, no, H0, Hd, KH9, training, cat, z8, z1, z2, [f[0] for f in fcs])
         return h3
 
@@ -446,8 +436,9 @@ class A2MTrunkMMFn(torch.autograd.Function):
 
     @staticmethod
     def _backward(ctx, be, dh3):
-        sv = ctx.sv
+        sv, pk = ctx.sv, ctx.pk
         B, no, H0, Hlast, KH9, training, cat, z8, z1, z2, fw = ctx.misc
+        unpack = []                                           # (packed weight gradient, gradient in the parameter's layout, layer): one a2f_relayout_batch at the end
         dev = cat.device
         ncat = 256 + no
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
@@ -479,22 +470,24 @@ class A2MTrunkMMFn(torch.autograd.Function):
         dwg, dbv = new(256, KH9 * 256), new(256)
         with _mm_precision(be, ctx.prec_wgrad):
             ops.mm_linear_wgrad(be, d, sv["conv_in"][9], dwg, B, 256, KH9 * 256, db=dbv)  # bias gradients: row sums inside the weight-gradient product
-        g_conv[18], g_conv[19] = _unpack_conv_w(dwg, 256, 256, KH9, 256).view(256, 256, KH9, 1), dbv
+        g_conv[18], g_conv[19] = new(256, 256, KH9, 1), dbv
+        unpack.append((dwg, g_conv[18], 9))
         dzb = new(B, KH9 * 256)
-        ops.mm_linear_dgrad(be, d, sv["wg"][9], dzb, B, 256, KH9 * 256)
+        ops.mm_linear_dgrad(be, d, sv["wg"][9], dzb, B, 256, KH9 * 256, WT=pk.wgT[9])
         dz = bn_bwd(9, dzb, B * Hlast, 256, 256, False)
-        dz = torch.where(z8 > 0, dz, torch.zeros_like(dz))    # conv 8's ReLU
+        dz = torch.ops.aten.threshold_backward(dz, z8, 0.0)   # conv 8's ReLU (z8 is its output): one launch
         Hd = 2 * Hlast
 
         def conv_bwd(i, dout, S, Lin, Lout, ci, co, cip, cop, shape, need_dx=True):
             dwg, dbv = new(cop, 3 * cip), new(cop)
             with _mm_precision(be, ctx.prec_wgrad):
                 ops.mm_conv_wgrad(be, sv["conv_in"][i], dout, dwg, S, Lin, Lout, cip, cop, 3, 2, pad=1, db=dbv)
-            g_conv[2 * i], g_conv[2 * i + 1] = _unpack_conv_w(dwg, co, ci, 3, cip).view(*shape), dbv[:co]
+            g_conv[2 * i], g_conv[2 * i + 1] = new(*shape), dbv[:co]
+            unpack.append((dwg, g_conv[2 * i], i))
             if not need_dx:
                 return None
             din = new(S * Lin, cip)                           # every position is written (Lin = 2 Lout, pad = 1)
-            ops.mm_conv_dgrad(be, dout, sv["wg"][i], din, S, Lin, Lout, cip, cop, 3, 2, pad=1)
+            ops.mm_conv_dgrad(be, dout, sv["wg"][i], din, S, Lin, Lout, cip, cop, 3, 2, pad=1, WgT=pk.wgT[i])
             return din
 
         dact = conv_bwd(8, dz, B, Hd, Hlast, 256, 256, 256, 256, (256, 256, 3, 1))
@@ -512,16 +505,15 @@ class A2MTrunkMMFn(torch.autograd.Function):
         # analysis layer 0 (Ci = 1): exact-fp32 generic kernels; no data gradient needed
         a0_, wg0_, cb0_ = sv["bn_x"][0]                      # layer 0: the convolution output is recomputed, not read
         mu0, istd0 = sv["stats"][0]
-        draw, dg0, dbt0 = new(B * H0 * Wd, 72), new(72), new(72)
-        be.bn_bwd_conv0(a0_, wg0_, cb0_, Wd, sv["bn_b"][0], d, B * H0 * Wd, 72, sv["bn_g"][0], mu0, istd0, training, True, draw, dg0, dbt0)
+        # ... and neither is its pre-activation gradient: the layer has no data gradient, so the same pass that forms it collects the layer's weight / bias gradient
+        # (a2f_bn_bwd_conv0 with dwg / dcbias; with Ci = 1 the (C, 3) result IS the parameter's (72, 1, 1, 3) layout) - 302 MB not written and not read back at B = 1024
+        dg0, dbt0, dw0, dbias0 = new(72), new(72), new(72, 1, 1, 3), new(72)
+        be.bn_bwd_conv0(a0_, wg0_, cb0_, Wd, sv["bn_b"][0], d, B * H0 * Wd, 72, sv["bn_g"][0], mu0, istd0, training, True, None, dg0, dbt0, dwg=dw0, dcbias=dbias0)
         g_bn[0], g_bn[1] = dg0, dbt0
-        dwg0, dbias0 = new(72, 3), new(72)
-        ops.conv_bwd_weight(be, sv["conv_in"][0], draw, dwg0, dbias0, B * H0 * Wd, Wd, 1, 72)
-        dw0 = new(72, 1, 1, 3)
-        be.conv_weight_pack(dwg0, dw0, 72, 1, 3, 1)
         g_conv[0], g_conv[1] = dw0, dbias0
-        ctx.sv = None
-        return (None, None, None) + (None,) * 20 + tuple(g_conv) + tuple(g_bn) + tuple(g_fc)
+        be.relayout_batch([(dwg, g, *pk.dims[l], 2) for dwg, g, l in unpack])
+        ctx.sv = ctx.pk = None
+        return (None, None, None, None) + (None,) * 20 + tuple(g_conv) + tuple(g_bn) + tuple(g_fc)
 
 
 # (Round 1's trunk on the generic split GEMM of gemm.hip - 11.4 ms at B = 1024 against 7.9 ms - was removed in round 3; a2f_mm with

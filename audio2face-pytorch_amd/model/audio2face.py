@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..functional import A2M_CH, A2MTrunkMMFn, HeadFn, HeadLossFusedFn
+from ..functional import A2M_CH, A2MPackBuffers, A2MTrunkMMFn, HeadFn, HeadLossFusedFn
 
 
 class Audio2Mesh(nn.Module):
@@ -51,7 +51,12 @@ class Audio2Mesh(nn.Module):
             params += [b.weight, b.bias]
         for i in (0, 1, 3):
             params += [self.output_net[i].weight, self.output_net[i].bias]
-        h3 = A2MTrunkMMFn.apply(x, one_hot, self.training, *bufs, *params)
+        # the step's packed / padded parameter copies live in buffers this module owns (one set per device; see functional.A2MPackBuffers)
+        table = self.__dict__.setdefault("_a2f_pack", {})
+        pk = table.get(x.device)
+        if pk is None:
+            pk = table[x.device] = A2MPackBuffers(x.device, self.articulation_net[13].weight.shape[2])
+        h3 = A2MTrunkMMFn.apply(x, one_hot, self.training, pk, *bufs, *params)
         if self.training:
             torch._foreach_add_([b.num_batches_tracked for b in bns], 1)          # one launch instead of ten
         return h3

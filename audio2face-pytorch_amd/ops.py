@@ -530,13 +530,32 @@ class HipBackend:
                                              int(training), int(relu), _ptr(y), _ptr(save_mean), _ptr(save_invstd), _ptr(ws), nb,
                                              self._stream(a0)), "a2f_bn_fwd_conv0")
 
-    def bn_bwd_conv0(self, a0, wg, cbias, P_out, beta, dy, R, Cc, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta):
-        _chk(a0, wg, cbias, beta, dy, gamma, save_mean, save_invstd, dx, dgamma, dbeta)
+    def bn_bwd_conv0(self, a0, wg, cbias, P_out, beta, dy, R, Cc, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta, dwg=None, dcbias=None):
+        """dwg (C, 3), dcbias (C): the convolution's own parameter gradients from the same pass; dx may then be None (never written)."""
+        _chk(a0, wg, cbias, beta, dy, gamma, save_mean, save_invstd, dx, dgamma, dbeta, dwg, dcbias)
         nb = self.lib.a2f_bn_ws_bytes(R, Cc)
         ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device=a0.device)
         _lib.check(self.lib.a2f_bn_bwd_conv0(_ptr(a0), _ptr(wg), _ptr(cbias), P_out, _ptr(beta), _ptr(dy), R, Cc, _ptr(gamma), _ptr(save_mean), _ptr(save_invstd),
-                                             int(training), int(relu), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), nb,
+                                             int(training), int(relu), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(dwg), _ptr(dcbias), _ptr(ws), nb,
                                              self._stream(a0)), "a2f_bn_bwd_conv0")
+
+    def relayout_batch(self, items):
+        """items: (src, dst, Co, Ci, KH, Cop, Cip, mode[, pad_value]) - a2f_relayout_batch: packed / transposed-packed weights (modes 0 / 1, padded elements = pad_value)
+        and unpacked weight gradients (mode 2) of many layers in one launch (<= 32 items per launch; longer lists are cut)."""
+        for i0 in range(0, len(items), 32):
+            chunk = items[i0:i0 + 32]
+            arr = (_lib.RelayoutItem * len(chunk))()
+            for a, it in zip(arr, chunk):
+                src, dst = it[0], it[1]
+                _chk(src, dst)
+                a.src, a.dst = _ptr(src), _ptr(dst)
+                a.Co, a.Ci, a.KH, a.Cop, a.Cip, a.mode = (int(v) for v in it[2:8])
+                a.pad_value = float(it[8]) if len(it) > 8 else 0.0
+                need_src = a.Co * a.Ci * a.KH if a.mode != 2 else a.Cop * a.KH * a.Cip
+                need_dst = a.Cop * a.KH * a.Cip if a.mode != 2 else a.Co * a.Ci * a.KH
+                if src.numel() < need_src or dst.numel() < need_dst:
+                    raise A2FError(f"relayout_batch: item of {src.numel()} -> {dst.numel()} elements is smaller than its extents say ({need_src} -> {need_dst})")
+            _lib.check(self.lib.a2f_relayout_batch(arr, len(chunk), self._stream(chunk[0][0])), "a2f_relayout_batch")
 
     # ---- FaceFormer recurrence ----------------------------------------------------------------
     def ff_save_floats(self, S, T):
@@ -718,12 +737,12 @@ def mm_linear_fwd(be, x, W, bias, out, M, N, K, *, act=MM_ACT_NONE, pre=None, au
     be.mm(MMOp(x, K), MMOp(W, K), out, M, N, K, N, bias=bias, act=act, C2=pre, aux=aux, ldaux=N, aux_mode=aux_mode, tag=tag)
 
 
-def mm_linear_dgrad(be, dy, W, dx, M, N, K, *, aux=None, aux_mode=MM_AUX_NONE, tag="gemm_mfma", keep=None):
+def mm_linear_dgrad(be, dy, W, dx, M, N, K, *, aux=None, aux_mode=MM_AUX_NONE, tag="gemm_mfma", keep=None, WT=None):
     """dx[M,K] = dy[M,N] W[N,K], optionally times an activation derivative evaluated on aux[M,K].  The weight is read through a
     transposed copy (K, N) so that BOTH operands are k-contiguous: the row-image staging path (one ds_read_b128 per fragment) is
     12-15 % faster than the transposing one, and the copy is 1/M of the product's traffic."""
-    if W.is_cuda and M >= 1024:
-        be.mm(MMOp(dy, N), MMOp(W.t().contiguous(), N), dx, M, K, N, K, aux=aux, ldaux=K, aux_mode=aux_mode, tag=tag, keep=keep)
+    if W.is_cuda and M >= 1024:                                # WT: the caller's own (K, N) copy of this step's weight
+        be.mm(MMOp(dy, N), MMOp(WT if WT is not None else W.t().contiguous(), N), dx, M, K, N, K, aux=aux, ldaux=K, aux_mode=aux_mode, tag=tag, keep=keep)
         return
     be.mm(MMOp(dy, N), MMOp(W, K, trans=True), dx, M, K, N, K, aux=aux, ldaux=K, aux_mode=aux_mode, tag=tag, keep=keep)
 
@@ -749,14 +768,17 @@ def mm_conv_wgrad(be, x, dy, dWg, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, ta
     be.mm(A, B, dWg, Co, KH * Ci, S * Lout, KH * Ci, split_k=0, tag=tag, a_rowsum=db)
 
 
-def mm_conv_dgrad(be, dy, Wg, dx, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, tag="gemm_mfma", mul=None):
+def mm_conv_dgrad(be, dy, Wg, dx, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, tag="gemm_mfma", mul=None, WgT=None):
     """dx (S,Lin,Ci) from dy (S,Lout,Co), gather form (no atomics, no col2im buffer); positions no window touches must be
     zero in dx on entry.  Supported: KH == stride, pad = 0 (non-overlapping windows) and KH = 3, stride = 2 with pad = 0
     (Lin >= 2 Lout + 1) or pad = 1 (Lin = 2 Lout).  mul (S,Lin,Ci), optional: every written element is multiplied by it in the
     epilogue (the saved activation derivative of the layer below: dx then IS that layer's pre-activation gradient)."""
     ex = dict(aux=mul, aux_mode=MM_AUX_MUL_LIKE_C) if mul is not None else {}
     # plain products read the packed weight through a transposed copy (KH*Ci, Co): both operands k-contiguous (see mm_linear_dgrad)
-    WgT = Wg.t().contiguous() if (Wg.is_cuda and S * Lout >= 1024) else None
+    if not (Wg.is_cuda and S * Lout >= 1024):
+        WgT = None
+    elif WgT is None:                                         # (a caller that keeps its own (KH*Ci, Co) copy of this step's weight passes it)
+        WgT = Wg.t().contiguous()
     if KH == stride and pad == 0:
         Bop = MMOp(WgT, Co) if WgT is not None else MMOp(Wg, KH * Ci, trans=True)
         be.mm(MMOp(dy, Co), Bop, dx, S * Lout, KH * Ci, Co, KH * Ci, c_rows_per_seq=Lout, c_seq_stride=Lin * Ci, tag=tag, **ex)

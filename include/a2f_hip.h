@@ -190,6 +190,22 @@ int a2f_voca_trunk_bwd_data(const float* dh3, const float* z2, const float* cat7
 /* Conv weight re-layout  w (Co,Ci,KH) <-> wg (Co, KH*Ci) [k = kh*Ci+ci]; dir 0: w->wg, 1: wg->w(+=0 overwrite) */
 int a2f_conv_weight_pack(const float* src, float* dst, int64_t Co, int64_t Ci, int64_t KH, int32_t dir, a2f_stream_t stream);
 
+/* A batch of such re-layouts in ONE launch (Audio2Mesh refreshes nine packed convolution weights, their transposes for the data-gradient products and eight
+ * padded BatchNorm vectors every step, and unpacks nine weight gradients: ~60 launches of ~5 us as separate copies).  The logical tensor is w (Co, Ci, KH) in the
+ * reference's parameter layout (a vector: Ci = KH = 1); the packed side has padded extents Cop >= Co, Cip >= Ci:
+ *   mode 0: dst = wg  (Cop, KH*Cip), wg[co][kh*Cip + ci] = w[co][ci][kh], every padded element = pad_value (the whole of dst is written)
+ *   mode 1: dst = wgT (KH*Cip, Cop), the transpose of mode 0's result (both operands of a data-gradient product k-contiguous), padded elements = pad_value
+ *   mode 2: dst = w   (Co, Ci, KH) from src = wg (Cop, KH*Cip): the gradient's way back (padding dropped)
+ * items: HOST array of n <= 32 entries (copied into the kernel arguments); src / dst of an entry must not overlap. */
+typedef struct a2f_relayout_item {
+  const float* src;
+  float* dst;
+  int32_t Co, Ci, KH, Cop, Cip, mode;
+  float pad_value;
+  int32_t reserved;
+} a2f_relayout_item;
+int a2f_relayout_batch(const a2f_relayout_item* items, int32_t n, a2f_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm2d over channels-last rows (audio2face.py:15-46), training-mode batch statistics:
@@ -215,9 +231,12 @@ int a2f_bn_bwd(const float* x, const float* beta, const float* dy, int64_t R, in
 int a2f_bn_fwd_conv0(const float* a0, const float* wg, const float* cbias, int64_t P_out, int64_t R, int64_t C, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float eps, int32_t training, int32_t relu,
                      float* y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, a2f_stream_t stream);
+/* a2f_bn_bwd_conv0 can also produce the convolution's OWN parameter gradients in the same pass: dwg (C, 3) = sum_r dx(r, c) a0[2r - 1 + kh] and dcbias (C) = sum_r
+ * dx(r, c) (both NULL: not computed).  Layer 0 has no data gradient, so with dwg given dx may be NULL - the (R, C) pre-activation gradient is then never written
+ * (302 MB at B = 1024) and no separate weight-gradient pass reads it back.  Sums: fp32 per thread over its rows, double across workgroups, fixed order. */
 int a2f_bn_bwd_conv0(const float* a0, const float* wg, const float* cbias, int64_t P_out, const float* beta, const float* dy, int64_t R, int64_t C,
                      const float* gamma, const float* save_mean, const float* save_invstd, int32_t training, int32_t relu,
-                     float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, a2f_stream_t stream);
+                     float* dx, float* dgamma, float* dbeta, float* dwg, float* dcbias, void* ws, size_t ws_bytes, a2f_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * FaceFormer decoder recurrence (faceformer.py:154-185 evaluated incrementally):

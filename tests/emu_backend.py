@@ -595,6 +595,18 @@ class EmuBackend:
             dxv = dyv * g * invstd
         dx.reshape(R, Cc).copy_(dxv.float()); dgamma.copy_(dg.float()); dbeta.copy_(db.float())
 
+    def relayout_batch(self, items):
+        for it in items:
+            src, dst, Co, Ci, KH, Cop, Cip, mode = it[:8]
+            pad = float(it[8]) if len(it) > 8 else 0.0
+            if mode == 2:
+                dst.reshape(-1)[: Co * Ci * KH].copy_(src.reshape(-1)[: Cop * KH * Cip].view(Cop, KH, Cip)[:Co, :, :Ci].permute(0, 2, 1).reshape(-1))
+                continue
+            wg = torch.full((Cop, KH, Cip), pad, dtype=src.dtype)
+            wg[:Co, :, :Ci] = src.reshape(-1)[: Co * Ci * KH].view(Co, Ci, KH).permute(0, 2, 1)
+            wg = wg.view(Cop, KH * Cip)
+            dst.reshape(-1)[: Cop * KH * Cip].copy_((wg if mode == 0 else wg.t()).reshape(-1))
+
     def _conv0(self, a0, wg, cbias, P_out, R, Cc):
         z = torch.empty(R, Cc, dtype=torch.float64)
         self.conv_k3s2_c1_fwd(a0.double(), wg.double(), cbias.double(), R, P_out, Cc, z)
@@ -603,8 +615,14 @@ class EmuBackend:
     def bn_fwd_conv0(self, a0, wg, cbias, P_out, R, Cc, gamma, beta, rmean, rvar, momentum, eps, training, relu, y, save_mean, save_invstd):
         self.bn_fwd(self._conv0(a0, wg, cbias, P_out, R, Cc), R, Cc, gamma, beta, rmean, rvar, momentum, eps, training, relu, y, save_mean, save_invstd)
 
-    def bn_bwd_conv0(self, a0, wg, cbias, P_out, beta, dy, R, Cc, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta):
-        self.bn_bwd(self._conv0(a0, wg, cbias, P_out, R, Cc), beta, dy, R, Cc, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta)
+    def bn_bwd_conv0(self, a0, wg, cbias, P_out, beta, dy, R, Cc, gamma, save_mean, save_invstd, training, relu, dx, dgamma, dbeta, dwg=None, dcbias=None):
+        dxv = dx if dx is not None else torch.empty(R, Cc)
+        self.bn_bwd(self._conv0(a0, wg, cbias, P_out, R, Cc), beta, dy, R, Cc, gamma, save_mean, save_invstd, training, relu, dxv, dgamma, dbeta)
+        if dwg is not None:                                # the convolution's own gradients: windows a0[2r - 1 + kh] (left pad at the first row of a group)
+            a = a0.double().reshape(-1, 2 * P_out)
+            win = torch.stack([torch.cat([torch.zeros_like(a[:, :1]), a[:, 1:-1:2]], dim=1), a[:, 0::2], a[:, 1::2]], dim=2).reshape(R, 3)
+            d = dxv.reshape(R, Cc).double()
+            dwg.view(Cc, 3).copy_((d.t() @ win).float()); dcbias.copy_(d.sum(dim=0).float())
 
     # ------------------------------------------------------------------ FaceFormer recurrence (autograd on the spec)
     @staticmethod

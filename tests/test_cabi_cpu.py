@@ -38,6 +38,23 @@ def test_gemm_desc_layout_matches_header():
     assert out[1:] == [getattr(_lib.GemmDesc, f).offset for f in fields]
 
 
+def test_relayout_item_layout_matches_header():
+    """Same check for a2f_relayout_item (the batched weight re-layout of the Audio2Mesh step)."""
+    import ctypes
+    import subprocess
+    import tempfile
+    fields = [f for f, _ in _lib.RelayoutItem._fields_]
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "a2f_hip.h"\nint main(void) {\n  printf("%zu\\n", sizeof(a2f_relayout_item));\n'
+    prog += "".join(f'  printf("%zu\\n", offsetof(a2f_relayout_item, {f}));\n' for f in fields) + "  return 0;\n}\n"
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "layout.c"), os.path.join(d, "layout")
+        open(src, "w").write(prog)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        out = [int(x) for x in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(_lib.RelayoutItem)
+    assert out[1:] == [getattr(_lib.RelayoutItem, f).offset for f in fields]
+
+
 def test_mm_desc_layout_matches_header():
     """Same check for a2f_mm_desc / a2f_mm_operand (the bf16-MFMA GEMM family)."""
     import ctypes

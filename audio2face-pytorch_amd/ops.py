@@ -170,7 +170,8 @@ class HipBackend:
             split_k = max(1, min(256 // max(tiles, 1), K // 512, 128))
         elif split_k == 0:                                      # auto: enough workgroups for the chip, slabs stay small
             tiles = ((M + 127) // 128) * ((N + (127 if N > 64 else 63)) // (128 if N > 64 else 64)) * batch
-            split_k = max(1, min(512 // max(tiles, 1), K // 256, 64)) if tiles < 192 else 1
+            # (a one- or two-tile weight gradient - Audio2Mesh's analysis layer 1: 108 x 216 over 524 288 rows - needs more than 64 cuts to put a workgroup on every CU)
+            split_k = max(1, min(512 // max(tiles, 1), K // 256, 64 if tiles >= 4 else 256 // max(tiles, 1))) if tiles < 192 else 1
         elif (split_k == 1 and SMALL_M_SPLIT and batch == 1 and not A.img and not A.trans and not accumulate and a_rowsum is None and c_colsum is None
               and M <= SMALL_M_SPLIT and N > 64 and K >= 384):
             # a product of few rows (the reference's own batch-1 FaceFormer step: 600 rows) makes (M / 128) (N / 128) workgroups - 30 for N = 768 - that

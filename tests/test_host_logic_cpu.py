@@ -353,6 +353,25 @@ def test_flat_adam_release_and_collect_grads(emu):
     for p in ps[:2]:
         o, n = opt._offsets[id(p)][0], p.numel()
         assert torch.equal(opt.flat_g[o:o + n], want[o:o + n])
+    # the pipelined step's form: the first pass set aside (stash_grads), the last pass handed out as it is, ONE multi-tensor add in collect_grads - the same
+    # sums, bit for bit; a parameter only the first pass reached (ps[1] here) and one no pass reached (ps[2]) included
+    def loss_b():
+        return (x @ ps[0]).pow(2).sum() * 0.5
+    opt.zero_grad()
+    loss().backward(); loss_b().backward()
+    want = opt.flat_g.clone()
+    opt.flat_g.fill_(7.0)
+    opt.release_grads()
+    loss().backward()
+    opt.stash_grads()
+    assert all(p.grad is None for p in ps)
+    loss_b().backward()
+    assert ps[1].grad is None
+    opt.collect_grads()
+    assert all(p.grad is v for p, v in zip(ps, views)) and not opt._stash
+    for p in ps:                                                             # (segments are padded to 16 bytes: the padding is nobody's)
+        o, n = opt._offsets[id(p)][0], p.numel()
+        assert torch.equal(opt.flat_g[o:o + n], want[o:o + n])
 
 
 def test_bucketed_allreduce_refuses_a_model_that_breaks_its_order_assumption():

@@ -321,6 +321,7 @@ class A2MPackBuffers:
 # 2.1e-5 worst at 8.2 ms per B = 1024 step; 2,1,1: 6.0e-5 at 6.7 ms; 1,x,x: 1.3e-2).
 _a2m_prec = [int(v) for v in os.environ.get("A2F_A2M_MM_PRECISION", "2,1,1").split(",")]
 A2M_PREC_FWD, A2M_PREC_WGRAD, A2M_PREC_DGRAD = (_a2m_prec * 3)[:3] if len(_a2m_prec) == 1 else tuple(_a2m_prec)
+A2M_PREC_FWD_LAYER = {}        # layer (1..9) -> precision of that convolution's forward product where it differs from A2M_PREC_FWD (tools/a2m_layer_precision_probe.py)
 
 
 
@@ -387,7 +388,7 @@ class A2MTrunkMMFn(torch.autograd.Function):
             Wo = Wd // 2
             R = B * H0 * Wo
             z = new(R, cop)
-            ops.mm_conv_fwd(be, act, wg, z, B * H0, Wd, Wo, cip, cop, 3, 2, pad=1, bias=pk.bias[l] if cop != co else convs[l][1])
+            ops.mm_conv_fwd(be, act, wg, z, B * H0, Wd, Wo, cip, cop, 3, 2, pad=1, bias=pk.bias[l] if cop != co else convs[l][1], precision=A2M_PREC_FWD_LAYER.get(l))
             sv["wg"][l], sv["conv_in"][l] = wg, act
             act = bn(l, z, R, co, cop, True)
             Wd = Wo
@@ -396,7 +397,7 @@ class A2MTrunkMMFn(torch.autograd.Function):
             wg, b = pk.wg[l], convs[l][1]
             Ho = Hd // 2
             z = new(B * Ho, 256)
-            ops.mm_conv_fwd(be, act, wg, z, B, Hd, Ho, 256, 256, 3, 2, pad=1, bias=b)
+            ops.mm_conv_fwd(be, act, wg, z, B, Hd, Ho, 256, 256, 3, 2, pad=1, bias=b, precision=A2M_PREC_FWD_LAYER.get(l))
             sv["wg"][l], sv["conv_in"][l] = wg, act
             act = bn(l, z, B * Ho, 256, 256, True)
             Hd = Ho
@@ -404,7 +405,7 @@ class A2MTrunkMMFn(torch.autograd.Function):
         wg, b = pk.wg[8], convs[8][1]
         Ho = Hd // 2
         z8 = new(B * Ho, 256)
-        ops.mm_conv_fwd(be, act, wg, z8, B, Hd, Ho, 256, 256, 3, 2, pad=1, bias=b, act=ops.MM_ACT_RELU)
+        ops.mm_conv_fwd(be, act, wg, z8, B, Hd, Ho, 256, 256, 3, 2, pad=1, bias=b, act=ops.MM_ACT_RELU, precision=A2M_PREC_FWD_LAYER.get(8))
         sv["wg"][8], sv["conv_in"][8] = wg, act
         Hd = Ho
         zb = bn(9, z8, B * Hd, 256, 256, False)                # BN -> conv(4,1)/s4 -> ReLU  (audio2face.py:44-46)

@@ -754,11 +754,11 @@ def mm_linear_wgrad(be, dy, x, dW, M, N, K, *, tag="gemm_mfma", db=None):
     be.mm(MMOp(dy, N, trans=True), MMOp(x, K, trans=True), dW, N, K, M, K, split_k=0, tag=tag, a_rowsum=db)
 
 
-def mm_conv_fwd(be, x, Wg, y, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, bias=None, act=MM_ACT_NONE, pre=None, tag="gemm_mfma"):
+def mm_conv_fwd(be, x, Wg, y, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, bias=None, act=MM_ACT_NONE, pre=None, tag="gemm_mfma", precision=None):
     """Conv1d over channels-last rows: x (S,Lin,Ci) -> y (S,Lout,Co), Wg (Co, KH*Ci) with k = kh*Ci + ci; `pad` zero
     positions on the left of every sequence."""
     A = MMOp(x, stride * Ci, lines_per_seq=Lout, seq_stride=Lin * Ci, off=-pad * Ci, seq_elems=Lin * Ci)
-    be.mm(A, MMOp(Wg, KH * Ci), y, S * Lout, Co, KH * Ci, Co, bias=bias, act=act, C2=pre, tag=tag)
+    be.mm(A, MMOp(Wg, KH * Ci), y, S * Lout, Co, KH * Ci, Co, bias=bias, act=act, C2=pre, tag=tag, precision=precision)
 
 
 def mm_conv_wgrad(be, x, dy, dWg, S, Lin, Lout, Ci, Co, KH, stride, *, pad=0, tag="gemm_mfma", db=None):

@@ -602,9 +602,9 @@ _EXACT_ZERO_GRADS = ("attention.k_proj.bias",)
 # The split-bf16 products carry 2^-16 per operand where fp32 carries 2^-24: on a gradient that is the small difference of large terms
 # (d loss / d q, k of a layer whose attention is nearly uniform: dS = P (dP - delta) with |dP - delta| << |dP|) the HIP path can be up to
 # 2^(24 - 16) = 256 times noisier than the reference's fp32 arithmetic - which itself misses the float64 value by up to 2e-2 there (layer
-# 11 of the formula weights at T = 600; measured ratios 30 - 80).  Such a gradient is judged against float64 with a floor proportional
+# 11 of the formula weights at T = 600; measured ratios 30 - 80 in round 3, 7 - 27 since the round-4 attention kernels).  Such a gradient is judged against float64 with a floor proportional
 # to the REFERENCE's own fp32 error; everywhere the reference resolves a gradient to 4e-7 or better the plain 1e-4 bar applies.
-_ILL_CONDITIONED_FLOOR = 256.0
+_ILL_CONDITIONED_FLOOR = 64.0          # T = 600: measured ratios 7 - 27 (round 5); the T = 3000 test passes its own (ratios up to 215: five times the keys per softmax row)
 
 
 def _t600_inputs(seed, subject):
@@ -628,9 +628,9 @@ def _g15_error(fix, key, t):
     return e
 
 
-def _assert_all_grads_g15(m, fix, tol=TOL, max_floor_share=0.15):
+def _assert_all_grads_g15(m, fix, tol=TOL, max_floor_share=0.15, floor=_ILL_CONDITIONED_FLOOR):
     """EVERY parameter gradient of the HIP path against a full-size oracle fixture (G15, tests/golden/gen_golden_fullsize.py): <= tol from the oracle's gradient
-    (_g15_error), or - ill-conditioned gradients, where the fp32 ORACLE itself sits `eref` from float64 - <= 256 eref from float64 (_ILL_CONDITIONED_FLOOR above).
+    (_g15_error), or - ill-conditioned gradients, where the fp32 ORACLE itself sits `eref` from float64 - <= `floor` x eref from float64 (_ILL_CONDITIONED_FLOOR above).
     Wherever the fp32 oracle resolves a gradient (eref ~ 1e-6) the float64 value and the fp32 one are the same number at the bar's resolution."""
     params = dict(m.named_parameters())
     rows, floored = [], []
@@ -645,13 +645,13 @@ def _assert_all_grads_g15(m, fix, tol=TOL, max_floor_share=0.15):
             rows.append((e, key))
             continue
         e64 = packed_error(fix, "g64::" + key, params[key].grad)
-        floored.append((key, f"hip {e64:.2e}", f"fp32 oracle {eref:.2e}"))
-        assert e64 <= max(tol, _ILL_CONDITIONED_FLOOR * eref), (key, e64, eref)
+        floored.append((key, f"hip {e64:.2e}", f"fp32 oracle {eref:.2e}", f"ratio {e64 / eref:.0f}"))
+        assert e64 <= max(tol, floor * eref), (key, e64, eref)
     rows.sort(reverse=True)
     print("gradients compared:", len(rows) + len(floored), "worst well-conditioned:", [(f"{e:.2e}", k) for e, k in rows[:8]])
     print("ill-conditioned (judged with the float64 floor):", floored)
     assert len(rows) + len(floored) >= 10 and len(floored) <= max_floor_share * (len(rows) + len(floored))
-    return [k for k, _h, _r in floored]
+    return [f[0] for f in floored]
 
 
 def _ff_long_inputs(T, seed):
@@ -700,7 +700,7 @@ def test_faceformer_config5_T3000_full_gradients_vs_oracle():
     assert err < TOL
     loss["loss"].backward()
     assert _g15_error(fix, "audio", a_gpu.grad) < TOL                   # (at 3000 frames the fp32 oracle's own d loss / d audio is 1e-4-class from float64: the nearer of the two)
-    _assert_all_grads_g15(m, fix)
+    _assert_all_grads_g15(m, fix, floor=256.0)                          # q / k gradients under near-uniform attention over 3000 keys: measured ratios up to 215
 
 
 def test_faceformer_config5_T3000_other_precision_settings_miss_the_tolerance():

@@ -239,8 +239,11 @@ struct Cfg {
   static constexpr int WPS = CFG == 3 ? 4 : (CFG == 2 ? 2 : 2);
 };
 
-template <bool AT, bool BT, int PREC, int CFG, bool PLAIN>
-__global__ __launch_bounds__(Cfg<CFG>::TH, PREC == 2 ? (CFG == 3 ? 2 : 1) : Cfg<CFG>::WPS) void gemm_mfma_kernel(const Args a) {   // bf16x6: three images per operand, one workgroup per CU
+// The second launch bound is WAVES PER SIMD (not workgroups per CU).  bf16x6 (three images per operand) at 128 x 128 on 8 waves: 4 = a 128-register budget and
+// ONE LDS stage (48 KB) put two workgroups on a CU; with the budget of 2 the compiler took 161 registers and a CU held one workgroup whatever its LDS use
+// (round 5: Audio2Mesh's four analysis convolutions 312 / 316 / 225 / 155 -> 265 / 271 / 201 / 135 us at B = 1024, tools/bench_a2m_conv.py).
+template <bool AT, bool BT, int PREC, int CFG, bool PLAIN, bool ONE_STAGE = false>
+__global__ __launch_bounds__(Cfg<CFG>::TH, PREC == 2 ? (CFG == 3 ? 4 : 1) : Cfg<CFG>::WPS) void gemm_mfma_kernel(const Args a) {
   constexpr int BM = Cfg<CFG>::BM, BN = Cfg<CFG>::BN, TH = Cfg<CFG>::TH;
   constexpr int WGN = Cfg<CFG>::WGN;
   constexpr int TM = Cfg<CFG>::TM, TN = Cfg<CFG>::TN;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, PREC == 2 ? (CFG == 3 ? 2 : 1) : Cfg<
   using SB = Stage<BT, BN, TH>;
   constexpr int A_BYTES = NIMG * SA::IMG, B_BYTES = NIMG * SB::IMG;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];          // two stages
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // two stages (ONE_STAGE: one)
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
@@ -305,12 +308,6 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, PREC == 2 ? (CFG == 3 ? 2 : 1) : Cfg<
   };
 
   f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // Two register sets: while k-tile kt is multiplied, tile kt+1 (fetched one iteration earlier) is converted and written
   // to the other LDS stage and the loads of tile kt+2 are issued - a fetch has two multiply phases to land (an L2 / HBM
@@ -332,10 +329,6 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, PREC == 2 ? (CFG == 3 ? 2 : 1) : Cfg<
     }
     sa.template commit<PREC>(img, q);
   };
-  commit_a(smem, ra0);
-  sb.template commit<PREC>(smem + A_BYTES, rb0);
-  __syncthreads();
-
   auto compute = [&](const char* cur) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -377,6 +370,18 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, PREC == 2 ? (CFG == 3 ? 2 : 1) : Cfg<
     char* nst = smem + ((kt + 1) & 1) * STAGE;
     const int k2 = kbeg + (kt + 2) * BK;
     fetch(k2, na, nb);                                          // `nxt` held tile kt, which went to LDS one iteration ago
+    if constexpr (ONE_STAGE) {
+      // ONE LDS stage (bf16x6: three images per operand are 48 KB per stage at 128 x 128 - two stages leave room for one workgroup per CU): tile kt is
+      // multiplied, then - behind a barrier - tile kt + 1 overwrites it.  The conversion no longer overlaps this workgroup's own MFMAs; the CU's other
+      // workgroup's MFMAs run under it instead, and so do its prologue and epilogue (short-K products run 7-23 k-tiles per tile of C).
+      __builtin_amdgcn_sched_barrier(0);
+      compute(smem);
+      __syncthreads();
+      commit_a(smem, ca);
+      sb.template commit<PREC>(smem + A_BYTES, cb);
+      __syncthreads();
+      return;
+    }
     // keep the load issue HERE: without the fence the machine scheduler sinks the buffer loads below the MFMA block, next
     // to their first use, and the fetch no longer overlaps the multiplication.  Below it the conversion / LDS writes of
     // tile kt+1 (other stage) and the MFMAs of tile kt are one scheduling region: the compiler interleaves VALU and MFMA.
@@ -393,6 +398,15 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, PREC == 2 ? (CFG == 3 ? 2 : 1) : Cfg<
     compute(smem + (kt & 1) * STAGE);
     __syncthreads();
   };
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  commit_a(smem, ra0);
+  sb.template commit<PREC>(smem + A_BYTES, rb0);
+  __syncthreads();
   int kt = 0;
   for (; kt + 2 < nkt; kt += 2) {
     body(kt, ra1, rb1, ra0, rb0);
@@ -402,7 +416,7 @@ __global__ __launch_bounds__(Cfg<CFG>::TH, PREC == 2 ? (CFG == 3 ? 2 : 1) : Cfg<
     body(kt, ra1, rb1, ra0, rb0);
     ++kt;
   }
-  if (nkt > 0) compute(smem + ((nkt - 1) & 1) * STAGE);
+  if (nkt > 0) compute(smem + (ONE_STAGE ? 0 : ((nkt - 1) & 1) * STAGE));
 
   if constexpr (CAN_ROWSUM) {
     if (do_rowsum && n0 == 0) {                                // one column of workgroups owns the sums (block-uniform)
@@ -499,8 +513,9 @@ template <bool AT, bool BT, int PREC, int CFG, bool PLAIN>
 static int launch(const Args& a, hipStream_t st) {
   constexpr int BM = Cfg<CFG>::BM, BN = Cfg<CFG>::BN, TH = Cfg<CFG>::TH;
   constexpr int NIMG = PREC == 2 ? 3 : PREC == 1 ? 2 : 1;
-  constexpr int smem = 2 * NIMG * (Stage<AT, BM, TH>::IMG + Stage<BT, BN, TH>::IMG);
-  auto kern = gemm_mfma_kernel<AT, BT, PREC, CFG, PLAIN>;
+  constexpr bool ONE_STAGE = PREC == 2 && CFG == 3;         // bf16x6 at 128 x 128: one 48-KB stage, two workgroups per CU (see the kernel's body())
+  constexpr int smem = (ONE_STAGE ? 1 : 2) * NIMG * (Stage<AT, BM, TH>::IMG + Stage<BT, BN, TH>::IMG);
+  auto kern = gemm_mfma_kernel<AT, BT, PREC, CFG, PLAIN, ONE_STAGE>;
   static bool attr_done = false;                        // set-once per instantiation (idempotent; safe to repeat)
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -709,8 +724,7 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   // LDS per 128 x 128 workgroup, so only one 8-wave workgroup would fit) -> 256 x 128 on 8 waves when there are enough tiles, else
   // 128 x 128 on 4 waves; everything else -> 128 x 128 on 8 waves, two workgroups per CU = four waves per SIMD (+10-25 % over 4 waves)
   int cfg = d->N <= 64 ? 1 : 3;
-  // (bf16x6: three images per operand = one workgroup per CU whatever the tile, so the 8-wave 128 x 128 form wins there too: 8.4 vs 10.6 ms
-  // for the Audio2Mesh step)
+  // (bf16x6: the 8-wave 128 x 128 form too, on one LDS stage and a 128-register budget = two workgroups per CU: see gemm_mfma_kernel)
   if (cfg == 3 && at && bt && d->precision != 2) cfg = (cdiv(d->M, 256) * cdiv(d->N, 128) * batch * split >= 200) ? 2 : 0;
   hipStream_t st = (hipStream_t)stream;
   const bool plain = a.A.lps == 0 && a.B.lps == 0 && (d->K % BK) == 0;

@@ -232,9 +232,11 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float4* __restrict_
   }
 }
 
+// Persistent workgroups of the backward: TWO per CU (218 registers = two waves per SIMD, 48 KB of LDS each) - 96 KB of row loads in flight per CU instead of 48;
+// 19 200 x 768 with keep bits and image output: 54.6 -> 47.1 us (4.3 -> 5.0 TB/s; 1024 workgroups: 50.5 us).  One slab row per workgroup in the workspace.
 static int ln_blocks_bwd(int64_t R) {
   int64_t b = cdiv(R, RO_THREADS / 64);
-  return (int)(b > 256 ? 256 : b);
+  return (int)(b > 512 ? 512 : b);
 }
 
 }  // namespace a2f

@@ -413,12 +413,12 @@ class A2MTrunkMMFn(torch.autograd.Function):
         be.mm(ops.MMOp(zb, KH9 * 256), ops.MMOp(wg, KH9 * 256), cat, B, 256, KH9 * 256, ncat, bias=b, act=ops.MM_ACT_RELU)
         sv["wg"][9], sv["conv_in"][9] = wg, zb
         z1, z2, h3 = new(B, 72), new(B, 128), new(B, 50)
-        # output_net.0 / .1 on a2f_mm as well (1024 x 72 x 268 takes 80 us on the exact-fp32 generic GEMM, a few us here); the 50-wide
-        # layer keeps the generic GEMM: its K = 50 rows are not 16-byte aligned
+        # output_net.0 / .1 / .3 on a2f_mm as well (1024 x 72 x 268 takes 80 us on the exact-fp32 generic GEMM, a few us here); only the BACKWARD of the
+        # 50-wide layer keeps the generic GEMM: there the 50-float rows of dh3 are the k-contiguous operand and they are not 16-byte aligned
         ops.mm_linear_fwd(be, cat, fcs[0][0], fcs[0][1], z1, B, 72, ncat)
         ops.mm_linear_fwd(be, z1, fcs[1][0], fcs[1][1], z2, B, 128, 72)
         torch.tanh_(z2)
-        ops.linear_fwd(be, z2, fcs[2][0], fcs[2][1], h3, B, 50, 128)
+        ops.mm_linear_fwd(be, z2, fcs[2][0], fcs[2][1], h3, B, 50, 128)
         if training:                                         # the padded layers' running statistics go back into the module's buffers: one launch for the four
             be.relayout_batch([(src, bufs[2 * l + j], A2M_CH[l + 1], 1, 1, A2M_CHP[l + 1], 1, 2) for l in A2M_PAD_LAYERS for j, src in enumerate(pk.bn[l][2:])])
         ctx.sv, ctx.pk = sv, pk

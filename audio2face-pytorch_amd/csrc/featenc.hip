@@ -17,9 +17,31 @@ constexpr int THREADS = 256;
 constexpr int LB = 64;                    // positions per inner chunk
 constexpr int XN = LB * STRIDE + KW;      // waveform samples a chunk touches (with slack)
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// GELU and its derivative from ONE exponential and one reciprocal (the form of csrc/gemm_img.hip's epilogues): Phi(-|x|) = 0.5 erfc(|x| / sqrt 2) by
+// Abramowitz-Stegun 7.1.26 (|error| <= 0.75e-7 on Phi; the small branch is never formed as 1 - (something near 1)), phi(x) = exp(-x^2 / 2) / sqrt(2 pi) shares
+// the exponential.  These passes are bound by their vector arithmetic, not by HBM (10 multiply-adds of the recomputed convolution + the GroupNorm affine + GELU per
+// element: ~43 vector operations per element with erff / expf, 0.57 ms of a 0.63-ms forward apply pass at 32 x 32 000 x 512), so the GELU's instruction count is what they cost
+// (same box, forward 0.943 -> 0.857 ms, backward 1.879 -> 1.646 ms against erff / expf: tools/bench_featenc0.py).
+__device__ __forceinline__ void gelu_cdf_pdf(float x, float& cdf, float& e) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.f));
+  e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);                                   // exp(-x^2 / 2)
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float q = 0.5f * p * t * e;                                                            // Phi(-|x|)
+  cdf = x < 0.f ? q : 1.f - q;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float cdf, e;
+  gelu_cdf_pdf(x, cdf, e);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+  float cdf, e;
+  gelu_cdf_pdf(x, cdf, e);
+  return fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
 struct Args {

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -42,19 +43,27 @@ class MMOp:
         o.lines_per_seq, o.seq_stride, o.off, o.seq_elems = self.lines_per_seq, self.seq_stride, self.off, self.seq_elems
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_TLS = threading.local()
+
+
 def _ptr(t: Optional[torch.Tensor], off: int = 0) -> Optional[int]:
     if t is None:
         return None
     return t.data_ptr() + 4 * off
 
 
+_F32 = torch.float32
+
+
 def _chk(*ts):
+    # (attribute reads only: `t.device.type` builds a torch.device per call - this guard runs ~360 times per batch-1 FaceFormer step, which the host's launch rate bounds)
     for t in ts:
         if t is None:
             continue
-        if t.device.type != "cuda":
+        if not t.is_cuda:
             raise A2FError("a2f ops need HIP (cuda) tensors; this package has no CPU path")
-        if t.dtype != torch.float32:
+        if t.dtype is not _F32:
             raise A2FError(f"a2f ops compute in fp32; got {t.dtype}")
         if not t.is_contiguous():
             raise A2FError("a2f ops need contiguous tensors")
@@ -65,7 +74,7 @@ SMALL_M_SPLIT = 1024      # products of at most this many rows are cut along K a
 
 def _chk_bits(*ts):
     for t in ts:
-        if t.device.type != "cuda" or t.dtype != torch.int32 or not t.is_contiguous():
+        if not t.is_cuda or t.dtype is not torch.int32 or not t.is_contiguous():
             raise A2FError("keep-bit masks are contiguous int32 HIP tensors (32 elements per word)")
 
 
@@ -81,7 +90,9 @@ class HipBackend:
 
     @staticmethod
     def _stream(t: torch.Tensor):
-        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        # the raw handle of torch's current stream on the tensor's device, straight from the C side: torch.cuda.current_stream(...).cuda_stream builds a Python
+        # Stream object per call (~4 us, 170 times per batch-1 FaceFormer step, on a step that is bound by the host's launch rate: tools/host_bound_probe.py)
+        return C.c_void_p(_raw_stream(t.get_device()))
 
     # ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----
     def _prof_begin(self, tag):
@@ -154,17 +165,7 @@ class HipBackend:
         keep = (bits int32 (M, wpr), scale): train-mode dropout of C in the epilogue.  c_img: C is written as a split-32 image.
         c_colsum (N): receives the column sums of the stored C (image operands only)."""
         _chk(A.t, B.t, Cout, C2, bias, aux)
-        d = MMDesc()
-        A.fill(d.A)
-        B.fill(d.B)
-        d.C, d.ldc, d.c_rows_per_seq, d.c_seq_stride = _ptr(Cout, c_off), ldc, c_rows_per_seq, c_seq_stride
-        d.C2 = _ptr(C2, c_off)
-        d.M, d.N, d.K = M, N, K
-        d.bias = _ptr(bias)
-        d.aux, d.ldaux = _ptr(aux, c_off if aux_mode == MM_AUX_MUL_LIKE_C else 0), ldaux
-        d.act, d.aux_mode = act, aux_mode
-        d.precision = self.mm_precision if precision is None else precision
-        d.c_format = 1 if c_img else 0
+        prec = self.mm_precision if precision is None else precision
         if split_k == 0 and A.img:                              # image operands: 256 x 256 tiles, one workgroup per CU
             tiles = ((M + 255) // 256) * ((N + 255) // 256)
             split_k = max(1, min(256 // max(tiles, 1), K // 512, 128))
@@ -179,25 +180,58 @@ class HipBackend:
             tiles = ((M + 127) // 128) * ((N + 127) // 128)
             if tiles <= 128:
                 split_k = max(1, min(256 // tiles, K // 96, 32))
-        d.split_k = split_k
+        if keep is not None:
+            bits, kscale = keep
+            _chk_bits(bits)
+            kwpr, kscale = bits.shape[-1], float(kscale)
+        else:
+            bits, kwpr, kscale = None, 0, 0.0
+        # Everything of the descriptor that is not an address is the same at every step for a given call site: the filled struct is kept under the tuple of those
+        # values and a call rewrites the dozen pointer / extent fields only (a ctypes field store costs ~0.2 us and the struct has 60 of them; a batch-1 FaceFormer
+        # step makes 157 products and is bound by the host's launch rate: tools/host_bound_probe.py).
+        key = (A.ld, A.trans, A.img, A.lines_per_seq, A.seq_stride, A.off, A.seq_elems, B.ld, B.trans, B.img, B.lines_per_seq, B.seq_stride, B.off, B.seq_elems,
+               M, N, K, ldc, c_rows_per_seq, c_seq_stride, ldaux, act, aux_mode, prec, c_img, split_k, batch, a_bstride, b_bstride, c_bstride, bias_bstride,
+               aux_bstride, accumulate, alpha, kwpr, kscale)
+        cache = getattr(_TLS, "mm_descs", None)                 # per thread: the autograd engine calls in from its own thread
+        if cache is None:
+            cache = _TLS.mm_descs = {}
+        d = cache.get(key)
+        if d is None:
+            if len(cache) > 4096:
+                cache.clear()
+            d = cache[key] = MMDesc()
+            A.fill(d.A)
+            B.fill(d.B)
+            d.ldc, d.c_rows_per_seq, d.c_seq_stride = ldc, c_rows_per_seq, c_seq_stride
+            d.M, d.N, d.K = M, N, K
+            d.ldaux = ldaux
+            d.act, d.aux_mode = act, aux_mode
+            d.precision = prec
+            d.c_format = 1 if c_img else 0
+            d.split_k = split_k
+            d.batch, d.accumulate = batch, int(accumulate)
+            d.a_bstride, d.b_bstride, d.c_bstride, d.bias_bstride, d.aux_bstride = a_bstride, b_bstride, c_bstride, bias_bstride, aux_bstride
+            d.alpha = alpha
+            d.keep_wpr, d.keep_scale = kwpr, kscale
+        ta, tb = A.t, B.t
+        d.A.p, d.A.bytes = ta.data_ptr() + 4 * A.ptr_off, 4 * (ta.numel() - A.ptr_off)
+        d.B.p, d.B.bytes = tb.data_ptr() + 4 * B.ptr_off, 4 * (tb.numel() - B.ptr_off)
+        d.C = _ptr(Cout, c_off)
+        d.C2 = _ptr(C2, c_off)
+        d.bias = _ptr(bias)
+        d.aux = _ptr(aux, c_off if aux_mode == MM_AUX_MUL_LIKE_C else 0)
+        d.keep_bits = bits.data_ptr() if bits is not None else None
         ws = None
         if split_k > 1:
             ws = torch.empty(batch * split_k * M * N + (split_k * M if a_rowsum is not None else 0), device=Cout.device, dtype=torch.float32)
-            d.ws = _ptr(ws)
         if c_colsum is not None:
             _chk(c_colsum)
             ws = torch.empty(2 * ((M + 255) // 256) * N, device=Cout.device, dtype=torch.float32)
-            d.ws, d.c_colsum = _ptr(ws), _ptr(c_colsum)
+        d.ws = _ptr(ws)
+        d.c_colsum = _ptr(c_colsum)
         if a_rowsum is not None:
             _chk(a_rowsum)
-            d.a_rowsum = _ptr(a_rowsum)
-        d.batch, d.accumulate = batch, int(accumulate)
-        d.a_bstride, d.b_bstride, d.c_bstride, d.bias_bstride, d.aux_bstride = a_bstride, b_bstride, c_bstride, bias_bstride, aux_bstride
-        d.alpha = alpha
-        if keep is not None:
-            bits, scale = keep
-            _chk_bits(bits)
-            d.keep_bits, d.keep_wpr, d.keep_scale = bits.data_ptr(), bits.shape[-1], float(scale)
+        d.a_rowsum = _ptr(a_rowsum)
         ev = self._prof_begin(tag)
         _lib.check(self.lib.a2f_mm(C.byref(d), self._stream(Cout)), "a2f_mm")
         self._prof_end(tag, ev)

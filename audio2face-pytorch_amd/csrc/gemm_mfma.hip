@@ -725,7 +725,9 @@ extern "C" int a2f_mm(const a2f_mm_desc* d, a2f_stream_t stream) {
   // 128 x 128 on 4 waves; everything else -> 128 x 128 on 8 waves, two workgroups per CU = four waves per SIMD (+10-25 % over 4 waves)
   int cfg = d->N <= 64 ? 1 : 3;
   // (bf16x6: the 8-wave 128 x 128 form too, on one LDS stage and a 128-register budget = two workgroups per CU: see gemm_mfma_kernel)
-  if (cfg == 3 && at && bt && d->precision != 2) cfg = (cdiv(d->M, 256) * cdiv(d->N, 128) * batch * split >= 200) ? 2 : 0;
+  // (a weight gradient of at most 128 output rows - Audio2Mesh's analysis layer 1, 108 x 216 over 524 288 rows - keeps the 8-wave 128 x 128 form: half of a 256-row
+  // tile would be empty and the 4-wave form leaves one wave per SIMD: 261 (256 x 128) / 232 (4 waves) / 198 us (8 waves, 128 x 128), same box)
+  if (cfg == 3 && at && bt && d->precision != 2 && d->M > 128) cfg = (cdiv(d->M, 256) * cdiv(d->N, 128) * batch * split >= 200) ? 2 : 0;
   hipStream_t st = (hipStream_t)stream;
   const bool plain = a.A.lps == 0 && a.B.lps == 0 && (d->K % BK) == 0;
   if (d->precision == 2) {                 // three images per operand: the 256 x 128 tile does not fit
